@@ -1,0 +1,170 @@
+"""Minimal heterogeneous-graph containers with the slice of the torch_geometric API that the reference's
+sampler touches (torch_geometric is not installed on the target image and the hot path does not need it).
+
+Mirrors what `utils/sampling.py:78-91,231-233` and `utils/diffusion_utils.py:60-64,150-179` use:
+  data['ligand'].pos / .x / .edge_mask / .mask_rotate / .num_nodes / .batch
+  data['ligand','ligand'].edge_index / .edge_attr / .num_edges
+  data['receptor'].x / .pos ; data['receptor','receptor'].edge_index
+  Batch.from_data_list, .num_graphs, .to(device), DataLoader(list, batch_size)
+A three-element key ('receptor','rec_contact','receptor') addresses the same store as ('receptor','receptor').
+"""
+from __future__ import annotations
+
+import copy
+from typing import Dict, Iterable, List
+
+import numpy as np
+import torch
+
+
+class Store:
+    """Attribute bag for one node type or edge type."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def keys(self):
+        return [k for k in self.__dict__ if not k.startswith("_")]
+
+    def __contains__(self, k):
+        return k in self.__dict__
+
+    @property
+    def num_nodes(self):
+        for k in ("pos", "x"):
+            if k in self.__dict__:
+                return int(self.__dict__[k].shape[0])
+        raise AttributeError("num_nodes")
+
+    @property
+    def num_edges(self):
+        return int(self.__dict__["edge_index"].shape[1])
+
+    def to(self, device):
+        for k, v in list(self.__dict__.items()):
+            if torch.is_tensor(v):
+                self.__dict__[k] = v.to(device)
+            elif isinstance(v, dict):
+                self.__dict__[k] = {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+        return self
+
+
+def _norm_key(key):
+    if isinstance(key, tuple):
+        if len(key) == 3:
+            return (key[0], key[2])
+        return tuple(key)
+    return key
+
+
+class HeteroData:
+    def __init__(self):
+        object.__setattr__(self, "_stores", {})
+
+    def __getitem__(self, key) -> Store:
+        key = _norm_key(key)
+        st = self._stores.get(key)
+        if st is None:
+            st = self._stores[key] = Store()
+        return st
+
+    def __contains__(self, key):
+        return _norm_key(key) in self._stores or key in self.__dict__
+
+    @property
+    def node_types(self):
+        return [k for k in self._stores if isinstance(k, str)]
+
+    @property
+    def edge_types(self):
+        return [k for k in self._stores if isinstance(k, tuple)]
+
+    @property
+    def num_graphs(self):
+        return 1
+
+    def to(self, device):
+        for st in self._stores.values():
+            st.to(device)
+        for k, v in list(self.__dict__.items()):
+            if k.startswith("_"):
+                continue
+            if torch.is_tensor(v):
+                self.__dict__[k] = v.to(device)
+            elif isinstance(v, dict):
+                self.__dict__[k] = {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
+        return self
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+
+_CAT_NODE = ("x", "pos")
+
+
+class Batch(HeteroData):
+    """Collation of a list of HeteroData: node tensors concatenated, edge_index offset per graph,
+    `batch` vectors added, non-tensor attributes (mask_rotate, name) gathered into lists."""
+
+    def __init__(self):
+        super().__init__()
+        object.__setattr__(self, "_num_graphs", 0)
+
+    @property
+    def num_graphs(self):
+        return self._num_graphs
+
+    @classmethod
+    def from_data_list(cls, data_list: List[HeteroData]) -> "Batch":
+        out = cls()
+        object.__setattr__(out, "_num_graphs", len(data_list))
+        first = data_list[0]
+        node_offsets: Dict[str, List[int]] = {}
+        for nt in first.node_types:
+            sizes = [d[nt].num_nodes for d in data_list]
+            offs = np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+            node_offsets[nt] = offs
+            st = out[nt]
+            for k in first[nt].keys():
+                vals = [getattr(d[nt], k) for d in data_list]
+                if torch.is_tensor(vals[0]):
+                    setattr(st, k, torch.cat(vals, dim=0))
+                else:
+                    setattr(st, k, list(vals))
+            st.batch = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)])
+        for et in first.edge_types:
+            st = out[et]
+            for k in first[et].keys():
+                vals = [getattr(d[et], k) for d in data_list]
+                if k == "edge_index":
+                    so, do = node_offsets[et[0]], node_offsets[et[-1]]
+                    vals = [v + torch.tensor([[so[i]], [do[i]]], dtype=v.dtype) for i, v in enumerate(vals)]
+                    setattr(st, k, torch.cat(vals, dim=1))
+                elif torch.is_tensor(vals[0]):
+                    setattr(st, k, torch.cat(vals, dim=0))
+                else:
+                    setattr(st, k, list(vals))
+        for k, v in first.__dict__.items():
+            if k.startswith("_"):
+                continue
+            vals = [d.__dict__.get(k) for d in data_list]
+            if torch.is_tensor(v):
+                out.__dict__[k] = torch.cat([x if x.dim() > 0 else x[None] for x in vals], dim=0)
+            else:
+                out.__dict__[k] = list(vals)
+        return out
+
+
+class DataLoader:
+    """`torch_geometric.loader.DataLoader(data_list, batch_size)` without shuffling."""
+
+    def __init__(self, data_list: Iterable[HeteroData], batch_size: int = 1):
+        self.data_list = list(data_list)
+        self.batch_size = int(batch_size)
+
+    def __len__(self):
+        return (len(self.data_list) + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        for i in range(0, len(self.data_list), self.batch_size):
+            yield Batch.from_data_list(self.data_list[i:i + self.batch_size])

@@ -1,0 +1,243 @@
+"""Deterministic synthetic protein-ligand complexes in the reference's graph schema.
+
+DockGen / PDBBind data and rdkit are unavailable (no network), so benchmarks and tests run on seeded
+synthetic complexes whose tensor layout is exactly what `datasets/process_mols.py:448-489,567-589` and
+`datasets/moad.py:202-212` produce:
+
+  ['ligand'].x [Nl,16] int64          categorical atom features within lig_feature_dims
+  ['ligand'].pos [Nl,3] f32           heavy-atom conformer
+  ['ligand'].edge_mask [2*bonds] bool rotatable-bond mask (one direction per rotatable bond)
+  ['ligand'].mask_rotate [R,Nl] bool  atoms moved by each torsion (side containing edge[1])
+  ['ligand','ligand'].edge_index [2, 2*bonds] (each bond twice, consecutive), .edge_attr [.,4] one-hot
+  ['receptor'].x [Nr, 1+1280] f32     col 0 residue type, cols 1.. language-model embedding
+  ['receptor'].pos [Nr,3] f32         C-alpha trace centred on its centroid
+  ['receptor','receptor'].edge_index [2, 24*Nr]  kNN graph, row0 = neighbour, row1 = centre
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.spatial import cKDTree
+
+from .hetero import HeteroData
+
+LIG_FEATURE_DIMS = [119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2]  # datasets/process_mols.py:95-112
+REC_RESIDUE_TYPES = 38                                                     # datasets/process_mols.py:121-123
+LM_DIM = 1280
+
+# named workloads of BASELINE.json / SURVEY.md section 8
+WORKLOADS = {
+    "tiny":   dict(Nl=12, Nr=40, R=2, knn=8),
+    "c2_dockgen_median": dict(Nl=28, Nr=384, R=6, knn=24),
+    "c4_large_pocket":   dict(Nl=64, Nr=1024, R=16, knn=24),
+}
+
+
+def _receptor_trace(rng, n):
+    """Compact self-avoiding C-alpha walk: 3.8 A steps inside a sphere sized for Rg ~ 2.2 n^0.38 A."""
+    rg = 2.2 * n ** 0.38
+    rs = 1.15 * rg / np.sqrt(0.6)
+    pts = np.zeros((n, 3))
+    i, stuck = 1, 0
+    while i < n:
+        ok = False
+        for _ in range(60):
+            d = rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            p = pts[i - 1] + 3.8 * d
+            if np.linalg.norm(p) > rs:
+                continue
+            if i > 1 and np.min(np.linalg.norm(pts[:i - 1] - p, axis=1)) < 3.6:
+                continue
+            pts[i], ok = p, True
+            break
+        if ok:
+            i, stuck = i + 1, 0
+        else:  # back-track a few residues
+            stuck += 1
+            i = max(1, i - min(8, 1 + stuck))
+            if stuck > 200:
+                rs *= 1.05
+                stuck = 0
+    return pts - pts.mean(0)
+
+
+def _ring(rng):
+    a = np.arange(6) * np.pi / 3
+    return np.stack([1.4 * np.cos(a), 1.4 * np.sin(a), np.zeros(6)], 1)
+
+
+def _rand_rot(rng):
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _ligand(rng, n):
+    """Rings and chain atoms joined by single bonds.  Returns pos [n,3], bonds [(i,j)], bond_type."""
+    pos, bonds, btype, deg = [], [], [], []
+
+    def add_fragment(frag, internal, anchor):
+        base = len(pos)
+        for p in frag:
+            pos.append(p)
+            deg.append(0)
+        for (a, b, t) in internal:
+            bonds.append((base + a, base + b))
+            btype.append(t)
+            deg[base + a] += 1
+            deg[base + b] += 1
+        if anchor is not None:
+            bonds.append((anchor, base))
+            btype.append(0)
+            deg[anchor] += 1
+            deg[base] += 1
+
+    while len(pos) < n:
+        left = n - len(pos)
+        use_ring = left >= 6 and rng.random() < 0.45
+        if use_ring:
+            frag = _ring(rng) @ _rand_rot(rng).T
+            internal = [(k, (k + 1) % 6, 3) for k in range(6)]
+        else:
+            frag = np.zeros((1, 3))
+            internal = []
+        if not pos:
+            add_fragment(list(frag), internal, None)
+            continue
+        P = np.asarray(pos)
+        cands = [k for k in range(len(pos)) if deg[k] < 3]
+        placed = False
+        for _ in range(200):
+            a = int(rng.choice(cands))
+            out = P[a] - P.mean(0)
+            d = out / (np.linalg.norm(out) + 1e-9) + 0.9 * rng.normal(size=3)
+            d /= np.linalg.norm(d)
+            f = frag - frag[0]
+            if use_ring:  # point the ring away from the anchor
+                f = f @ _rand_rot(rng).T
+                c = f.mean(0)
+                if np.dot(c, d) < 0.5 * np.linalg.norm(c):
+                    continue
+            f = f + P[a] + 1.5 * d
+            dist = np.linalg.norm(P[None, :, :] - f[:, None, :], axis=-1)
+            dist[0, a] = 10.0
+            if dist.min() < 2.1:
+                continue
+            add_fragment(list(f), internal, a)
+            placed = True
+            break
+        if not placed:
+            raise RuntimeError("ligand growth failed")
+    return np.asarray(pos[:n]), bonds, btype
+
+
+def _components_without(n, bonds, skip):
+    adj = [[] for _ in range(n)]
+    for k, (a, b) in enumerate(bonds):
+        if k == skip:
+            continue
+        adj[a].append(b)
+        adj[b].append(a)
+    comp = -np.ones(n, dtype=int)
+    c = 0
+    for s in range(n):
+        if comp[s] >= 0:
+            continue
+        stack = [s]
+        comp[s] = c
+        while stack:
+            u = stack.pop()
+            for v in adj[u]:
+                if comp[v] < 0:
+                    comp[v] = c
+                    stack.append(v)
+        c += 1
+    return comp, c
+
+
+def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None) -> HeteroData:
+    """One synthetic complex.  Raises if the requested number of rotatable bonds cannot be realised."""
+    for attempt in range(200):
+        rng = np.random.default_rng(seed + 7919 * attempt)
+        try:
+            lpos, bonds, btype = _ligand(rng, Nl)
+        except RuntimeError:
+            continue
+        # rotatable candidates: bridges with >= 2 atoms on both sides (utils/torsion.py:15-45 semantics)
+        cand = []
+        for k in range(len(bonds)):
+            comp, nc = _components_without(Nl, bonds, k)
+            if nc == 2:
+                sizes = np.bincount(comp)
+                if sizes.min() >= 2:
+                    cand.append((k, comp))
+        if len(cand) < R:
+            continue
+        pick = sorted(rng.choice(len(cand), size=R, replace=False).tolist()) if R > 0 else []
+        break
+    else:
+        raise RuntimeError(f"could not build a ligand with Nl={Nl}, R={R}")
+
+    nb = len(bonds)
+    edge_index = np.zeros((2, 2 * nb), dtype=np.int64)
+    edge_attr = np.zeros((2 * nb, 4), dtype=np.float32)
+    for k, (a, b) in enumerate(bonds):
+        edge_index[:, 2 * k] = (a, b)
+        edge_index[:, 2 * k + 1] = (b, a)
+        edge_attr[2 * k, btype[k]] = 1
+        edge_attr[2 * k + 1, btype[k]] = 1
+    edge_mask = np.zeros(2 * nb, dtype=bool)
+    mask_rotate = np.zeros((R, Nl), dtype=bool)
+    rows = []
+    for ci in pick:
+        k, comp = cand[ci]
+        a, b = bonds[k]
+        sizes = np.bincount(comp)
+        small = int(np.argmin(sizes))          # smaller side rotates (ties -> component 0)
+        side = comp == small
+        # the masked direction is the one whose SECOND endpoint lies in the rotated side
+        if side[a]:
+            rows.append((2 * k + 1, side))     # direction (b, a)
+        else:
+            rows.append((2 * k, side))         # direction (a, b)
+    rows.sort(key=lambda r: r[0])
+    for i, (e, side) in enumerate(rows):
+        edge_mask[e] = True
+        mask_rotate[i] = side
+
+    rpos = _receptor_trace(rng, Nr)
+    tree = cKDTree(rpos)
+    _, nbr = tree.query(rpos, k=min(knn, Nr - 1) + 1)
+    nbr = nbr[:, 1:]
+    centre = np.repeat(np.arange(Nr), nbr.shape[1])
+    rec_edge_index = np.stack([nbr.reshape(-1), centre]).astype(np.int64)  # [neighbour; centre]
+    rec_x = np.zeros((Nr, 1 + LM_DIM), dtype=np.float32)
+    rec_x[:, 0] = rng.integers(0, 20, size=Nr)
+    rec_x[:, 1:] = rng.normal(0, 0.5, size=(Nr, LM_DIM))
+
+    lig_x = np.stack([rng.integers(0, d, size=Nl) for d in LIG_FEATURE_DIMS], 1).astype(np.int64)
+    # put the crystal pose on the protein surface
+    surf = rpos[np.argmax(np.linalg.norm(rpos, axis=1))]
+    lpos = lpos - lpos.mean(0) + surf * 0.85
+
+    d = HeteroData()
+    d["ligand"].x = torch.from_numpy(lig_x)
+    d["ligand"].pos = torch.from_numpy(lpos.astype(np.float32))
+    d["ligand"].edge_mask = torch.from_numpy(edge_mask)
+    d["ligand"].mask_rotate = mask_rotate
+    d["ligand", "ligand"].edge_index = torch.from_numpy(edge_index)
+    d["ligand", "ligand"].edge_attr = torch.from_numpy(edge_attr)
+    d["receptor"].x = torch.from_numpy(rec_x)
+    d["receptor"].pos = torch.from_numpy(rpos.astype(np.float32))
+    d["receptor", "receptor"].edge_index = torch.from_numpy(rec_edge_index)
+    d.original_center = torch.zeros(1, 3)
+    d.name = name or f"synthetic_Nl{Nl}_Nr{Nr}_R{R}_s{seed}"
+    return d
+
+
+def make_workload(workload: str, seed=1234) -> HeteroData:
+    return make_complex(seed=seed, name=workload, **WORKLOADS[workload])

@@ -1,0 +1,94 @@
+"""`get_model` with the reference's signature and yml -> constructor mapping (reference
+utils/utils.py:175-288), plus helpers to read `model_parameters.yml` the way inference.py:246-267 does."""
+from __future__ import annotations
+
+import os
+from argparse import Namespace
+from functools import partial
+
+import torch
+import yaml
+
+from .diffusion_utils import get_timestep_embedding, t_to_sigma as t_to_sigma_compl
+from .score_model import TensorProductScoreModel
+
+_DEFAULT_YML = os.path.join(os.path.dirname(__file__), "data", "pretrained_score_model_parameters.yml")
+
+
+def load_model_args(path: str = None) -> Namespace:
+    """yaml.full_load -> Namespace with the back-compat defaults inference.py:246-267 applies."""
+    with open(path or _DEFAULT_YML) as f:
+        args = Namespace(**yaml.full_load(f))
+    for k, v in (("not_fixed_knn_radius_graph", True), ("not_knn_only_graph", True), ("include_miscellaneous_atoms", False),
+                 ("triple_training", False), ("train_multiplicity", 1), ("old_score_model", False)):
+        if not hasattr(args, k):
+            setattr(args, k, v)
+    return args
+
+
+def _has(args, k):
+    return k in args and getattr(args, k) is not None
+
+
+def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False, old=False):
+    if old:
+        raise NotImplementedError("old score-model variants are outside the MI355X hot path")
+    if ("all_atoms" in args and args.all_atoms) or confidence_mode:
+        raise NotImplementedError("all-atom / confidence model: SURVEY.md 8f-1 (next row), not built yet")
+    emb_type = args.embedding_type if "embedding_type" in args else "sinusoidal"
+    emb_scale = args.embedding_scale if "embedding_type" in args else 10000
+    timestep_emb_func = get_timestep_embedding(emb_type, args.sigma_embed_dim, emb_scale)
+    lm = None
+    if any(_has(args, k) for k in ("moad_esm_embeddings_path", "pdbbind_esm_embeddings_path",
+                                   "pdbsidechain_esm_embeddings_path", "esm_embeddings_path")):
+        lm = "precomputed"
+    if _has(args, "esm_embeddings_model"):
+        lm = args.esm_embeddings_model
+    g = lambda k, d: getattr(args, k) if k in args else d
+    model = TensorProductScoreModel(
+        t_to_sigma=t_to_sigma, device=device, no_torsion=args.no_torsion, timestep_emb_func=timestep_emb_func,
+        num_conv_layers=args.num_conv_layers, lig_max_radius=args.max_radius, scale_by_sigma=args.scale_by_sigma,
+        sigma_embed_dim=args.sigma_embed_dim, norm_by_sigma=g("norm_by_sigma", False), ns=args.ns, nv=args.nv,
+        distance_embed_dim=args.distance_embed_dim, cross_distance_embed_dim=args.cross_distance_embed_dim,
+        batch_norm=not args.no_batch_norm, dropout=args.dropout, use_second_order_repr=args.use_second_order_repr,
+        cross_max_distance=args.cross_max_distance, dynamic_max_cross=args.dynamic_max_cross,
+        separate_noise_schedule=args.separate_noise_schedule, smooth_edges=g("smooth_edges", False),
+        odd_parity=g("odd_parity", False), lm_embedding_type=lm, confidence_mode=confidence_mode,
+        asyncronous_noise_schedule=g("asyncronous_noise_schedule", False),
+        fixed_center_conv=(not args.not_fixed_center_conv) if "not_fixed_center_conv" in args else False,
+        no_aminoacid_identities=g("no_aminoacid_identities", False),
+        include_miscellaneous_atoms=g("include_miscellaneous_atoms", False), sh_lmax=g("sh_lmax", 2),
+        differentiate_convolutions=(not args.no_differentiate_convolutions) if "no_differentiate_convolutions" in args else True,
+        tp_weights_layers=g("tp_weights_layers", 2), num_prot_emb_layers=g("num_prot_emb_layers", 0),
+        reduce_pseudoscalars=g("reduce_pseudoscalars", False), embed_also_ligand=g("embed_also_ligand", False),
+        sidechain_pred=(g("sidechain_loss_weight", 0) > 0) or (g("backbone_loss_weight", 0) > 0),
+        depthwise_convolution=g("depthwise_convolution", False), embedding_scale=emb_scale)
+    # the reference wraps in torch_geometric DataParallel unless no_parallel; the MI355X build is one process
+    # per GPU (distributed.py), so the module is returned bare either way.
+    model.to(device)
+    return model
+
+
+def make_score_model(device="cpu", seed=0, args=None, eval_mode=True):
+    """Random-init score model of the shipped architecture with non-trivial BatchNorm statistics
+    (checkpoints are not available offline)."""
+    args = args or load_model_args()
+    gen = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    try:
+        model = get_model(args, torch.device("cpu"), partial(t_to_sigma_compl, args=args), no_parallel=True)
+        g = torch.Generator().manual_seed(seed + 1)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_var"):
+                buf.copy_(torch.rand(buf.shape, generator=g) + 0.5)
+            elif name.endswith("running_mean"):
+                buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
+        for name, p in model.named_parameters():
+            if "batch_norm" in name:
+                with torch.no_grad():
+                    p.copy_(p + 0.1 * torch.randn(p.shape, generator=g))
+    finally:
+        torch.random.set_rng_state(gen)
+    if eval_mode:
+        model.eval()
+    return model.to(device), args
