@@ -1,0 +1,79 @@
+// Shared device/host definitions of the MI355X docking engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cbd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- data layout in HBM -------------------------------------------------------------------------------------
+// Node features: one row of NODE_STRIDE floats per node (74 used: 32x0e | 6x1o | 6x1e | 6x0o, rest zero).
+// Joint node index = ligand nodes of all samples first ([b*Nl + a]), then receptor nodes ([nL + b*Nr + r]),
+// exactly the concatenation order of the reference (models/score_model.py:354).
+constexpr int NODE_STRIDE = 80;
+constexpr int NS = 32;
+constexpr int NV = 6;
+constexpr int COL_1O = 32, COL_1E = 50, COL_0O = 68, NODE_DIM = 74;
+
+// ---- tensor-product convolution tiling ----------------------------------------------------------------------
+// One wave owns 32 edges (the N dimension of v_mfma_f32_32x32x2_f32); a workgroup of 4 waves owns 128
+// consecutive edges of ONE edge group and shares the streamed weight tiles through LDS.
+constexpr int WAVE_EDGES = 32;
+constexpr int CONV_WAVES = 4;
+constexpr int CONV_WG_EDGES = WAVE_EDGES * CONV_WAVES;
+constexpr int KDIM = 96;                       // radial-MLP width (3*ns)
+constexpr int KSTEPS = KDIM / 2;               // 48 MFMA k-steps of 2
+constexpr int TILE_W_FLOATS = KSTEPS * 64;     // 3072 weight floats per 32-row tile
+constexpr int TILE_FLOATS = TILE_W_FLOATS + 32;  // + 32 bias floats  (12416 B)
+
+// Number of 32-row weight tiles of a layer with input level IN (0..3) and output level OUT (1..3):
+// 3 tiles of the first Linear, then the second Linear regrouped per output irrep block.
+struct ConvShape {
+  int n1o, n1e, n0o;          // input multiplicities
+  int fan0e, fan1o, fan1e, fan0o;
+  int t0e, t1o, t1e, t0o;     // tiles per block
+  int ntiles;
+  int weight_numel;           // reference weight_numel (1216/1480/1588/1660)
+  int in_dim, out_dim;
+};
+
+__host__ __device__ constexpr ConvShape conv_shape(int IN, int OUT) {
+  ConvShape s{};
+  s.n1o = IN >= 1 ? NV : 0;
+  s.n1e = IN >= 2 ? NV : 0;
+  s.n0o = IN >= 3 ? NV : 0;
+  s.fan0e = NS + s.n1o;
+  s.fan1o = NS + s.n1o + s.n1e;
+  s.fan1e = OUT >= 2 ? s.n1o + s.n1e + s.n0o : 0;
+  s.fan0o = OUT >= 3 ? s.n1e + s.n0o : 0;
+  s.t0e = s.fan0e;
+  s.t1o = (s.fan1o + 3) / 4;
+  s.t1e = (s.fan1e + 3) / 4;
+  s.t0o = (s.fan0o + 3) / 4;
+  s.ntiles = 3 + s.t0e + s.t1o + s.t1e + s.t0o;
+  s.weight_numel = s.fan0e * NS + s.fan1o * NV + s.fan1e * NV + s.fan0o * NV;
+  s.in_dim = NS + 3 * s.n1o + 3 * s.n1e + s.n0o;
+  s.out_dim = NS + 3 * NV + (OUT >= 2 ? 3 * NV : 0) + (OUT >= 3 ? NV : 0);
+  return s;
+}
+
+struct ConvGroup {
+  const int* src;        // [cap] aggregating node (reference edge_index[0]), joint index, sorted ascending
+  const int* dst;        // [cap] node whose features are read (edge_index[1])
+  const int* attr_idx;   // [cap] row of `attr`
+  const float* vec;      // [cap][4] unit edge vector (xyz, 0): sh = [1, sqrt3 * v]
+  const float* attr;     // [.][32] embedded edge attributes
+  const float* wstream;  // [ntiles][TILE_FLOATS] re-packed weights of this group's FCBlock
+  const int* count;      // device scalar: number of edges
+};
+
+struct ConvArgs {
+  ConvGroup g[4];
+  int n_groups;
+  const float* node_in;  // [N][NODE_STRIDE]
+  float* acc;            // [N][NODE_STRIDE] fp32 sums (atomic)
+};
+
+}  // namespace cbd

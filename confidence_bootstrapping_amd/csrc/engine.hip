@@ -1,0 +1,861 @@
+// Host side of the MI355X docking engine: C ABI of include/cbdock.h.
+// Owns weights (re-packed for the MFMA streams), the per-complex static data and the per-batch workspace, and
+// sequences the kernels of one score-model forward pass / one reverse-diffusion step.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/cbdock.h"
+#include "kernels.h"
+
+using namespace cbd;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+#define HIPCHK(x)                                                                                              \
+  do {                                                                                                         \
+    hipError_t _e = (x);                                                                                       \
+    if (_e != hipSuccess) return fail(CBD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+#define CHK(x)            \
+  do {                    \
+    int _r = (x);         \
+    if (_r != 0) return _r; \
+  } while (0)
+
+namespace {
+
+struct HostTensor {
+  std::vector<int64_t> shape;
+  std::vector<float> data;
+};
+
+// tracked device allocation helper
+struct DevPool {
+  std::vector<void*> ptrs;
+  template <typename T>
+  hipError_t alloc(T** p, size_t n) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return e;
+    ptrs.push_back(q);
+    *p = reinterpret_cast<T*>(q);
+    return hipSuccess;
+  }
+  template <typename T>
+  hipError_t upload(T** p, const std::vector<T>& h) {
+    hipError_t e = alloc(p, h.size());
+    if (e != hipSuccess) return e;
+    if (!h.empty()) e = hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    return e;
+  }
+  void release() {
+    for (void* p : ptrs) (void)hipFree(p);
+    ptrs.clear();
+  }
+};
+
+struct ConvLayerDev {
+  int in_level = 0, out_level = 0, n_groups = 0;
+  float* wstream[4] = {nullptr, nullptr, nullptr, nullptr};
+  float *bn_scale = nullptr, *bn_mean = nullptr, *bn_bias = nullptr;   // [NODE_STRIDE]
+};
+
+struct MlpDev {   // 2-layer edge MLP pieces
+  float *WgT = nullptr, *WbT = nullptr, *W1T = nullptr, *b0 = nullptr, *b1 = nullptr, *offset = nullptr;
+  float coeff = 0.f;
+};
+
+}  // namespace
+
+struct cbd_engine {
+  cbd_config cfg{};
+  std::map<std::string, HostTensor> host_w;
+  bool weights_ready = false, complex_ready = false;
+  DevPool wpool, cpool, bpool;   // weights / complex / batch workspace
+
+  // ---- weights on device
+  ConvLayerDev rec_emb[3], lig_emb[3], conv[5];
+  MlpDev m_lig_edge, m_cross, m_rec_edge, m_final_edge, m_center;
+  StepWeights sw{};
+  CenterHead ch{};
+  BondHead bh{};
+  float *rec_emb_table = nullptr, *rec_node_w = nullptr, *rec_node_b = nullptr;
+  std::vector<float> lig_node_w_host;   // additional_features_embedder [32][64]
+  std::vector<std::vector<float>> lig_emb_tables;
+
+  // ---- complex
+  GraphStatic gs{};
+  int cap_ll_per_sample = 0;
+  float *lig_static32 = nullptr, *rec_static = nullptr, *rr_attr0 = nullptr, *rr_attr_t = nullptr;
+  int *rr_src = nullptr, *rr_dst = nullptr, *rr_aidx = nullptr;
+  float* rr_vec = nullptr;
+  int* rr_count_dev = nullptr;
+
+  // ---- batch workspace
+  GraphDyn gd{};
+  float *X0 = nullptr, *X1 = nullptr, *acc = nullptr;
+  float *ll_attr = nullptr, *lr_attr = nullptr;
+  StepVectors sv{};
+  float* sigma_emb_dev = nullptr;   // [S_max][32]
+  int sigma_cap = 0;
+  float *tr_out = nullptr, *rot_out = nullptr, *tor_out = nullptr, *dbg_global = nullptr, *dbg_torfeat = nullptr;
+  int n_nodes_cap = 0;
+  int last_B = 0;
+  std::map<std::string, std::pair<const float*, size_t>> dbg;   // name -> (device ptr, count), valid after cbd_score
+  std::vector<std::pair<std::string, std::vector<float>>> dbg_snap;   // snapshots of ping-pong buffers
+  bool keep_debug = false;
+
+  // ---- timing of the dominant kernel
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  size_t ev_used = 0;
+  double t_total_ms = 0;
+  int64_t t_n = 0;
+};
+
+// ======================================================================================================== weights
+static const HostTensor* find_w(cbd_engine* e, const std::string& k) {
+  auto it = e->host_w.find(k);
+  return it == e->host_w.end() ? nullptr : &it->second;
+}
+
+static int need(cbd_engine* e, const std::string& k, std::initializer_list<int64_t> shape, const HostTensor** out) {
+  const HostTensor* t = find_w(e, k);
+  if (!t) return fail(CBD_ERR_WEIGHT, "missing tensor '%s' (load_state_dict strict=True)", k.c_str());
+  if (t->shape != std::vector<int64_t>(shape)) return fail(CBD_ERR_WEIGHT, "tensor '%s' has an unexpected shape", k.c_str());
+  *out = t;
+  return 0;
+}
+
+// Re-pack one FCBlock (Linear 96->96, ReLU, Linear 96->W) into the tile stream consumed by tp_conv_kernel.
+// See the layout notes at the top of tp_conv.hip.  W2's k order follows the C/D register layout of the first GEMM.
+static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+  const ConvShape S = conv_shape(IN, OUT);
+  std::vector<float> out((size_t)S.ntiles * TILE_FLOATS, 0.f);
+  auto widx = [](int s, int lane) { return ((s >> 2) * 64 + lane) * 4 + (s & 3); };
+  int T = 0;
+  for (int m = 0; m < 3; ++m, ++T) {
+    float* tile = out.data() + (size_t)T * TILE_FLOATS;
+    for (int s = 0; s < KSTEPS; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int i = lane & 31, h = lane >> 5;
+        const int f = 32 * (s / 16) + 16 * h + (s % 16);
+        tile[widx(s, lane)] = W1[(size_t)(32 * m + i) * KDIM + f];
+      }
+    for (int r = 0; r < 32; ++r) tile[TILE_W_FLOATS + r] = b1[32 * m + r];
+  }
+  auto kperm = [](int s, int h) { return 32 * (s / 16) + ((s % 16) & 3) + 8 * ((s % 16) >> 2) + 4 * h; };
+  auto fill_tile = [&](float* tile, const int* wc, const float* scale) {   // wc[r] < 0 => zero row
+    for (int s = 0; s < KSTEPS; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        tile[widx(s, lane)] = wc[r] < 0 ? 0.f : scale[r] * W2[(size_t)wc[r] * KDIM + kperm(s, h)];
+      }
+    for (int r = 0; r < 32; ++r) tile[TILE_W_FLOATS + r] = wc[r] < 0 ? 0.f : scale[r] * b2[wc[r]];
+  };
+  const float s3 = std::sqrt(3.0f), s15 = std::sqrt(1.5f);
+  int wc[32];
+  float sc[32];
+  // block 0e
+  for (int i = 0; i < S.fan0e; ++i, ++T) {
+    for (int r = 0; r < 32; ++r) { wc[r] = i * NS + r; sc[r] = 1.0f / std::sqrt((float)S.fan0e); }
+    fill_tile(out.data() + (size_t)T * TILE_FLOATS, wc, sc);
+  }
+  auto vec_tiles = [&](int off, int fan, int ntile, auto mid_factor) {
+    for (int t = 0; t < ntile; ++t, ++T) {
+      for (int r = 0; r < 32; ++r) {
+        const int o = (r & 3) + 4 * ((r >> 3) & 1), il = ((r >> 2) & 1) + 2 * (r >> 4), i = 4 * t + il;
+        if (o < NV && i < fan) { wc[r] = off + i * NV + o; sc[r] = mid_factor(i) / std::sqrt((float)fan); }
+        else { wc[r] = -1; sc[r] = 0.f; }
+      }
+      fill_tile(out.data() + (size_t)T * TILE_FLOATS, wc, sc);
+    }
+  };
+  int off = S.fan0e * NS;
+  vec_tiles(off, S.fan1o, S.t1o, [&](int i) { return i < NS ? s3 : (i < NS + S.n1o ? 1.0f : s15); });
+  off += S.fan1o * NV;
+  if (OUT >= 2) {
+    vec_tiles(off, S.fan1e, S.t1e, [&](int i) { return i < S.n1o ? s15 : (i < S.n1o + S.n1e ? 1.0f : s3); });
+    off += S.fan1e * NV;
+  }
+  if (OUT >= 3) vec_tiles(off, S.fan0o, S.t0o, [&](int) { return 1.0f; });
+  return out;
+}
+
+static int out_level_dim(int level) { return conv_shape(0, level).out_dim; }
+static int in_level_dim(int level) { return conv_shape(level, 3).in_dim; }
+
+static int build_conv_layer(cbd_engine* e, const std::string& prefix, int IN, int OUT, int groups, ConvLayerDev* L) {
+  const ConvShape S = conv_shape(IN, OUT);
+  L->in_level = IN; L->out_level = OUT; L->n_groups = groups;
+  for (int g = 0; g < groups; ++g) {
+    const std::string fc = groups == 1 ? prefix + ".fc" : prefix + ".fc." + std::to_string(g);
+    const HostTensor *w0, *b0, *w1, *b1;
+    CHK(need(e, fc + ".0.weight", {KDIM, KDIM}, &w0));
+    CHK(need(e, fc + ".0.bias", {KDIM}, &b0));
+    CHK(need(e, fc + ".3.weight", {S.weight_numel, KDIM}, &w1));
+    CHK(need(e, fc + ".3.bias", {S.weight_numel}, &b1));
+    std::vector<float> st = pack_conv_stream(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data());
+    HIPCHK(e->wpool.upload(&L->wstream[g], st));
+  }
+  // e3nn BatchNorm (eval) per output column
+  const int nf = NS + NV + (OUT >= 2 ? NV : 0) + (OUT >= 3 ? NV : 0);
+  const HostTensor *bw, *bb, *bm, *bv;
+  CHK(need(e, prefix + ".batch_norm.weight", {nf}, &bw));
+  CHK(need(e, prefix + ".batch_norm.bias", {NS}, &bb));
+  CHK(need(e, prefix + ".batch_norm.running_mean", {NS}, &bm));
+  CHK(need(e, prefix + ".batch_norm.running_var", {nf}, &bv));
+  std::vector<float> sc(NODE_STRIDE, 0.f), mean(NODE_STRIDE, 0.f), bias(NODE_STRIDE, 0.f);
+  for (int c = 0; c < S.out_dim; ++c) {
+    int chn;
+    if (c < COL_1O) chn = c;
+    else if (c < COL_1E) chn = NS + (c - COL_1O) / 3;
+    else if (c < COL_0O) chn = NS + NV + (c - COL_1E) / 3;
+    else chn = NS + 2 * NV + (c - COL_0O);
+    sc[c] = bw->data[chn] * (1.0f / std::sqrt(bv->data[chn] + 1e-5f));
+    if (c < NS) { mean[c] = bm->data[c]; bias[c] = bb->data[c]; }
+  }
+  HIPCHK(e->wpool.upload(&L->bn_scale, sc));
+  HIPCHK(e->wpool.upload(&L->bn_mean, mean));
+  HIPCHK(e->wpool.upload(&L->bn_bias, bias));
+  return 0;
+}
+
+static std::vector<float> transpose_block(const HostTensor* w, int col0, int ncol) {
+  // w [out=32][in] -> [ncol][32] with element (k, o) = w[o][col0 + k]
+  const int in = (int)w->shape[1], out = (int)w->shape[0];
+  std::vector<float> t((size_t)ncol * out);
+  for (int k = 0; k < ncol; ++k)
+    for (int o = 0; o < out; ++o) t[(size_t)k * out + o] = w->data[(size_t)o * in + col0 + k];
+  return t;
+}
+
+static int build_edge_mlp(cbd_engine* e, const std::string& prefix, int in_dim, int gauss_col0, int bond_col0,
+                          const std::string& offset_key, MlpDev* M) {
+  const HostTensor *w0, *b0, *w1, *b1, *off;
+  CHK(need(e, prefix + ".0.weight", {NS, in_dim}, &w0));
+  CHK(need(e, prefix + ".0.bias", {NS}, &b0));
+  CHK(need(e, prefix + ".3.weight", {NS, NS}, &w1));
+  CHK(need(e, prefix + ".3.bias", {NS}, &b1));
+  CHK(need(e, offset_key, {32}, &off));
+  HIPCHK(e->wpool.upload(&M->WgT, transpose_block(w0, gauss_col0, 32)));
+  if (bond_col0 >= 0) HIPCHK(e->wpool.upload(&M->WbT, transpose_block(w0, bond_col0, 4)));
+  HIPCHK(e->wpool.upload(&M->W1T, transpose_block(w1, 0, 32)));
+  HIPCHK(e->wpool.upload(&M->b0, b0->data));
+  HIPCHK(e->wpool.upload(&M->b1, b1->data));
+  HIPCHK(e->wpool.upload(&M->offset, off->data));
+  const double step = (double)off->data[1] - (double)off->data[0];   // GaussianSmearing.coeff (python float), score_model.py:672
+  M->coeff = (float)(-0.5 / (step * step));
+  return 0;
+}
+
+static int upload_named(cbd_engine* e, const std::string& k, std::initializer_list<int64_t> shape, const float** dev) {
+  const HostTensor* t;
+  CHK(need(e, k, shape, &t));
+  float* p;
+  HIPCHK(e->wpool.upload(&p, t->data));
+  *dev = p;
+  return 0;
+}
+
+// ======================================================================================================== C ABI
+extern "C" {
+
+const char* cbd_last_error(void) { return g_err.c_str(); }
+const char* cbd_version(void) { return "cbdock-mi355x 0.1 (gfx950, fp32 MFMA)"; }
+
+int cbd_create(const cbd_config* cfg, cbd_engine** out) {
+  if (!cfg || !out) return fail(CBD_ERR_ARG, "null argument");
+  if (cfg->ns != NS || cfg->nv != NV || cfg->num_conv_layers != 5 || cfg->num_prot_emb_layers != 3)
+    return fail(CBD_ERR_ARG, "unsupported architecture: the engine implements ns=32, nv=6, 3 embedding + 5 interaction layers");
+  if (cfg->lm_embedding_dim != 0 && cfg->lm_embedding_dim != 1280) return fail(CBD_ERR_ARG, "lm_embedding_dim must be 0 or 1280");
+  if (cfg->max_batch <= 0) return fail(CBD_ERR_ARG, "max_batch must be positive");
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(CBD_ERR_ARG, "device %d not available (%d devices)", cfg->device, ndev);
+  HIPCHK(hipSetDevice(cfg->device));
+  cbd_engine* e = new cbd_engine();
+  e->cfg = *cfg;
+  *out = e;
+  return 0;
+}
+
+int cbd_destroy(cbd_engine* e) {
+  if (!e) return 0;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  e->wpool.release(); e->cpool.release(); e->bpool.release();
+  for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  delete e;
+  return 0;
+}
+
+int cbd_load_weight(cbd_engine* e, const char* name, const float* data, const int64_t* shape, int32_t ndim) {
+  if (!e || !name || (!data && ndim > 0 && shape[0] != 0)) return fail(CBD_ERR_ARG, "null argument");
+  const std::string k(name);
+  for (const char* pre : {"final_conv.tp.", "tor_bond_conv.tp.", "final_tp_tor."})
+    if (k.rfind(pre, 0) == 0) return 0;   // e3nn persistent buffers: arithmetic is hard-wired
+  HostTensor t;
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+  t.data.assign(data, data + n);
+  e->host_w[k] = std::move(t);
+  e->weights_ready = false;
+  return 0;
+}
+
+int cbd_finalize_weights(cbd_engine* e) {
+  if (!e) return fail(CBD_ERR_ARG, "null engine");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  e->wpool.release();
+  const int lm = e->cfg.lm_embedding_dim;
+  for (int l = 0; l < 3; ++l) {
+    CHK(build_conv_layer(e, "rec_emb_layers." + std::to_string(l), l, l + 1, 1, &e->rec_emb[l]));
+    CHK(build_conv_layer(e, "lig_emb_layers." + std::to_string(l), l, l + 1, 1, &e->lig_emb[l]));
+  }
+  for (int l = 0; l < 5; ++l) CHK(build_conv_layer(e, "conv_layers." + std::to_string(l), 3, 3, l == 4 ? 2 : 4, &e->conv[l]));
+  // edge MLPs.  Input column order: lig [bond4 | sigma | gauss], cross [sigma | gauss], rec [gauss], center [gauss | sigma]
+  CHK(build_edge_mlp(e, "lig_edge_embedding", 68, 36, 0, "lig_distance_expansion.offset", &e->m_lig_edge));
+  CHK(build_edge_mlp(e, "cross_edge_embedding", 64, 32, -1, "cross_distance_expansion.offset", &e->m_cross));
+  CHK(build_edge_mlp(e, "rec_edge_embedding", 32, 0, -1, "rec_distance_expansion.offset", &e->m_rec_edge));
+  CHK(build_edge_mlp(e, "center_edge_embedding", 64, 0, -1, "center_distance_expansion.offset", &e->m_center));
+  if (!e->cfg.no_torsion) CHK(build_edge_mlp(e, "final_edge_embedding", 32, 0, -1, "lig_distance_expansion.offset", &e->m_final_edge));
+  // per-step small weights
+  StepWeights& sw = e->sw;
+  CHK(upload_named(e, "rec_sigma_embedding.0.weight", {32, 32}, &sw.rec_sig_w0));
+  CHK(upload_named(e, "rec_sigma_embedding.0.bias", {32}, &sw.rec_sig_b0));
+  CHK(upload_named(e, "rec_sigma_embedding.3.weight", {32, 32}, &sw.rec_sig_w1));
+  CHK(upload_named(e, "rec_sigma_embedding.3.bias", {32}, &sw.rec_sig_b1));
+  CHK(upload_named(e, "lig_edge_embedding.0.weight", {32, 68}, &sw.lig_edge_w0));
+  CHK(upload_named(e, "lig_edge_embedding.0.bias", {32}, &sw.lig_edge_b0));
+  CHK(upload_named(e, "cross_edge_embedding.0.weight", {32, 64}, &sw.cross_w0));
+  CHK(upload_named(e, "cross_edge_embedding.0.bias", {32}, &sw.cross_b0));
+  CHK(upload_named(e, "center_edge_embedding.0.weight", {32, 64}, &sw.center_w0));
+  CHK(upload_named(e, "center_edge_embedding.0.bias", {32}, &sw.center_b0));
+  CHK(upload_named(e, "lig_node_embedding.additional_features_embedder.weight", {32, 64}, &sw.lig_node_w));
+  CHK(upload_named(e, "lig_node_embedding.additional_features_embedder.bias", {32}, &sw.lig_node_b));
+  CHK(upload_named(e, "tr_final_layer.0.weight", {32, 33}, &sw.tr_w0));
+  CHK(upload_named(e, "tr_final_layer.0.bias", {32}, &sw.tr_b0));
+  CHK(upload_named(e, "rot_final_layer.0.weight", {32, 33}, &sw.rot_w0));
+  CHK(upload_named(e, "rot_final_layer.0.bias", {32}, &sw.rot_b0));
+  // ligand atom embedding tables stay on the host (folded into lig_static32 per complex)
+  static const int dims[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};   // datasets/process_mols.py:95-112
+  e->lig_emb_tables.clear();
+  for (int i = 0; i < 16; ++i) {
+    const HostTensor* t;
+    CHK(need(e, "lig_node_embedding.atom_embedding_list." + std::to_string(i) + ".weight", {dims[i], 32}, &t));
+    e->lig_emb_tables.push_back(t->data);
+  }
+  e->lig_node_w_host = find_w(e, "lig_node_embedding.additional_features_embedder.weight")->data;
+  // receptor node encoder
+  const float* tmp;
+  CHK(upload_named(e, "rec_node_embedding.atom_embedding_list.0.weight", {38, 32}, &tmp));
+  e->rec_emb_table = const_cast<float*>(tmp);
+  if (lm > 0) {
+    CHK(upload_named(e, "rec_node_embedding.additional_features_embedder.weight", {32, 32 + lm}, &tmp));
+    e->rec_node_w = const_cast<float*>(tmp);
+    CHK(upload_named(e, "rec_node_embedding.additional_features_embedder.bias", {32}, &tmp));
+    e->rec_node_b = const_cast<float*>(tmp);
+  }
+  // centre head
+  CenterHead& ch = e->ch;
+  ch.ce_WgT = e->m_center.WgT; ch.ce_W1T = e->m_center.W1T; ch.ce_b1 = e->m_center.b1; ch.offset = e->m_center.offset;
+  ch.coeff = e->m_center.coeff;
+  CHK(upload_named(e, "final_conv.fc.0.weight", {64, 64}, &ch.fc_w0));
+  CHK(upload_named(e, "final_conv.fc.0.bias", {64}, &ch.fc_b0));
+  CHK(upload_named(e, "final_conv.fc.3.weight", {124, 64}, &ch.fc_w1));
+  CHK(upload_named(e, "final_conv.fc.3.bias", {124}, &ch.fc_b1));
+  {
+    const HostTensor *bw, *bv;
+    CHK(need(e, "final_conv.batch_norm.weight", {4}, &bw));
+    CHK(need(e, "final_conv.batch_norm.running_var", {4}, &bv));
+    std::vector<float> sc(4);
+    for (int c = 0; c < 4; ++c) sc[c] = bw->data[c] * (1.0f / std::sqrt(bv->data[c] + 1e-5f));
+    float* p;
+    HIPCHK(e->wpool.upload(&p, sc));
+    ch.bn_scale = p;
+    for (int which = 0; which < 2; ++which) {
+      const std::string pre = which ? "rot_final_layer" : "tr_final_layer";
+      const HostTensor *w0, *w1, *b1;
+      CHK(need(e, pre + ".0.weight", {32, 33}, &w0));
+      CHK(need(e, pre + ".3.weight", {1, 32}, &w1));
+      CHK(need(e, pre + ".3.bias", {1}, &b1));
+      std::vector<float> col(32);
+      for (int o = 0; o < 32; ++o) col[o] = w0->data[(size_t)o * 33];
+      float *pc, *pw, *pb;
+      HIPCHK(e->wpool.upload(&pc, col));
+      HIPCHK(e->wpool.upload(&pw, w1->data));
+      HIPCHK(e->wpool.upload(&pb, b1->data));
+      if (which) { ch.rot_w0n = pc; ch.rot_w1 = pw; ch.rot_b1 = pb; } else { ch.tr_w0n = pc; ch.tr_w1 = pw; ch.tr_b1 = pb; }
+    }
+  }
+  // torsion head
+  if (!e->cfg.no_torsion) {
+    BondHead& bh = e->bh;
+    bh.fe.part = e->m_final_edge.b0; bh.fe.WgT = e->m_final_edge.WgT; bh.fe.WbT = nullptr; bh.fe.W1T = e->m_final_edge.W1T;
+    bh.fe.b1 = e->m_final_edge.b1; bh.fe.offset = e->m_final_edge.offset; bh.fe.coeff = e->m_final_edge.coeff;
+    CHK(upload_named(e, "tor_bond_conv.fc.0.weight", {96, 96}, &bh.fc_w0));
+    CHK(upload_named(e, "tor_bond_conv.fc.0.bias", {96}, &bh.fc_b0));
+    CHK(upload_named(e, "tor_bond_conv.fc.3.weight", {384, 96}, &bh.fc_w1));
+    CHK(upload_named(e, "tor_bond_conv.fc.3.bias", {384}, &bh.fc_b1));
+    const HostTensor *bw, *bb, *bm, *bv;
+    CHK(need(e, "tor_bond_conv.batch_norm.weight", {64}, &bw));
+    CHK(need(e, "tor_bond_conv.batch_norm.bias", {32}, &bb));
+    CHK(need(e, "tor_bond_conv.batch_norm.running_mean", {32}, &bm));
+    CHK(need(e, "tor_bond_conv.batch_norm.running_var", {64}, &bv));
+    // irreps 32x0o + 32x0e: columns 0..31 pseudoscalars (scale only), 32..63 scalars (mean/bias index c-32)
+    std::vector<float> sc(64), mean(64, 0.f), bias(64, 0.f);
+    for (int c = 0; c < 64; ++c) {
+      sc[c] = bw->data[c] * (1.0f / std::sqrt(bv->data[c] + 1e-5f));
+      if (c >= 32) { mean[c] = bm->data[c - 32]; bias[c] = bb->data[c - 32]; }
+    }
+    float *p0, *p1, *p2;
+    HIPCHK(e->wpool.upload(&p0, sc)); HIPCHK(e->wpool.upload(&p1, mean)); HIPCHK(e->wpool.upload(&p2, bias));
+    bh.bn_scale = p0; bh.bn_mean = p1; bh.bn_bias = p2;
+    CHK(upload_named(e, "tor_final_layer.0.weight", {32, 64}, &bh.tf_w0));
+    CHK(upload_named(e, "tor_final_layer.3.weight", {1, 32}, &bh.tf_w1));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  e->weights_ready = true;
+  e->complex_ready = false;   // the receptor embedding depends on the weights
+  return 0;
+}
+
+// ======================================================================================================== complex
+static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
+  EdgeMlp r{};
+  r.part = part ? part : m.b0; r.WgT = m.WgT; r.WbT = m.WbT; r.W1T = m.W1T; r.b1 = m.b1; r.offset = m.offset; r.coeff = m.coeff;
+  return r;
+}
+
+static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
+                    const float* node_in, hipStream_t s) {
+  ConvArgs a{};
+  a.n_groups = n_groups;
+  int grid = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    a.g[g] = groups[g];
+    a.g[g].wstream = L.wstream[g];
+    grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
+  }
+  a.node_in = node_in;
+  a.acc = e->acc;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (e->timing) {
+    if (e->ev_used == e->ev_pool.size()) {
+      hipEvent_t a0, a1;
+      HIPCHK(hipEventCreate(&a0)); HIPCHK(hipEventCreate(&a1));
+      e->ev_pool.push_back({a0, a1});
+    }
+    e0 = e->ev_pool[e->ev_used].first; e1 = e->ev_pool[e->ev_used].second;
+    ++e->ev_used;
+    HIPCHK(hipEventRecord(e0, s));
+  }
+  HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
+  if (e->timing) HIPCHK(hipEventRecord(e1, s));
+  return 0;
+}
+
+static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const int* deg, int n_nodes,
+                        int node_off, hipStream_t s) {
+  HIPCHK(launch_conv_finalize(e->acc, node_in, node_out, deg, L.bn_scale, L.bn_mean, L.bn_bias, n_nodes, in_level_dim(L.in_level),
+                              out_level_dim(L.out_level), node_off, s));
+  return 0;
+}
+
+int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t R, int32_t Err, const int64_t* lig_x,
+                    const int64_t* bond_index, const float* bond_attr, const uint8_t* edge_mask, const uint8_t* mask_rotate,
+                    const float* rec_x, const float* rec_pos, const int64_t* rec_edge_index) {
+  if (!e) return fail(CBD_ERR_ARG, "null engine");
+  if (!e->weights_ready) return fail(CBD_ERR_STATE, "cbd_finalize_weights must succeed before cbd_set_complex");
+  if (Nl <= 0 || Nr <= 0 || nbd < 0 || R < 0 || Err < 0) return fail(CBD_ERR_ARG, "bad sizes");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  e->cpool.release(); e->bpool.release();
+  e->complex_ready = false;
+  const int Bm = e->cfg.max_batch, lm = e->cfg.lm_embedding_dim;
+  GraphStatic& gs = e->gs;
+  gs = GraphStatic{};
+  gs.Nl = Nl; gs.Nr = Nr; gs.R = R; gs.nbd = nbd; gs.Err = Err; gs.rec_off = Bm * Nl;
+
+  // ---- ligand statics
+  static const int dims[16] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};
+  std::vector<float> lig_static((size_t)Nl * 32);
+  for (int a = 0; a < Nl; ++a) {
+    float emb[32] = {0};
+    for (int f = 0; f < 16; ++f) {
+      const int64_t v = lig_x[(size_t)a * 16 + f];
+      if (v < 0 || v >= dims[f]) return fail(CBD_ERR_ARG, "ligand feature %d of atom %d out of range", f, a);
+      for (int c = 0; c < 32; ++c) emb[c] += e->lig_emb_tables[f][(size_t)v * 32 + c];
+    }
+    for (int o = 0; o < 32; ++o) {   // first half of additional_features_embedder (the sigma half is per step)
+      float acc = 0.f;
+      for (int k = 0; k < 32; ++k) acc = std::fma(e->lig_node_w_host[(size_t)o * 64 + k], emb[k], acc);
+      lig_static[(size_t)a * 32 + o] = acc;
+    }
+  }
+  HIPCHK(e->cpool.upload(&e->lig_static32, lig_static));
+  // bonds sorted by source atom
+  std::vector<int> order(nbd);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return bond_index[a] < bond_index[b]; });
+  std::vector<int> bond_row(Nl + 1, 0), bond_dst(nbd);
+  std::vector<float> battr((size_t)nbd * 4);
+  int max_bdeg = 0;
+  for (int k = 0; k < nbd; ++k) {
+    const int o = order[k];
+    const int64_t s = bond_index[o], d = bond_index[nbd + o];
+    if (s < 0 || s >= Nl || d < 0 || d >= Nl) return fail(CBD_ERR_ARG, "bond index out of range");
+    bond_row[s + 1]++;
+    bond_dst[k] = (int)d;
+    for (int c = 0; c < 4; ++c) battr[(size_t)k * 4 + c] = bond_attr[(size_t)o * 4 + c];
+  }
+  for (int a = 0; a < Nl; ++a) { max_bdeg = std::max(max_bdeg, bond_row[a + 1]); bond_row[a + 1] += bond_row[a]; }
+  std::vector<int> rot_u, rot_v;
+  for (int k = 0; k < nbd; ++k)
+    if (edge_mask[k]) { rot_u.push_back((int)bond_index[k]); rot_v.push_back((int)bond_index[nbd + k]); }
+  if ((int)rot_u.size() != R) return fail(CBD_ERR_ARG, "edge_mask selects %d bonds but R = %d", (int)rot_u.size(), R);
+  for (int r = 0; r < R; ++r)
+    if (mask_rotate[(size_t)r * Nl + rot_u[r]] || !mask_rotate[(size_t)r * Nl + rot_v[r]])
+      return fail(CBD_ERR_ARG, "mask_rotate violates the u-outside / v-inside convention (utils/torsion.py:81-82)");
+  int *d_bond_row, *d_bond_dst, *d_rot_u, *d_rot_v;
+  float* d_battr;
+  uint8_t* d_mask;
+  HIPCHK(e->cpool.upload(&d_bond_row, bond_row)); HIPCHK(e->cpool.upload(&d_bond_dst, bond_dst));
+  HIPCHK(e->cpool.upload(&d_battr, battr));
+  HIPCHK(e->cpool.upload(&d_rot_u, rot_u)); HIPCHK(e->cpool.upload(&d_rot_v, rot_v));
+  HIPCHK(e->cpool.upload(&d_mask, std::vector<uint8_t>(mask_rotate, mask_rotate + (size_t)R * Nl)));
+  gs.bond_row = d_bond_row; gs.bond_dst = d_bond_dst; gs.bond_attr = d_battr; gs.rot_u = d_rot_u; gs.rot_v = d_rot_v;
+  gs.mask_rotate = d_mask;
+  e->cap_ll_per_sample = nbd + Nl * std::min(Nl - 1, e->cfg.lig_radius_cap);
+
+  // ---- receptor statics: kNN edges sorted by aggregating node (row 0)
+  std::vector<int> rorder(Err);
+  std::iota(rorder.begin(), rorder.end(), 0);
+  std::stable_sort(rorder.begin(), rorder.end(), [&](int a, int b) { return rec_edge_index[a] < rec_edge_index[b]; });
+  std::vector<int> src0(Err), dst0(Err), deg0(Nr, 0), ident(Err);
+  for (int k = 0; k < Err; ++k) {
+    const int64_t s = rec_edge_index[rorder[k]], d = rec_edge_index[Err + rorder[k]];
+    if (s < 0 || s >= Nr || d < 0 || d >= Nr) return fail(CBD_ERR_ARG, "receptor edge index out of range");
+    src0[k] = (int)s; dst0[k] = (int)d; deg0[s]++; ident[k] = k;
+  }
+  float* d_rec_pos;
+  int *d_src0, *d_dst0, *d_deg0, *d_ident;
+  HIPCHK(e->cpool.upload(&d_rec_pos, std::vector<float>(rec_pos, rec_pos + (size_t)Nr * 3)));
+  HIPCHK(e->cpool.upload(&d_src0, src0)); HIPCHK(e->cpool.upload(&d_dst0, dst0)); HIPCHK(e->cpool.upload(&d_deg0, deg0));
+  HIPCHK(e->cpool.upload(&d_ident, ident));
+  gs.rec_pos = d_rec_pos; gs.rr_deg0 = d_deg0;
+  float *d_rec_x, *d_vec0, *d_dist0;
+  HIPCHK(e->cpool.upload(&d_rec_x, std::vector<float>(rec_x, rec_x + (size_t)Nr * (1 + lm))));
+  HIPCHK(e->cpool.alloc(&d_vec0, (size_t)Err * 4)); HIPCHK(e->cpool.alloc(&d_dist0, (size_t)Err));
+  HIPCHK(e->cpool.alloc(&e->rr_attr0, (size_t)Err * 32)); HIPCHK(e->cpool.alloc(&e->rr_attr_t, (size_t)Err * 32));
+  HIPCHK(e->cpool.alloc(&e->rec_static, (size_t)Nr * NODE_STRIDE));
+
+  // ---- batch workspace (capacity max_batch)
+  const int N = Bm * (Nl + Nr);
+  e->n_nodes_cap = N;
+  GraphDyn& gd = e->gd;
+  gd = GraphDyn{};
+  const size_t cap_ll = (size_t)Bm * e->cap_ll_per_sample, cap_x = (size_t)Bm * Nl * Nr;
+  HIPCHK(e->bpool.alloc(&gd.cnt_ll, (size_t)Bm * Nl)); HIPCHK(e->bpool.alloc(&gd.cnt_lr, (size_t)Bm * Nl));
+  HIPCHK(e->bpool.alloc(&gd.cnt_rl, (size_t)Bm * Nr));
+  HIPCHK(e->bpool.alloc(&gd.start_ll, (size_t)Bm * Nl)); HIPCHK(e->bpool.alloc(&gd.start_lr, (size_t)Bm * Nl));
+  HIPCHK(e->bpool.alloc(&gd.start_rl, (size_t)Bm * Nr));
+  HIPCHK(e->bpool.alloc(&gd.counts, 8));
+  HIPCHK(e->bpool.alloc(&gd.deg_embed, (size_t)N)); HIPCHK(e->bpool.alloc(&gd.deg_full, (size_t)N));
+  HIPCHK(e->bpool.alloc(&gd.ll_src, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_dst, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_aidx, cap_ll));
+  HIPCHK(e->bpool.alloc(&gd.ll_vec, cap_ll * 4)); HIPCHK(e->bpool.alloc(&gd.ll_dist, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_bond4, cap_ll * 4));
+  HIPCHK(e->bpool.alloc(&gd.lr_src, cap_x)); HIPCHK(e->bpool.alloc(&gd.lr_dst, cap_x)); HIPCHK(e->bpool.alloc(&gd.lr_aidx, cap_x));
+  HIPCHK(e->bpool.alloc(&gd.lr_vec, cap_x * 4)); HIPCHK(e->bpool.alloc(&gd.lr_dist, cap_x));
+  HIPCHK(e->bpool.alloc(&gd.rl_src, cap_x)); HIPCHK(e->bpool.alloc(&gd.rl_dst, cap_x)); HIPCHK(e->bpool.alloc(&gd.rl_aidx, cap_x));
+  HIPCHK(e->bpool.alloc(&gd.rl_vec, cap_x * 4));
+  HIPCHK(e->bpool.alloc(&gd.pair_eid, cap_x));
+  HIPCHK(e->bpool.alloc(&e->ll_attr, cap_ll * 32)); HIPCHK(e->bpool.alloc(&e->lr_attr, cap_x * 32));
+  HIPCHK(e->bpool.alloc(&e->X0, (size_t)N * NODE_STRIDE)); HIPCHK(e->bpool.alloc(&e->X1, (size_t)N * NODE_STRIDE));
+  HIPCHK(e->bpool.alloc(&e->acc, (size_t)N * NODE_STRIDE));
+  HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
+  HIPCHK(hipMemset(e->acc, 0, (size_t)N * NODE_STRIDE * 4));
+  float* vecs;
+  HIPCHK(e->bpool.alloc(&vecs, 7 * 32));
+  e->sv = StepVectors{vecs, vecs + 32, vecs + 64, vecs + 96, vecs + 128, vecs + 160, vecs + 192};
+  e->sigma_cap = 64;
+  HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)e->sigma_cap * 32));
+  HIPCHK(e->bpool.alloc(&e->tr_out, (size_t)Bm * 3)); HIPCHK(e->bpool.alloc(&e->rot_out, (size_t)Bm * 3));
+  HIPCHK(e->bpool.alloc(&e->tor_out, (size_t)Bm * std::max(R, 1)));
+  HIPCHK(e->bpool.alloc(&e->dbg_global, (size_t)Bm * 12)); HIPCHK(e->bpool.alloc(&e->dbg_torfeat, (size_t)Bm * std::max(R, 1) * 64));
+  // batched receptor edges (independent of B: receptor rows start at rec_off)
+  std::vector<int> bsrc((size_t)Bm * Err), bdst((size_t)Bm * Err), baidx((size_t)Bm * Err);
+  for (int b = 0; b < Bm; ++b)
+    for (int k = 0; k < Err; ++k) {
+      bsrc[(size_t)b * Err + k] = gs.rec_off + b * Nr + src0[k];
+      bdst[(size_t)b * Err + k] = gs.rec_off + b * Nr + dst0[k];
+      baidx[(size_t)b * Err + k] = k;
+    }
+  HIPCHK(e->bpool.upload(&e->rr_src, bsrc)); HIPCHK(e->bpool.upload(&e->rr_dst, bdst)); HIPCHK(e->bpool.upload(&e->rr_aidx, baidx));
+  HIPCHK(e->bpool.alloc(&e->rr_vec, (size_t)Bm * Err * 4));
+  HIPCHK(e->bpool.alloc(&e->rr_count_dev, 1));
+
+  // ---- time-independent receptor embedding for ONE copy (score_model.py:297-320), reusing X0/X1/acc
+  hipStream_t s = nullptr;
+  HIPCHK(launch_rec_node_embed(d_rec_x, Nr, lm, e->rec_emb_table, e->rec_node_w, e->rec_node_b, e->X0, s));
+  HIPCHK(launch_edge_geom(d_rec_pos, d_src0, d_dst0, Err, d_vec0, d_dist0, s));
+  HIPCHK(launch_edge_mlp(make_mlp(e->m_rec_edge, nullptr), d_dist0, nullptr, nullptr, Err, e->rr_attr0, s));
+  HIPCHK(hipMemcpyAsync(e->rr_count_dev, &Err, sizeof(int), hipMemcpyHostToDevice, s));
+  {
+    float* in = e->X0;
+    float* out = e->X1;
+    for (int l = 0; l < 3; ++l) {
+      ConvGroup g{};
+      g.src = d_src0; g.dst = d_dst0; g.attr_idx = d_ident; g.vec = d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
+      int cap = Err;
+      const bool was_timing = e->timing;
+      e->timing = false;
+      CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
+      e->timing = was_timing;
+      CHK(run_finalize(e, e->rec_emb[l], in, out, d_deg0, Nr, 0, s));
+      std::swap(in, out);
+    }
+    HIPCHK(hipMemcpyAsync(e->rec_static, in, (size_t)Nr * NODE_STRIDE * 4, hipMemcpyDeviceToDevice, s));
+  }
+  for (int b = 0; b < Bm; ++b)
+    HIPCHK(hipMemcpyAsync(e->rr_vec + (size_t)b * Err * 4, d_vec0, (size_t)Err * 16, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));
+  HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
+  e->complex_ready = true;
+  return 0;
+}
+
+// ======================================================================================================== forward
+static void snap(cbd_engine* e, const char* name, const float* dev, size_t n, hipStream_t s) {
+  if (!e->keep_debug) return;
+  std::vector<float> h(n);
+  (void)hipStreamSynchronize(s);
+  (void)hipMemcpy(h.data(), dev, n * 4, hipMemcpyDeviceToHost);
+  e->dbg_snap.push_back({name, std::move(h)});
+}
+
+// One score-model forward on the engine's buffers.  sigma_emb_dev: device pointer to this step's 32-float embedding.
+static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& st, const float* sigma_emb_dev, float* tr_dev,
+                   float* rot_dev, float* tor_dev, hipStream_t s) {
+  const GraphStatic& gs = e->gs;
+  GraphDyn gd = e->gd;
+  gd.pos = const_cast<float*>(pos_dev);
+  const int Nl = gs.Nl, Nr = gs.Nr, R = gs.R, nL = B * Nl, nR = B * Nr;
+  e->last_B = B;
+  e->dbg_snap.clear();
+  HIPCHK(launch_step_prep(e->sw, e->sv, sigma_emb_dev, s));
+  HIPCHK(hipMemsetAsync(gd.counts, 0, 8 * sizeof(int), s));
+  HIPCHK(launch_graph_count(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
+  HIPCHK(launch_graph_scan(gs, gd, B, s));
+  HIPCHK(launch_graph_fill(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
+  const int cap_ll = B * e->cap_ll_per_sample, cap_x = B * Nl * Nr, cap_rr = B * gs.Err;
+  EdgeMlp mll = make_mlp(e->m_lig_edge, e->sv.ll_part), mlr = make_mlp(e->m_cross, e->sv.lr_part);
+  HIPCHK(launch_edge_mlp(mll, gd.ll_dist, gd.ll_bond4, gd.counts + 0, cap_ll, e->ll_attr, s));
+  HIPCHK(launch_edge_mlp(mlr, gd.lr_dist, nullptr, gd.counts + 1, cap_x, e->lr_attr, s));
+  HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, s));
+  HIPCHK(launch_lig_node_init(e->lig_static32, e->sv.lig_node_c, e->X0, B, Nl, s));
+  snap(e, "lig_node_emb0", e->X0, (size_t)nL * NODE_STRIDE, s);
+
+  ConvGroup gll{}, glr{}, grr{}, grl{};
+  gll.src = gd.ll_src; gll.dst = gd.ll_dst; gll.attr_idx = gd.ll_aidx; gll.vec = gd.ll_vec; gll.attr = e->ll_attr; gll.count = gd.counts + 0;
+  glr.src = gd.lr_src; glr.dst = gd.lr_dst; glr.attr_idx = gd.lr_aidx; glr.vec = gd.lr_vec; glr.attr = e->lr_attr; glr.count = gd.counts + 1;
+  grr.src = e->rr_src; grr.dst = e->rr_dst; grr.attr_idx = e->rr_aidx; grr.vec = e->rr_vec; grr.attr = e->rr_attr_t; grr.count = gd.counts + 2;
+  grl.src = gd.rl_src; grl.dst = gd.rl_dst; grl.attr_idx = gd.rl_aidx; grl.vec = gd.rl_vec; grl.attr = e->lr_attr; grl.count = gd.counts + 3;
+
+  float* in = e->X0;
+  float* out = e->X1;
+  static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
+  for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
+    CHK(run_conv(e, e->lig_emb[l], &gll, 1, &cap_ll, in, s));
+    CHK(run_finalize(e, e->lig_emb[l], in, out, gd.deg_embed, nL, 0, s));
+    std::swap(in, out);
+    snap(e, emb_names[l], in, (size_t)nL * NODE_STRIDE, s);
+  }
+  HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, in, B, gs.rec_off, Nr, s));
+  static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
+  for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
+    if (l < 4) {
+      const ConvGroup g4[4] = {gll, glr, grr, grl};
+      const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
+      CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
+      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));
+      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nR, gs.rec_off, s));
+    } else {
+      const ConvGroup g2[2] = {gll, glr};
+      const int caps[2] = {cap_ll, cap_x};
+      CHK(run_conv(e, e->conv[l], g2, 2, caps, in, s));
+      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));   // receptor rows are never read again (quirk 3)
+    }
+    std::swap(in, out);
+    snap(e, conv_names[l], in, (size_t)nL * NODE_STRIDE, s);
+    if (l < 4) snap(e, (std::string(conv_names[l]) + "_rec").c_str(), in + (size_t)gs.rec_off * NODE_STRIDE, (size_t)nR * NODE_STRIDE, s);
+  }
+  const float* lig_node = in;
+  HIPCHK(launch_center_head(e->ch, e->sv, pos_dev, lig_node, B, Nl, st.tr_sigma, st.rot_score_norm, tr_dev, rot_dev, e->dbg_global, s));
+  if (!e->cfg.no_torsion && R > 0)
+    HIPCHK(launch_bond_head(e->bh, gs, pos_dev, lig_node, B, e->cfg.lig_max_radius, 32, st.tor_score_norm_sqrt, tor_dev,
+                            gd.counts + 4, e->dbg_torfeat, s));
+  e->dbg.clear();
+  e->dbg["center_mean"] = {e->dbg_global, (size_t)B * 12};
+  e->dbg["tor_feat"] = {e->dbg_torfeat, (size_t)B * R * 64};
+  e->dbg["rec_node_static"] = {e->rec_static, (size_t)Nr * NODE_STRIDE};
+  e->dbg["rec_sigma_emb"] = {e->sv.rec_sigma_emb, 32};
+  e->dbg["lig_node_final"] = {lig_node, (size_t)nL * NODE_STRIDE};
+  e->dbg["ll_attr"] = {e->ll_attr, 0};   // count filled at fetch time
+  e->dbg["lr_attr"] = {e->lr_attr, 0};
+  return 0;
+}
+
+static int check_batch(cbd_engine* e, int B) {
+  if (!e) return fail(CBD_ERR_ARG, "null engine");
+  if (!e->weights_ready || !e->complex_ready) return fail(CBD_ERR_STATE, "weights and complex must be set first");
+  if (B <= 0) return fail(CBD_ERR_ARG, "batch must be positive");
+  if (B > e->cfg.max_batch) return fail(CBD_ERR_CAPACITY, "batch %d exceeds max_batch %d", B, e->cfg.max_batch);
+  return 0;
+}
+
+static void collect_timing(cbd_engine* e) {
+  for (size_t i = 0; i < e->ev_used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e->ev_pool[i].second) == hipSuccess &&
+        hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) {
+      e->t_total_ms += ms;
+      e->t_n += 1;
+    }
+  }
+  e->ev_used = 0;
+}
+
+int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* step, float* tr_dev, float* rot_dev, float* tor_dev,
+              void* stream) {
+  CHK(check_batch(e, B));
+  if (!pos_dev || !step || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 32 * sizeof(float), hipMemcpyHostToDevice, s));
+  CHK(forward(e, B, pos_dev, *step, e->sigma_emb_dev, tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, s));
+  if (e->timing) { HIPCHK(hipStreamSynchronize(s)); collect_timing(e); }
+  return 0;
+}
+
+int cbd_modify_conformer(cbd_engine* e, int32_t B, float* pos_dev, const float* tr_dev, const float* rot_dev, const float* tor_dev,
+                         void* stream) {
+  if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
+  if (B <= 0 || !pos_dev || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(launch_pose_update(e->gs, pos_dev, B, tr_dev, rot_dev, tor_dev, nullptr, nullptr, nullptr, nullptr,
+                            reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float* pos_dev, const float* noise_tr,
+               const float* noise_rot, const float* noise_tor, float* scores_out, void* stream) {
+  CHK(check_batch(e, B));
+  if (S <= 0 || !steps || !pos_dev) return fail(CBD_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const int R = e->gs.R;
+  if (S > e->sigma_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)S * 32));
+    e->sigma_cap = S;
+  }
+  std::vector<float> se((size_t)S * 32);
+  for (int i = 0; i < S; ++i) std::memcpy(se.data() + (size_t)i * 32, steps[i].sigma_emb, 32 * sizeof(float));
+  HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));   // `se` goes out of scope; also orders the upload before the loop
+  const bool tors = !e->cfg.no_torsion && R > 0;
+  for (int i = 0; i < S; ++i) {
+    const cbd_step& st = steps[i];
+    CHK(forward(e, B, pos_dev, st, e->sigma_emb_dev + (size_t)i * 32, e->tr_out, e->rot_out, e->tor_out, s));
+    if (scores_out) {
+      float* o = scores_out + (size_t)i * B * (6 + R);
+      HIPCHK(hipMemcpyAsync(o, e->tr_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
+      HIPCHK(hipMemcpyAsync(o + B * 3, e->rot_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
+      if (tors) HIPCHK(hipMemcpyAsync(o + B * 6, e->tor_out, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s));
+    }
+    SdeCoefs cf{st.tr_score_coef, st.tr_noise_coef, st.rot_score_coef, st.rot_noise_coef, st.tor_score_coef, st.tor_noise_coef};
+    const float* ztr = (noise_tr && st.tr_noise_coef != 0.f) ? noise_tr + (size_t)i * B * 3 : nullptr;
+    const float* zrot = (noise_rot && st.rot_noise_coef != 0.f) ? noise_rot + (size_t)i * B * 3 : nullptr;
+    const float* ztor = (noise_tor && st.tor_noise_coef != 0.f) ? noise_tor + (size_t)i * B * R : nullptr;
+    HIPCHK(launch_pose_update(e->gs, pos_dev, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
+  }
+  if (e->timing) { HIPCHK(hipStreamSynchronize(s)); collect_timing(e); }
+  return 0;
+}
+
+int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t capacity) {
+  if (!e || !name) return fail(CBD_ERR_ARG, "null argument");
+  const std::string k(name);
+  if (k == "enable") { e->keep_debug = true; return 0; }
+  if (k == "disable") { e->keep_debug = false; e->dbg_snap.clear(); return 0; }
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipDeviceSynchronize();
+  for (auto& p : e->dbg_snap)
+    if (p.first == k) {
+      if ((int64_t)p.second.size() > capacity) return fail(CBD_ERR_ARG, "capacity too small for '%s' (%zu)", name, p.second.size());
+      std::memcpy(out, p.second.data(), p.second.size() * 4);
+      return (int64_t)p.second.size();
+    }
+  auto it = e->dbg.find(k);
+  if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);
+  size_t n = it->second.second;
+  if (k == "ll_attr" || k == "lr_attr") {
+    int c[8];
+    if (hipMemcpy(c, e->gd.counts, sizeof c, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
+    n = (size_t)c[k == "ll_attr" ? 0 : 1] * 32;
+  }
+  if ((int64_t)n > capacity) return fail(CBD_ERR_ARG, "capacity too small for '%s' (%zu)", name, n);
+  if (hipMemcpy(out, it->second.first, n * 4, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
+  return (int64_t)n;
+}
+
+int cbd_last_edge_counts(cbd_engine* e, int64_t counts[5]) {
+  if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
+  (void)hipSetDevice(e->cfg.device);
+  int c[8];
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(c, e->gd.counts, sizeof c, hipMemcpyDeviceToHost));
+  for (int i = 0; i < 5; ++i) counts[i] = c[i];
+  return 0;
+}
+
+int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_ms, int64_t* n, double* total_ms) {
+  if (!e) return fail(CBD_ERR_ARG, "null engine");
+  if (reset) { e->t_total_ms = 0; e->t_n = 0; e->ev_used = 0; }
+  e->timing = enable != 0;
+  if (avg_ms) *avg_ms = e->t_n ? e->t_total_ms / (double)e->t_n : 0.0;
+  if (n) *n = e->t_n;
+  if (total_ms) *total_ms = e->t_total_ms;
+  return 0;
+}
+
+// Host-only helper for the CPU tests: pack one FCBlock into the MFMA tile stream (no GPU needed).
+// out must hold cbd_conv_stream_floats(in_level, out_level) floats.
+int64_t cbd_conv_stream_floats(int32_t in_level, int32_t out_level) {
+  return (int64_t)conv_shape(in_level, out_level).ntiles * TILE_FLOATS;
+}
+int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1, const float* b1, const float* w2, const float* b2,
+                         float* out) {
+  if (in_level < 0 || in_level > 3 || out_level < 1 || out_level > 3) return fail(CBD_ERR_ARG, "bad level");
+  std::vector<float> v = pack_conv_stream(in_level, out_level, w1, b1, w2, b2);
+  std::memcpy(out, v.data(), v.size() * 4);
+  return 0;
+}
+
+}  // extern "C"

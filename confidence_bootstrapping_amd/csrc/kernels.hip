@@ -1,0 +1,763 @@
+// Graph construction, edge featurisation, score heads and pose update for gfx950 (MI355X).
+// These are the HBM/latency-bound parts of one reverse-diffusion step; the matrix-core work lives in tp_conv.hip.
+// Each kernel cites the reference lines it replaces.  64-wide wavefronts throughout (ballot = 64-bit).
+#include "kernels.h"
+
+namespace cbd {
+
+#define CBD_DEV __device__ __forceinline__
+
+// Squared distance accumulated like torch_cluster's scalar loop (no FMA contraction, so that the
+// in/out decision of a pair is the same arithmetic in every kernel that evaluates it).
+CBD_DEV float dist2_nofma(float ax, float ay, float az, float bx, float by, float bz) {
+  const float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+  return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// radius(rec_pos / c, lig_pos / c, 1): models/score_model.py:568-570
+CBD_DEV bool cross_pair_in(const float* lp, const float* rp, float c) {
+  const float d2 = dist2_nofma(__fdiv_rn(rp[0], c), __fdiv_rn(rp[1], c), __fdiv_rn(rp[2], c),
+                               __fdiv_rn(lp[0], c), __fdiv_rn(lp[1], c), __fdiv_rn(lp[2], c));
+  return d2 < 1.0f;
+}
+
+// unit vector with F.normalize semantics (x / max(|x|, 1e-12)) and the norm
+CBD_DEV void unit_vec(float x, float y, float z, float& ux, float& uy, float& uz, float& n) {
+  n = sqrtf(x * x + y * y + z * z);
+  const float inv = 1.0f / fmaxf(n, 1e-12f);
+  ux = x * inv; uy = y * inv; uz = z * inv;
+}
+
+CBD_DEV int lane_id() { return threadIdx.x & 63; }
+CBD_DEV int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Graph construction.  One wave per node.  Blocks [0, B*Nl) handle ligand nodes (ligand radius graph,
+// score_model.py:502-507, and ligand->receptor cross edges, :564-573); blocks [B*Nl, B*Nl + B*Nr) handle
+// receptor nodes (the flipped cross edges, :356-357).  COUNT pass, single-block scan, FILL pass.
+template <bool FILL>
+__global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, int B, float lig_r2, int lig_cap, float cutoff) {
+  const int lane = lane_id();
+  const int nL = B * gs.Nl;
+  const int roff = gs.rec_off;
+  const int node = blockIdx.x;
+  if (node < nL) {
+    const int b = node / gs.Nl, a = node % gs.Nl;
+    const float* P = gd.pos + (size_t)b * gs.Nl * 3;
+    const float px = P[3 * a], py = P[3 * a + 1], pz = P[3 * a + 2];
+    // ---- ligand-ligand: bonds first, then radius neighbours (first lig_cap+1 hits in index order incl. self, self dropped)
+    const int nb0 = gs.bond_row[a], nb1 = gs.bond_row[a + 1];
+    int base = 0;
+    if (FILL) {
+      base = gd.start_ll[node];
+      for (int k = nb0 + lane; k < nb1; k += 64) {
+        const int e = base + (k - nb0), d = gs.bond_dst[k];
+        float ux, uy, uz, n;
+        unit_vec(P[3 * d] - px, P[3 * d + 1] - py, P[3 * d + 2] - pz, ux, uy, uz, n);
+        gd.ll_src[e] = node; gd.ll_dst[e] = b * gs.Nl + d; gd.ll_aidx[e] = e;
+        reinterpret_cast<f32x4*>(gd.ll_vec)[e] = f32x4{ux, uy, uz, 0.f};
+        gd.ll_dist[e] = n;
+        reinterpret_cast<f32x4*>(gd.ll_bond4)[e] = reinterpret_cast<const f32x4*>(gs.bond_attr)[k];
+      }
+      base += nb1 - nb0;
+    }
+    int hits = 0, kept = 0;   // hits counts self too (cap applies to lig_cap + 1 hits)
+    for (int c0 = 0; c0 < gs.Nl; c0 += 64) {
+      const int d = c0 + lane;
+      bool in = false;
+      if (d < gs.Nl) in = dist2_nofma(P[3 * d], P[3 * d + 1], P[3 * d + 2], px, py, pz) < lig_r2;
+      const unsigned long long m = __ballot(in);
+      const int rank = hits + popc_below(m, lane);
+      const bool keep = in && rank < lig_cap + 1 && d != a;
+      const unsigned long long mk = __ballot(keep);
+      if (FILL && keep) {
+        const int e = base + kept + popc_below(mk, lane);
+        float ux, uy, uz, n;
+        unit_vec(P[3 * d] - px, P[3 * d + 1] - py, P[3 * d + 2] - pz, ux, uy, uz, n);
+        gd.ll_src[e] = node; gd.ll_dst[e] = b * gs.Nl + d; gd.ll_aidx[e] = e;
+        reinterpret_cast<f32x4*>(gd.ll_vec)[e] = f32x4{ux, uy, uz, 0.f};
+        gd.ll_dist[e] = n;
+        reinterpret_cast<f32x4*>(gd.ll_bond4)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      hits += __popcll(m);
+      kept += __popcll(mk);
+    }
+    if (!FILL && lane == 0) gd.cnt_ll[node] = (nb1 - nb0) + kept;
+    // ---- ligand -> receptor cross edges (cap 10000 never binds for Nr <= 10000)
+    const float lp[3] = {px, py, pz};
+    int nlr = 0;
+    const int lbase = FILL ? gd.start_lr[node] : 0;
+    for (int c0 = 0; c0 < gs.Nr; c0 += 64) {
+      const int r = c0 + lane;
+      bool in = false;
+      if (r < gs.Nr) in = cross_pair_in(lp, gs.rec_pos + 3 * r, cutoff);
+      const unsigned long long m = __ballot(in);
+      if (FILL && r < gs.Nr) {
+        int eid = -1;
+        if (in) {
+          eid = lbase + nlr + popc_below(m, lane);
+          float ux, uy, uz, n;
+          unit_vec(gs.rec_pos[3 * r] - px, gs.rec_pos[3 * r + 1] - py, gs.rec_pos[3 * r + 2] - pz, ux, uy, uz, n);
+          gd.lr_src[eid] = node; gd.lr_dst[eid] = roff + b * gs.Nr + r; gd.lr_aidx[eid] = eid;
+          reinterpret_cast<f32x4*>(gd.lr_vec)[eid] = f32x4{ux, uy, uz, 0.f};
+          gd.lr_dist[eid] = n;
+        }
+        gd.pair_eid[(size_t)node * gs.Nr + r] = eid;
+      }
+      nlr += __popcll(m);
+    }
+    if (!FILL && lane == 0) gd.cnt_lr[node] = nlr;
+  } else {
+    // ---- receptor node: flipped cross edges (aggregating node = residue, features read from ligand atoms)
+    const int rn = node - nL;
+    const int b = rn / gs.Nr, r = rn % gs.Nr;
+    const float* P = gd.pos + (size_t)b * gs.Nl * 3;
+    const float* rp = gs.rec_pos + 3 * r;
+    int nrl = 0;
+    const int rbase = FILL ? gd.start_rl[rn] : 0;
+    for (int c0 = 0; c0 < gs.Nl; c0 += 64) {
+      const int a = c0 + lane;
+      bool in = false;
+      if (a < gs.Nl) in = cross_pair_in(P + 3 * a, rp, cutoff);
+      const unsigned long long m = __ballot(in);
+      if (FILL && in) {
+        const int e = rbase + nrl + popc_below(m, lane);
+        const int lr = gd.pair_eid[(size_t)(b * gs.Nl + a) * gs.Nr + r];
+        const f32x4 vv = reinterpret_cast<const f32x4*>(gd.lr_vec)[lr];
+        gd.rl_src[e] = roff + rn; gd.rl_dst[e] = b * gs.Nl + a; gd.rl_aidx[e] = lr;
+        reinterpret_cast<f32x4*>(gd.rl_vec)[e] = f32x4{-vv.x, -vv.y, -vv.z, 0.f};   // sh(-edge_vec), score_model.py:582
+      }
+      nrl += __popcll(m);
+    }
+    if (!FILL && lane == 0) gd.cnt_rl[rn] = nrl;
+  }
+}
+
+hipError_t launch_graph_count(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
+  hipLaunchKernelGGL((graph_kernel<false>), dim3(B * (gs.Nl + gs.Nr)), dim3(64), 0, s, gs, gd, B, lig_r * lig_r, lig_cap, cutoff);
+  return hipGetLastError();
+}
+__global__ __launch_bounds__(64) void graph_fill_rec(GraphStatic gs, GraphDyn gd, int B, float cutoff) {
+  const int lane = lane_id();
+  const int roff = gs.rec_off;
+  const int rn = blockIdx.x;
+  const int b = rn / gs.Nr, r = rn % gs.Nr;
+  const float* P = gd.pos + (size_t)b * gs.Nl * 3;
+  const float* rp = gs.rec_pos + 3 * r;
+  int nrl = 0;
+  const int rbase = gd.start_rl[rn];
+  for (int c0 = 0; c0 < gs.Nl; c0 += 64) {
+    const int a = c0 + lane;
+    bool in = false;
+    if (a < gs.Nl) in = cross_pair_in(P + 3 * a, rp, cutoff);
+    const unsigned long long m = __ballot(in);
+    if (in) {
+      const int e = rbase + nrl + popc_below(m, lane);
+      const int lr = gd.pair_eid[(size_t)(b * gs.Nl + a) * gs.Nr + r];
+      const f32x4 vv = reinterpret_cast<const f32x4*>(gd.lr_vec)[lr];
+      gd.rl_src[e] = roff + rn; gd.rl_dst[e] = b * gs.Nl + a; gd.rl_aidx[e] = lr;
+      reinterpret_cast<f32x4*>(gd.rl_vec)[e] = f32x4{-vv.x, -vv.y, -vv.z, 0.f};   // sh(-edge_vec), score_model.py:582
+    }
+    nrl += __popcll(m);
+  }
+}
+
+// The fill pass runs as two launches: receptor-node blocks read pair_eid / lr_vec written by the ligand-node blocks.
+hipError_t launch_graph_fill(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
+  hipLaunchKernelGGL((graph_kernel<true>), dim3(B * gs.Nl), dim3(64), 0, s, gs, gd, B, lig_r * lig_r, lig_cap, cutoff);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(graph_fill_rec, dim3(B * gs.Nr), dim3(64), 0, s, gs, gd, B, cutoff);
+  return hipGetLastError();
+}
+
+// Exclusive scans of the three per-node count arrays (single workgroup; <= ~1e5 entries) + in-degree tables.
+__global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphDyn gd, int B) {
+  __shared__ int part[1024];
+  __shared__ int carry;
+  const int tid = threadIdx.x;
+  const int nL = B * gs.Nl, nR = B * gs.Nr;
+  for (int which = 0; which < 3; ++which) {
+    const int* cnt = which == 0 ? gd.cnt_ll : which == 1 ? gd.cnt_lr : gd.cnt_rl;
+    int* start = which == 0 ? gd.start_ll : which == 1 ? gd.start_lr : gd.start_rl;
+    const int n = which == 2 ? nR : nL;
+    const int per = (n + 1023) / 1024;
+    const int i0 = tid * per, i1 = min(n, i0 + per);
+    int s = 0;
+    for (int i = i0; i < i1; ++i) s += cnt[i];
+    part[tid] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partial sums
+    for (int off = 1; off < 1024; off <<= 1) {
+      int v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    int run = tid == 0 ? 0 : part[tid - 1];
+    for (int i = i0; i < i1; ++i) { start[i] = run; run += cnt[i]; }
+    if (tid == 1023) gd.counts[which == 0 ? 0 : which == 1 ? 1 : 3] = part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) gd.counts[2] = B * gs.Err;
+  for (int n = tid; n < nL; n += 1024) {
+    gd.deg_embed[n] = gd.cnt_ll[n];
+    gd.deg_full[n] = gd.cnt_ll[n] + gd.cnt_lr[n];
+  }
+  for (int n = tid; n < nR; n += 1024) {
+    gd.deg_embed[gs.rec_off + n] = 0;
+    gd.deg_full[gs.rec_off + n] = gs.rr_deg0[n % gs.Nr] + gd.cnt_rl[n];
+  }
+  (void)carry;
+}
+
+hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, hipStream_t s) {
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, gs, gd, B);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Edge embedding MLP (GaussianSmearing + Linear/ReLU/Linear), 32 lanes per edge:
+// lig_edge_embedding / cross_edge_embedding / rec_edge_embedding / final_edge_embedding,
+// score_model.py:111,114,123,259-264 applied at :286,311,352,660 on the features built at :504-518,534-535,578-580,658.
+CBD_DEV float edge_mlp_eval(const EdgeMlp& m, float d, const float* bond4, int o, int sub_base) {
+  // gaussian k for this lane, then hidden pre-activation for output o
+  const float t = d - m.offset[o];
+  const float gk = expf(m.coeff * (t * t));
+  float h = m.part[o];
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) h = fmaf(m.WgT[k * 32 + o], __shfl(gk, sub_base + k), h);
+  if (m.WbT && bond4) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) h = fmaf(m.WbT[c * 32 + o], bond4[c], h);
+  }
+  h = fmaxf(h, 0.f);
+  float out = m.b1[o];
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) out = fmaf(m.W1T[k * 32 + o], __shfl(h, sub_base + k), out);
+  return out;
+}
+
+__global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlp m, const float* __restrict__ dist, const float* __restrict__ bond4,
+                                                       const int* __restrict__ count, int cap, float* __restrict__ out) {
+  const int n = count ? min(*count, cap) : cap;
+  const int e = (blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int o = threadIdx.x & 31;
+  const int sub_base = threadIdx.x & 32;   // lane offset of this half-wave inside the 64-wide wave
+  const bool ok = e < n;
+  const float d = ok ? dist[e] : 0.f;
+  const float v = edge_mlp_eval(m, d, (ok && bond4) ? bond4 + (size_t)e * 4 : nullptr, o, sub_base);
+  if (ok) out[(size_t)e * 32 + o] = v;
+}
+
+hipError_t launch_edge_mlp(const EdgeMlp& m, const float* dist, const float* bond4, const int* count, int cap, float* out, hipStream_t s) {
+  if (cap <= 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_mlp_kernel, dim3((cap * 32 + 255) / 256), dim3(256), 0, s, m, dist, bond4, count, cap, out);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Per-step constant vectors: everything that depends on the diffusion time only (the reference recomputes the
+// sinusoidal embedding per node/edge, score_model.py:323-326,499,510,579,645; here its linear images are
+// computed once per step).
+CBD_DEV float dot32(const float* w, const float* x) {
+  float s = 0.f;
+#pragma unroll 8
+  for (int k = 0; k < 32; ++k) s = fmaf(w[k], x[k], s);
+  return s;
+}
+
+__global__ __launch_bounds__(64) void step_prep_kernel(StepWeights w, StepVectors v, const float* __restrict__ se) {
+  __shared__ float hid[32];
+  const int o = threadIdx.x;
+  if (o < 32) hid[o] = fmaxf(dot32(w.rec_sig_w0 + o * 32, se) + w.rec_sig_b0[o], 0.f);
+  __syncthreads();
+  if (o < 32) {
+    v.rec_sigma_emb[o] = dot32(w.rec_sig_w1 + o * 32, hid) + w.rec_sig_b1[o];
+    v.ll_part[o] = dot32(w.lig_edge_w0 + o * 68 + 4, se) + w.lig_edge_b0[o];          // input = [bond4 | sigma_emb | gauss]
+    v.lr_part[o] = dot32(w.cross_w0 + o * 64, se) + w.cross_b0[o];                    // input = [sigma_emb | gauss]
+    v.center_part[o] = dot32(w.center_w0 + o * 64 + 32, se) + w.center_b0[o];         // input = [gauss | sigma_emb]
+    v.lig_node_c[o] = dot32(w.lig_node_w + o * 64 + 32, se) + w.lig_node_b[o];        // input = [emb sum | sigma_emb]
+    v.tr_part[o] = dot32(w.tr_w0 + o * 33 + 1, se) + w.tr_b0[o];                      // input = [norm | sigma_emb]
+    v.rot_part[o] = dot32(w.rot_w0 + o * 33 + 1, se) + w.rot_b0[o];
+  }
+}
+
+hipError_t launch_step_prep(const StepWeights& w, const StepVectors& v, const float* sigma_emb_dev, hipStream_t s) {
+  hipLaunchKernelGGL(step_prep_kernel, dim3(1), dim3(64), 0, s, w, v, sigma_emb_dev);
+  return hipGetLastError();
+}
+
+// node[b*Nl + a][c] = lig_static32[a][c] + lig_node_c[c] (c < 32), 0 elsewhere        (AtomEncoder, score_model.py:285)
+__global__ void lig_node_init_kernel(const float* __restrict__ st, const float* __restrict__ c32, float* __restrict__ node, int B, int Nl) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  if (n >= B * Nl) return;
+  node[(size_t)n * NODE_STRIDE + c] = c < 32 ? st[(n % Nl) * 32 + c] + c32[c] : 0.f;
+}
+hipError_t launch_lig_node_init(const float* st, const float* c32, float* node, int B, int Nl, hipStream_t s) {
+  const int total = B * Nl * NODE_STRIDE;
+  hipLaunchKernelGGL(lig_node_init_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, c32, node, B, Nl);
+  return hipGetLastError();
+}
+
+// node[nL + b*Nr + r] = rec_static[r] (+ rec_sigma_emb on the 32 scalars)              (score_model.py:324-325)
+__global__ void rec_node_init_kernel(const float* __restrict__ st, const float* __restrict__ se, float* __restrict__ node, int B, int rec_off, int Nr) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  if (n >= B * Nr) return;
+  const float v = st[(size_t)(n % Nr) * NODE_STRIDE + c];
+  node[(size_t)(rec_off + n) * NODE_STRIDE + c] = c < 32 ? v + se[c] : v;
+}
+hipError_t launch_rec_node_init(const float* st, const float* se, float* node, int B, int rec_off, int Nr, hipStream_t s) {
+  const int total = B * Nr * NODE_STRIDE;
+  hipLaunchKernelGGL(rec_node_init_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, se, node, B, rec_off, Nr);
+  return hipGetLastError();
+}
+
+__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ v32, float* __restrict__ out, int rows) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < rows * 32) out[idx] = a[idx] + v32[idx & 31];
+}
+hipError_t launch_add_rows(const float* a, const float* v32, float* out, int rows, hipStream_t s) {
+  hipLaunchKernelGGL(add_rows_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, a, v32, out, rows);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648): one workgroup per sample.
+// final_conv.tp is e3nn FullyConnectedTensorProduct(74 x (0e+1o) -> 2x1o + 2x1e); its six instructions reduce to the
+// closed forms below (prototype + check against the Wigner-3j einsum: tests/test_kernel_math.py::final_conv_tp).
+__global__ __launch_bounds__(128) void center_head_kernel(CenterHead h, StepVectors sv, const float* __restrict__ pos,
+                                                          const float* __restrict__ node, int Nl, float tr_sigma, float rot_norm,
+                                                          float* __restrict__ tr_out, float* __restrict__ rot_out, float* __restrict__ dbg) {
+  __shared__ float s_in[64], s_hid[64], s_w[124], s_acc[12], s_c[3], s_g[32], s_eh[32];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const float* P = pos + (size_t)b * Nl * 3;
+  if (tid < 12) s_acc[tid] = 0.f;
+  if (tid < 3) {
+    float c = 0.f;
+    for (int a = 0; a < Nl; ++a) c += P[3 * a + tid];
+    s_c[tid] = c / (float)Nl;
+  }
+  __syncthreads();
+  const float pw_o = sqrtf(3.f / 44.f), pw_e = sqrtf(3.f / 18.f);
+  const float is3 = 0.57735026918962576f, is6 = 0.40824829046386302f, s3 = 1.7320508075688772f;
+  for (int a = 0; a < Nl; ++a) {
+    const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
+    float ux, uy, uz, d;
+    unit_vec(P[3 * a] - s_c[0], P[3 * a + 1] - s_c[1], P[3 * a + 2] - s_c[2], ux, uy, uz, d);
+    // centre edge embedding: [gauss(d) | sigma_emb] -> 32 -> 32
+    if (tid < 32) { const float t = d - h.offset[tid]; s_g[tid] = expf(h.coeff * (t * t)); }
+    __syncthreads();
+    if (tid < 32) {
+      float v = sv.center_part[tid];
+      for (int k = 0; k < 32; ++k) v = fmaf(h.ce_WgT[k * 32 + tid], s_g[k], v);
+      s_eh[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    if (tid < 32) {
+      float v = h.ce_b1[tid];
+      for (int k = 0; k < 32; ++k) v = fmaf(h.ce_W1T[k * 32 + tid], s_eh[k], v);
+      s_in[tid] = v;
+    } else if (tid < 64) {
+      s_in[tid] = x[tid - 32];   // lig_node_attr[atom, :ns]  (fixed_center_conv, score_model.py:397)
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float v = h.fc_b0[tid];
+      for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w0[tid * 64 + k], s_in[k], v);
+      s_hid[tid] = fmaxf(v, 0.f);
+    }
+    __syncthreads();
+    if (tid < 124) {
+      float v = h.fc_b1[tid];
+      for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w1[tid * 64 + k], s_hid[k], v);
+      s_w[tid] = v;
+    }
+    __syncthreads();
+    if (tid < 12) {
+      const int blk = tid / 6, wv = (tid % 6) / 3, k = tid % 3;   // blk 0: 2x1o, 1: 2x1e ; wv = multiplicity ; k = component
+      const float sh[3] = {s3 * ux, s3 * uy, s3 * uz};
+      float r = 0.f;
+      if (blk == 0) {
+        float t0 = 0.f;
+        for (int u = 0; u < 32; ++u) t0 = fmaf(s_w[u * 2 + wv], x[u], t0);
+        r += pw_o * is3 * t0 * sh[k];
+        for (int u = 0; u < 6; ++u) {
+          r += pw_o * is3 * s_w[64 + u * 2 + wv] * x[COL_1O + 3 * u + k];
+          const float* e = x + COL_1E + 3 * u;
+          const float cr = k == 0 ? e[1] * sh[2] - e[2] * sh[1] : k == 1 ? e[2] * sh[0] - e[0] * sh[2] : e[0] * sh[1] - e[1] * sh[0];
+          r += pw_o * is6 * s_w[100 + u * 2 + wv] * cr;
+        }
+      } else {
+        for (int u = 0; u < 6; ++u) {
+          const float* o = x + COL_1O + 3 * u;
+          const float cr = k == 0 ? o[1] * sh[2] - o[2] * sh[1] : k == 1 ? o[2] * sh[0] - o[0] * sh[2] : o[0] * sh[1] - o[1] * sh[0];
+          r += pw_e * is6 * s_w[76 + u * 2 + wv] * cr;
+          r += pw_e * is3 * s_w[88 + u * 2 + wv] * x[COL_1E + 3 * u + k];
+          r += pw_e * is3 * s_w[112 + u * 2 + wv] * x[COL_0O + u] * sh[k];
+        }
+      }
+      s_acc[tid] += r;
+    }
+    __syncthreads();
+  }
+  if (tid < 12) {
+    const float mean = s_acc[tid] / (float)Nl;
+    if (dbg) dbg[b * 12 + tid] = mean;
+    s_acc[tid] = mean * h.bn_scale[tid / 3];   // e3nn BatchNorm on 2x1o+2x1e: scale per multiplicity channel, no shift
+  }
+  __syncthreads();
+  // tr = g[0:3] + g[6:9], rot = g[3:6] + g[9:12]; magnitude re-scaling MLPs (score_model.py:402-420)
+  if (tid < 64) {
+    const int which = tid >> 5, o = tid & 31;   // 0: tr, 1: rot
+    const float vx = s_acc[3 * which] + s_acc[6 + 3 * which], vy = s_acc[3 * which + 1] + s_acc[7 + 3 * which],
+                vz = s_acc[3 * which + 2] + s_acc[8 + 3 * which];
+    const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+    const float* w0n = which ? h.rot_w0n : h.tr_w0n;
+    const float* w1 = which ? h.rot_w1 : h.tr_w1;
+    const float* part = which ? sv.rot_part : sv.tr_part;
+    float hv = fmaxf(fmaf(w0n[o], nrm, part[o]), 0.f) * w1[o];
+    for (int off = 16; off > 0; off >>= 1) hv += __shfl_xor(hv, off);
+    const float mag = hv + (which ? h.rot_b1[0] : h.tr_b1[0]);
+    if (o < 3) {
+      const float comp = o == 0 ? vx : o == 1 ? vy : vz;
+      const float val = comp / nrm * mag;
+      if (which == 0) tr_out[b * 3 + o] = val / tr_sigma;
+      else rot_out[b * 3 + o] = val * rot_norm;
+    }
+  }
+}
+
+hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const float* pos, const float* node, int B, int Nl,
+                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, hipStream_t s) {
+  hipLaunchKernelGGL(center_head_kernel, dim3(B), dim3(128), 0, s, h, v, pos, node, Nl, tr_sigma, rot_norm, tr_out, rot_out, dbg_global);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Torsion head (score_model.py:431-448, 650-664): one workgroup per (sample, rotatable bond).
+// tor_bond_conv.tp has two live paths (6x1o x T1 -> 32x0e, 6x1e x T1 -> 32x0o) where T1 is the 1o block of
+// FullTensorProduct(sh(edge), Y2(bond)) = (3/sqrt2)(b b^T - I/3)(sqrt3 v)  (tests/test_kernel_math.py::tor_t1).
+__global__ __launch_bounds__(128) void bond_head_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
+                                                        const float* __restrict__ node, float lig_r2, int cap, float tor_norm_sqrt,
+                                                        float* __restrict__ tor_out, int* __restrict__ tor_edge_count,
+                                                        float* __restrict__ dbg_feat) {
+  __shared__ float s_in[96], s_hid[96], s_w[384], s_acc[64], s_da[6], s_db[6], s_feat[64];
+  __shared__ int s_nb[64];
+  __shared__ int s_n;
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x / gs.R, rho = blockIdx.x % gs.R;
+  const int Nl = gs.Nl;
+  const float* P = pos + (size_t)b * Nl * 3;
+  const int u = gs.rot_u[rho], v = gs.rot_v[rho];   // bonds = edge_index[:, edge_mask]; [0] = u, [1] = v
+  const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
+  float bux, buy, buz, bn;
+  unit_vec(P[3 * v] - P[3 * u], P[3 * v + 1] - P[3 * u + 1], P[3 * v + 2] - P[3 * u + 2], bux, buy, buz, bn);
+  if (tid < 64) s_acc[tid] = 0.f;
+  // radius(lig_pos, bond_pos, 5) with cap: first `cap` atoms in index order (wave 0 does the compaction)
+  if (tid < 64) {
+    int n = 0;
+    for (int c0 = 0; c0 < Nl && n < cap; c0 += 64) {
+      const int a = c0 + tid;
+      bool in = false;
+      if (a < Nl) in = dist2_nofma(P[3 * a], P[3 * a + 1], P[3 * a + 2], bx, by, bz) < lig_r2;
+      const unsigned long long m = __ballot(in);
+      const int slot = n + popc_below(m, tid);
+      if (in && slot < cap && slot < 64) s_nb[slot] = a;
+      n += __popcll(m);
+    }
+    if (tid == 0) s_n = min(n, min(cap, 64));
+  }
+  __syncthreads();
+  const int ne = s_n;
+  const float* xu = node + (size_t)(b * Nl + u) * NODE_STRIDE;
+  const float* xv = node + (size_t)(b * Nl + v) * NODE_STRIDE;
+  const float is3 = 0.57735026918962576f, pw = 0.40824829046386302f /* sqrt(1/6) */;
+  for (int k = 0; k < ne; ++k) {
+    const int a = s_nb[k];
+    const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
+    float ux, uy, uz, d;
+    unit_vec(P[3 * a] - bx, P[3 * a + 1] - by, P[3 * a + 2] - bz, ux, uy, uz, d);
+    // final_edge_embedding on the gaussian-expanded distance (lanes 0..31 of wave 0), node / bond scalars
+    if (tid < 64) {
+      const float e = edge_mlp_eval(h.fe, d, nullptr, tid & 31, tid & 32);
+      if (tid < 32) s_in[tid] = e;
+    } else if (tid < 96) {
+      s_in[tid - 32] = x[tid - 64];                       // lig_node_attr[atom, :ns]
+    } else {
+      s_in[tid - 32] = xu[tid - 96] + xv[tid - 96];       // tor_bond_attr[bond, :ns]
+    }
+    if (tid < 12) {
+      const float bv = bux * ux + buy * uy + buz * uz;
+      const float c = 3.6742346141747673f;   // (3/sqrt2) * sqrt3
+      const float t1[3] = {c * (bux * bv - ux / 3.f), c * (buy * bv - uy / 3.f), c * (buz * bv - uz / 3.f)};
+      const int uu = tid % 6;
+      const float* p = x + (tid < 6 ? COL_1O : COL_1E) + 3 * uu;
+      const float dd = (p[0] * t1[0] + p[1] * t1[1] + p[2] * t1[2]) * is3 * pw;
+      if (tid < 6) s_da[uu] = dd; else s_db[uu] = dd;
+    }
+    __syncthreads();
+    if (tid < 96) {
+      float acc = h.fc_b0[tid];
+      for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w0[tid * 96 + q], s_in[q], acc);
+      s_hid[tid] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int r = tid; r < 384; r += 128) {
+      float acc = h.fc_b1[r];
+      for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w1[r * 96 + q], s_hid[q], acc);
+      s_w[r] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      // output columns: [32x0o (path B: 1e x T1) | 32x0e (path A: 1o x T1)]; weights: path A first, each [u=6][w=32]
+      const int wcol = tid & 31;
+      float r = 0.f;
+      if (tid < 32) { for (int q = 0; q < 6; ++q) r = fmaf(s_w[192 + q * 32 + wcol], s_db[q], r); }
+      else          { for (int q = 0; q < 6; ++q) r = fmaf(s_w[q * 32 + wcol], s_da[q], r); }
+      s_acc[tid] += r;
+    }
+    __syncthreads();
+  }
+  if (tid < 64) {
+    const float mean = s_acc[tid] / (float)(ne > 1 ? ne : 1);
+    const float f = (mean - h.bn_mean[tid]) * h.bn_scale[tid] + h.bn_bias[tid];
+    s_feat[tid] = f;
+    if (dbg_feat) dbg_feat[(size_t)blockIdx.x * 64 + tid] = f;
+  }
+  __syncthreads();
+  if (tid < 32) {
+    float acc = 0.f;
+    for (int q = 0; q < 64; ++q) acc = fmaf(h.tf_w0[tid * 64 + q], s_feat[q], acc);
+    float t = tanhf(acc) * h.tf_w1[tid];
+    for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (tid == 0) {
+      tor_out[blockIdx.x] = t * tor_norm_sqrt;
+      if (tor_edge_count) atomicAdd(tor_edge_count, ne);
+    }
+  }
+}
+
+hipError_t launch_bond_head(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, float lig_r,
+                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, hipStream_t s) {
+  if (gs.R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bond_head_kernel, dim3(B * gs.R), dim3(128), 0, s, h, gs, pos, node, lig_r * lig_r, cap, tor_norm_sqrt,
+                     tor_out, tor_edge_count, dbg_feat);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Reverse-SDE perturbation (utils/sampling.py:119-141) + modify_conformer_batch (utils/diffusion_utils.py:60-78):
+// rigid update about the centroid, R sequential torsion rotations (utils/torsion.py:75-90, order dependent),
+// Kabsch re-alignment of the flexible pose onto the rigid one (utils/geometry.py:246-276; closed form via Horn's
+// quaternion + fp64 Jacobi, tests/test_kernel_math.py::horn_rotation).  One wave per sample, one lane per atom.
+CBD_DEV void axis_angle_to_matrix(float ax, float ay, float az, float (&R)[9]) {
+  // via quaternion, incl. the |angle| < 1e-6 series branch (utils/geometry.py:39-86)
+  const float ang = sqrtf(ax * ax + ay * ay + az * az);
+  const float half = 0.5f * ang;
+  const float k = fabsf(ang) < 1e-6f ? 0.5f - (ang * ang) / 48.f : sinf(half) / ang;
+  const float r = cosf(half), i = ax * k, j = ay * k, kk = az * k;
+  const float two_s = 2.0f / (r * r + i * i + j * j + kk * kk);
+  R[0] = 1 - two_s * (j * j + kk * kk); R[1] = two_s * (i * j - kk * r);     R[2] = two_s * (i * kk + j * r);
+  R[3] = two_s * (i * j + kk * r);     R[4] = 1 - two_s * (i * i + kk * kk); R[5] = two_s * (j * kk - i * r);
+  R[6] = two_s * (i * kk - j * r);     R[7] = two_s * (j * kk + i * r);     R[8] = 1 - two_s * (i * i + j * j);
+}
+
+CBD_DEV float wave_sum(float v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+CBD_DEV double wave_sum_d(double v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+__global__ __launch_bounds__(64) void pose_update_kernel(GraphStatic gs, float* __restrict__ pos, const float* __restrict__ tr,
+                                                         const float* __restrict__ rot, const float* __restrict__ tor,
+                                                         const float* __restrict__ z_tr, const float* __restrict__ z_rot,
+                                                         const float* __restrict__ z_tor, SdeCoefs cf, int use_coefs) {
+  extern __shared__ float sp[];   // [Nl][3] flexible pose, [Nl][3] rigid pose
+  const int b = blockIdx.x, lane = lane_id();
+  const int Nl = gs.Nl, R = gs.R;
+  float* flex = sp;
+  float* rigid = sp + 3 * Nl;
+  float* P = pos + (size_t)b * Nl * 3;
+  // perturbations
+  float trp[3], rotp[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (use_coefs) {
+      trp[c] = cf.tr_s * tr[b * 3 + c] + (z_tr ? cf.tr_n * z_tr[b * 3 + c] : 0.f);
+      rotp[c] = cf.rot_s * rot[b * 3 + c] + (z_rot ? cf.rot_n * z_rot[b * 3 + c] : 0.f);
+    } else {
+      trp[c] = tr[b * 3 + c];
+      rotp[c] = rot[b * 3 + c];
+    }
+  }
+  // centroid
+  float cx = 0.f, cy = 0.f, cz = 0.f;
+  for (int a = lane; a < Nl; a += 64) { cx += P[3 * a]; cy += P[3 * a + 1]; cz += P[3 * a + 2]; }
+  cx = wave_sum(cx) / (float)Nl; cy = wave_sum(cy) / (float)Nl; cz = wave_sum(cz) / (float)Nl;
+  float Rm[9];
+  axis_angle_to_matrix(rotp[0], rotp[1], rotp[2], Rm);
+  for (int a = lane; a < Nl; a += 64) {
+    const float x = P[3 * a] - cx, y = P[3 * a + 1] - cy, z = P[3 * a + 2] - cz;
+    const float nx = Rm[0] * x + Rm[1] * y + Rm[2] * z + trp[0] + cx;
+    const float ny = Rm[3] * x + Rm[4] * y + Rm[5] * z + trp[1] + cy;
+    const float nz = Rm[6] * x + Rm[7] * y + Rm[8] * z + trp[2] + cz;
+    rigid[3 * a] = nx; rigid[3 * a + 1] = ny; rigid[3 * a + 2] = nz;
+    flex[3 * a] = nx; flex[3 * a + 1] = ny; flex[3 * a + 2] = nz;
+  }
+  __syncthreads();
+  if (tor == nullptr || R == 0) {
+    for (int a = lane; a < Nl; a += 64) { P[3 * a] = rigid[3 * a]; P[3 * a + 1] = rigid[3 * a + 1]; P[3 * a + 2] = rigid[3 * a + 2]; }
+    return;
+  }
+  // sequential torsions on the already-updated coordinates
+  for (int rho = 0; rho < R; ++rho) {
+    float th = use_coefs ? cf.tor_s * tor[b * R + rho] + (z_tor ? cf.tor_n * z_tor[b * R + rho] : 0.f) : tor[b * R + rho];
+    const int u = gs.rot_u[rho], v = gs.rot_v[rho];
+    const float vx = flex[3 * v], vy = flex[3 * v + 1], vz = flex[3 * v + 2];
+    float ax = flex[3 * u] - vx, ay = flex[3 * u + 1] - vy, az = flex[3 * u + 2] - vz;
+    const float n = sqrtf(ax * ax + ay * ay + az * az);
+    ax = ax / n * th; ay = ay / n * th; az = az / n * th;
+    float Q[9];
+    axis_angle_to_matrix(ax, ay, az, Q);
+    __syncthreads();
+    for (int a = lane; a < Nl; a += 64) {
+      if (gs.mask_rotate[rho * Nl + a]) {
+        const float x = flex[3 * a] - vx, y = flex[3 * a + 1] - vy, z = flex[3 * a + 2] - vz;
+        flex[3 * a] = Q[0] * x + Q[1] * y + Q[2] * z + vx;
+        flex[3 * a + 1] = Q[3] * x + Q[4] * y + Q[5] * z + vy;
+        flex[3 * a + 2] = Q[6] * x + Q[7] * y + Q[8] * z + vz;
+      }
+    }
+    __syncthreads();
+  }
+  // Kabsch: R, t minimising |R flex + t - rigid|
+  float fa[3] = {0, 0, 0}, fb[3] = {0, 0, 0};
+  for (int a = lane; a < Nl; a += 64)
+    for (int c = 0; c < 3; ++c) { fa[c] += flex[3 * a + c]; fb[c] += rigid[3 * a + c]; }
+  for (int c = 0; c < 3; ++c) { fa[c] = wave_sum(fa[c]) / (float)Nl; fb[c] = wave_sum(fb[c]) / (float)Nl; }
+  double S[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = lane; a < Nl; a += 64) {
+    const float am[3] = {flex[3 * a] - fa[0], flex[3 * a + 1] - fa[1], flex[3 * a + 2] - fa[2]};
+    const float bm[3] = {rigid[3 * a] - fb[0], rigid[3 * a + 1] - fb[1], rigid[3 * a + 2] - fb[2]};
+    for (int i = 0; i < 3; ++i)
+      for (int k = 0; k < 3; ++k) S[3 * i + k] += (double)(am[i] * bm[k]);
+  }
+  for (int i = 0; i < 9; ++i) S[i] = wave_sum_d(S[i]);
+  double N[4][4] = {{S[0] + S[4] + S[8], S[5] - S[7], S[6] - S[2], S[1] - S[3]},
+                    {S[5] - S[7], S[0] - S[4] - S[8], S[1] + S[3], S[6] + S[2]},
+                    {S[6] - S[2], S[1] + S[3], -S[0] + S[4] - S[8], S[5] + S[7]},
+                    {S[1] - S[3], S[6] + S[2], S[5] + S[7], -S[0] - S[4] + S[8]}};
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    for (int p = 0; p < 3; ++p)
+      for (int q = p + 1; q < 4; ++q) {
+        const double apq = N[p][q];
+        if (fabs(apq) < 1e-280) continue;
+        const double th = (N[q][q] - N[p][p]) / (2.0 * apq);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+        const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {   // N <- N J
+          const double nkp = N[k][p], nkq = N[k][q];
+          N[k][p] = c * nkp - s * nkq; N[k][q] = s * nkp + c * nkq;
+        }
+        for (int k = 0; k < 4; ++k) {   // N <- J^T N
+          const double npk = N[p][k], nqk = N[q][k];
+          N[p][k] = c * npk - s * nqk; N[q][k] = s * npk + c * nqk;
+        }
+        for (int k = 0; k < 4; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k) if (N[k][k] > N[best][best]) best = k;
+  const double w = V[0][best], x = V[1][best], y = V[2][best], z = V[3][best];
+  const float Rk[9] = {(float)(w * w + x * x - y * y - z * z), (float)(2 * (x * y - w * z)), (float)(2 * (x * z + w * y)),
+                       (float)(2 * (x * y + w * z)), (float)(w * w - x * x + y * y - z * z), (float)(2 * (y * z - w * x)),
+                       (float)(2 * (x * z - w * y)), (float)(2 * (y * z + w * x)), (float)(w * w - x * x - y * y + z * z)};
+  // t = -R ca + cb ; aligned = flex R^T + t
+  const float tx = fb[0] - (Rk[0] * fa[0] + Rk[1] * fa[1] + Rk[2] * fa[2]);
+  const float ty = fb[1] - (Rk[3] * fa[0] + Rk[4] * fa[1] + Rk[5] * fa[2]);
+  const float tz = fb[2] - (Rk[6] * fa[0] + Rk[7] * fa[1] + Rk[8] * fa[2]);
+  for (int a = lane; a < Nl; a += 64) {
+    const float fx = flex[3 * a], fy = flex[3 * a + 1], fz = flex[3 * a + 2];
+    P[3 * a] = Rk[0] * fx + Rk[1] * fy + Rk[2] * fz + tx;
+    P[3 * a + 1] = Rk[3] * fx + Rk[4] * fy + Rk[5] * fz + ty;
+    P[3 * a + 2] = Rk[6] * fx + Rk[7] * fy + Rk[8] * fz + tz;
+  }
+}
+
+hipError_t launch_pose_update(const GraphStatic& gs, float* pos, int B, const float* tr, const float* rot, const float* tor,
+                              const float* z_tr, const float* z_rot, const float* z_tor, const SdeCoefs* coefs, hipStream_t s) {
+  SdeCoefs c{};
+  if (coefs) c = *coefs;
+  hipLaunchKernelGGL(pose_update_kernel, dim3(B), dim3(64), gs.Nl * 6 * sizeof(float), s, gs, pos, tr, rot, tor, z_tr, z_rot, z_tor,
+                     c, coefs ? 1 : 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Receptor node encoder: embedding(residue type) then Linear over [embedding | LM features]  (score_model.py:33-41,310).
+__global__ __launch_bounds__(64) void rec_node_embed_kernel(const float* __restrict__ rec_x, int Nr, int lm_dim,
+                                                            const float* __restrict__ emb, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ node) {
+  const int r = blockIdx.x, lane = lane_id();
+  const float* x = rec_x + (size_t)r * (1 + lm_dim);
+  const int type = (int)x[0];
+  const int in_dim = 32 + lm_dim;
+  for (int c = lane; c < NODE_STRIDE; c += 64) {
+    float v = 0.f;
+    if (c < 32) {
+      if (lm_dim > 0) {
+        v = bias[c];
+        const float* wr = w + (size_t)c * in_dim;
+        for (int k = 0; k < 32; ++k) v = fmaf(wr[k], emb[type * 32 + k], v);
+        for (int k = 0; k < lm_dim; ++k) v = fmaf(wr[32 + k], x[1 + k], v);
+      } else {
+        v = emb[type * 32 + c];
+      }
+    }
+    node[(size_t)r * NODE_STRIDE + c] = v;
+  }
+}
+hipError_t launch_rec_node_embed(const float* rec_x, int Nr, int lm_dim, const float* emb_table, const float* w, const float* b,
+                                 float* node, hipStream_t s) {
+  hipLaunchKernelGGL(rec_node_embed_kernel, dim3(Nr), dim3(64), 0, s, rec_x, Nr, lm_dim, emb_table, w, b, node);
+  return hipGetLastError();
+}
+
+// vec4[e] = unit(pos[dst] - pos[src]), dist[e] = |.|      (receptor kNN edges, score_model.py:531-536)
+__global__ void edge_geom_kernel(const float* __restrict__ pos, const int* __restrict__ src, const int* __restrict__ dst, int n,
+                                 float* __restrict__ vec4, float* __restrict__ dist) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  const int s = src[e], d = dst[e];
+  float ux, uy, uz, nn;
+  unit_vec(pos[3 * d] - pos[3 * s], pos[3 * d + 1] - pos[3 * s + 1], pos[3 * d + 2] - pos[3 * s + 2], ux, uy, uz, nn);
+  reinterpret_cast<f32x4*>(vec4)[e] = f32x4{ux, uy, uz, 0.f};
+  dist[e] = nn;
+}
+hipError_t launch_edge_geom(const float* pos, const int* src, const int* dst, int n, float* vec4, float* dist, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_geom_kernel, dim3((n + 255) / 256), dim3(256), 0, s, pos, src, dst, n, vec4, dist);
+  return hipGetLastError();
+}
+
+__global__ void fill_i32_kernel(int* p, int v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, s, p, v, n);
+  return hipGetLastError();
+}
+
+}  // namespace cbd

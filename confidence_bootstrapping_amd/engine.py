@@ -1,0 +1,332 @@
+"""ctypes binding of libcbdock.so (include/cbdock.h) and the glue between the reference-shaped Python API
+(`TensorProductScoreModel.forward(batch)`, `sampling()`) and the C ABI.
+
+PyTorch is used here only for device memory and streams.  There is no CPU or eager fallback: if the HIP library
+cannot be loaded every entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import so3, torus
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcbdock.so")
+_lib = None
+
+
+class cbd_config(C.Structure):
+    _fields_ = [("ns", C.c_int32), ("nv", C.c_int32), ("num_conv_layers", C.c_int32), ("num_prot_emb_layers", C.c_int32),
+                ("lm_embedding_dim", C.c_int32), ("no_torsion", C.c_int32), ("lig_max_radius", C.c_float),
+                ("rec_max_radius", C.c_float), ("cross_max_distance", C.c_float), ("center_max_distance", C.c_float),
+                ("lig_radius_cap", C.c_int32), ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
+class cbd_step(C.Structure):
+    _fields_ = [("t", C.c_float), ("tr_sigma", C.c_float), ("cross_cutoff", C.c_float), ("rot_score_norm", C.c_float),
+                ("tor_score_norm_sqrt", C.c_float), ("tr_score_coef", C.c_float), ("tr_noise_coef", C.c_float),
+                ("rot_score_coef", C.c_float), ("rot_noise_coef", C.c_float), ("tor_score_coef", C.c_float),
+                ("tor_noise_coef", C.c_float), ("sigma_emb", C.c_float * 32)]
+
+
+# every symbol include/cbdock.h declares: name -> (restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = {
+    "cbd_last_error": (C.c_char_p, []),
+    "cbd_version": (C.c_char_p, []),
+    "cbd_create": (C.c_int, [C.POINTER(cbd_config), C.POINTER(_P)]),
+    "cbd_destroy": (C.c_int, [_P]),
+    "cbd_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
+    "cbd_finalize_weights": (C.c_int, [_P]),
+    "cbd_set_complex": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_score": (C.c_int, [_P, C.c_int32, _P, C.POINTER(cbd_step), _P, _P, _P, _P]),
+    "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
+    "cbd_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
+    "cbd_last_edge_counts": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "cbd_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "cbd_conv_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "cbd_pack_conv_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+}
+
+
+def load_library(path: Optional[str] = None):
+    """dlopen the in-tree HIP library and bind every declared symbol.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(f"{p} not found: build the HIP engine first (python __graft_entry__.py); "
+                           "there is no CPU fallback for the score model / sampler")
+    lib = C.CDLL(p)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"cbdock error {rc}: {load_library().cbd_last_error().decode()}")
+
+
+def _dptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _hptr(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def make_steps(t_schedule, model_args, timestep_emb_func, ode=False, no_random=False, no_final_step_noise=False,
+               temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+    """Per-step host scalars, computed with the reference's own scalar arithmetic and dtypes
+    (utils/sampling.py:94-167; models/score_model.py:338,347,419-420,447).  Returns a ctypes array of cbd_step."""
+    S = len(t_schedule)
+    steps = (cbd_step * S)()
+    a = model_args
+    temp_sampling = list(temp_sampling) if np.iterable(temp_sampling) else [temp_sampling] * 3
+    temp_psi = list(temp_psi) if np.iterable(temp_psi) else [temp_psi] * 3
+    lims = [(a.tr_sigma_min, a.tr_sigma_max), (a.rot_sigma_min, a.rot_sigma_max), (a.tor_sigma_min, a.tor_sigma_max)]
+    for i in range(S):
+        t = t_schedule[i]
+        dt = t_schedule[i] - t_schedule[i + 1] if i < S - 1 else t_schedule[i]
+        st = steps[i]
+        st.t = float(t)
+        # model side: complex_t is an fp32 tensor, t_to_sigma evaluated on it
+        ct = float(t) * torch.ones(1)
+        sig_t = [lo ** (1 - ct) * hi ** ct for lo, hi in lims]
+        st.tr_sigma = float(sig_t[0][0])
+        st.cross_cutoff = float((sig_t[0] * 3 + 20)[0])
+        st.rot_score_norm = float(so3.score_norm(sig_t[1])[0])
+        st.tor_score_norm_sqrt = float(torch.sqrt(torch.tensor(torus.score_norm(sig_t[2].numpy())).float())[0])
+        emb = timestep_emb_func(ct)[0]
+        for k in range(32):
+            st.sigma_emb[k] = float(emb[k])
+        # sampler side: float64 sigma, fp32 g (0-dim tensor), python/numpy scalars for dt
+        noise_on = not (no_random or ode or (no_final_step_noise and i == S - 1))
+        coefs = []
+        for k, (lo, hi) in enumerate(lims):
+            sigma = lo ** (1 - t) * hi ** t
+            g = sigma * torch.sqrt(torch.tensor(2 * np.log(hi / lo)))
+            if ode:
+                sc, nc = 0.5 * g ** 2 * dt, 0.0
+            elif temp_sampling[k] != 1.0:
+                sigma_data = np.exp(temp_sigma_data * np.log(hi) + (1 - temp_sigma_data) * np.log(lo))
+                lam = (sigma_data + sigma) / (sigma_data + sigma / temp_sampling[k])
+                sc = g ** 2 * dt * (lam + temp_sampling[k] * temp_psi[k] / 2)
+                nc = g * np.sqrt(dt * (1 + temp_psi[k]))
+            else:
+                sc, nc = g ** 2 * dt, g * np.sqrt(dt)
+            coefs.append((float(sc), float(nc) if noise_on else 0.0))
+        (st.tr_score_coef, st.tr_noise_coef), (st.rot_score_coef, st.rot_noise_coef), (st.tor_score_coef, st.tor_noise_coef) = coefs
+    return steps
+
+
+class DockEngine:
+    """One engine per (model weights, device).  Holds the C handle; methods mirror the C ABI."""
+
+    def __init__(self, device: torch.device, max_batch: int = 64, lm_embedding_dim: int = 1280, no_torsion: bool = False,
+                 lig_max_radius=5.0, rec_max_radius=30.0, cross_max_distance=80.0, center_max_distance=30.0):
+        self.lib = load_library()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the docking engine runs on an MI355X (device type 'cuda' under ROCm); got " + str(device))
+        self.device = device
+        cfg = cbd_config(32, 6, 5, 3, lm_embedding_dim, int(no_torsion), lig_max_radius, rec_max_radius, cross_max_distance,
+                         center_max_distance, 32, max_batch, device.index or 0)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _check(self.lib.cbd_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+        self.complex_key = None
+        self.Nl = self.Nr = self.R = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.cbd_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- weights
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.detach().cpu().float().numpy())
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape) if a.ndim else (C.c_int64 * 1)(1)
+            _check(self.lib.cbd_load_weight(self.h, k.encode(), _hptr(a), shape, a.ndim))
+        _check(self.lib.cbd_finalize_weights(self.h))
+        self.complex_key = None
+
+    @classmethod
+    def from_model(cls, model, device, max_batch: int = 64):
+        eng = cls(device, max_batch=max_batch, lm_embedding_dim=1280 if model.lm_embedding_type == "precomputed" else 0,
+                  no_torsion=model.no_torsion, lig_max_radius=model.lig_max_radius, rec_max_radius=model.rec_max_radius,
+                  cross_max_distance=model.cross_max_distance, center_max_distance=model.center_max_distance)
+        eng.load_state_dict(model.state_dict())
+        return eng
+
+    # ---- complex
+    def set_complex(self, graph, key=None):
+        """graph: one HeteroData-like complex (un-batched; a 1-graph Batch is fine)."""
+        lig, rec = graph["ligand"], graph["receptor"]
+        mr = lig.mask_rotate
+        while isinstance(mr, (list, tuple)):
+            mr = mr[0]
+        mr = np.ascontiguousarray(np.asarray(mr), dtype=np.uint8)
+        lig_x = np.ascontiguousarray(lig.x.cpu().numpy().astype(np.int64))
+        bidx = np.ascontiguousarray(graph["ligand", "ligand"].edge_index.cpu().numpy().astype(np.int64))
+        battr = np.ascontiguousarray(graph["ligand", "ligand"].edge_attr.cpu().float().numpy())
+        emask = np.ascontiguousarray(lig.edge_mask.cpu().numpy().astype(np.uint8))
+        rec_x = np.ascontiguousarray(rec.x.cpu().float().numpy())
+        rec_pos = np.ascontiguousarray(rec.pos.cpu().float().numpy())
+        ridx = np.ascontiguousarray(graph["receptor", "receptor"].edge_index.cpu().numpy().astype(np.int64))
+        Nl, Nr, nbd, R, Err = lig_x.shape[0], rec_x.shape[0], bidx.shape[1], int(emask.sum()), ridx.shape[1]
+        if rec_x.shape[1] != 1 + self.cfg.lm_embedding_dim:
+            raise RuntimeError(f"receptor features have {rec_x.shape[1]} columns, expected {1 + self.cfg.lm_embedding_dim}")
+        if mr.size and mr.shape != (R, Nl):
+            raise RuntimeError(f"mask_rotate shape {mr.shape} != ({R}, {Nl})")
+        _check(self.lib.cbd_set_complex(self.h, Nl, Nr, nbd, R, Err, _hptr(lig_x), _hptr(bidx), _hptr(battr), _hptr(emask),
+                                        _hptr(mr) if mr.size else None, _hptr(rec_x), _hptr(rec_pos), _hptr(ridx)))
+        self.Nl, self.Nr, self.R = Nl, Nr, R
+        self.complex_key = key
+
+    # ---- compute
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def score(self, pos: torch.Tensor, step: cbd_step):
+        B = pos.shape[0]
+        pos = pos.to(self.device, torch.float32).contiguous()
+        tr = torch.empty(B, 3, device=self.device)
+        rot = torch.empty(B, 3, device=self.device)
+        tor = torch.empty(B * self.R, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_score(self.h, B, _dptr(pos), C.byref(step), _dptr(tr), _dptr(rot), _dptr(tor), self._stream()))
+        return tr, rot, tor
+
+    def modify_conformer(self, pos, tr, rot, tor):
+        B = pos.shape[0]
+        pos = pos.to(self.device, torch.float32).contiguous().clone()
+        f = lambda x: None if x is None else x.to(self.device, torch.float32).contiguous()
+        tr, rot, tor = f(tr), f(rot), f(tor)
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_modify_conformer(self.h, B, _dptr(pos), _dptr(tr), _dptr(rot), _dptr(tor), self._stream()))
+        return pos
+
+    def sample(self, pos, steps, noise_tr=None, noise_rot=None, noise_tor=None, return_scores=False):
+        """In-place reverse diffusion of pos [B,Nl,3] (device tensor) over len(steps) steps."""
+        B, S = pos.shape[0], len(steps)
+        assert pos.is_cuda and pos.dtype == torch.float32 and pos.is_contiguous()
+        f = lambda x: None if x is None else x.to(self.device, torch.float32).contiguous()
+        noise_tr, noise_rot, noise_tor = f(noise_tr), f(noise_rot), f(noise_tor)
+        scores = torch.empty(S, B * (6 + self.R), device=self.device) if return_scores else None
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_sample(self.h, B, S, steps, _dptr(pos), _dptr(noise_tr), _dptr(noise_rot), _dptr(noise_tor),
+                                       _dptr(scores), self._stream()))
+        return scores
+
+    # ---- introspection
+    def debug(self, enable=True):
+        self.lib.cbd_debug_fetch(self.h, b"enable" if enable else b"disable", None, 0)
+
+    def fetch(self, name: str, capacity: int = 1 << 24):
+        buf = np.empty(capacity, dtype=np.float32)
+        n = self.lib.cbd_debug_fetch(self.h, name.encode(), _hptr(buf), capacity)
+        if n < 0:
+            raise RuntimeError(self.lib.cbd_last_error().decode())
+        return buf[:n].copy()
+
+    def edge_counts(self):
+        c = (C.c_int64 * 5)()
+        _check(self.lib.cbd_last_edge_counts(self.h, c))
+        return dict(zip(("ll", "lr", "rr", "rl", "tor"), list(c)))
+
+    def kernel_timing(self, enable=True, reset=False):
+        avg, n, tot = C.c_double(), C.c_int64(), C.c_double()
+        _check(self.lib.cbd_kernel_timing(self.h, int(enable), int(reset), C.byref(avg), C.byref(n), C.byref(tot)))
+        return avg.value, n.value, tot.value
+
+
+def pack_conv_stream(in_level, out_level, w1, b1, w2, b2):
+    """Host-only: the MFMA weight-tile stream of one FCBlock (for the CPU emulation tests)."""
+    lib = load_library()
+    n = lib.cbd_conv_stream_floats(in_level, out_level)
+    out = np.empty(n, dtype=np.float32)
+    arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (w1, b1, w2, b2)]
+    _check(lib.cbd_pack_conv_stream(in_level, out_level, *[_hptr(a) for a in arrs], _hptr(out)))
+    return out
+
+
+def _single_complex(data):
+    """Un-batched view of the (identical) complexes in a batch: node/edge slices of graph 0."""
+    B = data.num_graphs
+    lig, rec = data["ligand"], data["receptor"]
+    Nl, Nr = lig.num_nodes // B, rec.num_nodes // B
+    M, Err = data["ligand", "ligand"].num_edges // B, data["receptor", "receptor"].num_edges // B
+    from .hetero import HeteroData
+    g = HeteroData()
+    g["ligand"].x = lig.x[:Nl]
+    g["ligand"].pos = lig.pos[:Nl]
+    g["ligand"].edge_mask = lig.edge_mask[:M]
+    mr = lig.mask_rotate
+    while isinstance(mr, (list, tuple)):
+        mr = mr[0]
+    g["ligand"].mask_rotate = mr
+    g["ligand", "ligand"].edge_index = data["ligand", "ligand"].edge_index[:, :M]
+    g["ligand", "ligand"].edge_attr = data["ligand", "ligand"].edge_attr[:M]
+    g["receptor"].x = rec.x[:Nr]
+    g["receptor"].pos = rec.pos[:Nr]
+    g["receptor", "receptor"].edge_index = data["receptor", "receptor"].edge_index[:, :Err]
+    return g, B, Nl
+
+
+def complex_fingerprint(data):
+    """Cheap identity of the complex a batch is made of (names + sizes), to skip re-uploading it every step."""
+    name = getattr(data, "name", None)
+    if isinstance(name, (list, tuple)):
+        name = name[0]
+        while isinstance(name, (list, tuple)):
+            name = name[0]
+    B = data.num_graphs
+    return (name, data["ligand"].num_nodes // B, data["receptor"].num_nodes // B,
+            data["ligand", "ligand"].num_edges // B, int(data["receptor"].pos[0].sum().item() * 1e3))
+
+
+def score_batch(model, data):
+    """TensorProductScoreModel.forward(batch): returns (tr_pred, rot_pred, tor_pred, None)."""
+    eng = model.engine()
+    ct = data.complex_t
+    t_tr = ct["tr"].detach().cpu()
+    if not (torch.all(t_tr == t_tr[0]) and torch.equal(ct["rot"].cpu(), t_tr) and torch.equal(ct["tor"].cpu(), t_tr)):
+        raise NotImplementedError("per-sample / separate diffusion times are outside the MI355X hot path")
+    g, B, Nl = _single_complex(data)
+    key = complex_fingerprint(data)
+    if eng.complex_key != key:
+        eng.set_complex(g, key)
+    t = float(t_tr[0])
+    steps = make_steps(np.array([t]), _ArgsFromModel(model), model.timestep_emb_func)
+    pos = data["ligand"].pos.reshape(B, Nl, 3)
+    tr, rot, tor = eng.score(pos, steps[0])
+    if model.no_torsion or eng.R == 0:
+        tor = torch.empty(0, device=eng.device)
+    return tr, rot, tor, None
+
+
+class _ArgsFromModel:
+    """sigma limits for a bare forward call: recovered from model.t_to_sigma (a partial over args)."""
+
+    def __init__(self, model):
+        a = getattr(model.t_to_sigma, "keywords", {}).get("args")
+        if a is None:
+            raise RuntimeError("model.t_to_sigma must be functools.partial(t_to_sigma, args=model_args)")
+        for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max", "tor_sigma_min", "tor_sigma_max"):
+            setattr(self, k, getattr(a, k))

@@ -1,0 +1,147 @@
+"""`sampling()` and `randomize_position()` with the reference's signatures and semantics
+(reference utils/sampling.py:15-48, 59-274), driving the MI355X engine.
+
+What stays on the host (as in the reference): batching the data list, the schedule scalars of every step
+(engine.make_steps), drawing the N(0,1) noise in the reference's order, writing poses back into `data_list`.
+What moves to the GPU as ONE call per batch: the whole step loop (score model + perturbation + pose update),
+`cbd_sample` in include/cbdock.h -- no per-step host round trips, no `.item()` syncs.
+
+Differences from the reference that are deliberate and documented:
+  * noise for a partial last batch is drawn with the batch's real size b (the reference draws min(batch_size, N)
+    rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
+  * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
+    rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
+  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond, asynchronous schedules raise
+    NotImplementedError (the first three also raise in the reference).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+from scipy.spatial.transform import Rotation as R
+
+from .engine import make_steps, complex_fingerprint, _single_complex
+from .hetero import DataLoader
+
+
+def _mask_rotate_of(graph):
+    mr = graph["ligand"].mask_rotate
+    while isinstance(mr, (list, tuple)):
+        mr = mr[0]
+    return np.asarray(mr)
+
+
+def modify_conformer_torsion_angles(pos, edge_index, mask_rotate, torsion_updates, as_numpy=False):
+    """Sequential torsion rotations on the host (reference utils/torsion.py:48-72); used by randomize_position only."""
+    pos = pos.cpu().numpy().copy() if torch.is_tensor(pos) else np.array(pos, copy=True)
+    edge_index = edge_index.cpu().numpy() if torch.is_tensor(edge_index) else np.asarray(edge_index)
+    for idx_edge, (u, v) in enumerate(edge_index):
+        if torsion_updates[idx_edge] == 0:
+            continue
+        rot_vec = pos[u] - pos[v]
+        rot_vec = rot_vec * torsion_updates[idx_edge] / np.linalg.norm(rot_vec)
+        rot_mat = R.from_rotvec(rot_vec).as_matrix()
+        pos[mask_rotate[idx_edge]] = (pos[mask_rotate[idx_edge]] - pos[v]) @ rot_mat.T + pos[v]
+    return pos if as_numpy else torch.from_numpy(pos.astype(np.float32))
+
+
+def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, pocket_knowledge=False, pocket_cutoff=7):
+    """In-place initial pose randomisation; RNG use identical to the reference (numpy global for torsions,
+    scipy Rotation.random, torch global for the translation)."""
+    center_pocket = data_list[0]["receptor"].pos.mean(dim=0)
+    if pocket_knowledge:
+        cg = data_list[0]
+        orig = cg["ligand"].orig_pos
+        orig = orig[0] if isinstance(orig, (list, tuple)) else orig
+        d = torch.cdist(cg["receptor"].pos, torch.from_numpy(np.asarray(orig)).float() - cg.original_center)
+        label = torch.any(d < pocket_cutoff, dim=1)
+        if torch.any(label):
+            center_pocket = cg["receptor"].pos[label].mean(dim=0)
+        else:
+            center_pocket = cg["receptor"].pos[torch.argmin(torch.min(d, dim=1)[0])]
+    if not no_torsion:
+        for g in data_list:
+            n_tor = int(g["ligand"].edge_mask.sum())
+            torsion_updates = np.random.uniform(low=-np.pi, high=np.pi, size=n_tor)
+            g["ligand"].pos = modify_conformer_torsion_angles(
+                g["ligand"].pos, g["ligand", "ligand"].edge_index.T[g["ligand"].edge_mask], _mask_rotate_of(g), torsion_updates)
+    for g in data_list:
+        molecule_center = torch.mean(g["ligand"].pos, dim=0, keepdim=True)
+        random_rotation = torch.from_numpy(R.random().as_matrix()).float()
+        g["ligand"].pos = (g["ligand"].pos - molecule_center) @ random_rotation.T + center_pocket
+        if not no_random:
+            g["ligand"].pos += torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
+
+
+def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
+             no_random=False, ode=False, visualization_list=None, confidence_model=None, filtering_data_list=None,
+             filtering_model_args=None, asyncronous_noise_schedule=False, t_schedule=None, batch_size=32,
+             no_final_step_noise=False, pivot=None, return_full_trajectory=False, temp_sampling=1.0, temp_psi=0.0,
+             temp_sigma_data=0.5, return_features=False, svgd_weight_log_0=None, svgd_repulsive_weight_log_0=None,
+             svgd_weight_log_1=None, svgd_repulsive_weight_log_1=None, svgd_kernel_size_log_0=None,
+             svgd_kernel_size_log_1=None, svgd_langevin_weight_log_0=None, svgd_langevin_weight_log_1=None,
+             svgd_rot_log_rel_weight=0.0, svgd_tor_log_rel_weight=0.0, svgd_use_x0=False, noise=None):
+    """Reverse diffusion of every pose in `data_list`; returns (data_list, confidence) like the reference.
+    `noise` (optional, extension): dict of pre-drawn 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R] CPU tensors."""
+    N = len(data_list)
+    assert not (return_full_trajectory or return_features or pivot), "Not implemented yet in new inference version"
+    if svgd_weight_log_0 is not None and svgd_weight_log_1 is not None:
+        raise NotImplementedError("SVGD sampling (O(B^2) host loop in the reference) is outside the MI355X hot path")
+    if asyncronous_noise_schedule or t_schedule is not None:
+        raise NotImplementedError("asynchronous noise schedules are outside the MI355X hot path")
+    if getattr(model_args, "crop_beyond", None) is not None:
+        raise NotImplementedError("crop_beyond is only used by the all-atom / confidence model (SURVEY.md 8f-1)")
+    if confidence_model is not None:
+        raise NotImplementedError("confidence model scoring: SURVEY.md 8f-1 (next row)")
+    tr_schedule, rot_schedule, tor_schedule = (np.asarray(s, dtype=np.float64) for s in (tr_schedule, rot_schedule, tor_schedule))
+    if not (np.array_equal(tr_schedule, rot_schedule) and np.array_equal(tr_schedule, tor_schedule)):
+        raise NotImplementedError("--different_schedules: the engine takes one diffusion time per step")
+    if len(tr_schedule) != inference_steps:
+        raise ValueError("schedule length != inference_steps")
+    device = torch.device(device)
+    model = getattr(model, "module", model)
+    eng = model.engine()
+    steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
+                       no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
+                       temp_sigma_data=temp_sigma_data)
+    S = inference_steps
+    use_noise = not (no_random or ode)
+    loader = DataLoader(data_list, batch_size=batch_size)
+    offset = 0
+    with torch.no_grad():
+        for batch_id, batch in enumerate(loader):
+            b = batch.num_graphs
+            if b > eng.max_batch:
+                raise RuntimeError(f"batch of {b} exceeds the engine capacity {eng.max_batch}")
+            g, _, Nl = _single_complex(batch)
+            key = complex_fingerprint(batch)
+            if eng.complex_key != key:
+                eng.set_complex(g, key)
+            R_ = eng.R if not model_args.no_torsion else 0
+            z_tr = z_rot = z_tor = None
+            if use_noise:
+                if noise is not None:
+                    z_tr = noise["tr"][:, offset:offset + b]
+                    z_rot = noise["rot"][:, offset:offset + b]
+                    z_tor = noise["tor"][:, offset * R_:(offset + b) * R_] if R_ > 0 else None
+                else:
+                    tr_l, rot_l, tor_l = [], [], []
+                    for s in range(S):   # same order and sizes as the reference's torch.normal calls
+                        last_quiet = no_final_step_noise and s == S - 1
+                        tr_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
+                        rot_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
+                        if R_ > 0:
+                            tor_l.append(torch.zeros(b * R_) if last_quiet else torch.normal(mean=0, std=1, size=(b * R_,)))
+                    z_tr, z_rot = torch.stack(tr_l), torch.stack(rot_l)
+                    z_tor = torch.stack(tor_l) if R_ > 0 else None
+            pos = batch["ligand"].pos.reshape(b, Nl, 3).to(device, torch.float32).contiguous()
+            eng.sample(pos, steps, z_tr, z_rot, z_tor)
+            flat = pos.reshape(b * Nl, 3)
+            for i in range(b):
+                data_list[batch_id * batch_size + i]["ligand"].pos = flat[i * Nl:(i + 1) * Nl]
+            offset += b
+            if visualization_list is not None:
+                for idx, visualization in enumerate(visualization_list):
+                    visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),
+                                      part=1, order=2)
+    return data_list, None

@@ -1,0 +1,136 @@
+/* cbdock.h -- C ABI of the MI355X (gfx950) reverse-diffusion docking engine.
+ *
+ * Drop-in boundary for ONE hot path of LDeng0205/confidence-bootstrapping: the score-model forward
+ * pass and the reverse-SDE pose update that `utils/sampling.sampling()` drives.  The reference has no
+ * FFI layer (it is pure Python over PyTorch/e3nn/PyG), so each entry point cites the Python interface it
+ * stands behind; the Python host shim (confidence_bootstrapping_amd/engine.py, ctypes) is the only
+ * intended caller, and INTEGRATION.md shows the binding a maintainer of the reference would add.
+ *
+ * Conventions: plain pointers and sizes only, no torch types.  Every function returns 0 on success and a
+ * negative cbd_status otherwise (cbd_last_error() gives the text); the Python shim raises RuntimeError so
+ * the reference's "catch, halve batch_size, retry" protocol (inference.py:566-570) keeps working.
+ * Caller owns every buffer passed in; weights/complex data are COPIED.  Pointers named *_host are host
+ * memory; pointers named *_dev are ROCm device memory on the engine's device.  One engine per GPU,
+ * not thread-safe, independent across engines.  All floating point is IEEE fp32, indices int32/int64 as typed.
+ */
+#ifndef CBDOCK_H
+#define CBDOCK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cbd_engine cbd_engine;
+
+typedef enum {
+  CBD_OK = 0,
+  CBD_ERR_ARG = -1,        /* bad argument / unsupported configuration            */
+  CBD_ERR_HIP = -2,        /* a HIP runtime call failed                            */
+  CBD_ERR_STATE = -3,      /* call order violated (weights/complex not set yet)    */
+  CBD_ERR_CAPACITY = -4,   /* batch larger than the capacity given to cbd_create  */
+  CBD_ERR_WEIGHT = -5      /* unknown tensor name or shape mismatch                */
+} cbd_status;
+
+/* Architecture + schedule constants.  Mirrors the keys of workdir/pretrained_score/model_parameters.yml that
+ * utils/utils.py:239-283 maps onto TensorProductScoreModel.__init__ (models/score_model.py:45-56).  Only the
+ * shipped architecture is implemented: ns=32, nv=6, sh_lmax=1, 3 embedding + 5 interaction layers. */
+typedef struct {
+  int32_t ns, nv;                   /* 32, 6                                              */
+  int32_t num_conv_layers;          /* 5                                                  */
+  int32_t num_prot_emb_layers;      /* 3                                                  */
+  int32_t lm_embedding_dim;         /* 1280 ('precomputed') or 0                          */
+  int32_t no_torsion;               /* 0/1                                                */
+  float lig_max_radius;             /* 5    (args.max_radius)                             */
+  float rec_max_radius;             /* 30                                                 */
+  float cross_max_distance;         /* 80                                                 */
+  float center_max_distance;        /* 30                                                 */
+  int32_t lig_radius_cap;           /* 32   torch_cluster max_num_neighbors default       */
+  int32_t max_batch;                /* capacity: poses per cbd_score / cbd_sample call    */
+  int32_t device;                   /* HIP device ordinal                                 */
+} cbd_config;
+
+/* Per-step scalars.  The reference computes these on the HOST in numpy/torch scalar code every step
+ * (utils/sampling.py:94-141, models/score_model.py:338,347,419-420,447 via utils/so3.py:90-94 and
+ * utils/torus.py:78-82); the Python shim does the same and hands them over, so the look-up tables and
+ * float64 scalar arithmetic stay bit-identical to the reference. */
+typedef struct {
+  float t;                 /* diffusion time (tr = rot = tor schedules coincide on this path)            */
+  float tr_sigma;          /* t_to_sigma on fp32 tensors, score_model.py:338                             */
+  float cross_cutoff;      /* 3*tr_sigma + 20, score_model.py:347                                        */
+  float rot_score_norm;    /* so3.score_norm(rot_sigma), score_model.py:420                              */
+  float tor_score_norm_sqrt; /* sqrt(torus.score_norm(tor_sigma)), score_model.py:447                    */
+  float tr_score_coef, tr_noise_coef;    /* g^2 dt (or 0.5 g^2 dt for ODE) and g sqrt(dt), sampling.py:119-132 */
+  float rot_score_coef, rot_noise_coef;
+  float tor_score_coef, tor_noise_coef;
+  float sigma_emb[32];     /* sinusoidal_embedding(embedding_scale * t, 32), diffusion_utils.py:99-110   */
+} cbd_step;
+
+const char* cbd_last_error(void);
+const char* cbd_version(void);
+
+/* TensorProductScoreModel.__init__ + .to(device)  (models/score_model.py:44-280, utils/utils.py:285-287). */
+int cbd_create(const cbd_config* cfg, cbd_engine** out);
+int cbd_destroy(cbd_engine* e);
+
+/* model.load_state_dict (inference.py:307): one call per state-dict tensor, name = checkpoint key
+ * (e.g. "conv_layers.0.fc.2.3.weight"), fp32 host data, row-major, shape as in the checkpoint.
+ * Unknown keys under final_conv.tp. / tor_bond_conv.tp. / final_tp_tor. are accepted and ignored. */
+int cbd_load_weight(cbd_engine* e, const char* name, const float* data_host, const int64_t* shape, int32_t ndim);
+/* Re-pack the weights into the MFMA operand streams; fails if a required tensor was never loaded (strict=True). */
+int cbd_finalize_weights(cbd_engine* e);
+
+/* The complex that the batch consists of copies of (utils/sampling.py assumes every sample in a batch is the
+ * same molecule, diffusion_utils.py:62-63).  Graph schema = datasets/process_mols.py:448-489,567-589:
+ *   lig_x [Nl,16] categorical features; lig_bond_index [2, n_bond_dir] (each bond twice, consecutive);
+ *   lig_bond_attr [n_bond_dir,4]; edge_mask [n_bond_dir] (0/1); mask_rotate [R, Nl] (0/1);
+ *   rec_x [Nr, 1+lm_dim] (col 0 residue type); rec_pos [Nr,3]; rec_edge_index [2, Err].
+ * Also runs the time-independent receptor embedding once (score_model.py:297-320). */
+int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t n_bond_dir, int32_t R, int32_t Err,
+                    const int64_t* lig_x_host, const int64_t* lig_bond_index_host, const float* lig_bond_attr_host,
+                    const uint8_t* edge_mask_host, const uint8_t* mask_rotate_host,
+                    const float* rec_x_host, const float* rec_pos_host, const int64_t* rec_edge_index_host);
+
+/* model(batch) -- TensorProductScoreModel.forward (models/score_model.py:333-449) for B copies of the complex
+ * at ligand poses pos [B,Nl,3].  Outputs: tr [B,3], rot [B,3], tor [B*R].  Device pointers; runs on `stream`
+ * (a hipStream_t passed as void*, NULL = default stream) and returns without synchronising. */
+int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* step_host,
+              float* tr_dev, float* rot_dev, float* tor_dev, void* stream);
+
+/* modify_conformer_batch (utils/diffusion_utils.py:60-78): rigid update + sequential torsions + Kabsch
+ * re-alignment.  tor_dev may be NULL (rigid only).  pos updated in place ([B,Nl,3]). */
+int cbd_modify_conformer(cbd_engine* e, int32_t B, float* pos_dev, const float* tr_dev, const float* rot_dev,
+                         const float* tor_dev, void* stream);
+
+/* The step loop of sampling() (utils/sampling.py:93-223) for one batch: S steps of score -> perturbation ->
+ * pose update.  noise_* are the N(0,1) draws the reference takes from torch.normal, lifted into inputs:
+ * noise_tr [S,B,3], noise_rot [S,B,3], noise_tor [S,B*R] (NULL => zeros, i.e. no_random).  A step whose
+ * *_noise_coef is 0 ignores its noise (no_final_step_noise / ODE).  pos_dev [B,Nl,3] is updated in place.
+ * If scores_out_dev != NULL it receives the per-step scores [S, B*(6+R)] (tr,rot,tor per step) for tests. */
+int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, float* pos_dev,
+               const float* noise_tr_dev, const float* noise_rot_dev, const float* noise_tor_dev,
+               float* scores_out_dev, void* stream);
+
+/* Introspection used by the parity tests and the benchmark.  After a cbd_score call, copies a named
+ * intermediate (see csrc/engine.hip: debug_names) to host memory; returns the element count or <0. */
+int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out_host, int64_t capacity);
+/* Device-side edge counts of the last forward pass: [ll, lr, rr, rl, tor]. */
+int cbd_last_edge_counts(cbd_engine* e, int64_t counts_host[5]);
+/* Average duration (ms) of the dominant kernel (tp_conv) over the launches since the last reset, measured
+ * with HIP events on the launch stream when timing is enabled; n_launches out.  enable: 0/1. */
+int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_ms_out, int64_t* n_launches_out,
+                      double* total_ms_out);
+
+/* Host-only helpers (no GPU needed), used by the CPU tests that emulate the MFMA tile algorithm:
+ * re-pack one FCBlock (Linear 96->96 [w1 96x96, b1 96], Linear 96->W [w2 Wx96, b2 W]; reference models/layers.py:8-15 as
+ * instantiated at models/tensor_layers.py:187-191) into the weight-tile stream of the tp_conv kernel.
+ * in_level 0..3 / out_level 1..3 index get_irrep_seq (models/tensor_layers.py:21-26). */
+int64_t cbd_conv_stream_floats(int32_t in_level, int32_t out_level);
+int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host,
+                         const float* w2_host, const float* b2_host, float* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CBDOCK_H */

@@ -45,7 +45,7 @@ def kabsch_batch(A: torch.Tensor, B: torch.Tensor):
     H = torch.bmm(A - ca, (B - cb).transpose(1, 2))
     U, S, Vt = torch.linalg.svd(H)
     R = torch.bmm(Vt.transpose(1, 2), U.transpose(1, 2))
-    SS = torch.diag(torch.tensor([1., 1., -1.]))
+    SS = torch.diag(torch.tensor([1., 1., -1.], dtype=A.dtype))
     Rm = torch.bmm(Vt.transpose(1, 2) @ SS, U.transpose(1, 2))
     R = torch.where(torch.linalg.det(R)[:, None, None] < 0, Rm, R)
     t = torch.bmm(-R, ca) + cb

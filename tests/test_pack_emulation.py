@@ -1,0 +1,158 @@
+"""CPU emulation of the tp_conv kernel's tile algorithm on the REAL packed weight stream produced by the C
+library (cbd_pack_conv_stream, host-only), compared with the oracle's FCBlock + FasterTensorProduct.
+
+This pins, without a GPU: the weight re-packing (k-permutation between the two GEMMs, row layout of the vector
+blocks, folded normalisation factors) and the lane/register index arithmetic the HIP kernel uses
+(csrc/tp_conv.hip).  The MFMA itself is emulated as an exact matrix product with its documented operand layout:
+  v_mfma_f32_32x32x2_f32: A[i = lane&31][k = lane>>5], B[k = lane>>5][j = lane&31],
+                          D[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31].
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import score_ref as sr
+from oracle.e3nn_ref import sh_l1
+
+KSTEPS, TILE_W, TILE = 48, 48 * 64, 48 * 64 + 32
+COL_1O, COL_1E, COL_0O = 32, 50, 68
+
+
+def row_of(reg, hf):
+    return (reg & 3) + 8 * (reg >> 2) + 4 * hf
+
+
+def gemm_tile(tile, B):
+    """tile: TILE floats; B[s][lane] -> acc[reg][lane] exactly as gemm_tile() in tp_conv.hip."""
+    A = tile[:TILE_W].reshape(12, 64, 4)            # [sg][lane][4]
+    bias = tile[TILE_W:]
+    D = np.zeros((32, 32), dtype=np.float64)        # [row][edge]
+    for s in range(KSTEPS):
+        a = A[s >> 2, :, s & 3]                     # per lane
+        for hf in range(2):
+            D += np.outer(a[32 * hf:32 * hf + 32], B[s][32 * hf:32 * hf + 32])   # A[i][k=hf] * B[k=hf][j]
+    D += bias[:, None]
+    acc = np.zeros((16, 64))
+    for lane in range(64):
+        for reg in range(16):
+            acc[reg, lane] = D[row_of(reg, lane >> 5), lane & 31]
+    return acc
+
+
+def shape(IN, OUT):
+    n1o, n1e, n0o = (6 if IN >= 1 else 0), (6 if IN >= 2 else 0), (6 if IN >= 3 else 0)
+    fan0e, fan1o = 32 + n1o, 32 + n1o + n1e
+    fan1e = n1o + n1e + n0o if OUT >= 2 else 0
+    fan0o = n1e + n0o if OUT >= 3 else 0
+    return dict(n1o=n1o, n1e=n1e, n0o=n0o, fan0e=fan0e, fan1o=fan1o, fan1e=fan1e, fan0o=fan0o,
+                t0e=fan0e, t1o=(fan1o + 3) // 4, t1e=(fan1e + 3) // 4, t0o=(fan0o + 3) // 4)
+
+
+def cross(a, v):
+    return np.array([a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]])
+
+
+def emulate(stream, IN, OUT, xin, xrow, v):
+    """One 32-edge wave tile.  xin [32,96] = [edge_attr | x_src[:32] | x_dst[:32]], xrow [32,80], v [32,3] unit."""
+    S = shape(IN, OUT)
+    tiles = stream.reshape(-1, TILE)
+    lanes = np.arange(64)
+    j, hf = lanes & 31, lanes >> 5
+    # first-Linear B operand: lane half hf holds columns 16hf..16hf+15 of each 32-wide source
+    Bx = np.zeros((KSTEPS, 64))
+    for s in range(KSTEPS):
+        Bx[s] = xin[j, 32 * (s // 16) + 16 * hf + (s % 16)]
+    T = 0
+    h1 = np.zeros((KSTEPS, 64))
+    for m in range(3):
+        acc = gemm_tile(tiles[T], Bx); T += 1
+        h1[16 * m:16 * m + 16] = np.maximum(acc, 0)
+
+    def mid0e(e, i):
+        return xrow[e, i] if i < 32 else float(xrow[e, COL_1O + 3 * (i - 32):COL_1O + 3 * (i - 32) + 3] @ v[e])
+
+    def mid1o(e, i):
+        if i < 32: return xrow[e, i] * v[e]
+        if i < 32 + S["n1o"]: return xrow[e, COL_1O + 3 * (i - 32):COL_1O + 3 * (i - 32) + 3]
+        if i < S["fan1o"]: return cross(xrow[e, COL_1E + 3 * (i - 32 - S["n1o"]):][:3], v[e])
+        return np.zeros(3)
+
+    def mid1e(e, i):
+        if i < S["n1o"]: return cross(xrow[e, COL_1O + 3 * i:][:3], v[e])
+        if i < S["n1o"] + S["n1e"]: return xrow[e, COL_1E + 3 * (i - S["n1o"]):][:3]
+        if i < S["fan1e"]: return xrow[e, COL_0O + (i - S["n1o"] - S["n1e"])] * v[e]
+        return np.zeros(3)
+
+    def mid0o(e, i):
+        if i < S["n1e"]: return float(xrow[e, COL_1E + 3 * i:][:3] @ v[e])
+        if i < S["fan0o"]: return xrow[e, COL_0O + (i - S["n1e"])]
+        return 0.0
+
+    out = np.zeros((32, 80))
+    o0e = np.zeros((16, 64))
+    for i in range(S["t0e"]):
+        acc = gemm_tile(tiles[T], h1); T += 1
+        for lane in range(64):
+            o0e[:, lane] += mid0e(lane & 31, i) * acc[:, lane]
+    for lane in range(64):
+        for reg in range(16):
+            out[lane & 31, row_of(reg, lane >> 5)] = o0e[reg, lane]
+
+    def vec_block(ntile, mid, col0):
+        ov = np.zeros((6, 3, 64))
+        nonlocal T
+        for t in range(ntile):
+            acc = gemm_tile(tiles[T], h1); T += 1
+            for lane in range(64):
+                for q in range(2):
+                    m = mid(lane & 31, 4 * t + (lane >> 5) + 2 * q)
+                    for o in range(6):
+                        ov[o, :, lane] += m * acc[8 * q + o, lane]
+        tot = ov[:, :, :32] + ov[:, :, 32:]
+        for e in range(32):
+            for o in range(6):
+                out[e, col0 + 3 * o:col0 + 3 * o + 3] = tot[o, :, e]
+
+    vec_block(S["t1o"], mid1o, COL_1O)
+    if OUT >= 2:
+        vec_block(S["t1e"], mid1e, COL_1E)
+    if OUT >= 3:
+        os_ = np.zeros((6, 64))
+        for t in range(S["t0o"]):
+            acc = gemm_tile(tiles[T], h1); T += 1
+            for lane in range(64):
+                for q in range(2):
+                    m = mid0o(lane & 31, 4 * t + (lane >> 5) + 2 * q)
+                    os_[:, lane] += m * acc[8 * q:8 * q + 6, lane]
+        out[:, COL_0O:COL_0O + 6] = (os_[:, :32] + os_[:, 32:]).T
+    assert T == tiles.shape[0]
+    return out
+
+
+@pytest.mark.parametrize("IN,OUT", [(0, 1), (1, 2), (2, 3), (3, 3)])
+def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
+    from confidence_bootstrapping_amd.engine import pack_conv_stream, load_library
+    lib = load_library()
+    g = torch.Generator().manual_seed(10 * IN + OUT)
+    in_irr, out_irr = sr.IRREP_SEQ[IN], sr.IRREP_SEQ[OUT]
+    W = sr.faster_tp_weight_numel(in_irr, out_irr)
+    w1, b1 = torch.randn(96, 96, generator=g) / 8, torch.randn(96, generator=g) / 4
+    w2, b2 = torch.randn(W, 96, generator=g) / 8, torch.randn(W, generator=g) / 4
+    stream = pack_conv_stream(IN, OUT, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
+    ntiles = {(0, 1): 3 + 32 + 8, (1, 2): 3 + 38 + 10 + 2, (2, 3): 3 + 38 + 11 + 3 + 2, (3, 3): 3 + 38 + 11 + 5 + 3}[(IN, OUT)]
+    assert stream.size == ntiles * TILE == lib.cbd_conv_stream_floats(IN, OUT)
+    E = 32
+    in_dim, out_dim = sr.e3.Irreps(in_irr).dim, sr.e3.Irreps(out_irr).dim
+    xin = torch.randn(E, 96, generator=g)
+    xd = torch.randn(E, in_dim, generator=g)
+    vec = torch.randn(E, 3, generator=g)
+    # oracle: FCBlock then FasterTensorProduct (reference arithmetic), in float64
+    hid = torch.relu(xin.double() @ w1.double().T + b1.double())
+    tpw = hid @ w2.double().T + b2.double()
+    ref = sr.faster_tensor_product(xd.double(), sh_l1(vec.double()), tpw, in_irr, out_irr).numpy()
+    xrow = np.zeros((E, 80))
+    xrow[:, :in_dim] = xd.double().numpy()
+    v = torch.nn.functional.normalize(vec.double(), dim=-1).numpy()
+    got = emulate(stream.astype(np.float64), IN, OUT, xin.double().numpy(), xrow, v)
+    np.testing.assert_allclose(got[:, :out_dim], ref, rtol=2e-5, atol=2e-5)   # fp32-rounded folded factors in the stream
+    assert np.all(got[:, out_dim:] == 0)
