@@ -1,0 +1,184 @@
+"""Benchmark of the hot path: reverse-diffusion docking sampler on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+One "step" = one complex of the named workload: 40 poses x 20 denoise steps (BASELINE.json configs[1],
+synthetic DockGen-median complex: Nl=28, Nr=384, R=6), i.e. the time-independent receptor embedding +
+20 x (score-model forward + reverse-SDE perturbation + pose update) for a batch of 40 poses.
+Inputs (weights, complex, initial poses, pre-drawn noise) are resident in HBM before the timed region.
+Multi-GPU: complexes are independent -> every rank runs K complexes of its own (weak scaling), no collective in
+the data path; the only exchange is the final gather of poses to rank 0 (kept inside the timed region).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = tp_conv,
+fp32 MFMA bound, duration from HIP events on the launch stream) and `cpu_baseline` (the oracle's PyTorch-CPU
+restatement of the same path, timed on a bounded sample on rank 0 at N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOAD = "c2_dockgen_median"
+SAMPLES, DENOISE_STEPS = 40, 20
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def flops_per_edge(in_level: int, out_level: int) -> float:
+    """Algorithmic FLOPs of one edge of a tensor-product layer: 2(F*H + H*W) + 2*sum_blocks fan*m_out*dim."""
+    ns, nv = 32, 6
+    n1o, n1e, n0o = (nv if in_level >= 1 else 0), (nv if in_level >= 2 else 0), (nv if in_level >= 3 else 0)
+    fan0e, fan1o = ns + n1o, ns + n1o + n1e
+    fan1e = n1o + n1e + n0o if out_level >= 2 else 0
+    fan0o = n1e + n0o if out_level >= 3 else 0
+    W = fan0e * ns + fan1o * nv + fan1e * nv + fan0o * nv
+    tp = fan0e * ns * 1 + fan1o * nv * 3 + fan1e * nv * 3 + fan0o * nv * 1
+    return 2.0 * (96 * 96 + 96 * W) + 2.0 * tp
+
+
+def cpu_baseline(model, cplx, args, sched):
+    """Oracle (PyTorch-CPU port of the reference arithmetic) on a bounded sample of the same workload."""
+    from oracle import score_ref as sr, pose_ref as pr
+    from tests.helpers import to_cx
+    d = os.path.join(ROOT, "confidence_bootstrapping_amd", "data")
+    so3, torus = np.load(os.path.join(d, "so3_exp_score_norms.npy")), np.load(os.path.join(d, "torus_score_norm.npy"))
+    cx = to_cx(cplx)
+    b, steps = 2, 4
+    g = torch.Generator().manual_seed(0)
+    pos = cplx["ligand"].pos[None].repeat(b, 1, 1) - cplx["ligand"].pos.mean(0) + cplx["receptor"].pos.mean(0) \
+        + 10 * torch.randn(b, 1, 3, generator=g)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    cfg = sr.ScoreConfig()
+    # time `steps` of the 20 schedule points spread over the schedule (the cross graph shrinks with t)
+    idx = np.linspace(0, len(sched) - 1, steps).round().astype(int)
+    t0 = time.perf_counter()
+    rec_cache = sr.receptor_embedding(sd, cx, cfg)
+    t_rec = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for i in idx:
+        t = sched[i]
+        out = sr.score_forward(sd, cx, pos, t, t, t, cfg, so3, torus, rec_cache=rec_cache)
+        pos = pr.modify_conformer_batch(pos, cx, 0.01 * out["tr_pred"], 0.01 * out["rot_pred"], 0.01 * out["tor_pred"])
+    t_steps = time.perf_counter() - t0
+    per_pose = (t_steps / steps / b) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
+    return {"value": round(1.0 / per_pose, 5), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{b} poses x {steps} of {DENOISE_STEPS} denoise steps (+ receptor embedding) of {WORKLOAD}, "
+                      f"oracle PyTorch-CPU fp32, {t_steps + t_rec:.1f}s measured, extrapolated to 20 steps/pose"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.distributed import gather_poses
+
+    model, margs = make_score_model(seed=0)
+    cplx = make_workload(WORKLOAD, seed=1234)
+    eng = DockEngine(dev, max_batch=SAMPLES)
+    eng.load_state_dict(model.state_dict())
+    eng.set_complex(cplx)
+    sched = get_t_schedule("expbeta", DENOISE_STEPS)
+    steps = make_steps(sched, margs, model.timestep_emb_func)
+    R = eng.R
+    n_runs = a.warmup + a.steps
+    # initial poses via the reference's randomisation, noise pre-drawn (seeded per (rank, complex)), all resident in HBM
+    pos0, noise = [], []
+    for k in range(n_runs):
+        torch.manual_seed(42 + 1000 * rank + k)
+        np.random.seed(42 + 1000 * rank + k)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(SAMPLES)]
+        randomize_position(dl, False, False, margs.tr_sigma_max)
+        pos0.append(torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous())
+        noise.append((torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev), torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev),
+                      torch.randn(DENOISE_STEPS, SAMPLES * R).to(dev)))
+
+    def one_complex(k):
+        eng.recompute_receptor()
+        eng.sample(pos0[k], steps, *noise[k])
+
+    for k in range(a.warmup):
+        one_complex(k)
+    torch.cuda.synchronize()
+    eng.kernel_timing(enable=True, reset=True)
+    eng.stats(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(a.warmup, n_runs):
+        one_complex(k)
+    final = gather_poses(pos0[n_runs - 1], world, rank)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    avg_ms, n_launch, total_ms = eng.kernel_timing(enable=False)
+    st = eng.stats()
+    assert torch.isfinite(pos0[n_runs - 1]).all(), "non-finite poses"
+
+    if rank == 0:
+        poses = SAMPLES * a.steps * world
+        f33 = flops_per_edge(3, 3)
+        femb = flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3)
+        total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
+        flops_per_launch = total_flops / max(n_launch, 1)
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        out = {
+            "metric": "poses/sec (whole node), 40-sample x 20-step diffusion, DockGen median complex",
+            "value": round(poses / elapsed, 3), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS,
+                       "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
+                       "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                         "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                         "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
+                         "pose_steps_per_s": round(poses * DENOISE_STEPS / elapsed, 1)},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

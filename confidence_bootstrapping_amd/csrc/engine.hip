@@ -105,6 +105,9 @@ struct cbd_engine {
   int *rr_src = nullptr, *rr_dst = nullptr, *rr_aidx = nullptr;
   float* rr_vec = nullptr;
   int* rr_count_dev = nullptr;
+  float *d_rec_x = nullptr, *d_vec0 = nullptr, *d_dist0 = nullptr;
+  int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
+  unsigned long long* stats_dev = nullptr;   // [4] edge-layer visits: ll (embedding layers), joint conv layers, forwards
 
   // ---- batch workspace
   GraphDyn gd{};
@@ -478,6 +481,33 @@ static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_
   return 0;
 }
 
+// Time-independent receptor embedding for ONE copy of the receptor (score_model.py:297-320): node encoder,
+// edge embedding, three rec_emb_layers; result cached in rec_static (the reference caches it on the batch object).
+static int embed_receptor(cbd_engine* e, hipStream_t s) {
+  const GraphStatic& gs = e->gs;
+  const int Nr = gs.Nr, Err = gs.Err, lm = e->cfg.lm_embedding_dim;
+  HIPCHK(launch_rec_node_embed(e->d_rec_x, Nr, lm, e->rec_emb_table, e->rec_node_w, e->rec_node_b, e->X0, s));
+  HIPCHK(launch_edge_geom(gs.rec_pos, e->d_src0, e->d_dst0, Err, e->d_vec0, e->d_dist0, s));
+  HIPCHK(launch_edge_mlp(make_mlp(e->m_rec_edge, nullptr), e->d_dist0, nullptr, nullptr, Err, e->rr_attr0, s));
+  HIPCHK(hipMemcpyAsync(e->rr_count_dev, &gs.Err, sizeof(int), hipMemcpyHostToDevice, s));
+  float* in = e->X0;
+  float* out = e->X1;
+  for (int l = 0; l < 3; ++l) {
+    ConvGroup g{};
+    g.src = e->d_src0; g.dst = e->d_dst0; g.attr_idx = e->d_ident; g.vec = e->d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
+    int cap = Err;
+    CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
+    CHK(run_finalize(e, e->rec_emb[l], in, out, e->d_deg0, Nr, 0, s));
+    std::swap(in, out);
+  }
+  HIPCHK(hipMemcpyAsync(e->rec_static, in, (size_t)Nr * NODE_STRIDE * 4, hipMemcpyDeviceToDevice, s));
+  // X0/X1 rows [0, Nr) were used as scratch: the ligand rows of the next forward are rewritten in full, but clear the
+  // columns a lower-level layer does not write
+  HIPCHK(hipMemsetAsync(e->X0, 0, (size_t)Nr * NODE_STRIDE * 4, s));
+  HIPCHK(hipMemsetAsync(e->X1, 0, (size_t)Nr * NODE_STRIDE * 4, s));
+  return 0;
+}
+
 int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t R, int32_t Err, const int64_t* lig_x,
                     const int64_t* bond_index, const float* bond_attr, const uint8_t* edge_mask, const uint8_t* mask_rotate,
                     const float* rec_x, const float* rec_pos, const int64_t* rec_edge_index) {
@@ -610,28 +640,12 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&e->rr_vec, (size_t)Bm * Err * 4));
   HIPCHK(e->bpool.alloc(&e->rr_count_dev, 1));
 
-  // ---- time-independent receptor embedding for ONE copy (score_model.py:297-320), reusing X0/X1/acc
+  e->d_rec_x = d_rec_x; e->d_vec0 = d_vec0; e->d_dist0 = d_dist0; e->d_src0 = d_src0; e->d_dst0 = d_dst0;
+  e->d_ident = d_ident; e->d_deg0 = d_deg0;
+  HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
+  HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
   hipStream_t s = nullptr;
-  HIPCHK(launch_rec_node_embed(d_rec_x, Nr, lm, e->rec_emb_table, e->rec_node_w, e->rec_node_b, e->X0, s));
-  HIPCHK(launch_edge_geom(d_rec_pos, d_src0, d_dst0, Err, d_vec0, d_dist0, s));
-  HIPCHK(launch_edge_mlp(make_mlp(e->m_rec_edge, nullptr), d_dist0, nullptr, nullptr, Err, e->rr_attr0, s));
-  HIPCHK(hipMemcpyAsync(e->rr_count_dev, &Err, sizeof(int), hipMemcpyHostToDevice, s));
-  {
-    float* in = e->X0;
-    float* out = e->X1;
-    for (int l = 0; l < 3; ++l) {
-      ConvGroup g{};
-      g.src = d_src0; g.dst = d_dst0; g.attr_idx = d_ident; g.vec = d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
-      int cap = Err;
-      const bool was_timing = e->timing;
-      e->timing = false;
-      CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
-      e->timing = was_timing;
-      CHK(run_finalize(e, e->rec_emb[l], in, out, d_deg0, Nr, 0, s));
-      std::swap(in, out);
-    }
-    HIPCHK(hipMemcpyAsync(e->rec_static, in, (size_t)Nr * NODE_STRIDE * 4, hipMemcpyDeviceToDevice, s));
-  }
+  CHK(embed_receptor(e, s));
   for (int b = 0; b < Bm; ++b)
     HIPCHK(hipMemcpyAsync(e->rr_vec + (size_t)b * Err * 4, d_vec0, (size_t)Err * 16, hipMemcpyDeviceToDevice, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -661,7 +675,7 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   HIPCHK(launch_step_prep(e->sw, e->sv, sigma_emb_dev, s));
   HIPCHK(hipMemsetAsync(gd.counts, 0, 8 * sizeof(int), s));
   HIPCHK(launch_graph_count(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
-  HIPCHK(launch_graph_scan(gs, gd, B, s));
+  HIPCHK(launch_graph_scan(gs, gd, B, e->stats_dev, s));
   HIPCHK(launch_graph_fill(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
   const int cap_ll = B * e->cap_ll_per_sample, cap_x = B * Nl * Nr, cap_rr = B * gs.Err;
   EdgeMlp mll = make_mlp(e->m_lig_edge, e->sv.ll_part), mlr = make_mlp(e->m_cross, e->sv.lr_part);
@@ -796,6 +810,22 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
     HIPCHK(launch_pose_update(e->gs, pos_dev, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
   }
   if (e->timing) { HIPCHK(hipStreamSynchronize(s)); collect_timing(e); }
+  return 0;
+}
+
+int cbd_recompute_receptor(cbd_engine* e, void* stream) {
+  if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  CHK(embed_receptor(e, reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
+int cbd_stats(cbd_engine* e, int32_t reset, uint64_t out[4]) {
+  if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
+  HIPCHK(hipSetDevice(e->cfg.device));
+  HIPCHK(hipDeviceSynchronize());
+  if (out) HIPCHK(hipMemcpy(out, e->stats_dev, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (reset) HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
   return 0;
 }
 

@@ -41,7 +41,7 @@ struct GraphDyn {        // per forward pass, device pointers (capacity sized)
 };
 
 hipError_t launch_graph_count(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s);
-hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, hipStream_t s);
+hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, unsigned long long* stats, hipStream_t s);
 hipError_t launch_graph_fill(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s);
 hipError_t launch_edge_mlp(const EdgeMlp& m, const float* dist, const float* bond4, const int* count, int cap, float* out, hipStream_t s);
 

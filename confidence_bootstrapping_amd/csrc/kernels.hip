@@ -172,7 +172,7 @@ hipError_t launch_graph_fill(const GraphStatic& gs, const GraphDyn& gd, int B, f
 }
 
 // Exclusive scans of the three per-node count arrays (single workgroup; <= ~1e5 entries) + in-degree tables.
-__global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphDyn gd, int B) {
+__global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphDyn gd, int B, unsigned long long* stats) {
   __shared__ int part[1024];
   __shared__ int carry;
   const int tid = threadIdx.x;
@@ -199,7 +199,15 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphD
     if (tid == 1023) gd.counts[which == 0 ? 0 : which == 1 ? 1 : 3] = part[1023];
     __syncthreads();
   }
-  if (tid == 0) gd.counts[2] = B * gs.Err;
+  if (tid == 0) {
+    gd.counts[2] = B * gs.Err;
+    if (stats) {   // edge-layer visits of this forward pass (algorithmic work accounting for bench.py)
+      const unsigned long long ll = gd.counts[0], lr = gd.counts[1], rr = B * gs.Err, rl = gd.counts[3];
+      stats[0] += ll;                                  // each of the 3 ligand embedding layers visits ll edges
+      stats[1] += 4ull * (ll + lr + rr + rl) + (ll + lr);   // 4 full interaction layers + the ligand-only last one
+      stats[2] += 1ull;
+    }
+  }
   for (int n = tid; n < nL; n += 1024) {
     gd.deg_embed[n] = gd.cnt_ll[n];
     gd.deg_full[n] = gd.cnt_ll[n] + gd.cnt_lr[n];
@@ -211,8 +219,8 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphD
   (void)carry;
 }
 
-hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, hipStream_t s) {
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, gs, gd, B);
+hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, unsigned long long* stats, hipStream_t s) {
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, gs, gd, B, stats);
   return hipGetLastError();
 }
 

@@ -46,6 +46,8 @@ SYMBOLS = {
     "cbd_score": (C.c_int, [_P, C.c_int32, _P, C.POINTER(cbd_step), _P, _P, _P, _P]),
     "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
+    "cbd_recompute_receptor": (C.c_int, [_P, _P]),
+    "cbd_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64)]),
     "cbd_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
     "cbd_last_edge_counts": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "cbd_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
@@ -233,6 +235,15 @@ class DockEngine:
             _check(self.lib.cbd_sample(self.h, B, S, steps, _dptr(pos), _dptr(noise_tr), _dptr(noise_rot), _dptr(noise_tor),
                                        _dptr(scores), self._stream()))
         return scores
+
+    def recompute_receptor(self):
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_recompute_receptor(self.h, self._stream()))
+
+    def stats(self, reset=False):
+        out = (C.c_uint64 * 4)()
+        _check(self.lib.cbd_stats(self.h, int(reset), out))
+        return {"ll_edges": out[0], "conv_edge_visits": out[1], "forwards": out[2]}
 
     # ---- introspection
     def debug(self, enable=True):

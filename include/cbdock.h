@@ -112,6 +112,16 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, 
                const float* noise_tr_dev, const float* noise_rot_dev, const float* noise_tor_dev,
                float* scores_out_dev, void* stream);
 
+/* Re-run the time-independent receptor embedding of the current complex (models/score_model.py:297-320, which the
+ * reference executes in the first model call of every batch).  cbd_set_complex already does this once; the
+ * benchmark calls it per complex so that this work stays inside the timed region. */
+int cbd_recompute_receptor(cbd_engine* e, void* stream);
+
+/* Work accounting since the last reset (device-side counters, synchronises): out[0] = ligand-graph edges summed
+ * over forward passes (each of the 3 ligand embedding layers visits them once), out[1] = edge visits of the 5
+ * interaction layers, out[2] = forward passes, out[3] = reserved. */
+int cbd_stats(cbd_engine* e, int32_t reset, uint64_t out[4]);
+
 /* Introspection used by the parity tests and the benchmark.  After a cbd_score call, copies a named
  * intermediate (see csrc/engine.hip: debug_names) to host memory; returns the element count or <0. */
 int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out_host, int64_t capacity);

@@ -1,0 +1,241 @@
+"""Parity of the HIP engine (through the C ABI) against (a) the reference's own outputs stored in tests/golden/ and
+(b) the CPU oracle on seeded synthetic inputs.  Needs an MI355X:  pytest -m gpu
+
+Tolerances (fp32 path, stated per north star):
+  * score-model outputs and node features: max |err| <= 2e-5 * max|ref|   (observed ~5e-7)
+  * pose update: RMSD <= 5e-5 A (coordinates are ~30 A from the origin: fp32 spacing 2e-6 A, up to 16 sequential
+    torsion rotations + Kabsch; observed <= 1.4e-5) ; 20-step trajectory: final pose RMSD <= 1e-3 A vs the reference trajectory
+"""
+import copy
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import to_cx, rmsd, rel_err
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+SCORE_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def engine_tiny(dev, score_model):
+    from confidence_bootstrapping_amd.engine import DockEngine
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    model, _ = score_model
+    eng = DockEngine(dev, max_batch=8)
+    eng.load_state_dict(model.state_dict())
+    cplx = make_workload("tiny")
+    eng.set_complex(cplx)
+    return eng, cplx
+
+
+def test_forward_matches_reference_golden(engine_tiny, golden, score_model, dev):
+    """cbd_score vs the reference TensorProductScoreModel.forward outputs (g6_forward.npz)."""
+    from confidence_bootstrapping_amd.engine import make_steps
+    eng, _ = engine_tiny
+    model, args = score_model
+    g = golden("g6_forward.npz")
+    pos0 = T(g["pos0"]).to(dev)
+    for t in (1.0, 0.5, 0.05):
+        st = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+        tr, rot, tor = eng.score(pos0, st)
+        for k, v in (("tr", tr), ("rot", rot), ("tor", tor)):
+            assert rel_err(v.cpu(), T(g[f"t{t}_{k}"])) < SCORE_TOL, (t, k)
+
+
+def test_intermediates_match_oracle(engine_tiny, tables, score_model, dev):
+    from confidence_bootstrapping_amd.engine import make_steps
+    from oracle import score_ref as sr
+    eng, cplx = engine_tiny
+    model, args = score_model
+    cx = to_cx(cplx)
+    so3, torus = tables
+    gen = torch.Generator().manual_seed(3)
+    B = 5
+    pos = cplx["ligand"].pos[None].repeat(B, 1, 1) + torch.randn(B, 1, 3, generator=gen) * 6 + 0.2 * torch.randn(B, cx.Nl, 3, generator=gen)
+    t = 0.35
+    eng.debug(True)
+    try:
+        st = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+        tr, rot, tor = eng.score(pos.to(dev), st)
+        ref = sr.score_forward(model.state_dict(), cx, pos, t, t, t, sr.ScoreConfig(), so3, torus)
+        c = eng.edge_counts()
+        assert c["ll"] == ref["lig_edge_index"].shape[1] and c["lr"] == c["rl"] == ref["lr_edge_index"].shape[1]
+        assert c["rr"] == B * cx.rec_edge_index.shape[1] and c["tor"] == ref["tor_edge_index"].shape[1]
+        nL = B * cx.Nl
+        for l, dim in enumerate((50, 68, 74)):
+            assert rel_err(eng.fetch(f"lig_emb_{l}").reshape(-1, 80)[:, :dim], ref[f"lig_emb_{l}"]) < SCORE_TOL
+        for l in range(5):
+            assert rel_err(eng.fetch(f"conv_{l}").reshape(-1, 80)[:, :74], ref[f"conv_{l}"][:nL]) < SCORE_TOL, l
+            if l < 4:
+                assert rel_err(eng.fetch(f"conv_{l}_rec").reshape(-1, 80)[:, :74], ref[f"conv_{l}"][nL:]) < SCORE_TOL, l
+        assert np.all(eng.fetch("conv_3").reshape(-1, 80)[:, 74:] == 0)   # padding columns stay zero
+        assert rel_err(eng.fetch("center_mean").reshape(B, 12), ref["center_mean"]) < SCORE_TOL
+        assert rel_err(eng.fetch("tor_feat").reshape(-1, 64), ref["tor_feat"]) < SCORE_TOL
+        assert rel_err(tr.cpu(), ref["tr_pred"]) < SCORE_TOL and rel_err(rot.cpu(), ref["rot_pred"]) < SCORE_TOL
+        assert rel_err(tor.cpu(), ref["tor_pred"]) < SCORE_TOL
+    finally:
+        eng.debug(False)
+
+
+def test_modify_conformer_matches_reference_golden(dev, score_model, golden):
+    from confidence_bootstrapping_amd.engine import DockEngine
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    model, _ = score_model
+    g = golden("g4_pose.npz")
+    eng = DockEngine(dev, max_batch=4)
+    eng.load_state_dict(model.state_dict())
+    for wl in ("tiny", "c2_dockgen_median", "c4_large_pocket"):
+        eng.set_complex(make_workload(wl))
+        b = 3
+        pos = T(g[f"{wl}_pos"]).reshape(b, -1, 3)
+        new = eng.modify_conformer(pos, T(g[f"{wl}_tr"]), T(g[f"{wl}_rot"]), T(g[f"{wl}_tor"])).cpu()
+        assert float(rmsd(new, T(g[f"{wl}_new"]).reshape(b, -1, 3)).max()) < 5e-5, wl
+        rigid = eng.modify_conformer(pos, T(g[f"{wl}_tr"]), T(g[f"{wl}_rot"]), None).cpu()
+        assert float(rmsd(rigid, T(g[f"{wl}_rigid"]).reshape(b, -1, 3)).max()) < 5e-5, wl
+    # identity: zero updates leave the pose unchanged (SURVEY.md section 4 invariant)
+    z = eng.modify_conformer(pos, torch.zeros(b, 3), torch.zeros(b, 3), torch.zeros(b * eng.R)).cpu()
+    assert float(rmsd(z, pos).max()) < 1e-5
+
+
+def test_sampling_matches_reference_trajectory(engine_tiny, golden, score_model, dev):
+    """cbd_sample on the noise the reference drew vs the reference's utils.sampling.sampling() result."""
+    from confidence_bootstrapping_amd.engine import make_steps
+    eng, _ = engine_tiny
+    model, args = score_model
+    g = golden("g6_sampling.npz")
+    steps = make_steps(g["schedule"], args, model.timestep_emb_func)
+    pos = T(g["pos0"]).to(dev).contiguous().clone()
+    B = pos.shape[0]
+    scores = eng.sample(pos, steps, T(g["noise_tr"]), T(g["noise_rot"]), T(g["noise_tor"]), return_scores=True).cpu()
+    assert rel_err(scores[0, :3 * B], T(g["step_tr"][0]).reshape(-1)) < SCORE_TOL
+    assert rel_err(scores[0, 6 * B:], T(g["step_tor"][0]).reshape(-1)) < SCORE_TOL
+    d = rmsd(pos.cpu(), T(g["final_pos"]))
+    assert float(d.max()) < 1e-3, d
+
+
+def test_python_api_sampling_matches_reference(golden, score_model, dev):
+    """The reference-shaped entry point sampling(data_list, model, ...) with the same torch seed as the reference run."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.sampling import sampling
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma, set_time
+    g = golden("g6_sampling.npz")
+    model, args = make_score_model(device=dev, seed=0)
+    cplx = make_workload("tiny")
+    pos0 = T(g["pos0"])
+    data_list = []
+    for i in range(pos0.shape[0]):
+        d = Batch.from_data_list([copy.deepcopy(cplx)])
+        d["ligand"].pos = pos0[i].clone()
+        data_list.append(d)
+    torch.manual_seed(42)   # the seed oracle/make_golden.py set before the reference's sampling()
+    out, conf = sampling(data_list, model, 20, g["schedule"], g["schedule"], g["schedule"], dev, partial(t_to_sigma, args=args),
+                         args, batch_size=3)
+    assert conf is None
+    got = torch.stack([d["ligand"].pos.cpu() for d in out])
+    assert float(rmsd(got, T(g["final_pos"])).max()) < 1e-3
+    # model(batch) keeps the reference's forward contract
+    b = Batch.from_data_list([copy.deepcopy(d) for d in data_list])
+    b.to(dev)
+    set_time(b, None, 0.5, 0.5, 0.5, 3, False, False, dev)
+    tr, rot, tor, sc = model(b)
+    assert tr.shape == (3, 3) and rot.shape == (3, 3) and tor.shape == (3 * 2,) and sc is None and tr.is_cuda
+
+
+def test_median_workload_and_invariants(dev, score_model, tables):
+    """C2-sized complex at reduced batch: oracle parity + SE(3) equivariance + batch-permutation consistency."""
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from oracle import score_ref as sr, pose_ref as pr
+    model, args = score_model
+    cplx = make_workload("c2_dockgen_median")
+    cx = to_cx(cplx)
+    so3, torus = tables
+    eng = DockEngine(dev, max_batch=8)
+    eng.load_state_dict(model.state_dict())
+    eng.set_complex(cplx)
+    gen = torch.Generator().manual_seed(9)
+    B = 2
+    pos = cplx["ligand"].pos[None].repeat(B, 1, 1) - cplx["ligand"].pos.mean(0) + torch.randn(B, 1, 3, generator=gen) * 12
+    for t in (0.9, 0.1):
+        st = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+        tr, rot, tor = eng.score(pos.to(dev), st)
+        ref = sr.score_forward(model.state_dict(), cx, pos, t, t, t, sr.ScoreConfig(), so3, torus)
+        assert eng.edge_counts()["lr"] == ref["lr_edge_index"].shape[1]
+        assert rel_err(tr.cpu(), ref["tr_pred"]) < SCORE_TOL and rel_err(rot.cpu(), ref["rot_pred"]) < SCORE_TOL
+        assert rel_err(tor.cpu(), ref["tor_pred"]) < SCORE_TOL
+    # identical samples in a batch give identical outputs; permuting samples permutes outputs
+    st = make_steps(np.array([0.4]), args, model.timestep_emb_func)[0]
+    p3 = torch.stack([pos[0], pos[1], pos[0]]).to(dev)
+    tr, rot, tor = eng.score(p3, st)
+    assert torch.allclose(tr[0], tr[2], rtol=1e-5, atol=1e-7) and torch.allclose(tor[:6], tor[12:], rtol=1e-5, atol=1e-7)
+    tr2, rot2, tor2 = eng.score(torch.stack([pos[1], pos[0]]).to(dev), st)
+    assert torch.allclose(tr2[0], tr[1], rtol=1e-5, atol=1e-7) and torch.allclose(rot2[1], rot[0], rtol=1e-5, atol=1e-7)
+    # SE(3) equivariance: rotate + translate receptor and ligand together => tr/rot rotate (proper rotation), tor invariant
+    Rm = pr.axis_angle_to_matrix(torch.tensor([[0.3, -1.1, 0.7]]))[0]
+    shift = torch.tensor([3.0, -2.0, 5.0])
+    c2 = copy.deepcopy(cplx)
+    c2["receptor"].pos = cplx["receptor"].pos @ Rm.T + shift
+    eng2 = DockEngine(dev, max_batch=8)
+    eng2.load_state_dict(model.state_dict())
+    eng2.set_complex(c2)
+    trr, rotr, torr = eng2.score((pos @ Rm.T + shift).to(dev), st)
+    tr0, rot0, tor0 = eng.score(pos.to(dev), st)
+    assert torch.allclose(trr.cpu(), tr0.cpu() @ Rm.T, rtol=2e-4, atol=2e-6)
+    assert torch.allclose(rotr.cpu(), rot0.cpu() @ Rm.T, rtol=2e-4, atol=2e-6)
+    assert torch.allclose(torr.cpu(), tor0.cpu(), rtol=2e-4, atol=2e-6)
+
+
+def test_full_size_batch_properties(dev, score_model):
+    """BASELINE.json configs[1] at full size (40 poses x 20 steps): size-independent properties of the result --
+    finite poses, bond lengths preserved along the trajectory, the step loop is deterministic up to fp32 atomics."""
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    model, args = score_model
+    cplx = make_workload("c2_dockgen_median")
+    eng = DockEngine(dev, max_batch=40)
+    eng.load_state_dict(model.state_dict())
+    eng.set_complex(cplx)
+    B, S = 40, 20
+    gen = torch.Generator().manual_seed(11)
+    pos0 = (cplx["ligand"].pos[None].repeat(B, 1, 1) - cplx["ligand"].pos.mean(0) + 19 * torch.randn(B, 1, 3, generator=gen)).to(dev)
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    noise = [torch.randn(S, B, 3, generator=gen), torch.randn(S, B, 3, generator=gen), torch.randn(S, B * eng.R, generator=gen)]
+    p1 = pos0.clone()
+    eng.sample(p1, steps, *noise)
+    p2 = pos0.clone()
+    eng.sample(p2, steps, *noise)
+    assert torch.isfinite(p1).all()
+    bi = cplx["ligand", "ligand"].edge_index
+    bl0 = (cplx["ligand"].pos[bi[0]] - cplx["ligand"].pos[bi[1]]).norm(dim=-1)
+    bl1 = (p1.cpu()[:, bi[0]] - p1.cpu()[:, bi[1]]).norm(dim=-1)
+    assert float((bl1 - bl0).abs().max()) < 2e-3       # rigid + torsional moves never stretch a bond
+    assert float(rmsd(p1.cpu(), p2.cpu()).max()) < 1e-3
+    c = eng.edge_counts()
+    assert c["rr"] == B * 24 * 384 and 0 < c["lr"] <= B * 28 * 384
+
+
+def test_errors_are_raised_not_swallowed(engine_tiny, dev, score_model):
+    from confidence_bootstrapping_amd.engine import make_steps
+    eng, cplx = engine_tiny
+    model, args = score_model
+    st = make_steps(np.array([0.5]), args, model.timestep_emb_func)[0]
+    with pytest.raises(RuntimeError, match="max_batch"):
+        eng.score(torch.zeros(9, eng.Nl, 3, device=dev), st)      # capacity 8: callers catch this and halve the batch
+
+
+def test_smoke_entry():
+    import __graft_entry__ as ge
+    ge.smoke()
