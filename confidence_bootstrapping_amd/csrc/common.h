@@ -27,6 +27,9 @@ constexpr int KDIM = 96;                       // radial-MLP width (3*ns)
 constexpr int KSTEPS = KDIM / 2;               // 48 MFMA k-steps of 2
 constexpr int TILE_W_FLOATS = KSTEPS * 64;     // 3072 weight floats per 32-row tile
 constexpr int TILE_FLOATS = TILE_W_FLOATS + 32;  // + 32 bias floats  (12416 B)
+// Row layout of a vector / pseudoscalar block tile (m_out = 6): accumulator register reg < 15 of lane half hf holds
+// (mid index i = 5*tile + reg/3, output o = 3*hf + reg%3); 30 of the 32 rows carry weights (reg 15 is zero).
+constexpr int VEC_TILE_I = 5;
 
 // Number of 32-row weight tiles of a layer with input level IN (0..3) and output level OUT (1..3):
 // 3 tiles of the first Linear, then the second Linear regrouped per output irrep block.
@@ -49,9 +52,9 @@ __host__ __device__ constexpr ConvShape conv_shape(int IN, int OUT) {
   s.fan1e = OUT >= 2 ? s.n1o + s.n1e + s.n0o : 0;
   s.fan0o = OUT >= 3 ? s.n1e + s.n0o : 0;
   s.t0e = s.fan0e;
-  s.t1o = (s.fan1o + 3) / 4;
-  s.t1e = (s.fan1e + 3) / 4;
-  s.t0o = (s.fan0o + 3) / 4;
+  s.t1o = (s.fan1o + VEC_TILE_I - 1) / VEC_TILE_I;
+  s.t1e = (s.fan1e + VEC_TILE_I - 1) / VEC_TILE_I;
+  s.t0o = (s.fan0o + VEC_TILE_I - 1) / VEC_TILE_I;
   s.ntiles = 3 + s.t0e + s.t1o + s.t1e + s.t0o;
   s.weight_numel = s.fan0e * NS + s.fan1o * NV + s.fan1e * NV + s.fan0o * NV;
   s.in_dim = NS + 3 * s.n1o + 3 * s.n1e + s.n0o;

@@ -182,8 +182,10 @@ static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, con
   auto vec_tiles = [&](int off, int fan, int ntile, auto mid_factor) {
     for (int t = 0; t < ntile; ++t, ++T) {
       for (int r = 0; r < 32; ++r) {
-        const int o = (r & 3) + 4 * ((r >> 3) & 1), il = ((r >> 2) & 1) + 2 * (r >> 4), i = 4 * t + il;
-        if (o < NV && i < fan) { wc[r] = off + i * NV + o; sc[r] = mid_factor(i) / std::sqrt((float)fan); }
+        // row r = (reg&3) + 8*(reg>>2) + 4*hf  <->  reg = (r&3) + 4*(r>>3), hf = (r>>2)&1
+        const int reg = (r & 3) + 4 * (r >> 3), hf = (r >> 2) & 1;
+        const int i = VEC_TILE_I * t + reg / 3, o = 3 * hf + reg % 3;
+        if (reg < 15 && i < fan) { wc[r] = off + i * NV + o; sc[r] = mid_factor(i) / std::sqrt((float)fan); }
         else { wc[r] = -1; sc[r] = 0.f; }
       }
       fill_tile(out.data() + (size_t)T * TILE_FLOATS, wc, sc);

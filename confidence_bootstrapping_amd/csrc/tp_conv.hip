@@ -19,9 +19,9 @@
 //     products of x_dst and the unit edge vector, read from a per-wave LDS copy of the gathered row) and adds
 //     into per-lane output accumulators.  1/sqrt(fan_in), sqrt(3) (sh scale) and 1/sqrt(2) factors are folded
 //     into the packed weights.
-//   * Rows of a vector-block tile are laid out (i_local, o) -> row = (o&3) + 4*(i_local&1) + 8*(o>>2) +
-//     16*(i_local>>1) with o padded 6 -> 8, so the output slot of an accumulator register is a compile-time
-//     function of the register index and only the mid index depends on the lane half.
+//   * Rows of a vector-block tile hold 5 mid indices x 6 outputs: accumulator register reg < 15 of lane half hf is
+//     (i = 5*tile + reg/3, o = 3*hf + reg%3), so both the mid index and the output slot are compile-time functions of
+//     the register index, each half owns three of the six outputs, and 30 of the 32 MFMA rows carry weights.
 //   * Segmented reduction: edges are sorted by aggregating node; each wave run-length sums its 32 messages in
 //     LDS and issues one 256-byte-contiguous fp32 atomic add per (node run, 64 columns).
 #include "common.h"
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   int T = 0;
   f32x16 acc;
   float h1[KSTEPS];
-  auto advance = [&](bool more) {   // finish tile T: publish tile T+1 and flip
+  auto advance = [&](bool more) __attribute__((always_inline)) {   // finish tile T: publish tile T+1 and flip
     if (more) stage_store(st, abuf + ((T + 1) & 1) * TILE_FLOATS, tid);
     __syncthreads();
     ++T;
@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   float o0e[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
+#pragma unroll 1
   for (int i = 0; i < S.t0e; ++i) {
     const bool more = (T + 1) < S.ntiles;
     if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
@@ -242,68 +243,52 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
     advance(more);
   }
 
-  // ---- vector / pseudoscalar blocks: tile = 4 mid indices x 8 (6 used) outputs
-  float k1o[9], k1e[9], k0o[3];   // kept results: lane half hf keeps outputs o = 3hf .. 3hf+2
+  // ---- vector / pseudoscalar blocks: tile = 5 mid indices x 6 outputs; lane half hf owns outputs 3hf..3hf+2, register
+  //      reg < 15 holds (i = 5t + reg/3, o = 3hf + reg%3) -- no cross-lane traffic, mids identical in both halves
+  float k1o[9], k1e[9], k0o[3];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
   k0o[0] = k0o[1] = k0o[2] = 0.f;
 
-  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) {
-    float ov[6][3];
-#pragma unroll
-    for (int o = 0; o < 6; ++o) ov[o][0] = ov[o][1] = ov[o][2] = 0.f;
+  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
+#pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
       const bool more = (T + 1) < S.ntiles;
       if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
       gemm_tile(abuf + (T & 1) * TILE_FLOATS, h1, acc, lane);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < VEC_TILE_I; ++q) {
         float m[3];
-        mid_fn(xc, 4 * t + hf + 2 * q, v, m);
+        mid_fn(xc, VEC_TILE_I * t + q, v, m);
 #pragma unroll
-        for (int o = 0; o < 6; ++o) {
-          const float w = acc[8 * q + o];
-          ov[o][0] = fmaf(m[0], w, ov[o][0]);
-          ov[o][1] = fmaf(m[1], w, ov[o][1]);
-          ov[o][2] = fmaf(m[2], w, ov[o][2]);
+        for (int o = 0; o < 3; ++o) {
+          const float w = acc[3 * q + o];
+          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
+          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
+          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
         }
       }
       advance(more);
     }
-    // the two lane halves hold partial sums over different mid indices: add across, keep half each
-#pragma unroll
-    for (int o = 0; o < 6; ++o)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) ov[o][c] += __shfl_xor(ov[o][c], 32);
-#pragma unroll
-    for (int o = 0; o < 3; ++o)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) keep[3 * o + c] = hf ? ov[3 + o][c] : ov[o][c];
   };
 
-  vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) { mid1o<IN>(x, i, vv, m); }, S.t1o, k1o);
+  vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); }, S.t1o, k1o);
   if constexpr (OUT >= 2)
-    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) { mid1e<IN>(x, i, vv, m); }, S.t1e, k1e);
+    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); }, S.t1e, k1e);
   if constexpr (OUT >= 3) {
-    float os[6];
-#pragma unroll
-    for (int o = 0; o < 6; ++o) os[o] = 0.f;
+#pragma unroll 1
     for (int t = 0; t < S.t0o; ++t) {
       const bool more = (T + 1) < S.ntiles;
       if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
       gemm_tile(abuf + (T & 1) * TILE_FLOATS, h1, acc, lane);
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float m = mid0o<IN>(xc, 4 * t + hf + 2 * q, v);
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
 #pragma unroll
-        for (int o = 0; o < 6; ++o) os[o] = fmaf(m, acc[8 * q + o], os[o]);
+        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
       }
       advance(more);
     }
-#pragma unroll
-    for (int o = 0; o < 6; ++o) os[o] += __shfl_xor(os[o], 32);
-#pragma unroll
-    for (int o = 0; o < 3; ++o) k0o[o] = hf ? os[3 + o] : os[o];
   }
 
   // ---- messages -> LDS (re-using the gathered-row tile), then run-length sum per aggregating node

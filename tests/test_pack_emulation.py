@@ -45,7 +45,7 @@ def shape(IN, OUT):
     fan1e = n1o + n1e + n0o if OUT >= 2 else 0
     fan0o = n1e + n0o if OUT >= 3 else 0
     return dict(n1o=n1o, n1e=n1e, n0o=n0o, fan0e=fan0e, fan1o=fan1o, fan1e=fan1e, fan0o=fan0o,
-                t0e=fan0e, t1o=(fan1o + 3) // 4, t1e=(fan1e + 3) // 4, t0o=(fan0o + 3) // 4)
+                t0e=fan0e, t1o=(fan1o + 4) // 5, t1e=(fan1e + 4) // 5, t0o=(fan0o + 4) // 5)
 
 
 def cross(a, v):
@@ -99,32 +99,33 @@ def emulate(stream, IN, OUT, xin, xrow, v):
             out[lane & 31, row_of(reg, lane >> 5)] = o0e[reg, lane]
 
     def vec_block(ntile, mid, col0):
-        ov = np.zeros((6, 3, 64))
+        keep = np.zeros((3, 3, 64))          # [o local][c][lane]; lane half hf owns outputs 3hf..3hf+2
         nonlocal T
         for t in range(ntile):
             acc = gemm_tile(tiles[T], h1); T += 1
             for lane in range(64):
-                for q in range(2):
-                    m = mid(lane & 31, 4 * t + (lane >> 5) + 2 * q)
-                    for o in range(6):
-                        ov[o, :, lane] += m * acc[8 * q + o, lane]
-        tot = ov[:, :, :32] + ov[:, :, 32:]
-        for e in range(32):
-            for o in range(6):
-                out[e, col0 + 3 * o:col0 + 3 * o + 3] = tot[o, :, e]
+                for q in range(5):
+                    m = mid(lane & 31, 5 * t + q)
+                    for o in range(3):
+                        keep[o, :, lane] += m * acc[3 * q + o, lane]
+        for lane in range(64):
+            for o in range(3):
+                oo = 3 * (lane >> 5) + o
+                out[lane & 31, col0 + 3 * oo:col0 + 3 * oo + 3] = keep[o, :, lane]
 
     vec_block(S["t1o"], mid1o, COL_1O)
     if OUT >= 2:
         vec_block(S["t1e"], mid1e, COL_1E)
     if OUT >= 3:
-        os_ = np.zeros((6, 64))
+        k0 = np.zeros((3, 64))
         for t in range(S["t0o"]):
             acc = gemm_tile(tiles[T], h1); T += 1
             for lane in range(64):
-                for q in range(2):
-                    m = mid0o(lane & 31, 4 * t + (lane >> 5) + 2 * q)
-                    os_[:, lane] += m * acc[8 * q:8 * q + 6, lane]
-        out[:, COL_0O:COL_0O + 6] = (os_[:, :32] + os_[:, 32:]).T
+                for q in range(5):
+                    m = mid0o(lane & 31, 5 * t + q)
+                    k0[:, lane] += m * acc[3 * q:3 * q + 3, lane]
+        for lane in range(64):
+            out[lane & 31, COL_0O + 3 * (lane >> 5):COL_0O + 3 * (lane >> 5) + 3] = k0[:, lane]
     assert T == tiles.shape[0]
     return out
 
@@ -139,7 +140,7 @@ def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
     w1, b1 = torch.randn(96, 96, generator=g) / 8, torch.randn(96, generator=g) / 4
     w2, b2 = torch.randn(W, 96, generator=g) / 8, torch.randn(W, generator=g) / 4
     stream = pack_conv_stream(IN, OUT, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
-    ntiles = {(0, 1): 3 + 32 + 8, (1, 2): 3 + 38 + 10 + 2, (2, 3): 3 + 38 + 11 + 3 + 2, (3, 3): 3 + 38 + 11 + 5 + 3}[(IN, OUT)]
+    ntiles = {(0, 1): 3 + 32 + 7, (1, 2): 3 + 38 + 8 + 2, (2, 3): 3 + 38 + 9 + 3 + 2, (3, 3): 3 + 38 + 9 + 4 + 3}[(IN, OUT)]
     assert stream.size == ntiles * TILE == lib.cbd_conv_stream_floats(IN, OUT)
     E = 32
     in_dim, out_dim = sr.e3.Irreps(in_irr).dim, sr.e3.Irreps(out_irr).dim
