@@ -18,15 +18,15 @@ constexpr int NV = 6;
 constexpr int COL_1O = 32, COL_1E = 50, COL_0O = 68, NODE_DIM = 74;
 
 // ---- tensor-product convolution tiling ----------------------------------------------------------------------
-// One wave owns 32 edges (the N dimension of v_mfma_f32_32x32x2_f32); a workgroup of 4 waves owns 128
-// consecutive edges of ONE edge group and shares the streamed weight tiles through LDS.
+// One wave (= one workgroup) owns 32 consecutive edges of ONE edge group (the N dimension of v_mfma_f32_32x32x2_f32).
 constexpr int WAVE_EDGES = 32;
-constexpr int CONV_WAVES = 4;
-constexpr int CONV_WG_EDGES = WAVE_EDGES * CONV_WAVES;
+constexpr int CONV_WG_EDGES = WAVE_EDGES;      // one wave per workgroup
 constexpr int KDIM = 96;                       // radial-MLP width (3*ns)
 constexpr int KSTEPS = KDIM / 2;               // 48 MFMA k-steps of 2
 constexpr int TILE_W_FLOATS = KSTEPS * 64;     // 3072 weight floats per 32-row tile
-constexpr int TILE_FLOATS = TILE_W_FLOATS + 32;  // + 32 bias floats  (12416 B)
+// Weight stream of one FCBlock: (ntiles + 1) tiles of TILE_W_FLOATS (the last one zero: prefetch target of the last
+// real tile), followed by ntiles x 32 bias floats.
+__host__ __device__ constexpr size_t conv_stream_floats(int ntiles) { return (size_t)(ntiles + 1) * TILE_W_FLOATS + (size_t)ntiles * 32; }
 // Row layout of a vector / pseudoscalar block tile (m_out = 6): accumulator register reg < 15 of lane half hf holds
 // (mid index i = 5*tile + reg/3, output o = 3*hf + reg%3); 30 of the 32 rows carry weights (reg 15 is zero).
 constexpr int VEC_TILE_I = 5;
@@ -68,7 +68,7 @@ struct ConvGroup {
   const int* attr_idx;   // [cap] row of `attr`
   const float* vec;      // [cap][4] unit edge vector (xyz, 0): sh = [1, sqrt3 * v]
   const float* attr;     // [.][32] embedded edge attributes
-  const float* wstream;  // [ntiles][TILE_FLOATS] re-packed weights of this group's FCBlock
+  const float* wstream;  // conv_stream_floats(ntiles) re-packed weights of this group's FCBlock
   const int* count;      // device scalar: number of edges
 };
 

@@ -149,27 +149,29 @@ static int need(cbd_engine* e, const std::string& k, std::initializer_list<int64
 // See the layout notes at the top of tp_conv.hip.  W2's k order follows the C/D register layout of the first GEMM.
 static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
   const ConvShape S = conv_shape(IN, OUT);
-  std::vector<float> out((size_t)S.ntiles * TILE_FLOATS, 0.f);
+  std::vector<float> out(conv_stream_floats(S.ntiles), 0.f);
+  float* const bias_tab = out.data() + (size_t)(S.ntiles + 1) * TILE_W_FLOATS;
   auto widx = [](int s, int lane) { return ((s >> 2) * 64 + lane) * 4 + (s & 3); };
   int T = 0;
   for (int m = 0; m < 3; ++m, ++T) {
-    float* tile = out.data() + (size_t)T * TILE_FLOATS;
+    float* tile = out.data() + (size_t)T * TILE_W_FLOATS;
     for (int s = 0; s < KSTEPS; ++s)
       for (int lane = 0; lane < 64; ++lane) {
         const int i = lane & 31, h = lane >> 5;
         const int f = 32 * (s / 16) + 16 * h + (s % 16);
         tile[widx(s, lane)] = W1[(size_t)(32 * m + i) * KDIM + f];
       }
-    for (int r = 0; r < 32; ++r) tile[TILE_W_FLOATS + r] = b1[32 * m + r];
+    for (int r = 0; r < 32; ++r) bias_tab[(size_t)T * 32 + r] = b1[32 * m + r];
   }
   auto kperm = [](int s, int h) { return 32 * (s / 16) + ((s % 16) & 3) + 8 * ((s % 16) >> 2) + 4 * h; };
-  auto fill_tile = [&](float* tile, const int* wc, const float* scale) {   // wc[r] < 0 => zero row
+  auto fill_tile = [&](int Tt, const int* wc, const float* scale) {   // wc[r] < 0 => zero row
+    float* tile = out.data() + (size_t)Tt * TILE_W_FLOATS;
     for (int s = 0; s < KSTEPS; ++s)
       for (int lane = 0; lane < 64; ++lane) {
         const int r = lane & 31, h = lane >> 5;
         tile[widx(s, lane)] = wc[r] < 0 ? 0.f : scale[r] * W2[(size_t)wc[r] * KDIM + kperm(s, h)];
       }
-    for (int r = 0; r < 32; ++r) tile[TILE_W_FLOATS + r] = wc[r] < 0 ? 0.f : scale[r] * b2[wc[r]];
+    for (int r = 0; r < 32; ++r) bias_tab[(size_t)Tt * 32 + r] = wc[r] < 0 ? 0.f : scale[r] * b2[wc[r]];
   };
   const float s3 = std::sqrt(3.0f), s15 = std::sqrt(1.5f);
   int wc[32];
@@ -177,7 +179,7 @@ static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, con
   // block 0e
   for (int i = 0; i < S.fan0e; ++i, ++T) {
     for (int r = 0; r < 32; ++r) { wc[r] = i * NS + r; sc[r] = 1.0f / std::sqrt((float)S.fan0e); }
-    fill_tile(out.data() + (size_t)T * TILE_FLOATS, wc, sc);
+    fill_tile(T, wc, sc);
   }
   auto vec_tiles = [&](int off, int fan, int ntile, auto mid_factor) {
     for (int t = 0; t < ntile; ++t, ++T) {
@@ -188,7 +190,7 @@ static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, con
         if (reg < 15 && i < fan) { wc[r] = off + i * NV + o; sc[r] = mid_factor(i) / std::sqrt((float)fan); }
         else { wc[r] = -1; sc[r] = 0.f; }
       }
-      fill_tile(out.data() + (size_t)T * TILE_FLOATS, wc, sc);
+      fill_tile(T, wc, sc);
     }
   };
   int off = S.fan0e * NS;
@@ -880,7 +882,7 @@ int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_
 // Host-only helper for the CPU tests: pack one FCBlock into the MFMA tile stream (no GPU needed).
 // out must hold cbd_conv_stream_floats(in_level, out_level) floats.
 int64_t cbd_conv_stream_floats(int32_t in_level, int32_t out_level) {
-  return (int64_t)conv_shape(in_level, out_level).ntiles * TILE_FLOATS;
+  return (int64_t)conv_stream_floats(conv_shape(in_level, out_level).ntiles);
 }
 int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1, const float* b1, const float* w2, const float* b2,
                          float* out) {

@@ -12,8 +12,9 @@
 //     act[edge j][k(s, hf)] for the 48 k-steps s.  The accumulator of the first Linear (after bias+ReLU) IS the
 //     B operand of the second Linear -- the k order of W2 is permuted at weight-packing time to the C/D layout
 //     row(reg, hf) = (reg&3) + 8*(reg>>2) + 4*hf, so nothing moves between the two GEMMs.
-//   * A (weights) is streamed as 32-row tiles [12 x 64 lanes x float4 | 32 bias] through a double-buffered LDS
-//     stage shared by the 4 waves of the workgroup (each wave owns 32 edges -> 128 edges per 12 KB of weights).
+//   * A (weights) is streamed as 32-row tiles [12 x 64 lanes x float4] straight from L2 into registers in MFMA
+//     operand order, one tile ahead of its use (every wave streams the whole 0.7 MB of its group's FCBlock, which
+//     is L2 resident: no LDS staging, no barrier in the tile loop, waves fully independent -> one wave per workgroup).
 //   * Each finished 32x32 tile of w is consumed immediately by the CG contraction on the VALU: lane (j, hf)
 //     multiplies its 16 accumulator rows with the "mid" value(s) of edge j (scalar, dot, cross or outer
 //     products of x_dst and the unit edge vector, read from a per-wave LDS copy of the gathered row) and adds
@@ -32,44 +33,30 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// D = bias + A_tile * B ; A tile and bias read from LDS.
-__device__ __forceinline__ void gemm_tile(const float* __restrict__ tile, const float (&B)[KSTEPS], f32x16& acc, int lane) {
-  const int hf = lane >> 5;
-  const f32x4* bp = reinterpret_cast<const f32x4*>(tile + TILE_W_FLOATS);
+// One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers (a[12], 48 VGPRs,
+// loaded one tile ahead straight from global/L2 in MFMA operand order: 12 fully coalesced 1 KB wave loads per tile);
+// each fragment register is refilled with the NEXT tile's data right after its last use, so the loads have a whole
+// tile of MFMA time (~3000 cycles) to land and no barrier or LDS staging is involved.
+__device__ __forceinline__ void gemm_tile(f32x4 (&a)[KSTEPS / 4], const f32x4* __restrict__ next, const float* __restrict__ bias_l,
+                                          const float (&B)[KSTEPS], f32x16& acc, int hf) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 b = bp[2 * q + hf];
     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
   }
-  const f32x4* ap = reinterpret_cast<const f32x4*>(tile) + lane;
 #pragma unroll
   for (int sg = 0; sg < KSTEPS / 4; ++sg) {
-    f32x4 a = ap[sg * 64];
-    acc = mfma32(a.x, B[4 * sg + 0], acc);
-    acc = mfma32(a.y, B[4 * sg + 1], acc);
-    acc = mfma32(a.z, B[4 * sg + 2], acc);
-    acc = mfma32(a.w, B[4 * sg + 3], acc);
+    const f32x4 w = a[sg];
+    acc = mfma32(w.x, B[4 * sg + 0], acc);
+    acc = mfma32(w.y, B[4 * sg + 1], acc);
+    acc = mfma32(w.z, B[4 * sg + 2], acc);
+    acc = mfma32(w.w, B[4 * sg + 3], acc);
+    a[sg] = next[sg * 64];
+    // keep the refill right behind its last use: without this hipcc sinks all 12 loads to the end of the tile and the
+    // next tile then starts by waiting a full L2 round trip
+    __builtin_amdgcn_sched_barrier(0);
   }
-}
-
-struct Stage {  // one thread's share of a weight tile in flight: 3 x 16 B of weights (+ 16 B of bias for tid < 8)
-  f32x4 w0, w1, w2, bb;
-};
-
-__device__ __forceinline__ void stage_load(Stage& st, const float* __restrict__ gtile, int tid) {
-  const f32x4* p = reinterpret_cast<const f32x4*>(gtile);
-  st.w0 = p[tid];
-  st.w1 = p[tid + 256];
-  st.w2 = p[tid + 512];
-  if (tid < 8) st.bb = p[768 + tid];
-}
-
-__device__ __forceinline__ void stage_store(const Stage& st, float* __restrict__ ltile, int tid) {
-  f32x4* p = reinterpret_cast<f32x4*>(ltile);
-  p[tid] = st.w0;
-  p[tid + 256] = st.w1;
-  p[tid + 512] = st.w2;
-  if (tid < 8) p[768 + tid] = st.bb;
 }
 
 // "mid" evaluators: value of the CG intermediate with index i for edge j (xc = &xT[0][j], column stride 32).
@@ -135,22 +122,20 @@ __device__ __forceinline__ float mid0o(const float* xc, int i, const float (&v)[
 }
 
 constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed copy of the gathered rows
-constexpr int WAVE_LDS_FLOATS = XT_FLOATS + 32;          // + 32 ints of src ids
-constexpr int CONV_LDS_FLOATS = 2 * TILE_FLOATS + CONV_WAVES * WAVE_LDS_FLOATS;
-constexpr int CONV_LDS_BYTES = CONV_LDS_FLOATS * 4;
+constexpr int OUT_STRIDE = 33;                           // message tile stride (conflict-free column reads)
+__host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
 template <int IN, int OUT>
-__global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
+__global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* abuf = lds;                                   // 2 x TILE_FLOATS
-  const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  float* bias_l = lds;                                 // [ntiles][32]
+  float* xT = lds + S.ntiles * 32;                     // [80][32] gathered destination rows, transposed
+  int* srcl = reinterpret_cast<int*>(xT + XT_FLOATS);  // [32]
+  const int lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
-  float* xT = lds + 2 * TILE_FLOATS + wave * WAVE_LDS_FLOATS;
-  int* srcl = reinterpret_cast<int*>(xT + XT_FLOATS);
 
-  // ---- which group / edge range does this workgroup own?  (edge counts live on the device)
+  // ---- which group / edge range does this wave own?  (edge counts live on the device)
   int grp = -1, e0 = 0, cnt = 0;
   {
     int t = blockIdx.x;
@@ -165,30 +150,43 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   }
   if (grp < 0) return;
   const ConvGroup G = args.g[grp];
-  const float* wst = G.wstream;
 
-  // ---- gather the edge's inputs
-  const int e = e0 + wave * WAVE_EDGES + j;
-  const bool valid = e < cnt;
-  int src = -1, dst = 0, aidx = 0;
-  float v[3] = {0.f, 0.f, 0.f};
-  if (valid) {
-    src = G.src[e]; dst = G.dst[e]; aidx = G.attr_idx[e];
-    const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[e];
-    v[0] = vv.x; v[1] = vv.y; v[2] = vv.z;
+  // ---- start the weight stream: tile 0 fragments + the bias table of the group
+  const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*768 + sg*64]
+  f32x4 a[KSTEPS / 4];
+#pragma unroll
+  for (int sg = 0; sg < KSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  {  // bias table -> LDS: fixed number of unconditional, clamped loads (a counted loop compiles to a load/wait waterfall)
+    const f32x4* gb = reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * TILE_W_FLOATS);
+    constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
+    f32x4 bt[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; bt[i] = gb[k < NB4 ? k : NB4 - 1]; }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; reinterpret_cast<f32x4*>(bias_l)[k < NB4 ? k : NB4 - 1] = bt[i]; }
   }
+
+  // ---- gather the edge's inputs.  Lanes past the end of the group read the group's last edge (unconditional loads:
+  //      a per-lane `valid ? load : 0` makes hipcc branch around every load and wait vmcnt(0) each time) and are
+  //      dropped at the end through src = -1.
+  const int e = e0 + j;
+  const bool valid = e < cnt;
+  const int ec = valid ? e : cnt - 1;
+  const int src_r = G.src[ec], dst = G.dst[ec], aidx = G.attr_idx[ec];
+  const int src = valid ? src_r : -1;
+  const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[ec];
+  const float v[3] = {vv.x, vv.y, vv.z};
   if (hf == 0) srcl[j] = src;
 
   float Bx[KSTEPS];  // first-Linear input: [edge_attr(32) | x_src[:32] | x_dst[:32]], lane half hf holds cols 16hf..16hf+15
   {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)(src < 0 ? 0 : src) * NODE_STRIDE + 16 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
     const f32x4* pd = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 a = valid ? pa[q] : z, s = valid ? ps[q] : z, d = valid ? pd[q] : z;
-      Bx[4 * q + 0] = a.x; Bx[4 * q + 1] = a.y; Bx[4 * q + 2] = a.z; Bx[4 * q + 3] = a.w;
+      const f32x4 aa = pa[q], s = ps[q], d = pd[q];
+      Bx[4 * q + 0] = aa.x; Bx[4 * q + 1] = aa.y; Bx[4 * q + 2] = aa.z; Bx[4 * q + 3] = aa.w;
       Bx[16 + 4 * q + 0] = s.x; Bx[16 + 4 * q + 1] = s.y; Bx[16 + 4 * q + 2] = s.z; Bx[16 + 4 * q + 3] = s.w;
       Bx[32 + 4 * q + 0] = d.x; Bx[32 + 4 * q + 1] = d.y; Bx[32 + 4 * q + 2] = d.z; Bx[32 + 4 * q + 3] = d.w;
     }
@@ -196,35 +194,27 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
     const f32x4* pr = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
-      const f32x4 r = valid ? pr[q] : z;
+      const f32x4 r = pr[q];
       float* o = xT + (40 * hf + 4 * q) * 32 + j;
       o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
     }
   }
-
-  // ---- weight-tile pipeline prologue
-  Stage st;
-  stage_load(st, wst, tid);
-  stage_store(st, abuf, tid);
-  __syncthreads();
+  __syncthreads();   // single-wave workgroup: orders the LDS writes above before the reads below
 
   int T = 0;
   f32x16 acc;
   float h1[KSTEPS];
-  auto advance = [&](bool more) __attribute__((always_inline)) {   // finish tile T: publish tile T+1 and flip
-    if (more) stage_store(st, abuf + ((T + 1) & 1) * TILE_FLOATS, tid);
-    __syncthreads();
-    ++T;
-  };
+  // the stream carries one zero tile after the last real one, so the prefetch of tile T+1 is always in bounds
+#define CBD_TILE(BOP)                                                                  \
+  gemm_tile(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf); \
+  ++T
 
   // ---- first Linear (3 tiles): h1 = ReLU(W1 x + b1), kept in the C/D register layout
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
-    gemm_tile(abuf + (T & 1) * TILE_FLOATS, Bx, acc, lane);
+    CBD_TILE(Bx);
 #pragma unroll
     for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
-    advance(true);
   }
 
   const float* xc = xT + j;
@@ -234,13 +224,10 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
 #pragma unroll 1
   for (int i = 0; i < S.t0e; ++i) {
-    const bool more = (T + 1) < S.ntiles;
-    if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
-    gemm_tile(abuf + (T & 1) * TILE_FLOATS, h1, acc, lane);
+    CBD_TILE(h1);
     const float m = mid0e<IN>(xc, i, v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
-    advance(more);
   }
 
   // ---- vector / pseudoscalar blocks: tile = 5 mid indices x 6 outputs; lane half hf owns outputs 3hf..3hf+2, register
@@ -253,9 +240,7 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
-      const bool more = (T + 1) < S.ntiles;
-      if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
-      gemm_tile(abuf + (T & 1) * TILE_FLOATS, h1, acc, lane);
+      CBD_TILE(h1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
         float m[3];
@@ -268,7 +253,6 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
           keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
         }
       }
-      advance(more);
     }
   };
 
@@ -278,37 +262,36 @@ __global__ __launch_bounds__(256, 2) void tp_conv_kernel(ConvArgs args) {
   if constexpr (OUT >= 3) {
 #pragma unroll 1
     for (int t = 0; t < S.t0o; ++t) {
-      const bool more = (T + 1) < S.ntiles;
-      if (more) stage_load(st, wst + (size_t)(T + 1) * TILE_FLOATS, tid);
-      gemm_tile(abuf + (T & 1) * TILE_FLOATS, h1, acc, lane);
+      CBD_TILE(h1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
         const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
 #pragma unroll
         for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
       }
-      advance(more);
     }
   }
 
-  // ---- messages -> LDS (re-using the gathered-row tile), then run-length sum per aggregating node
-  // (all reads of xT by this wave are complete: they feed the FMAs above, and xT is private to the wave)
+#undef CBD_TILE
+  // ---- messages -> LDS (re-using the gathered-row tile, stride 33 so that the column reads below are conflict free),
+  //      then run-length sum per aggregating node
+  __syncthreads();   // every read of xT (mids) is complete before it is overwritten
 #pragma unroll
-  for (int r = 0; r < 16; ++r) xT[((r & 3) + 8 * (r >> 2) + 4 * hf) * 32 + j] = o0e[r];
+  for (int r = 0; r < 16; ++r) xT[((r & 3) + 8 * (r >> 2) + 4 * hf) * OUT_STRIDE + j] = o0e[r];
 #pragma unroll
   for (int o = 0; o < 3; ++o)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      xT[(COL_1O + 3 * (3 * hf + o) + c) * 32 + j] = k1o[3 * o + c];
-      if constexpr (OUT >= 2) xT[(COL_1E + 3 * (3 * hf + o) + c) * 32 + j] = k1e[3 * o + c];
+      xT[(COL_1O + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1o[3 * o + c];
+      if constexpr (OUT >= 2) xT[(COL_1E + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1e[3 * o + c];
     }
   if constexpr (OUT >= 3) {
 #pragma unroll
-    for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * 32 + j] = k0o[o];
+    for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
   }
   __syncthreads();
   for (int col = lane; col < S.out_dim; col += 64) {
-    const float* oc = xT + col * 32;
+    const float* oc = xT + col * OUT_STRIDE;
     float sum = 0.f;
     int cur = srcl[0];
     for (int jj = 0; jj < 32; ++jj) {
@@ -351,14 +334,8 @@ __global__ void conv_finalize_kernel(float* __restrict__ acc, const float* __res
 // ---------------------------------------------------------------------------------------------- host launchers
 template <int IN, int OUT>
 static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv_kernel<IN, OUT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, CONV_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT>), dim3(grid), dim3(256), CONV_LDS_BYTES, s, a);
+  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
+  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }
 

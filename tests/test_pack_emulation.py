@@ -23,9 +23,9 @@ def row_of(reg, hf):
 
 
 def gemm_tile(tile, B):
-    """tile: TILE floats; B[s][lane] -> acc[reg][lane] exactly as gemm_tile() in tp_conv.hip."""
-    A = tile[:TILE_W].reshape(12, 64, 4)            # [sg][lane][4]
-    bias = tile[TILE_W:]
+    """tile: (weights [TILE_W], bias [32]); B[s][lane] -> acc[reg][lane] exactly as gemm_tile() in tp_conv.hip."""
+    A = tile[0].reshape(12, 64, 4)                  # [sg][lane][4]
+    bias = tile[1]
     D = np.zeros((32, 32), dtype=np.float64)        # [row][edge]
     for s in range(KSTEPS):
         a = A[s >> 2, :, s & 3]                     # per lane
@@ -55,7 +55,11 @@ def cross(a, v):
 def emulate(stream, IN, OUT, xin, xrow, v):
     """One 32-edge wave tile.  xin [32,96] = [edge_attr | x_src[:32] | x_dst[:32]], xrow [32,80], v [32,3] unit."""
     S = shape(IN, OUT)
-    tiles = stream.reshape(-1, TILE)
+    nt = 3 + S["t0e"] + S["t1o"] + (S["t1e"] if OUT >= 2 else 0) + (S["t0o"] if OUT >= 3 else 0)
+    assert stream.size == (nt + 1) * TILE_W + nt * 32
+    assert np.all(stream[nt * TILE_W:(nt + 1) * TILE_W] == 0)      # prefetch target after the last tile
+    wts, bias = stream[:nt * TILE_W].reshape(nt, TILE_W), stream[(nt + 1) * TILE_W:].reshape(nt, 32)
+    tiles = [(wts[k], bias[k]) for k in range(nt)]
     lanes = np.arange(64)
     j, hf = lanes & 31, lanes >> 5
     # first-Linear B operand: lane half hf holds columns 16hf..16hf+15 of each 32-wide source
@@ -126,7 +130,7 @@ def emulate(stream, IN, OUT, xin, xrow, v):
                     k0[:, lane] += m * acc[3 * q:3 * q + 3, lane]
         for lane in range(64):
             out[lane & 31, COL_0O + 3 * (lane >> 5):COL_0O + 3 * (lane >> 5) + 3] = k0[:, lane]
-    assert T == tiles.shape[0]
+    assert T == len(tiles)
     return out
 
 
@@ -141,7 +145,7 @@ def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
     w2, b2 = torch.randn(W, 96, generator=g) / 8, torch.randn(W, generator=g) / 4
     stream = pack_conv_stream(IN, OUT, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
     ntiles = {(0, 1): 3 + 32 + 7, (1, 2): 3 + 38 + 8 + 2, (2, 3): 3 + 38 + 9 + 3 + 2, (3, 3): 3 + 38 + 9 + 4 + 3}[(IN, OUT)]
-    assert stream.size == ntiles * TILE == lib.cbd_conv_stream_floats(IN, OUT)
+    assert stream.size == (ntiles + 1) * TILE_W + ntiles * 32 == lib.cbd_conv_stream_floats(IN, OUT)
     E = 32
     in_dim, out_dim = sr.e3.Irreps(in_irr).dim, sr.e3.Irreps(out_irr).dim
     xin = torch.randn(E, 96, generator=g)
