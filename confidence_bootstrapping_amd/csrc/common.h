@@ -77,6 +77,7 @@ struct ConvArgs {
   int n_groups;
   const float* node_in;  // [N][NODE_STRIDE]
   float* acc;            // [N][NODE_STRIDE] fp32 sums (atomic)
+  unsigned long long* stamps;   // diagnostic build only (CBD_CONV_VARIANT=8): [grid][4] s_memtime/s_memrealtime at start/end
 };
 
 }  // namespace cbd

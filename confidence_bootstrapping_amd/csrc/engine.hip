@@ -107,6 +107,10 @@ struct cbd_engine {
   int* rr_count_dev = nullptr;
   float *d_rec_x = nullptr, *d_vec0 = nullptr, *d_dist0 = nullptr;
   int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
+  float* rr_shared = nullptr;       // [Nr][NODE_STRIDE] layer-0 receptor->receptor message sums (identical for all samples)
+  hipStream_t side = nullptr;       // forked stream for work that only depends on the diffusion time
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  unsigned long long* stamps_dev = nullptr;   // diagnostic (CBD_CONV_VARIANT=8)
   unsigned long long* stats_dev = nullptr;   // [4] edge-layer visits: ll (embedding layers), joint conv layers, forwards
 
   // ---- batch workspace
@@ -298,6 +302,9 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   HIPCHK(hipSetDevice(cfg->device));
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
+  HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   *out = e;
   return 0;
 }
@@ -308,6 +315,9 @@ int cbd_destroy(cbd_engine* e) {
   (void)hipDeviceSynchronize();
   e->wpool.release(); e->cpool.release(); e->bpool.release();
   for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+  if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+  if (e->side) (void)hipStreamDestroy(e->side);
   delete e;
   return 0;
 }
@@ -451,17 +461,18 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
 }
 
 static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
-                    const float* node_in, hipStream_t s) {
+                    const float* node_in, hipStream_t s, const int* widx = nullptr, float* acc_override = nullptr) {
   ConvArgs a{};
   a.n_groups = n_groups;
   int grid = 0;
   for (int g = 0; g < n_groups; ++g) {
     a.g[g] = groups[g];
-    a.g[g].wstream = L.wstream[g];
+    a.g[g].wstream = L.wstream[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
     grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
   }
   a.node_in = node_in;
-  a.acc = e->acc;
+  a.acc = acc_override ? acc_override : e->acc;
+  a.stamps = e->stamps_dev;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
     if (e->ev_used == e->ev_pool.size()) {
@@ -479,9 +490,9 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
 }
 
 static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const int* deg, int n_nodes,
-                        int node_off, hipStream_t s) {
+                        int node_off, hipStream_t s, const float* extra = nullptr, int extra_mod = 1) {
   HIPCHK(launch_conv_finalize(e->acc, node_in, node_out, deg, L.bn_scale, L.bn_mean, L.bn_bias, n_nodes, in_level_dim(L.in_level),
-                              out_level_dim(L.out_level), node_off, s));
+                              out_level_dim(L.out_level), node_off, extra, extra_mod, s));
   return 0;
 }
 
@@ -643,10 +654,15 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.upload(&e->rr_src, bsrc)); HIPCHK(e->bpool.upload(&e->rr_dst, bdst)); HIPCHK(e->bpool.upload(&e->rr_aidx, baidx));
   HIPCHK(e->bpool.alloc(&e->rr_vec, (size_t)Bm * Err * 4));
   HIPCHK(e->bpool.alloc(&e->rr_count_dev, 1));
+  HIPCHK(e->bpool.alloc(&e->rr_shared, (size_t)Nr * NODE_STRIDE));
 
   e->d_rec_x = d_rec_x; e->d_vec0 = d_vec0; e->d_dist0 = d_dist0; e->d_src0 = d_src0; e->d_dst0 = d_dst0;
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
   HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
+  if (getenv("CBD_CONV_VARIANT") && atoi(getenv("CBD_CONV_VARIANT")) == 8) {
+    HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 4));
+    HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 4 * 8));
+  } else e->stamps_dev = nullptr;
   HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
   hipStream_t s = nullptr;
   CHK(embed_receptor(e, s));
@@ -677,6 +693,26 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   e->last_B = B;
   e->dbg_snap.clear();
   HIPCHK(launch_step_prep(e->sw, e->sv, sigma_emb_dev, s));
+  // ---- fork: everything that depends only on the diffusion time runs on the side stream, concurrently with the
+  //      pose-dependent graph construction and ligand embedding: receptor rows (static embedding + sigma embedding,
+  //      score_model.py:323-326) and the receptor->receptor messages of interaction layer 0.  Those messages read only
+  //      receptor features and shared edge attributes, so they are IDENTICAL for the B samples of a complex: they are
+  //      computed once (Err edges instead of B*Err) into rr_shared and added to every sample's sum by the finalize kernel.
+  float* const Xa = e->X0;          // ligand embedding ping-pong: X0 -> X1 -> X0 -> X1 ; interaction layers read X1 first
+  float* const Xb = e->X1;
+  HIPCHK(hipEventRecord(e->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+  {
+    hipStream_t ss = e->side;
+    HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, ss));
+    HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, Xb, B, gs.rec_off, Nr, ss));
+    HIPCHK(hipMemsetAsync(e->rr_shared, 0, (size_t)Nr * NODE_STRIDE * 4, ss));
+    ConvGroup g0{};
+    g0.src = e->rr_src; g0.dst = e->rr_dst; g0.attr_idx = e->rr_aidx; g0.vec = e->rr_vec; g0.attr = e->rr_attr_t; g0.count = e->rr_count_dev;
+    const int cap0 = gs.Err, w_rr = 2;
+    CHK(run_conv(e, e->conv[0], &g0, 1, &cap0, Xb, ss, &w_rr, e->rr_shared - (size_t)gs.rec_off * NODE_STRIDE));
+    HIPCHK(hipEventRecord(e->ev_join, ss));
+  }
   HIPCHK(hipMemsetAsync(gd.counts, 0, 8 * sizeof(int), s));
   HIPCHK(launch_graph_count(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
   HIPCHK(launch_graph_scan(gs, gd, B, e->stats_dev, s));
@@ -685,9 +721,8 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   EdgeMlp mll = make_mlp(e->m_lig_edge, e->sv.ll_part), mlr = make_mlp(e->m_cross, e->sv.lr_part);
   HIPCHK(launch_edge_mlp(mll, gd.ll_dist, gd.ll_bond4, gd.counts + 0, cap_ll, e->ll_attr, s));
   HIPCHK(launch_edge_mlp(mlr, gd.lr_dist, nullptr, gd.counts + 1, cap_x, e->lr_attr, s));
-  HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, s));
-  HIPCHK(launch_lig_node_init(e->lig_static32, e->sv.lig_node_c, e->X0, B, Nl, s));
-  snap(e, "lig_node_emb0", e->X0, (size_t)nL * NODE_STRIDE, s);
+  HIPCHK(launch_lig_node_init(e->lig_static32, e->sv.lig_node_c, Xa, B, Nl, s));
+  snap(e, "lig_node_emb0", Xa, (size_t)nL * NODE_STRIDE, s);
 
   ConvGroup gll{}, glr{}, grr{}, grl{};
   gll.src = gd.ll_src; gll.dst = gd.ll_dst; gll.attr_idx = gd.ll_aidx; gll.vec = gd.ll_vec; gll.attr = e->ll_attr; gll.count = gd.counts + 0;
@@ -695,8 +730,8 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   grr.src = e->rr_src; grr.dst = e->rr_dst; grr.attr_idx = e->rr_aidx; grr.vec = e->rr_vec; grr.attr = e->rr_attr_t; grr.count = gd.counts + 2;
   grl.src = gd.rl_src; grl.dst = gd.rl_dst; grl.attr_idx = gd.rl_aidx; grl.vec = gd.rl_vec; grl.attr = e->lr_attr; grl.count = gd.counts + 3;
 
-  float* in = e->X0;
-  float* out = e->X1;
+  float* in = Xa;
+  float* out = Xb;
   static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
   for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
     CHK(run_conv(e, e->lig_emb[l], &gll, 1, &cap_ll, in, s));
@@ -704,10 +739,17 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
     std::swap(in, out);
     snap(e, emb_names[l], in, (size_t)nL * NODE_STRIDE, s);
   }
-  HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, in, B, gs.rec_off, Nr, s));
+  // ---- join: `in` == Xb now holds the embedded ligand rows (main stream) and the receptor rows (side stream)
+  HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
   static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
   for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
-    if (l < 4) {
+    if (l == 0) {
+      const ConvGroup g3[3] = {gll, glr, grl};
+      const int caps[3] = {cap_ll, cap_x, cap_x}, widx[3] = {0, 1, 3};
+      CHK(run_conv(e, e->conv[l], g3, 3, caps, in, s, widx));
+      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));
+      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nR, gs.rec_off, s, e->rr_shared, Nr));
+    } else if (l < 4) {
       const ConvGroup g4[4] = {gll, glr, grr, grl};
       const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
       CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
@@ -846,6 +888,20 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
       std::memcpy(out, p.second.data(), p.second.size() * 4);
       return (int64_t)p.second.size();
     }
+  if (k == "conv_clock_ghz") {   // median in-kernel shader clock of the last tp_conv<3,3> launch (diagnostic build)
+    if (!e->stamps_dev || capacity < 3) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_CONV_VARIANT=8)");
+    std::vector<unsigned long long> h(8192 * 4);
+    if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
+    std::vector<double> ghz, dur;
+    for (int i = 0; i < 8192; ++i) {
+      const double dt = (double)(h[4 * i + 2] - h[4 * i]), dr = (double)(h[4 * i + 3] - h[4 * i + 1]);
+      if (h[4 * i + 3] && dr > 0) { ghz.push_back(dt / dr * 0.1); dur.push_back(dr * 10.0); }   // memrealtime ticks at 100 MHz
+    }
+    if (ghz.empty()) return fail(CBD_ERR_STATE, "no stamps recorded");
+    std::sort(ghz.begin(), ghz.end()); std::sort(dur.begin(), dur.end());
+    out[0] = (float)ghz[ghz.size() / 2]; out[1] = (float)dur[dur.size() / 2]; out[2] = (float)ghz.size();
+    return 3;
+  }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);
   size_t n = it->second.second;

@@ -25,6 +25,8 @@
 //     the register index, each half owns three of the six outputs, and 30 of the 32 MFMA rows carry weights.
 //   * Segmented reduction: edges are sorted by aggregating node; each wave run-length sums its 32 messages in
 //     LDS and issues one 256-byte-contiguous fp32 atomic add per (node run, 64 columns).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cbd {
@@ -37,6 +39,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // loaded one tile ahead straight from global/L2 in MFMA operand order: 12 fully coalesced 1 KB wave loads per tile);
 // each fragment register is refilled with the NEXT tile's data right after its last use, so the loads have a whole
 // tile of MFMA time (~3000 cycles) to land and no barrier or LDS staging is involved.
+template <int VAR>
 __device__ __forceinline__ void gemm_tile(f32x4 (&a)[KSTEPS / 4], const f32x4* __restrict__ next, const float* __restrict__ bias_l,
                                           const float (&B)[KSTEPS], f32x16& acc, int hf) {
   const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
@@ -125,7 +128,7 @@ constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed 
 constexpr int OUT_STRIDE = 33;                           // message tile stride (conflict-free column reads)
 __host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
-template <int IN, int OUT>
+template <int IN, int OUT, int VAR>
 __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -150,6 +153,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
   if (grp < 0) return;
   const ConvGroup G = args.g[grp];
+  unsigned long long st_t0 = 0, st_r0 = 0;
+  if constexpr (VAR == 8) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
   const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*768 + sg*64]
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   float h1[KSTEPS];
   // the stream carries one zero tile after the last real one, so the prefetch of tile T+1 is always in bounds
 #define CBD_TILE(BOP)                                                                  \
-  gemm_tile(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf); \
+  gemm_tile<VAR>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf); \
   ++T
 
   // ---- first Linear (3 tiles): h1 = ReLU(W1 x + b1), kept in the C/D register layout
@@ -305,6 +310,12 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     }
     if (cur >= 0) atomicAdd(args.acc + (size_t)cur * NODE_STRIDE + col, sum);
   }
+  if constexpr (VAR == 8) {
+    if (lane == 0 && args.stamps && blockIdx.x < 8192) {
+      unsigned long long* o = args.stamps + (size_t)blockIdx.x * 4;
+      o[0] = st_t0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -315,7 +326,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 __global__ void conv_finalize_kernel(float* __restrict__ acc, const float* __restrict__ node_in, float* __restrict__ node_out,
                                      const int* __restrict__ deg, const float* __restrict__ bn_scale,
                                      const float* __restrict__ bn_mean, const float* __restrict__ bn_bias,
-                                     int n_nodes, int in_dim, int out_dim, int node_off) {
+                                     int n_nodes, int in_dim, int out_dim, int node_off,
+                                     const float* __restrict__ extra, int extra_mod) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
   if (n >= n_nodes) return;
@@ -323,7 +335,9 @@ __global__ void conv_finalize_kernel(float* __restrict__ acc, const float* __res
   float r = 0.f;
   if (c < out_dim) {
     const int d = deg[n + node_off];
-    float m = acc[o] / (float)(d > 1 ? d : 1);
+    float sum = acc[o];
+    if (extra) sum += extra[(size_t)(n % extra_mod) * NODE_STRIDE + c];   // message sums shared by all samples (layer-0 rr)
+    float m = sum / (float)(d > 1 ? d : 1);
     m = (m - bn_mean[c]) * bn_scale[c] + bn_bias[c];
     r = m + (c < in_dim ? node_in[o] : 0.f);
   }
@@ -335,7 +349,10 @@ __global__ void conv_finalize_kernel(float* __restrict__ acc, const float* __res
 template <int IN, int OUT>
 static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
-  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
+  // CBD_CONV_VARIANT=8 selects the diagnostic build of the 74->74 kernel that stamps s_memtime/s_memrealtime
+  static const int var = getenv("CBD_CONV_VARIANT") ? atoi(getenv("CBD_CONV_VARIANT")) : 0;
+  if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }
 
@@ -350,11 +367,11 @@ hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int gr
 
 hipError_t launch_conv_finalize(float* acc, const float* node_in, float* node_out, const int* deg, const float* bn_scale,
                                 const float* bn_mean, const float* bn_bias, int n_nodes, int in_dim, int out_dim,
-                                int node_off, hipStream_t s) {
+                                int node_off, const float* extra, int extra_mod, hipStream_t s) {
   if (n_nodes <= 0) return hipSuccess;
   const int total = n_nodes * NODE_STRIDE;
   hipLaunchKernelGGL(conv_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, acc, node_in, node_out, deg,
-                     bn_scale, bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off);
+                     bn_scale, bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off, extra, extra_mod);
   return hipGetLastError();
 }
 

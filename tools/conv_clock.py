@@ -1,0 +1,24 @@
+"""Diagnostic: in-kernel shader clock of tp_conv<3,3> (s_memtime / s_memrealtime stamps), run with CBD_CONV_VARIANT=8
+after >= 2 s of back-to-back work on random data (MI355X_MICROARCH.md 'DVFS give-back' item 6)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from confidence_bootstrapping_amd.synthetic import make_workload
+from confidence_bootstrapping_amd.utils import make_score_model
+from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+assert os.environ.get("CBD_CONV_VARIANT") == "8"
+dev = torch.device("cuda:0")
+model, args = make_score_model(seed=0)
+cplx = make_workload("c2_dockgen_median")
+eng = DockEngine(dev, max_batch=40); eng.load_state_dict(model.state_dict()); eng.set_complex(cplx)
+steps = make_steps(get_t_schedule("expbeta", 20), args, model.timestep_emb_func)
+g = torch.Generator().manual_seed(0)
+B = 40
+pos0 = (cplx["ligand"].pos[None].repeat(B, 1, 1) - cplx["ligand"].pos.mean(0) + 10 * torch.randn(B, 1, 3, generator=g)).to(dev)
+noise = [torch.randn(20, B, 3, generator=g), torch.randn(20, B, 3, generator=g), torch.randn(20, B * eng.R, generator=g)]
+t0 = time.time()
+while time.time() - t0 < 4.0:
+    p = pos0.clone(); eng.sample(p, steps, *noise); torch.cuda.synchronize()
+ghz, dur_ns, n = eng.fetch("conv_clock_ghz", 16)
+print(f"in-kernel clock of tp_conv<3,3>: median {ghz:.3f} GHz over {int(n)} workgroups, median workgroup lifetime {dur_ns/1e3:.1f} us")
