@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the 40-pose batch is split over")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -96,7 +97,7 @@ def main():
 
     from confidence_bootstrapping_amd.synthetic import make_workload
     from confidence_bootstrapping_amd.utils import make_score_model
-    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.engine import DockEnginePool, make_steps
     from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
     from confidence_bootstrapping_amd.sampling import randomize_position
     from confidence_bootstrapping_amd import Batch
@@ -104,8 +105,7 @@ def main():
 
     model, margs = make_score_model(seed=0)
     cplx = make_workload(WORKLOAD, seed=1234)
-    eng = DockEngine(dev, max_batch=SAMPLES)
-    eng.load_state_dict(model.state_dict())
+    eng = DockEnginePool.from_model(model, dev, n=a.streams, max_batch=SAMPLES)
     eng.set_complex(cplx)
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
     steps = make_steps(sched, margs, model.timestep_emb_func)
@@ -163,8 +163,8 @@ def main():
             "value": round(poses / elapsed, 3), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS,
-                       "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
+            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS, "streams": a.streams,
+                       "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

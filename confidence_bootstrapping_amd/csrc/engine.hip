@@ -121,6 +121,8 @@ struct cbd_engine {
   float* sigma_emb_dev = nullptr;   // [S_max][32]
   int sigma_cap = 0;
   float *tr_out = nullptr, *rot_out = nullptr, *tor_out = nullptr, *dbg_global = nullptr, *dbg_torfeat = nullptr;
+  float *center_msg = nullptr, *tor_msg = nullptr;
+  int *tor_nb = nullptr, *tor_nb_cnt = nullptr;
   int n_nodes_cap = 0;
   int last_B = 0;
   std::map<std::string, std::pair<const float*, size_t>> dbg;   // name -> (device ptr, count), valid after cbd_score
@@ -642,6 +644,9 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)e->sigma_cap * 32));
   HIPCHK(e->bpool.alloc(&e->tr_out, (size_t)Bm * 3)); HIPCHK(e->bpool.alloc(&e->rot_out, (size_t)Bm * 3));
   HIPCHK(e->bpool.alloc(&e->tor_out, (size_t)Bm * std::max(R, 1)));
+  HIPCHK(e->bpool.alloc(&e->center_msg, (size_t)Bm * Nl * 12));
+  HIPCHK(e->bpool.alloc(&e->tor_msg, (size_t)Bm * std::max(R, 1) * 32 * 64));
+  HIPCHK(e->bpool.alloc(&e->tor_nb, (size_t)Bm * std::max(R, 1) * 32)); HIPCHK(e->bpool.alloc(&e->tor_nb_cnt, (size_t)Bm * std::max(R, 1)));
   HIPCHK(e->bpool.alloc(&e->dbg_global, (size_t)Bm * 12)); HIPCHK(e->bpool.alloc(&e->dbg_torfeat, (size_t)Bm * std::max(R, 1) * 64));
   // batched receptor edges (independent of B: receptor rows start at rec_off)
   std::vector<int> bsrc((size_t)Bm * Err), bdst((size_t)Bm * Err), baidx((size_t)Bm * Err);
@@ -766,10 +771,10 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
     if (l < 4) snap(e, (std::string(conv_names[l]) + "_rec").c_str(), in + (size_t)gs.rec_off * NODE_STRIDE, (size_t)nR * NODE_STRIDE, s);
   }
   const float* lig_node = in;
-  HIPCHK(launch_center_head(e->ch, e->sv, pos_dev, lig_node, B, Nl, st.tr_sigma, st.rot_score_norm, tr_dev, rot_dev, e->dbg_global, s));
+  HIPCHK(launch_center_head(e->ch, e->sv, pos_dev, lig_node, B, Nl, st.tr_sigma, st.rot_score_norm, tr_dev, rot_dev, e->dbg_global, e->center_msg, s));
   if (!e->cfg.no_torsion && R > 0)
     HIPCHK(launch_bond_head(e->bh, gs, pos_dev, lig_node, B, e->cfg.lig_max_radius, 32, st.tor_score_norm_sqrt, tor_dev,
-                            gd.counts + 4, e->dbg_torfeat, s));
+                            gd.counts + 4, e->dbg_torfeat, e->tor_nb, e->tor_nb_cnt, e->tor_msg, s));
   e->dbg.clear();
   e->dbg["center_mean"] = {e->dbg_global, (size_t)B * 12};
   e->dbg["tor_feat"] = {e->dbg_torfeat, (size_t)B * R * 64};
@@ -809,7 +814,6 @@ int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* st
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 32 * sizeof(float), hipMemcpyHostToDevice, s));
   CHK(forward(e, B, pos_dev, *step, e->sigma_emb_dev, tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, s));
-  if (e->timing) { HIPCHK(hipStreamSynchronize(s)); collect_timing(e); }
   return 0;
 }
 
@@ -855,7 +859,24 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
     const float* ztor = (noise_tor && st.tor_noise_coef != 0.f) ? noise_tor + (size_t)i * B * R : nullptr;
     HIPCHK(launch_pose_update(e->gs, pos_dev, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
   }
-  if (e->timing) { HIPCHK(hipStreamSynchronize(s)); collect_timing(e); }
+  return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
+}
+
+int cbd_share_weights(cbd_engine* dst, cbd_engine* src) {
+  if (!dst || !src || dst == src) return fail(CBD_ERR_ARG, "bad argument");
+  if (!src->weights_ready) return fail(CBD_ERR_STATE, "source engine has no finalized weights");
+  if (dst->cfg.device != src->cfg.device) return fail(CBD_ERR_ARG, "engines live on different devices");
+  HIPCHK(hipSetDevice(dst->cfg.device));
+  dst->wpool.release();          // dst becomes a non-owning view of src's device weights (src must outlive dst)
+  for (int l = 0; l < 3; ++l) { dst->rec_emb[l] = src->rec_emb[l]; dst->lig_emb[l] = src->lig_emb[l]; }
+  for (int l = 0; l < 5; ++l) dst->conv[l] = src->conv[l];
+  dst->m_lig_edge = src->m_lig_edge; dst->m_cross = src->m_cross; dst->m_rec_edge = src->m_rec_edge;
+  dst->m_final_edge = src->m_final_edge; dst->m_center = src->m_center;
+  dst->sw = src->sw; dst->ch = src->ch; dst->bh = src->bh;
+  dst->rec_emb_table = src->rec_emb_table; dst->rec_node_w = src->rec_node_w; dst->rec_node_b = src->rec_node_b;
+  dst->lig_node_w_host = src->lig_node_w_host; dst->lig_emb_tables = src->lig_emb_tables;
+  dst->weights_ready = true;
+  dst->complex_ready = false;
   return 0;
 }
 
@@ -927,6 +948,8 @@ int cbd_last_edge_counts(cbd_engine* e, int64_t counts[5]) {
 
 int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_ms, int64_t* n, double* total_ms) {
   if (!e) return fail(CBD_ERR_ARG, "null engine");
+  (void)hipSetDevice(e->cfg.device);
+  if (e->ev_used) { HIPCHK(hipDeviceSynchronize()); collect_timing(e); }
   if (reset) { e->t_total_ms = 0; e->t_n = 0; e->ev_used = 0; }
   e->timing = enable != 0;
   if (avg_ms) *avg_ms = e->t_n ? e->t_total_ms / (double)e->t_n : 0.0;

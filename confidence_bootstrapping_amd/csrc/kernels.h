@@ -70,7 +70,8 @@ struct CenterHead {
   const float *tr_w0n, *tr_w1, *tr_b1, *rot_w0n, *rot_w1, *rot_b1;   // first-layer norm column [32], second layer [32], [1]
 };
 hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const float* pos, const float* node, int B, int Nl,
-                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, hipStream_t s);
+                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, float* msg_ws,
+                              hipStream_t s);   // msg_ws: [B*Nl][12]
 
 struct BondHead {
   EdgeMlp fe;                                                        // final_edge_embedding (part = b0)
@@ -79,7 +80,8 @@ struct BondHead {
   const float *tf_w0, *tf_w1;                                        // tor_final_layer [32][64], [32]
 };
 hipError_t launch_bond_head(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, float lig_r,
-                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, hipStream_t s);
+                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, int* nb_ws,
+                            int* nb_cnt_ws, float* msg_ws, hipStream_t s);   // nb_ws [B*R][32], nb_cnt_ws [B*R], msg_ws [B*R*32][64]
 
 struct SdeCoefs { float tr_s, tr_n, rot_s, rot_n, tor_s, tor_n; };
 // perturbation (if scores != null) + modify_conformer_batch.  If coefs == null the tr/rot/tor inputs are the updates.

@@ -246,21 +246,47 @@ CBD_DEV float edge_mlp_eval(const EdgeMlp& m, float d, const float* bond4, int o
   return out;
 }
 
+// One lane per edge: all weight addresses are wave-uniform (scalar loads), the 2 x 32x32 products are straight-line
+// FMAs on register arrays, no cross-lane traffic; each lane writes its own 128-B row.
 __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlp m, const float* __restrict__ dist, const float* __restrict__ bond4,
                                                        const int* __restrict__ count, int cap, float* __restrict__ out) {
   const int n = count ? min(*count, cap) : cap;
-  const int e = (blockIdx.x * 256 + threadIdx.x) >> 5;
-  const int o = threadIdx.x & 31;
-  const int sub_base = threadIdx.x & 32;   // lane offset of this half-wave inside the 64-wide wave
-  const bool ok = e < n;
-  const float d = ok ? dist[e] : 0.f;
-  const float v = edge_mlp_eval(m, d, (ok && bond4) ? bond4 + (size_t)e * 4 : nullptr, o, sub_base);
-  if (ok) out[(size_t)e * 32 + o] = v;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= n) return;
+  const float d = dist[e];
+  float h[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) h[o] = m.part[o];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    const float t = d - m.offset[k];
+    const float gk = expf(m.coeff * (t * t));
+#pragma unroll
+    for (int o = 0; o < 32; ++o) h[o] = fmaf(m.WgT[k * 32 + o], gk, h[o]);
+  }
+  if (m.WbT && bond4) {
+    const f32x4 b = reinterpret_cast<const f32x4*>(bond4)[e];
+    const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int o = 0; o < 32; ++o) h[o] = fmaf(m.WbT[c * 32 + o], bb[c], h[o]);
+  }
+  float r[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) { h[o] = fmaxf(h[o], 0.f); r[o] = m.b1[o]; }
+#pragma unroll
+  for (int k = 0; k < 32; ++k)
+#pragma unroll
+    for (int o = 0; o < 32; ++o) r[o] = fmaf(m.W1T[k * 32 + o], h[k], r[o]);
+  f32x4* po = reinterpret_cast<f32x4*>(out + (size_t)e * 32);
+#pragma unroll
+  for (int q = 0; q < 8; ++q) po[q] = f32x4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
 }
 
 hipError_t launch_edge_mlp(const EdgeMlp& m, const float* dist, const float* bond4, const int* count, int cap, float* out, hipStream_t s) {
   if (cap <= 0) return hipSuccess;
-  hipLaunchKernelGGL(edge_mlp_kernel, dim3((cap * 32 + 255) / 256), dim3(256), 0, s, m, dist, bond4, count, cap, out);
+  hipLaunchKernelGGL(edge_mlp_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, m, dist, bond4, count, cap, out);
   return hipGetLastError();
 }
 
@@ -333,226 +359,248 @@ hipError_t launch_add_rows(const float* a, const float* v32, float* out, int row
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648): one workgroup per sample.
+// Centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648).
 // final_conv.tp is e3nn FullyConnectedTensorProduct(74 x (0e+1o) -> 2x1o + 2x1e); its six instructions reduce to the
 // closed forms below (prototype + check against the Wigner-3j einsum: tests/test_kernel_math.py::final_conv_tp).
-__global__ __launch_bounds__(128) void center_head_kernel(CenterHead h, StepVectors sv, const float* __restrict__ pos,
-                                                          const float* __restrict__ node, int Nl, float tr_sigma, float rot_norm,
-                                                          float* __restrict__ tr_out, float* __restrict__ rot_out, float* __restrict__ dbg) {
-  __shared__ float s_in[64], s_hid[64], s_w[124], s_acc[12], s_c[3], s_g[32], s_eh[32];
-  const int b = blockIdx.x, tid = threadIdx.x;
+// Stage 1: one workgroup per (sample, atom) edge -> 12-value message.  Stage 2: one wave per sample: mean over atoms in
+// index order (deterministic), BatchNorm, magnitude MLPs.
+__global__ __launch_bounds__(128) void center_msg_kernel(CenterHead h, StepVectors sv, const float* __restrict__ pos,
+                                                         const float* __restrict__ node, int Nl, float* __restrict__ msg) {
+  __shared__ float s_in[64], s_hid[64], s_w[124], s_c[3], s_g[32], s_eh[32];
+  const int b = blockIdx.x / Nl, a = blockIdx.x % Nl, tid = threadIdx.x;
   const float* P = pos + (size_t)b * Nl * 3;
-  if (tid < 12) s_acc[tid] = 0.f;
   if (tid < 3) {
     float c = 0.f;
-    for (int a = 0; a < Nl; ++a) c += P[3 * a + tid];
+    for (int k = 0; k < Nl; ++k) c += P[3 * k + tid];
     s_c[tid] = c / (float)Nl;
   }
   __syncthreads();
   const float pw_o = sqrtf(3.f / 44.f), pw_e = sqrtf(3.f / 18.f);
   const float is3 = 0.57735026918962576f, is6 = 0.40824829046386302f, s3 = 1.7320508075688772f;
-  for (int a = 0; a < Nl; ++a) {
-    const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
-    float ux, uy, uz, d;
-    unit_vec(P[3 * a] - s_c[0], P[3 * a + 1] - s_c[1], P[3 * a + 2] - s_c[2], ux, uy, uz, d);
-    // centre edge embedding: [gauss(d) | sigma_emb] -> 32 -> 32
-    if (tid < 32) { const float t = d - h.offset[tid]; s_g[tid] = expf(h.coeff * (t * t)); }
-    __syncthreads();
-    if (tid < 32) {
-      float v = sv.center_part[tid];
-      for (int k = 0; k < 32; ++k) v = fmaf(h.ce_WgT[k * 32 + tid], s_g[k], v);
-      s_eh[tid] = fmaxf(v, 0.f);
-    }
-    __syncthreads();
-    if (tid < 32) {
-      float v = h.ce_b1[tid];
-      for (int k = 0; k < 32; ++k) v = fmaf(h.ce_W1T[k * 32 + tid], s_eh[k], v);
-      s_in[tid] = v;
-    } else if (tid < 64) {
-      s_in[tid] = x[tid - 32];   // lig_node_attr[atom, :ns]  (fixed_center_conv, score_model.py:397)
-    }
-    __syncthreads();
-    if (tid < 64) {
-      float v = h.fc_b0[tid];
-      for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w0[tid * 64 + k], s_in[k], v);
-      s_hid[tid] = fmaxf(v, 0.f);
-    }
-    __syncthreads();
-    if (tid < 124) {
-      float v = h.fc_b1[tid];
-      for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w1[tid * 64 + k], s_hid[k], v);
-      s_w[tid] = v;
-    }
-    __syncthreads();
-    if (tid < 12) {
-      const int blk = tid / 6, wv = (tid % 6) / 3, k = tid % 3;   // blk 0: 2x1o, 1: 2x1e ; wv = multiplicity ; k = component
-      const float sh[3] = {s3 * ux, s3 * uy, s3 * uz};
-      float r = 0.f;
-      if (blk == 0) {
-        float t0 = 0.f;
-        for (int u = 0; u < 32; ++u) t0 = fmaf(s_w[u * 2 + wv], x[u], t0);
-        r += pw_o * is3 * t0 * sh[k];
-        for (int u = 0; u < 6; ++u) {
-          r += pw_o * is3 * s_w[64 + u * 2 + wv] * x[COL_1O + 3 * u + k];
-          const float* e = x + COL_1E + 3 * u;
-          const float cr = k == 0 ? e[1] * sh[2] - e[2] * sh[1] : k == 1 ? e[2] * sh[0] - e[0] * sh[2] : e[0] * sh[1] - e[1] * sh[0];
-          r += pw_o * is6 * s_w[100 + u * 2 + wv] * cr;
-        }
-      } else {
-        for (int u = 0; u < 6; ++u) {
-          const float* o = x + COL_1O + 3 * u;
-          const float cr = k == 0 ? o[1] * sh[2] - o[2] * sh[1] : k == 1 ? o[2] * sh[0] - o[0] * sh[2] : o[0] * sh[1] - o[1] * sh[0];
-          r += pw_e * is6 * s_w[76 + u * 2 + wv] * cr;
-          r += pw_e * is3 * s_w[88 + u * 2 + wv] * x[COL_1E + 3 * u + k];
-          r += pw_e * is3 * s_w[112 + u * 2 + wv] * x[COL_0O + u] * sh[k];
-        }
-      }
-      s_acc[tid] += r;
-    }
-    __syncthreads();
+  const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
+  float ux, uy, uz, d;
+  unit_vec(P[3 * a] - s_c[0], P[3 * a + 1] - s_c[1], P[3 * a + 2] - s_c[2], ux, uy, uz, d);
+  // centre edge embedding: [gauss(d) | sigma_emb] -> 32 -> 32
+  if (tid < 32) { const float t = d - h.offset[tid]; s_g[tid] = expf(h.coeff * (t * t)); }
+  __syncthreads();
+  if (tid < 32) {
+    float v = sv.center_part[tid];
+    for (int k = 0; k < 32; ++k) v = fmaf(h.ce_WgT[k * 32 + tid], s_g[k], v);
+    s_eh[tid] = fmaxf(v, 0.f);
   }
+  __syncthreads();
+  if (tid < 32) {
+    float v = h.ce_b1[tid];
+    for (int k = 0; k < 32; ++k) v = fmaf(h.ce_W1T[k * 32 + tid], s_eh[k], v);
+    s_in[tid] = v;
+  } else if (tid < 64) {
+    s_in[tid] = x[tid - 32];   // lig_node_attr[atom, :ns]  (fixed_center_conv, score_model.py:397)
+  }
+  __syncthreads();
+  if (tid < 64) {
+    float v = h.fc_b0[tid];
+    for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w0[tid * 64 + k], s_in[k], v);
+    s_hid[tid] = fmaxf(v, 0.f);
+  }
+  __syncthreads();
+  if (tid < 124) {
+    float v = h.fc_b1[tid];
+    for (int k = 0; k < 64; ++k) v = fmaf(h.fc_w1[tid * 64 + k], s_hid[k], v);
+    s_w[tid] = v;
+  }
+  __syncthreads();
   if (tid < 12) {
-    const float mean = s_acc[tid] / (float)Nl;
+    const int blk = tid / 6, wv = (tid % 6) / 3, k = tid % 3;   // blk 0: 2x1o, 1: 2x1e ; wv = multiplicity ; k = component
+    const float sh[3] = {s3 * ux, s3 * uy, s3 * uz};
+    float r = 0.f;
+    if (blk == 0) {
+      float t0 = 0.f;
+      for (int u = 0; u < 32; ++u) t0 = fmaf(s_w[u * 2 + wv], x[u], t0);
+      r += pw_o * is3 * t0 * sh[k];
+      for (int u = 0; u < 6; ++u) {
+        r += pw_o * is3 * s_w[64 + u * 2 + wv] * x[COL_1O + 3 * u + k];
+        const float* e = x + COL_1E + 3 * u;
+        const float cr = k == 0 ? e[1] * sh[2] - e[2] * sh[1] : k == 1 ? e[2] * sh[0] - e[0] * sh[2] : e[0] * sh[1] - e[1] * sh[0];
+        r += pw_o * is6 * s_w[100 + u * 2 + wv] * cr;
+      }
+    } else {
+      for (int u = 0; u < 6; ++u) {
+        const float* o = x + COL_1O + 3 * u;
+        const float cr = k == 0 ? o[1] * sh[2] - o[2] * sh[1] : k == 1 ? o[2] * sh[0] - o[0] * sh[2] : o[0] * sh[1] - o[1] * sh[0];
+        r += pw_e * is6 * s_w[76 + u * 2 + wv] * cr;
+        r += pw_e * is3 * s_w[88 + u * 2 + wv] * x[COL_1E + 3 * u + k];
+        r += pw_e * is3 * s_w[112 + u * 2 + wv] * x[COL_0O + u] * sh[k];
+      }
+    }
+    msg[(size_t)blockIdx.x * 12 + tid] = r;
+  }
+}
+
+__global__ __launch_bounds__(64) void center_final_kernel(CenterHead h, StepVectors sv, const float* __restrict__ msg, int Nl,
+                                                          float tr_sigma, float rot_norm, float* __restrict__ tr_out,
+                                                          float* __restrict__ rot_out, float* __restrict__ dbg) {
+  __shared__ float s_acc[12];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 12) {
+    float a = 0.f;
+    for (int k = 0; k < Nl; ++k) a += msg[((size_t)b * Nl + k) * 12 + tid];
+    const float mean = a / (float)Nl;
     if (dbg) dbg[b * 12 + tid] = mean;
     s_acc[tid] = mean * h.bn_scale[tid / 3];   // e3nn BatchNorm on 2x1o+2x1e: scale per multiplicity channel, no shift
   }
   __syncthreads();
   // tr = g[0:3] + g[6:9], rot = g[3:6] + g[9:12]; magnitude re-scaling MLPs (score_model.py:402-420)
-  if (tid < 64) {
-    const int which = tid >> 5, o = tid & 31;   // 0: tr, 1: rot
-    const float vx = s_acc[3 * which] + s_acc[6 + 3 * which], vy = s_acc[3 * which + 1] + s_acc[7 + 3 * which],
-                vz = s_acc[3 * which + 2] + s_acc[8 + 3 * which];
-    const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
-    const float* w0n = which ? h.rot_w0n : h.tr_w0n;
-    const float* w1 = which ? h.rot_w1 : h.tr_w1;
-    const float* part = which ? sv.rot_part : sv.tr_part;
-    float hv = fmaxf(fmaf(w0n[o], nrm, part[o]), 0.f) * w1[o];
-    for (int off = 16; off > 0; off >>= 1) hv += __shfl_xor(hv, off);
-    const float mag = hv + (which ? h.rot_b1[0] : h.tr_b1[0]);
-    if (o < 3) {
-      const float comp = o == 0 ? vx : o == 1 ? vy : vz;
-      const float val = comp / nrm * mag;
-      if (which == 0) tr_out[b * 3 + o] = val / tr_sigma;
-      else rot_out[b * 3 + o] = val * rot_norm;
-    }
+  const int which = tid >> 5, o = tid & 31;   // 0: tr, 1: rot
+  const float vx = s_acc[3 * which] + s_acc[6 + 3 * which], vy = s_acc[3 * which + 1] + s_acc[7 + 3 * which],
+              vz = s_acc[3 * which + 2] + s_acc[8 + 3 * which];
+  const float nrm = sqrtf(vx * vx + vy * vy + vz * vz);
+  const float* w0n = which ? h.rot_w0n : h.tr_w0n;
+  const float* w1 = which ? h.rot_w1 : h.tr_w1;
+  const float* part = which ? sv.rot_part : sv.tr_part;
+  float hv = fmaxf(fmaf(w0n[o], nrm, part[o]), 0.f) * w1[o];
+  for (int off = 16; off > 0; off >>= 1) hv += __shfl_xor(hv, off);
+  const float mag = hv + (which ? h.rot_b1[0] : h.tr_b1[0]);
+  if (o < 3) {
+    const float comp = o == 0 ? vx : o == 1 ? vy : vz;
+    const float val = comp / nrm * mag;
+    if (which == 0) tr_out[b * 3 + o] = val / tr_sigma;
+    else rot_out[b * 3 + o] = val * rot_norm;
   }
 }
 
 hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const float* pos, const float* node, int B, int Nl,
-                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, hipStream_t s) {
-  hipLaunchKernelGGL(center_head_kernel, dim3(B), dim3(128), 0, s, h, v, pos, node, Nl, tr_sigma, rot_norm, tr_out, rot_out, dbg_global);
+                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, float* msg_ws,
+                              hipStream_t s) {
+  hipLaunchKernelGGL(center_msg_kernel, dim3(B * Nl), dim3(128), 0, s, h, v, pos, node, Nl, msg_ws);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(center_final_kernel, dim3(B), dim3(64), 0, s, h, v, msg_ws, Nl, tr_sigma, rot_norm, tr_out, rot_out, dbg_global);
   return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Torsion head (score_model.py:431-448, 650-664): one workgroup per (sample, rotatable bond).
+// Torsion head (score_model.py:431-448, 650-664).
 // tor_bond_conv.tp has two live paths (6x1o x T1 -> 32x0e, 6x1e x T1 -> 32x0o) where T1 is the 1o block of
 // FullTensorProduct(sh(edge), Y2(bond)) = (3/sqrt2)(b b^T - I/3)(sqrt3 v)  (tests/test_kernel_math.py::tor_t1).
-__global__ __launch_bounds__(128) void bond_head_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
-                                                        const float* __restrict__ node, float lig_r2, int cap, float tor_norm_sqrt,
-                                                        float* __restrict__ tor_out, int* __restrict__ tor_edge_count,
-                                                        float* __restrict__ dbg_feat) {
-  __shared__ float s_in[96], s_hid[96], s_w[384], s_acc[64], s_da[6], s_db[6], s_feat[64];
-  __shared__ int s_nb[64];
-  __shared__ int s_n;
+// Stage 1: one wave per (sample, bond): radius(lig_pos, bond_pos, 5) -> first `cap` atoms in index order.
+// Stage 2: one workgroup per (sample, bond, neighbour slot): edge MLPs + tensor product -> 64-value message.
+// Stage 3: one wave per (sample, bond): mean over slots in order, BatchNorm, tor_final_layer.
+constexpr int TOR_SLOTS = 32;
+
+__global__ __launch_bounds__(64) void bond_nb_kernel(GraphStatic gs, const float* __restrict__ pos, float lig_r2, int cap,
+                                                     int* __restrict__ nb, int* __restrict__ nb_cnt, int* __restrict__ tor_edge_count) {
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / gs.R, rho = blockIdx.x % gs.R;
-  const int Nl = gs.Nl;
+  const int b = blockIdx.x / gs.R, rho = blockIdx.x % gs.R, Nl = gs.Nl;
+  const float* P = pos + (size_t)b * Nl * 3;
+  const int u = gs.rot_u[rho], v = gs.rot_v[rho];
+  const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
+  int n = 0;
+  for (int c0 = 0; c0 < Nl && n < cap; c0 += 64) {
+    const int a = c0 + tid;
+    bool in = false;
+    if (a < Nl) in = dist2_nofma(P[3 * a], P[3 * a + 1], P[3 * a + 2], bx, by, bz) < lig_r2;
+    const unsigned long long m = __ballot(in);
+    const int slot = n + popc_below(m, tid);
+    if (in && slot < cap && slot < TOR_SLOTS) nb[(size_t)blockIdx.x * TOR_SLOTS + slot] = a;
+    n += __popcll(m);
+  }
+  if (tid == 0) {
+    const int ne = min(n, min(cap, TOR_SLOTS));
+    nb_cnt[blockIdx.x] = ne;
+    if (tor_edge_count) atomicAdd(tor_edge_count, ne);
+  }
+}
+
+__global__ __launch_bounds__(128) void bond_msg_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
+                                                       const float* __restrict__ node, const int* __restrict__ nb,
+                                                       const int* __restrict__ nb_cnt, float* __restrict__ msg) {
+  __shared__ float s_in[96], s_hid[96], s_w[384], s_da[6], s_db[6];
+  const int tid = threadIdx.x;
+  const int bond = blockIdx.x / TOR_SLOTS, slot = blockIdx.x % TOR_SLOTS;
+  if (slot >= nb_cnt[bond]) return;
+  const int b = bond / gs.R, rho = bond % gs.R, Nl = gs.Nl;
   const float* P = pos + (size_t)b * Nl * 3;
   const int u = gs.rot_u[rho], v = gs.rot_v[rho];   // bonds = edge_index[:, edge_mask]; [0] = u, [1] = v
   const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
   float bux, buy, buz, bn;
   unit_vec(P[3 * v] - P[3 * u], P[3 * v + 1] - P[3 * u + 1], P[3 * v + 2] - P[3 * u + 2], bux, buy, buz, bn);
-  if (tid < 64) s_acc[tid] = 0.f;
-  // radius(lig_pos, bond_pos, 5) with cap: first `cap` atoms in index order (wave 0 does the compaction)
-  if (tid < 64) {
-    int n = 0;
-    for (int c0 = 0; c0 < Nl && n < cap; c0 += 64) {
-      const int a = c0 + tid;
-      bool in = false;
-      if (a < Nl) in = dist2_nofma(P[3 * a], P[3 * a + 1], P[3 * a + 2], bx, by, bz) < lig_r2;
-      const unsigned long long m = __ballot(in);
-      const int slot = n + popc_below(m, tid);
-      if (in && slot < cap && slot < 64) s_nb[slot] = a;
-      n += __popcll(m);
-    }
-    if (tid == 0) s_n = min(n, min(cap, 64));
-  }
-  __syncthreads();
-  const int ne = s_n;
   const float* xu = node + (size_t)(b * Nl + u) * NODE_STRIDE;
   const float* xv = node + (size_t)(b * Nl + v) * NODE_STRIDE;
   const float is3 = 0.57735026918962576f, pw = 0.40824829046386302f /* sqrt(1/6) */;
-  for (int k = 0; k < ne; ++k) {
-    const int a = s_nb[k];
-    const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
-    float ux, uy, uz, d;
-    unit_vec(P[3 * a] - bx, P[3 * a + 1] - by, P[3 * a + 2] - bz, ux, uy, uz, d);
-    // final_edge_embedding on the gaussian-expanded distance (lanes 0..31 of wave 0), node / bond scalars
-    if (tid < 64) {
-      const float e = edge_mlp_eval(h.fe, d, nullptr, tid & 31, tid & 32);
-      if (tid < 32) s_in[tid] = e;
-    } else if (tid < 96) {
-      s_in[tid - 32] = x[tid - 64];                       // lig_node_attr[atom, :ns]
-    } else {
-      s_in[tid - 32] = xu[tid - 96] + xv[tid - 96];       // tor_bond_attr[bond, :ns]
-    }
-    if (tid < 12) {
-      const float bv = bux * ux + buy * uy + buz * uz;
-      const float c = 3.6742346141747673f;   // (3/sqrt2) * sqrt3
-      const float t1[3] = {c * (bux * bv - ux / 3.f), c * (buy * bv - uy / 3.f), c * (buz * bv - uz / 3.f)};
-      const int uu = tid % 6;
-      const float* p = x + (tid < 6 ? COL_1O : COL_1E) + 3 * uu;
-      const float dd = (p[0] * t1[0] + p[1] * t1[1] + p[2] * t1[2]) * is3 * pw;
-      if (tid < 6) s_da[uu] = dd; else s_db[uu] = dd;
-    }
-    __syncthreads();
-    if (tid < 96) {
-      float acc = h.fc_b0[tid];
-      for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w0[tid * 96 + q], s_in[q], acc);
-      s_hid[tid] = fmaxf(acc, 0.f);
-    }
-    __syncthreads();
-    for (int r = tid; r < 384; r += 128) {
-      float acc = h.fc_b1[r];
-      for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w1[r * 96 + q], s_hid[q], acc);
-      s_w[r] = acc;
-    }
-    __syncthreads();
-    if (tid < 64) {
-      // output columns: [32x0o (path B: 1e x T1) | 32x0e (path A: 1o x T1)]; weights: path A first, each [u=6][w=32]
-      const int wcol = tid & 31;
-      float r = 0.f;
-      if (tid < 32) { for (int q = 0; q < 6; ++q) r = fmaf(s_w[192 + q * 32 + wcol], s_db[q], r); }
-      else          { for (int q = 0; q < 6; ++q) r = fmaf(s_w[q * 32 + wcol], s_da[q], r); }
-      s_acc[tid] += r;
-    }
-    __syncthreads();
-  }
+  const int a = nb[(size_t)bond * TOR_SLOTS + slot];
+  const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
+  float ux, uy, uz, d;
+  unit_vec(P[3 * a] - bx, P[3 * a + 1] - by, P[3 * a + 2] - bz, ux, uy, uz, d);
+  // final_edge_embedding on the gaussian-expanded distance (wave 0), node / bond scalars
   if (tid < 64) {
-    const float mean = s_acc[tid] / (float)(ne > 1 ? ne : 1);
-    const float f = (mean - h.bn_mean[tid]) * h.bn_scale[tid] + h.bn_bias[tid];
-    s_feat[tid] = f;
-    if (dbg_feat) dbg_feat[(size_t)blockIdx.x * 64 + tid] = f;
+    const float e = edge_mlp_eval(h.fe, d, nullptr, tid & 31, tid & 32);
+    if (tid < 32) s_in[tid] = e;
+  } else if (tid < 96) {
+    s_in[tid - 32] = x[tid - 64];                       // lig_node_attr[atom, :ns]
+  } else {
+    s_in[tid - 32] = xu[tid - 96] + xv[tid - 96];       // tor_bond_attr[bond, :ns]
   }
+  if (tid < 12) {
+    const float bv = bux * ux + buy * uy + buz * uz;
+    const float c = 3.6742346141747673f;   // (3/sqrt2) * sqrt3
+    const float t1[3] = {c * (bux * bv - ux / 3.f), c * (buy * bv - uy / 3.f), c * (buz * bv - uz / 3.f)};
+    const int uu = tid % 6;
+    const float* p = x + (tid < 6 ? COL_1O : COL_1E) + 3 * uu;
+    const float dd = (p[0] * t1[0] + p[1] * t1[1] + p[2] * t1[2]) * is3 * pw;
+    if (tid < 6) s_da[uu] = dd; else s_db[uu] = dd;
+  }
+  __syncthreads();
+  if (tid < 96) {
+    float acc = h.fc_b0[tid];
+    for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w0[tid * 96 + q], s_in[q], acc);
+    s_hid[tid] = fmaxf(acc, 0.f);
+  }
+  __syncthreads();
+  for (int r = tid; r < 384; r += 128) {
+    float acc = h.fc_b1[r];
+    for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w1[r * 96 + q], s_hid[q], acc);
+    s_w[r] = acc;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    // output columns: [32x0o (path B: 1e x T1) | 32x0e (path A: 1o x T1)]; weights: path A first, each [u=6][w=32]
+    const int wcol = tid & 31;
+    float r = 0.f;
+    if (tid < 32) { for (int q = 0; q < 6; ++q) r = fmaf(s_w[192 + q * 32 + wcol], s_db[q], r); }
+    else          { for (int q = 0; q < 6; ++q) r = fmaf(s_w[q * 32 + wcol], s_da[q], r); }
+    msg[(size_t)blockIdx.x * 64 + tid] = r;
+  }
+}
+
+__global__ __launch_bounds__(64) void bond_final_kernel(BondHead h, const int* __restrict__ nb_cnt, const float* __restrict__ msg,
+                                                        float tor_norm_sqrt, float* __restrict__ tor_out, float* __restrict__ dbg_feat) {
+  __shared__ float s_feat[64];
+  const int tid = threadIdx.x, bond = blockIdx.x;
+  const int ne = nb_cnt[bond];
+  float a = 0.f;
+  for (int k = 0; k < ne; ++k) a += msg[((size_t)bond * TOR_SLOTS + k) * 64 + tid];
+  const float mean = a / (float)(ne > 1 ? ne : 1);
+  const float f = (mean - h.bn_mean[tid]) * h.bn_scale[tid] + h.bn_bias[tid];
+  s_feat[tid] = f;
+  if (dbg_feat) dbg_feat[(size_t)bond * 64 + tid] = f;
   __syncthreads();
   if (tid < 32) {
     float acc = 0.f;
     for (int q = 0; q < 64; ++q) acc = fmaf(h.tf_w0[tid * 64 + q], s_feat[q], acc);
     float t = tanhf(acc) * h.tf_w1[tid];
     for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    if (tid == 0) {
-      tor_out[blockIdx.x] = t * tor_norm_sqrt;
-      if (tor_edge_count) atomicAdd(tor_edge_count, ne);
-    }
+    if (tid == 0) tor_out[bond] = t * tor_norm_sqrt;
   }
 }
 
 hipError_t launch_bond_head(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, float lig_r,
-                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, hipStream_t s) {
+                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, int* nb_ws,
+                            int* nb_cnt_ws, float* msg_ws, hipStream_t s) {
   if (gs.R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bond_head_kernel, dim3(B * gs.R), dim3(128), 0, s, h, gs, pos, node, lig_r * lig_r, cap, tor_norm_sqrt,
-                     tor_out, tor_edge_count, dbg_feat);
+  const int nbond = B * gs.R;
+  hipLaunchKernelGGL(bond_nb_kernel, dim3(nbond), dim3(64), 0, s, gs, pos, lig_r * lig_r, cap, nb_ws, nb_cnt_ws, tor_edge_count);
+  hipLaunchKernelGGL(bond_msg_kernel, dim3(nbond * TOR_SLOTS), dim3(128), 0, s, h, gs, pos, node, nb_ws, nb_cnt_ws, msg_ws);
+  hipLaunchKernelGGL(bond_final_kernel, dim3(nbond), dim3(64), 0, s, h, nb_cnt_ws, msg_ws, tor_norm_sqrt, tor_out, dbg_feat);
   return hipGetLastError();
 }
 

@@ -46,6 +46,7 @@ SYMBOLS = {
     "cbd_score": (C.c_int, [_P, C.c_int32, _P, C.POINTER(cbd_step), _P, _P, _P, _P]),
     "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
+    "cbd_share_weights": (C.c_int, [_P, _P]),
     "cbd_recompute_receptor": (C.c_int, [_P, _P]),
     "cbd_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64)]),
     "cbd_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
@@ -265,6 +266,88 @@ class DockEngine:
         avg, n, tot = C.c_double(), C.c_int64(), C.c_double()
         _check(self.lib.cbd_kernel_timing(self.h, int(enable), int(reset), C.byref(avg), C.byref(n), C.byref(tot)))
         return avg.value, n.value, tot.value
+
+
+class DockEnginePool:
+    """n engines with the same weights on one GPU, each on its own HIP stream.  A batch of independent pose samples is
+    split into n contiguous chunks whose step loops run concurrently: the latency-bound small kernels and the tail of
+    one chunk's tensor-product launches overlap with the other chunk's matrix-core work.  Results are identical to a
+    single engine (samples never interact)."""
+
+    def __init__(self, state_dict, device, n: int = 1, max_batch: int = 64, **engine_kw):
+        self.device = torch.device(device)
+        self.n = max(1, int(n))
+        per = (max_batch + self.n - 1) // self.n
+        self.engines = [DockEngine(self.device, max_batch=per, **engine_kw) for _ in range(self.n)]
+        self.engines[0].load_state_dict(state_dict)
+        for e in self.engines[1:]:     # one copy of the weights in HBM/L2, shared by all streams
+            _check(e.lib.cbd_share_weights(e.h, self.engines[0].h))
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
+        self.max_batch = per * self.n
+        self.complex_key = None
+
+    @classmethod
+    def from_model(cls, model, device, n=1, max_batch=64):
+        return cls(model.state_dict(), device, n=n, max_batch=max_batch,
+                   lm_embedding_dim=1280 if model.lm_embedding_type == "precomputed" else 0, no_torsion=model.no_torsion,
+                   lig_max_radius=model.lig_max_radius, rec_max_radius=model.rec_max_radius,
+                   cross_max_distance=model.cross_max_distance, center_max_distance=model.center_max_distance)
+
+    @property
+    def R(self):
+        return self.engines[0].R
+
+    @property
+    def Nl(self):
+        return self.engines[0].Nl
+
+    def set_complex(self, graph, key=None):
+        for e in self.engines:
+            e.set_complex(graph, key)
+        self.complex_key = key
+
+    def recompute_receptor(self):
+        cur = torch.cuda.current_stream(self.device)
+        for e, st in zip(self.engines, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                e.recompute_receptor()
+
+    def _chunks(self, B):
+        per = (B + self.n - 1) // self.n
+        return [(lo, min(B, lo + per)) for lo in range(0, B, per)]
+
+    def sample(self, pos, steps, noise_tr=None, noise_rot=None, noise_tor=None):
+        B = pos.shape[0]
+        if B > self.max_batch:
+            raise RuntimeError(f"cbdock error -4: batch {B} exceeds max_batch {self.max_batch}")
+        cur = torch.cuda.current_stream(self.device)
+        R = self.R
+        f = lambda x: None if x is None else x.to(self.device, torch.float32)
+        noise_tr, noise_rot, noise_tor = f(noise_tr), f(noise_rot), f(noise_tor)
+        for (lo, hi), e, st in zip(self._chunks(B), self.engines, self.streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                e.sample(pos[lo:hi], steps,
+                         None if noise_tr is None else noise_tr[:, lo:hi].contiguous(),
+                         None if noise_rot is None else noise_rot[:, lo:hi].contiguous(),
+                         None if noise_tor is None or R == 0 else noise_tor[:, lo * R:hi * R].contiguous())
+        for st in self.streams:
+            cur.wait_stream(st)
+
+    def kernel_timing(self, enable=True, reset=False):
+        tot_ms, n = 0.0, 0
+        for e in self.engines:
+            _, k, t = e.kernel_timing(enable, reset)
+            tot_ms, n = tot_ms + t, n + k
+        return (tot_ms / n if n else 0.0), n, tot_ms
+
+    def stats(self, reset=False):
+        out = {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0}
+        for e in self.engines:
+            for k, v in e.stats(reset).items():
+                out[k] += v
+        return out
 
 
 def pack_conv_stream(in_level, out_level, w1, b1, w2, b2):

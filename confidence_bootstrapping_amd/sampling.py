@@ -80,9 +80,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              temp_sigma_data=0.5, return_features=False, svgd_weight_log_0=None, svgd_repulsive_weight_log_0=None,
              svgd_weight_log_1=None, svgd_repulsive_weight_log_1=None, svgd_kernel_size_log_0=None,
              svgd_kernel_size_log_1=None, svgd_langevin_weight_log_0=None, svgd_langevin_weight_log_1=None,
-             svgd_rot_log_rel_weight=0.0, svgd_tor_log_rel_weight=0.0, svgd_use_x0=False, noise=None):
+             svgd_rot_log_rel_weight=0.0, svgd_tor_log_rel_weight=0.0, svgd_use_x0=False, noise=None, n_streams=1):
     """Reverse diffusion of every pose in `data_list`; returns (data_list, confidence) like the reference.
-    `noise` (optional, extension): dict of pre-drawn 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R] CPU tensors."""
+    `noise` (optional, extension): dict of pre-drawn 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R] CPU tensors.
+    `n_streams` (extension): each batch is split over this many concurrent HIP streams (identical results)."""
     N = len(data_list)
     assert not (return_full_trajectory or return_features or pivot), "Not implemented yet in new inference version"
     if svgd_weight_log_0 is not None and svgd_weight_log_1 is not None:
@@ -100,7 +101,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         raise ValueError("schedule length != inference_steps")
     device = torch.device(device)
     model = getattr(model, "module", model)
-    eng = model.engine()
+    eng = model.engine_pool(n_streams=n_streams, max_batch=max(int(batch_size), 1)) if n_streams > 1 else model.engine()
     steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
                        no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
                        temp_sigma_data=temp_sigma_data)

@@ -250,6 +250,18 @@ class TensorProductScoreModel(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def engine_pool(self, n_streams: int = 1, max_batch: int = 64):
+        """n-stream engine pool used by sampling() (see engine.DockEnginePool)."""
+        from .engine import DockEnginePool
+        if self.training:
+            raise RuntimeError("the MI355X engine implements the eval-mode forward pass only; call model.eval()")
+        dev = next(self.parameters()).device
+        key = (str(dev), self._weights_version(), n_streams, max_batch)
+        if getattr(self, "_pool", None) is None or self._pool_key != key:
+            self._pool = DockEnginePool.from_model(self, dev, n=n_streams, max_batch=max_batch)
+            self._pool_key = key
+        return self._pool
+
     def _weights_version(self):
         return sum(int(p._version) for p in self.parameters())
 

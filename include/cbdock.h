@@ -112,6 +112,10 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, 
                const float* noise_tr_dev, const float* noise_rot_dev, const float* noise_tor_dev,
                float* scores_out_dev, void* stream);
 
+/* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
+ * GPU (one per HIP stream) then stream the same L2-resident weight tiles.  `src` must outlive `dst`. */
+int cbd_share_weights(cbd_engine* dst, cbd_engine* src);
+
 /* Re-run the time-independent receptor embedding of the current complex (models/score_model.py:297-320, which the
  * reference executes in the first model call of every batch).  cbd_set_complex already does this once; the
  * benchmark calls it per complex so that this work stays inside the timed region. */
