@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", type=int, default=0, help="1: replay the 20-step loop as one hipGraph (no per-kernel HIP events)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the 40-pose batch is split over")
     a = ap.parse_args()
 
@@ -107,6 +108,7 @@ def main():
     cplx = make_workload(WORKLOAD, seed=1234)
     eng = DockEnginePool.from_model(model, dev, n=a.streams, max_batch=SAMPLES)
     eng.set_complex(cplx)
+    eng.set_option("graph", a.graph)
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
     steps = make_steps(sched, margs, model.timestep_emb_func)
     R = eng.R
@@ -129,7 +131,7 @@ def main():
     for k in range(a.warmup):
         one_complex(k)
     torch.cuda.synchronize()
-    eng.kernel_timing(enable=True, reset=True)
+    eng.kernel_timing(enable=not a.graph, reset=True)
     eng.stats(reset=True)
     if world > 1:
         dist.barrier()

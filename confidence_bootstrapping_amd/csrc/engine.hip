@@ -107,7 +107,15 @@ struct cbd_engine {
   int* rr_count_dev = nullptr;
   float *d_rec_x = nullptr, *d_vec0 = nullptr, *d_dist0 = nullptr;
   int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
+  // hipGraph of the step loop (optional)
+  bool use_graph = false;
+  hipGraphExec_t graph_exec = nullptr;
+  std::string graph_key;
+  float *g_pos = nullptr, *g_ztr = nullptr, *g_zrot = nullptr, *g_ztor = nullptr;
+  int g_S_cap = 0;
   float* rr_shared = nullptr;       // [Nr][NODE_STRIDE] layer-0 receptor->receptor message sums (identical for all samples)
+  hipStream_t own = nullptr;        // used instead of the legacy default stream for graph capture (which cannot be captured)
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipStream_t side = nullptr;       // forked stream for work that only depends on the diffusion time
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned long long* stamps_dev = nullptr;   // diagnostic (CBD_CONV_VARIANT=8)
@@ -305,6 +313,9 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
   *out = e;
@@ -315,11 +326,15 @@ int cbd_destroy(cbd_engine* e) {
   if (!e) return 0;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
+  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
   e->wpool.release(); e->cpool.release(); e->bpool.release();
   for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
+  if (e->own) (void)hipStreamDestroy(e->own);
+  if (e->ev_a) (void)hipEventDestroy(e->ev_a);
+  if (e->ev_b) (void)hipEventDestroy(e->ev_b);
   delete e;
   return 0;
 }
@@ -533,6 +548,8 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   if (Nl <= 0 || Nr <= 0 || nbd < 0 || R < 0 || Err < 0) return fail(CBD_ERR_ARG, "bad sizes");
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
+  if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+  e->graph_key.clear(); e->g_pos = nullptr; e->g_S_cap = 0;
   e->cpool.release(); e->bpool.release();
   e->complex_ready = false;
   const int Bm = e->cfg.max_batch, lm = e->cfg.lm_embedding_dim;
@@ -844,22 +861,83 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
   HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // `se` goes out of scope; also orders the upload before the loop
   const bool tors = !e->cfg.no_torsion && R > 0;
-  for (int i = 0; i < S; ++i) {
-    const cbd_step& st = steps[i];
-    CHK(forward(e, B, pos_dev, st, e->sigma_emb_dev + (size_t)i * 32, e->tr_out, e->rot_out, e->tor_out, s));
-    if (scores_out) {
-      float* o = scores_out + (size_t)i * B * (6 + R);
-      HIPCHK(hipMemcpyAsync(o, e->tr_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
-      HIPCHK(hipMemcpyAsync(o + B * 3, e->rot_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
-      if (tors) HIPCHK(hipMemcpyAsync(o + B * 6, e->tor_out, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s));
+  auto run_steps = [&](float* pos, const float* ntr, const float* nrot, const float* ntor, float* scores) -> int {
+    for (int i = 0; i < S; ++i) {
+      const cbd_step& st = steps[i];
+      CHK(forward(e, B, pos, st, e->sigma_emb_dev + (size_t)i * 32, e->tr_out, e->rot_out, e->tor_out, s));
+      if (scores) {
+        float* o = scores + (size_t)i * B * (6 + R);
+        HIPCHK(hipMemcpyAsync(o, e->tr_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(o + B * 3, e->rot_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
+        if (tors) HIPCHK(hipMemcpyAsync(o + B * 6, e->tor_out, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s));
+      }
+      SdeCoefs cf{st.tr_score_coef, st.tr_noise_coef, st.rot_score_coef, st.rot_noise_coef, st.tor_score_coef, st.tor_noise_coef};
+      const float* ztr = (ntr && st.tr_noise_coef != 0.f) ? ntr + (size_t)i * B * 3 : nullptr;
+      const float* zrot = (nrot && st.rot_noise_coef != 0.f) ? nrot + (size_t)i * B * 3 : nullptr;
+      const float* ztor = (ntor && st.tor_noise_coef != 0.f) ? ntor + (size_t)i * B * R : nullptr;
+      HIPCHK(launch_pose_update(e->gs, pos, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
     }
-    SdeCoefs cf{st.tr_score_coef, st.tr_noise_coef, st.rot_score_coef, st.rot_noise_coef, st.tor_score_coef, st.tor_noise_coef};
-    const float* ztr = (noise_tr && st.tr_noise_coef != 0.f) ? noise_tr + (size_t)i * B * 3 : nullptr;
-    const float* zrot = (noise_rot && st.rot_noise_coef != 0.f) ? noise_rot + (size_t)i * B * 3 : nullptr;
-    const float* ztor = (noise_tor && st.tor_noise_coef != 0.f) ? noise_tor + (size_t)i * B * R : nullptr;
-    HIPCHK(launch_pose_update(e->gs, pos_dev, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
+    return 0;
+  };
+  if (e->use_graph && !e->timing && !scores_out && !e->keep_debug) {
+    hipStream_t user = s;
+    if (!user) {   // the legacy default stream cannot be captured: run on the engine's own stream, ordered after/before it
+      HIPCHK(hipEventRecord(e->ev_a, user));
+      HIPCHK(hipStreamWaitEvent(e->own, e->ev_a, 0));
+      s = e->own;
+    }
+    // The whole S-step loop as ONE hipGraph launch (static capacities + device-side edge counts make every launch
+    // shape independent of the data).  Inputs are staged into engine-owned buffers so that the instantiated graph
+    // can be replayed for every batch with the same (B, S, schedule).
+    const int Bm = e->cfg.max_batch, Nl = e->gs.Nl;
+    if (!e->g_pos || e->g_S_cap < S) {
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(e->bpool.alloc(&e->g_pos, (size_t)Bm * Nl * 3));
+      HIPCHK(e->bpool.alloc(&e->g_ztr, (size_t)S * Bm * 3)); HIPCHK(e->bpool.alloc(&e->g_zrot, (size_t)S * Bm * 3));
+      HIPCHK(e->bpool.alloc(&e->g_ztor, (size_t)S * Bm * std::max(R, 1)));
+      e->g_S_cap = S;
+      e->graph_key.clear();
+    }
+    std::string key(reinterpret_cast<const char*>(steps), sizeof(cbd_step) * (size_t)S);
+    key += "|" + std::to_string(B) + "|" + std::to_string((noise_tr != nullptr) + 2 * (noise_rot != nullptr) + 4 * (noise_tor != nullptr));
+    if (!e->graph_exec || key != e->graph_key) {
+      if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
+      hipGraph_t graph = nullptr;
+      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      const int rc = run_steps(e->g_pos, noise_tr ? e->g_ztr : nullptr, noise_rot ? e->g_zrot : nullptr,
+                               noise_tor ? e->g_ztor : nullptr, nullptr);
+      const hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+      HIPCHK(ce);
+      HIPCHK(hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0));
+      HIPCHK(hipGraphDestroy(graph));
+      e->graph_key = key;
+    }
+    HIPCHK(hipMemcpyAsync(e->g_pos, pos_dev, (size_t)B * Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (noise_tr) HIPCHK(hipMemcpyAsync(e->g_ztr, noise_tr, (size_t)S * B * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (noise_rot) HIPCHK(hipMemcpyAsync(e->g_zrot, noise_rot, (size_t)S * B * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (noise_tor && R > 0) HIPCHK(hipMemcpyAsync(e->g_ztor, noise_tor, (size_t)S * B * R * 4, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGraphLaunch(e->graph_exec, s));
+    HIPCHK(hipMemcpyAsync(pos_dev, e->g_pos, (size_t)B * Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (!user) {
+      HIPCHK(hipEventRecord(e->ev_b, s));
+      HIPCHK(hipStreamWaitEvent(user, e->ev_b, 0));
+    }
+    return 0;
   }
+  CHK(run_steps(pos_dev, noise_tr, noise_rot, noise_tor, scores_out));
   return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
+}
+
+int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
+  if (!e || !name) return fail(CBD_ERR_ARG, "null argument");
+  const std::string k(name);
+  if (k == "graph") {
+    e->use_graph = value != 0;
+    if (!e->use_graph && e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    return 0;
+  }
+  return fail(CBD_ERR_ARG, "unknown option '%s'", name);
 }
 
 int cbd_share_weights(cbd_engine* dst, cbd_engine* src) {

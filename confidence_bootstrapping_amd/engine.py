@@ -46,6 +46,7 @@ SYMBOLS = {
     "cbd_score": (C.c_int, [_P, C.c_int32, _P, C.POINTER(cbd_step), _P, _P, _P, _P]),
     "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
+    "cbd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cbd_share_weights": (C.c_int, [_P, _P]),
     "cbd_recompute_receptor": (C.c_int, [_P, _P]),
     "cbd_stats": (C.c_int, [_P, C.c_int32, C.POINTER(C.c_uint64)]),
@@ -241,6 +242,9 @@ class DockEngine:
         with torch.cuda.device(self.device):
             _check(self.lib.cbd_recompute_receptor(self.h, self._stream()))
 
+    def set_option(self, name: str, value: int):
+        _check(self.lib.cbd_set_option(self.h, name.encode(), int(value)))
+
     def stats(self, reset=False):
         out = (C.c_uint64 * 4)()
         _check(self.lib.cbd_stats(self.h, int(reset), out))
@@ -305,6 +309,10 @@ class DockEnginePool:
         for e in self.engines:
             e.set_complex(graph, key)
         self.complex_key = key
+
+    def set_option(self, name, value):
+        for e in self.engines:
+            e.set_option(name, value)
 
     def recompute_receptor(self):
         cur = torch.cuda.current_stream(self.device)

@@ -112,6 +112,10 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, 
                const float* noise_tr_dev, const float* noise_rot_dev, const float* noise_tor_dev,
                float* scores_out_dev, void* stream);
 
+/* Engine options.  "graph" (0/1): capture the S-step loop of cbd_sample into a hipGraph that is instantiated once per
+ * (batch size, schedule) and replayed with one launch per batch (inputs are staged into engine-owned buffers). */
+int cbd_set_option(cbd_engine* e, const char* name, int64_t value);
+
 /* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
  * GPU (one per HIP stream) then stream the same L2-resident weight tiles.  `src` must outlive `dst`. */
 int cbd_share_weights(cbd_engine* dst, cbd_engine* src);

@@ -223,8 +223,84 @@ def test_full_size_batch_properties(dev, score_model):
     bl1 = (p1.cpu()[:, bi[0]] - p1.cpu()[:, bi[1]]).norm(dim=-1)
     assert float((bl1 - bl0).abs().max()) < 2e-3       # rigid + torsional moves never stretch a bond
     assert float(rmsd(p1.cpu(), p2.cpu()).max()) < 1e-3
+    # the hipGraph replay of the same loop gives the same trajectory (twice: capture + cached replay)
+    eng.set_option("graph", 1)
+    for _ in range(2):
+        p3 = pos0.clone()
+        eng.sample(p3, steps, *noise)
+        assert float(rmsd(p1.cpu(), p3.cpu()).max()) < 1e-3
+    eng.set_option("graph", 0)
     c = eng.edge_counts()
     assert c["rr"] == B * 24 * 384 and 0 < c["lr"] <= B * 28 * 384
+
+
+def test_config_c1_1a0q_single_sample_trajectory(dev, score_model, tables):
+    """BASELINE.json configs[0]: data/1a0q (416 residues, 23 heavy atoms, 11 torsions), 1 sample, 20 steps, through the
+    reference-shaped sampling() vs the CPU oracle on the same seed."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from oracle import score_ref as sr, pose_ref as pr
+    from tests.helpers import load_c1_complex
+    model, args = make_score_model(device=dev, seed=0)
+    cplx = load_c1_complex()
+    cx = to_cx(cplx)
+    assert (cx.Nl, cx.Nr, cx.R) == (23, 416, 11)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    dl = [Batch.from_data_list([copy.deepcopy(cplx)])]
+    randomize_position(dl, False, False, args.tr_sigma_max)
+    pos0 = dl[0]["ligand"].pos.clone()[None]
+    S = 20
+    sched = get_t_schedule("expbeta", S)
+    torch.manual_seed(4)
+    out, _ = sampling(dl, model, S, sched, sched, sched, dev, partial(t_to_sigma, args=args), args, batch_size=1)
+    torch.manual_seed(4)
+    noise = {"tr": [], "rot": [], "tor": []}
+    for _ in range(S):
+        noise["tr"].append(torch.normal(0, 1, (1, 3)))
+        noise["rot"].append(torch.normal(0, 1, (1, 3)))
+        noise["tor"].append(torch.normal(0, 1, (cx.R,)))
+    noise = {k: torch.stack(v) for k, v in noise.items()}
+    so3, torus = tables
+    ref = pr.sampling_ref({k: v.cpu() for k, v in model.state_dict().items()}, cx, pos0, sched, sr.ScoreConfig(), so3, torus, noise=noise)
+    assert float(rmsd(out[0]["ligand"].pos.cpu()[None], ref).max()) < 1e-3
+
+
+def test_config_c4_large_pocket_forward(dev, score_model, tables):
+    """BASELINE.json configs[3] geometry (Nl=64, Nr=1024, R=16) in fp32 at batch 1 vs the oracle (the bf16 variant of
+    this stress config is not built yet), plus a 40-step run at batch 8 for finiteness / bond preservation."""
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from oracle import score_ref as sr
+    model, args = score_model
+    cplx = make_workload("c4_large_pocket")
+    cx = to_cx(cplx)
+    so3, torus = tables
+    eng = DockEngine(dev, max_batch=8)
+    eng.load_state_dict(model.state_dict())
+    eng.set_complex(cplx)
+    gen = torch.Generator().manual_seed(21)
+    pos = cplx["ligand"].pos[None] - cplx["ligand"].pos.mean(0) + torch.randn(1, 1, 3, generator=gen) * 10
+    t = 0.6
+    st = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+    tr, rot, tor = eng.score(pos.to(dev), st)
+    ref = sr.score_forward(model.state_dict(), cx, pos, t, t, t, sr.ScoreConfig(), so3, torus)
+    c = eng.edge_counts()
+    assert c["lr"] == ref["lr_edge_index"].shape[1] and c["ll"] == ref["lig_edge_index"].shape[1]
+    assert rel_err(tr.cpu(), ref["tr_pred"]) < SCORE_TOL and rel_err(rot.cpu(), ref["rot_pred"]) < SCORE_TOL
+    assert rel_err(tor.cpu(), ref["tor_pred"]) < SCORE_TOL
+    B, S = 8, 40
+    p = (cplx["ligand"].pos[None].repeat(B, 1, 1) - cplx["ligand"].pos.mean(0) + 19 * torch.randn(B, 1, 3, generator=gen)).to(dev)
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    eng.sample(p, steps, torch.randn(S, B, 3, generator=gen), torch.randn(S, B, 3, generator=gen), torch.randn(S, B * eng.R, generator=gen))
+    assert torch.isfinite(p).all()
+    bi = cplx["ligand", "ligand"].edge_index
+    bl0 = (cplx["ligand"].pos[bi[0]] - cplx["ligand"].pos[bi[1]]).norm(dim=-1)
+    bl1 = (p.cpu()[:, bi[0]] - p.cpu()[:, bi[1]]).norm(dim=-1)
+    assert float((bl1 - bl0).abs().max()) < 5e-3
 
 
 def test_errors_are_raised_not_swallowed(engine_tiny, dev, score_model):
