@@ -682,8 +682,8 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
   HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
   if (getenv("CBD_CONV_VARIANT") && atoi(getenv("CBD_CONV_VARIANT")) == 8) {
-    HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 4));
-    HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 4 * 8));
+    HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 8));
+    HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 8 * 8));
   } else e->stamps_dev = nullptr;
   HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
   hipStream_t s = nullptr;
@@ -989,17 +989,24 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     }
   if (k == "conv_clock_ghz") {   // median in-kernel shader clock of the last tp_conv<3,3> launch (diagnostic build)
     if (!e->stamps_dev || capacity < 3) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_CONV_VARIANT=8)");
-    std::vector<unsigned long long> h(8192 * 4);
+    std::vector<unsigned long long> h(8192 * 8);
     if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
-    std::vector<double> ghz, dur;
+    std::vector<double> ghz, dur, pro, g1, tiles, fin;
     for (int i = 0; i < 8192; ++i) {
-      const double dt = (double)(h[4 * i + 2] - h[4 * i]), dr = (double)(h[4 * i + 3] - h[4 * i + 1]);
-      if (h[4 * i + 3] && dr > 0) { ghz.push_back(dt / dr * 0.1); dur.push_back(dr * 10.0); }   // memrealtime ticks at 100 MHz
+      const unsigned long long* q = h.data() + 8 * i;
+      const double dt = (double)(q[2] - q[0]), dr = (double)(q[3] - q[1]);
+      if (q[3] && dr > 0) {
+        ghz.push_back(dt / dr * 0.1); dur.push_back(dr * 10.0);   // memrealtime ticks at 100 MHz
+        pro.push_back((double)(q[4] - q[0])); g1.push_back((double)(q[5] - q[4])); tiles.push_back((double)(q[6] - q[5]));
+        fin.push_back((double)(q[2] - q[6]));
+      }
     }
     if (ghz.empty()) return fail(CBD_ERR_STATE, "no stamps recorded");
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    if (capacity >= 7) { out[3] = (float)med(pro); out[4] = (float)med(g1); out[5] = (float)med(tiles); out[6] = (float)med(fin); }
     std::sort(ghz.begin(), ghz.end()); std::sort(dur.begin(), dur.end());
     out[0] = (float)ghz[ghz.size() / 2]; out[1] = (float)dur[dur.size() / 2]; out[2] = (float)ghz.size();
-    return 3;
+    return capacity >= 7 ? 7 : 3;
   }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);

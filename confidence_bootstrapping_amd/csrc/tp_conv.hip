@@ -31,6 +31,15 @@
 
 namespace cbd {
 
+// diagnostic stamp (CBD_CONV_VARIANT=8 build only): s_memtime pinned in place (cdna_hip_programming.md section 7)
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -153,8 +162,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
   if (grp < 0) return;
   const ConvGroup G = args.g[grp];
-  unsigned long long st_t0 = 0, st_r0 = 0;
-  if constexpr (VAR == 8) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+  if constexpr (VAR == 8) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
   const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*768 + sg*64]
@@ -205,6 +214,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     }
   }
   __syncthreads();   // single-wave workgroup: orders the LDS writes above before the reads below
+  if constexpr (VAR == 8) st_t1 = stamp();
 
   int T = 0;
   f32x16 acc;
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
   }
 
+  if constexpr (VAR == 8) st_t2 = stamp();
   const float* xc = xT + j;
   // ---- block 0e: one tile per mid index, 32 output scalars
   float o0e[16];
@@ -278,6 +289,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
 
 #undef CBD_TILE
+  if constexpr (VAR == 8) st_t3 = stamp();
   // ---- messages -> LDS (re-using the gathered-row tile, stride 33 so that the column reads below are conflict free),
   //      then run-length sum per aggregating node
   __syncthreads();   // every read of xT (mids) is complete before it is overwritten
@@ -312,8 +324,9 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
   if constexpr (VAR == 8) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
-      unsigned long long* o = args.stamps + (size_t)blockIdx.x * 4;
-      o[0] = st_t0; o[1] = st_r0; o[2] = __builtin_amdgcn_s_memtime(); o[3] = __builtin_amdgcn_s_memrealtime();
+      unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
+      o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
+      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = 0;
     }
   }
 }
