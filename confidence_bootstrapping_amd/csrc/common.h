@@ -70,14 +70,33 @@ struct ConvGroup {
   const float* attr;     // [.][32] embedded edge attributes
   const float* wstream;  // conv_stream_floats(ntiles) re-packed weights of this group's FCBlock
   const int* count;      // device scalar: number of edges
+  // deterministic segmented reduction (no atomics): per 32-edge tile the sum of its first run, of its last run, and
+  // direct stores for runs that lie strictly inside the tile (the aggregating node then has no other tile in this group)
+  float* first_sum;      // [tiles][NODE_STRIDE]
+  float* last_sum;       // [tiles][NODE_STRIDE]
+  float* run_acc;        // [N][NODE_STRIDE], row = aggregating node
 };
 
 struct ConvArgs {
   ConvGroup g[4];
   int n_groups;
   const float* node_in;  // [N][NODE_STRIDE]
-  float* acc;            // [N][NODE_STRIDE] fp32 sums (atomic)
   unsigned long long* stamps;   // diagnostic build only (CBD_CONV_VARIANT=8): [grid][4] s_memtime/s_memrealtime at start/end
+};
+
+// One edge group as seen by the finalize kernel: CSR range of every node + the partial sums written by tp_conv.
+struct FinGroup {
+  const int* start;        // [nodes of this type] first edge of the node in the group's edge list
+  const int* cnt;          // [nodes of this type] number of edges
+  const int* total;        // device scalar: number of edges in the group
+  const float* first_sum;
+  const float* last_sum;
+  const float* run_acc;
+  int node_mod;            // > 0: the group is shared by all samples, node k = i % node_mod (layer-0 receptor edges)
+};
+struct FinArgs {
+  FinGroup g[2];
+  int n_groups;
 };
 
 }  // namespace cbd

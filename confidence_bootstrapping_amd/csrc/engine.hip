@@ -113,7 +113,11 @@ struct cbd_engine {
   std::string graph_key;
   float *g_pos = nullptr, *g_ztr = nullptr, *g_zrot = nullptr, *g_ztor = nullptr;
   int g_S_cap = 0;
-  float* rr_shared = nullptr;       // [Nr][NODE_STRIDE] layer-0 receptor->receptor message sums (identical for all samples)
+  // per edge group (ll, lr, rr, rl, rr0 = single-copy receptor graph): pieces of the deterministic segmented reduction
+  float *fsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *lsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* racc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
+  int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges
   hipStream_t own = nullptr;        // used instead of the legacy default stream for graph capture (which cannot be captured)
   hipEvent_t ev_a = nullptr, ev_b = nullptr;
   hipStream_t side = nullptr;       // forked stream for work that only depends on the diffusion time
@@ -123,7 +127,7 @@ struct cbd_engine {
 
   // ---- batch workspace
   GraphDyn gd{};
-  float *X0 = nullptr, *X1 = nullptr, *acc = nullptr;
+  float *X0 = nullptr, *X1 = nullptr;
   float *ll_attr = nullptr, *lr_attr = nullptr;
   StepVectors sv{};
   float* sigma_emb_dev = nullptr;   // [S_max][32]
@@ -478,7 +482,7 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
 }
 
 static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
-                    const float* node_in, hipStream_t s, const int* widx = nullptr, float* acc_override = nullptr) {
+                    const float* node_in, hipStream_t s, const int* widx = nullptr) {
   ConvArgs a{};
   a.n_groups = n_groups;
   int grid = 0;
@@ -488,7 +492,6 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
   }
   a.node_in = node_in;
-  a.acc = acc_override ? acc_override : e->acc;
   a.stamps = e->stamps_dev;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
@@ -506,10 +509,20 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
   return 0;
 }
 
-static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const int* deg, int n_nodes,
-                        int node_off, hipStream_t s, const float* extra = nullptr, int extra_mod = 1) {
-  HIPCHK(launch_conv_finalize(e->acc, node_in, node_out, deg, L.bn_scale, L.bn_mean, L.bn_bias, n_nodes, in_level_dim(L.in_level),
-                              out_level_dim(L.out_level), node_off, extra, extra_mod, s));
+static FinGroup fin_group(const ConvGroup& g, const int* start, const int* cnt, int node_mod = 0) {
+  FinGroup f{};
+  f.start = start; f.cnt = cnt; f.total = g.count; f.first_sum = g.first_sum; f.last_sum = g.last_sum; f.run_acc = g.run_acc;
+  f.node_mod = node_mod;
+  return f;
+}
+
+static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const FinGroup* groups,
+                        int n_groups, int n_nodes, int node_off, hipStream_t s) {
+  FinArgs fa{};
+  fa.n_groups = n_groups;
+  for (int g = 0; g < n_groups; ++g) fa.g[g] = groups[g];
+  HIPCHK(launch_conv_finalize(fa, node_in, node_out, L.bn_scale, L.bn_mean, L.bn_bias, n_nodes, in_level_dim(L.in_level),
+                              out_level_dim(L.out_level), node_off, s));
   return 0;
 }
 
@@ -527,9 +540,11 @@ static int embed_receptor(cbd_engine* e, hipStream_t s) {
   for (int l = 0; l < 3; ++l) {
     ConvGroup g{};
     g.src = e->d_src0; g.dst = e->d_dst0; g.attr_idx = e->d_ident; g.vec = e->d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
+    g.first_sum = e->fsum[4]; g.last_sum = e->lsum[4]; g.run_acc = e->racc[4];
     int cap = Err;
     CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
-    CHK(run_finalize(e, e->rec_emb[l], in, out, e->d_deg0, Nr, 0, s));
+    const FinGroup fg = fin_group(g, e->rr0_start, e->d_deg0);
+    CHK(run_finalize(e, e->rec_emb[l], in, out, &fg, 1, Nr, 0, s));
     std::swap(in, out);
   }
   HIPCHK(hipMemcpyAsync(e->rec_static, in, (size_t)Nr * NODE_STRIDE * 4, hipMemcpyDeviceToDevice, s));
@@ -651,9 +666,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&gd.pair_eid, cap_x));
   HIPCHK(e->bpool.alloc(&e->ll_attr, cap_ll * 32)); HIPCHK(e->bpool.alloc(&e->lr_attr, cap_x * 32));
   HIPCHK(e->bpool.alloc(&e->X0, (size_t)N * NODE_STRIDE)); HIPCHK(e->bpool.alloc(&e->X1, (size_t)N * NODE_STRIDE));
-  HIPCHK(e->bpool.alloc(&e->acc, (size_t)N * NODE_STRIDE));
   HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
-  HIPCHK(hipMemset(e->acc, 0, (size_t)N * NODE_STRIDE * 4));
   float* vecs;
   HIPCHK(e->bpool.alloc(&vecs, 7 * 32));
   e->sv = StepVectors{vecs, vecs + 32, vecs + 64, vecs + 96, vecs + 128, vecs + 160, vecs + 192};
@@ -676,7 +689,23 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.upload(&e->rr_src, bsrc)); HIPCHK(e->bpool.upload(&e->rr_dst, bdst)); HIPCHK(e->bpool.upload(&e->rr_aidx, baidx));
   HIPCHK(e->bpool.alloc(&e->rr_vec, (size_t)Bm * Err * 4));
   HIPCHK(e->bpool.alloc(&e->rr_count_dev, 1));
-  HIPCHK(e->bpool.alloc(&e->rr_shared, (size_t)Nr * NODE_STRIDE));
+  {
+    const size_t caps[5] = {cap_ll, cap_x, (size_t)Bm * Err, cap_x, (size_t)Err};
+    for (int g = 0; g < 5; ++g) {
+      const size_t tiles = (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES + 1;
+      HIPCHK(e->bpool.alloc(&e->fsum[g], tiles * NODE_STRIDE));
+      HIPCHK(e->bpool.alloc(&e->lsum[g], tiles * NODE_STRIDE));
+      HIPCHK(e->bpool.alloc(&e->racc[g], (size_t)(g == 4 ? Nr : N) * NODE_STRIDE));
+    }
+    std::vector<int> row0(Nr + 1, 0);
+    for (int r = 0; r < Nr; ++r) row0[r + 1] = row0[r] + deg0[r];
+    std::vector<int> bstart((size_t)Bm * Nr), bcnt((size_t)Bm * Nr);
+    for (int b = 0; b < Bm; ++b)
+      for (int r = 0; r < Nr; ++r) { bstart[(size_t)b * Nr + r] = b * Err + row0[r]; bcnt[(size_t)b * Nr + r] = deg0[r]; }
+    HIPCHK(e->bpool.upload(&e->rr_start, bstart)); HIPCHK(e->bpool.upload(&e->rr_cnt, bcnt));
+    row0.pop_back();
+    HIPCHK(e->bpool.upload(&e->rr0_start, row0));
+  }
 
   e->d_rec_x = d_rec_x; e->d_vec0 = d_vec0; e->d_dist0 = d_dist0; e->d_src0 = d_src0; e->d_dst0 = d_dst0;
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
@@ -719,7 +748,11 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   //      pose-dependent graph construction and ligand embedding: receptor rows (static embedding + sigma embedding,
   //      score_model.py:323-326) and the receptor->receptor messages of interaction layer 0.  Those messages read only
   //      receptor features and shared edge attributes, so they are IDENTICAL for the B samples of a complex: they are
-  //      computed once (Err edges instead of B*Err) into rr_shared and added to every sample's sum by the finalize kernel.
+  //      computed once (Err edges instead of B*Err) and added to every sample's sum by the finalize kernel (node_mod = Nr).
+  ConvGroup g_rr_shared{};   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
+  g_rr_shared.src = e->rr_src; g_rr_shared.dst = e->rr_dst; g_rr_shared.attr_idx = e->rr_aidx; g_rr_shared.vec = e->rr_vec;
+  g_rr_shared.attr = e->rr_attr_t; g_rr_shared.count = e->rr_count_dev;
+  g_rr_shared.first_sum = e->fsum[4]; g_rr_shared.last_sum = e->lsum[4]; g_rr_shared.run_acc = e->racc[2];
   float* const Xa = e->X0;          // ligand embedding ping-pong: X0 -> X1 -> X0 -> X1 ; interaction layers read X1 first
   float* const Xb = e->X1;
   HIPCHK(hipEventRecord(e->ev_fork, s));
@@ -728,11 +761,8 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
     hipStream_t ss = e->side;
     HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, ss));
     HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, Xb, B, gs.rec_off, Nr, ss));
-    HIPCHK(hipMemsetAsync(e->rr_shared, 0, (size_t)Nr * NODE_STRIDE * 4, ss));
-    ConvGroup g0{};
-    g0.src = e->rr_src; g0.dst = e->rr_dst; g0.attr_idx = e->rr_aidx; g0.vec = e->rr_vec; g0.attr = e->rr_attr_t; g0.count = e->rr_count_dev;
     const int cap0 = gs.Err, w_rr = 2;
-    CHK(run_conv(e, e->conv[0], &g0, 1, &cap0, Xb, ss, &w_rr, e->rr_shared - (size_t)gs.rec_off * NODE_STRIDE));
+    CHK(run_conv(e, e->conv[0], &g_rr_shared, 1, &cap0, Xb, ss, &w_rr));
     HIPCHK(hipEventRecord(e->ev_join, ss));
   }
   HIPCHK(hipMemsetAsync(gd.counts, 0, 8 * sizeof(int), s));
@@ -751,13 +781,21 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   glr.src = gd.lr_src; glr.dst = gd.lr_dst; glr.attr_idx = gd.lr_aidx; glr.vec = gd.lr_vec; glr.attr = e->lr_attr; glr.count = gd.counts + 1;
   grr.src = e->rr_src; grr.dst = e->rr_dst; grr.attr_idx = e->rr_aidx; grr.vec = e->rr_vec; grr.attr = e->rr_attr_t; grr.count = gd.counts + 2;
   grl.src = gd.rl_src; grl.dst = gd.rl_dst; grl.attr_idx = gd.rl_aidx; grl.vec = gd.rl_vec; grl.attr = e->lr_attr; grl.count = gd.counts + 3;
+  {
+    ConvGroup* gg[4] = {&gll, &glr, &grr, &grl};
+    for (int g = 0; g < 4; ++g) { gg[g]->first_sum = e->fsum[g]; gg[g]->last_sum = e->lsum[g]; gg[g]->run_acc = e->racc[g]; }
+  }
+  const FinGroup f_ll = fin_group(gll, gd.start_ll, gd.cnt_ll), f_lr = fin_group(glr, gd.start_lr, gd.cnt_lr);
+  const FinGroup f_rl = fin_group(grl, gd.start_rl, gd.cnt_rl), f_rr = fin_group(grr, e->rr_start, e->rr_cnt);
+  const FinGroup f_rr_shared = fin_group(g_rr_shared, e->rr_start, e->rr_cnt, Nr);
+  const FinGroup lig2[2] = {f_ll, f_lr}, rec2[2] = {f_rr, f_rl}, rec2_shared[2] = {f_rr_shared, f_rl};
 
   float* in = Xa;
   float* out = Xb;
   static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
   for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
     CHK(run_conv(e, e->lig_emb[l], &gll, 1, &cap_ll, in, s));
-    CHK(run_finalize(e, e->lig_emb[l], in, out, gd.deg_embed, nL, 0, s));
+    CHK(run_finalize(e, e->lig_emb[l], in, out, &f_ll, 1, nL, 0, s));
     std::swap(in, out);
     snap(e, emb_names[l], in, (size_t)nL * NODE_STRIDE, s);
   }
@@ -769,19 +807,19 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
       const ConvGroup g3[3] = {gll, glr, grl};
       const int caps[3] = {cap_ll, cap_x, cap_x}, widx[3] = {0, 1, 3};
       CHK(run_conv(e, e->conv[l], g3, 3, caps, in, s, widx));
-      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));
-      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nR, gs.rec_off, s, e->rr_shared, Nr));
+      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));
+      CHK(run_finalize(e, e->conv[l], in, out, rec2_shared, 2, nR, gs.rec_off, s));
     } else if (l < 4) {
       const ConvGroup g4[4] = {gll, glr, grr, grl};
       const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
       CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
-      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));
-      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nR, gs.rec_off, s));
+      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));
+      CHK(run_finalize(e, e->conv[l], in, out, rec2, 2, nR, gs.rec_off, s));
     } else {
       const ConvGroup g2[2] = {gll, glr};
       const int caps[2] = {cap_ll, cap_x};
       CHK(run_conv(e, e->conv[l], g2, 2, caps, in, s));
-      CHK(run_finalize(e, e->conv[l], in, out, gd.deg_full, nL, 0, s));   // receptor rows are never read again (quirk 3)
+      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));   // receptor rows are never read again (quirk 3)
     }
     std::swap(in, out);
     snap(e, conv_names[l], in, (size_t)nL * NODE_STRIDE, s);

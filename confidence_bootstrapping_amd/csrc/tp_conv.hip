@@ -23,8 +23,9 @@
 //   * Rows of a vector-block tile hold 5 mid indices x 6 outputs: accumulator register reg < 15 of lane half hf is
 //     (i = 5*tile + reg/3, o = 3*hf + reg%3), so both the mid index and the output slot are compile-time functions of
 //     the register index, each half owns three of the six outputs, and 30 of the 32 MFMA rows carry weights.
-//   * Segmented reduction: edges are sorted by aggregating node; each wave run-length sums its 32 messages in
-//     LDS and issues one 256-byte-contiguous fp32 atomic add per (node run, 64 columns).
+//   * Segmented reduction without atomics: edges are sorted by aggregating node; each wave run-length sums its 32
+//     messages in LDS and stores per-tile pieces (first run / last run / interior runs) that conv_finalize_kernel adds
+//     in a fixed order -> bitwise reproducible results.
 #include <cstdlib>
 
 #include "common.h"
@@ -148,14 +149,14 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const int j = lane & 31, hf = lane >> 5;
 
   // ---- which group / edge range does this wave own?  (edge counts live on the device)
-  int grp = -1, e0 = 0, cnt = 0;
+  int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
   {
     int t = blockIdx.x;
     for (int g = 0; g < args.n_groups; ++g) {
       const int c = *args.g[g].count;
       const int nt = (c + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
       if (grp < 0) {
-        if (t < nt) { grp = g; e0 = t * CONV_WG_EDGES; cnt = c; }
+        if (t < nt) { grp = g; e0 = t * CONV_WG_EDGES; cnt = c; tile_local = t; }
         else t -= nt;
       }
     }
@@ -307,20 +308,28 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
   }
   __syncthreads();
+  // Run-length sums without atomics (bitwise reproducible): a run that starts at the tile's first edge goes to
+  // first_sum[tile], one that ends at edge 31 to last_sum[tile], any other run (strictly inside the tile) is the
+  // node's only contribution from this group and is stored directly; conv_finalize_kernel adds the pieces in tile order.
+  float* const fs = G.first_sum + (size_t)tile_local * NODE_STRIDE;
+  float* const ls = G.last_sum + (size_t)tile_local * NODE_STRIDE;
   for (int col = lane; col < S.out_dim; col += 64) {
     const float* oc = xT + col * OUT_STRIDE;
     float sum = 0.f;
-    int cur = srcl[0];
+    int cur = srcl[0], a0 = 0;
     for (int jj = 0; jj < 32; ++jj) {
-      const int s = srcl[jj];
-      if (s != cur) {
-        if (cur >= 0) atomicAdd(args.acc + (size_t)cur * NODE_STRIDE + col, sum);
+      const int sj = srcl[jj];
+      if (sj != cur) {   // run [a0, jj-1] of node cur is complete (invalid lanes, src = -1, only follow valid ones)
+        // (a run that ends at the last edge of the group's partial tile has no other tile either: stored as interior)
+        float* dst = a0 == 0 ? fs : G.run_acc + (size_t)cur * NODE_STRIDE;
+        dst[col] = sum;
         sum = 0.f;
-        cur = s;
+        a0 = jj;
+        cur = sj;
       }
       sum += oc[jj];
     }
-    if (cur >= 0) atomicAdd(args.acc + (size_t)cur * NODE_STRIDE + col, sum);
+    if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;   // run that reaches edge 31 of a full tile
   }
   if constexpr (VAR == 8) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
@@ -332,30 +341,44 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// mean -> e3nn BatchNorm (eval) -> residual, reference tensor_layers.py:206-216.
-//   out[n][c] = bn(acc[n][c] / max(deg[n],1)) + (c < in_dim ? node_in[n][c] : 0) ; acc is cleared for the next layer.
-// bn_scale[c] = weight * rsqrt(running_var + eps) per column, bn_shift[c] = bias - running_mean*scale (0e columns
-// only, 0 elsewhere), prepared on the host per column.
-__global__ void conv_finalize_kernel(float* __restrict__ acc, const float* __restrict__ node_in, float* __restrict__ node_out,
-                                     const int* __restrict__ deg, const float* __restrict__ bn_scale,
-                                     const float* __restrict__ bn_mean, const float* __restrict__ bn_bias,
-                                     int n_nodes, int in_dim, int out_dim, int node_off,
-                                     const float* __restrict__ extra, int extra_mod) {
+// segmented sum (fixed order) -> mean -> e3nn BatchNorm (eval) -> residual, reference tensor_layers.py:206-216.
+//   out[n][c] = bn(sum_{edges into n} msg / max(deg[n],1)) + (c < in_dim ? node_in[n][c] : 0)
+// The message sums were left by tp_conv as per-tile pieces (see the end of tp_conv_kernel); they are combined here group by
+// group, tile by tile -- a fixed order, so results are bitwise reproducible.  bn_scale[c] = weight * rsqrt(running_var +
+// eps) per column; bn_mean / bn_bias are zero outside the 0e columns.
+__global__ void conv_finalize_kernel(FinArgs fa, const float* __restrict__ node_in, float* __restrict__ node_out,
+                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_mean,
+                                     const float* __restrict__ bn_bias, int n_nodes, int in_dim, int out_dim, int node_off) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
-  if (n >= n_nodes) return;
-  const size_t o = (size_t)(n + node_off) * NODE_STRIDE + c;
+  const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  if (i >= n_nodes) return;
+  const size_t o = (size_t)(i + node_off) * NODE_STRIDE + c;
   float r = 0.f;
   if (c < out_dim) {
-    const int d = deg[n + node_off];
-    float sum = acc[o];
-    if (extra) sum += extra[(size_t)(n % extra_mod) * NODE_STRIDE + c];   // message sums shared by all samples (layer-0 rr)
-    float m = sum / (float)(d > 1 ? d : 1);
+    float sum = 0.f;
+    int deg = 0;
+    for (int g = 0; g < fa.n_groups; ++g) {
+      const FinGroup& G = fa.g[g];
+      const int k = G.node_mod > 0 ? i % G.node_mod : i;
+      const int s = G.start[k], n = G.cnt[k];
+      deg += n;
+      if (n <= 0) continue;
+      const int e = s + n, t0 = s / WAVE_EDGES, t1 = (e - 1) / WAVE_EDGES;
+      const bool at_start = (s % WAVE_EDGES) == 0;
+      if (t0 == t1) {
+        if (at_start) sum += G.first_sum[(size_t)t0 * NODE_STRIDE + c];
+        else if ((e % WAVE_EDGES) == 0) sum += G.last_sum[(size_t)t0 * NODE_STRIDE + c];
+        else sum += G.run_acc[(size_t)(k + node_off) * NODE_STRIDE + c];
+      } else {
+        sum += (at_start ? G.first_sum : G.last_sum)[(size_t)t0 * NODE_STRIDE + c];
+        for (int t = t0 + 1; t <= t1; ++t) sum += G.first_sum[(size_t)t * NODE_STRIDE + c];
+      }
+    }
+    float m = sum / (float)(deg > 1 ? deg : 1);
     m = (m - bn_mean[c]) * bn_scale[c] + bn_bias[c];
     r = m + (c < in_dim ? node_in[o] : 0.f);
   }
   node_out[o] = r;
-  acc[o] = 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------- host launchers
@@ -378,13 +401,13 @@ hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int gr
   return hipErrorInvalidValue;
 }
 
-hipError_t launch_conv_finalize(float* acc, const float* node_in, float* node_out, const int* deg, const float* bn_scale,
+hipError_t launch_conv_finalize(const FinArgs& fa, const float* node_in, float* node_out, const float* bn_scale,
                                 const float* bn_mean, const float* bn_bias, int n_nodes, int in_dim, int out_dim,
-                                int node_off, const float* extra, int extra_mod, hipStream_t s) {
+                                int node_off, hipStream_t s) {
   if (n_nodes <= 0) return hipSuccess;
   const int total = n_nodes * NODE_STRIDE;
-  hipLaunchKernelGGL(conv_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, acc, node_in, node_out, deg,
-                     bn_scale, bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off, extra, extra_mod);
+  hipLaunchKernelGGL(conv_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, fa, node_in, node_out, bn_scale,
+                     bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off);
   return hipGetLastError();
 }
 
