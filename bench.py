@@ -159,6 +159,10 @@ def main():
         femb = flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3)
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
         flops_per_launch = total_flops / max(n_launch, 1)
+        traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
+        tp = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        if os.path.exists(tp):
+            traffic = round(json.load(open(tp))["hbm_bytes_per_launch"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         out = {
             "metric": "poses/sec (whole node), 40-sample x 20-step diffusion, DockGen median complex",
@@ -169,7 +173,7 @@ def main():
                        "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
                          "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
