@@ -621,7 +621,9 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->cpool.upload(&d_mask, std::vector<uint8_t>(mask_rotate, mask_rotate + (size_t)R * Nl)));
   gs.bond_row = d_bond_row; gs.bond_dst = d_bond_dst; gs.bond_attr = d_battr; gs.rot_u = d_rot_u; gs.rot_v = d_rot_v;
   gs.mask_rotate = d_mask;
-  e->cap_ll_per_sample = nbd + Nl * std::min(Nl - 1, e->cfg.lig_radius_cap);
+  // radius_graph keeps the first cap+1 hits INCLUDING self and then drops self: an atom whose own index comes after its
+  // first cap+1 neighbours keeps cap+1 of them
+  e->cap_ll_per_sample = nbd + Nl * std::min(Nl - 1, e->cfg.lig_radius_cap + 1);
 
   // ---- receptor statics: kNN edges sorted by aggregating node (row 0)
   std::vector<int> rorder(Err);

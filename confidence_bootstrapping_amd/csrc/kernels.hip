@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, 
     const int b = node / gs.Nl, a = node % gs.Nl;
     const float* P = gd.pos + (size_t)b * gs.Nl * 3;
     const float px = P[3 * a], py = P[3 * a + 1], pz = P[3 * a + 2];
-    // ---- ligand-ligand: bonds first, then radius neighbours (first lig_cap+1 hits in index order incl. self, self dropped)
+    // ---- ligand-ligand: bonds first, then radius-graph edges
     const int nb0 = gs.bond_row[a], nb1 = gs.bond_row[a + 1];
     int base = 0;
     if (FILL) {
@@ -61,14 +61,21 @@ __global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, 
       }
       base += nb1 - nb0;
     }
-    int hits = 0, kept = 0;   // hits counts self too (cap applies to lig_cap + 1 hits)
+    // radius_graph(pos, r, batch) (score_model.py:502) returns [neighbour; centre] rows and the layer aggregates into row 0:
+    // node a receives an edge from every centre y that has a among the first lig_cap+1 in-radius atoms of ITS scan (index
+    // order, self included, torch_cluster radius with max_num_neighbors+1).  rank_y(a) = #{x < a : |x - y| < r}.
+    int kept = 0;
     for (int c0 = 0; c0 < gs.Nl; c0 += 64) {
-      const int d = c0 + lane;
-      bool in = false;
-      if (d < gs.Nl) in = dist2_nofma(P[3 * d], P[3 * d + 1], P[3 * d + 2], px, py, pz) < lig_r2;
-      const unsigned long long m = __ballot(in);
-      const int rank = hits + popc_below(m, lane);
-      const bool keep = in && rank < lig_cap + 1 && d != a;
+      const int d = c0 + lane;   // candidate centre y
+      bool keep = false;
+      if (d < gs.Nl && d != a) {
+        const float yx = P[3 * d], yy = P[3 * d + 1], yz = P[3 * d + 2];
+        if (dist2_nofma(px, py, pz, yx, yy, yz) < lig_r2) {
+          int rank = 0;
+          for (int x = 0; x < a; ++x) rank += dist2_nofma(P[3 * x], P[3 * x + 1], P[3 * x + 2], yx, yy, yz) < lig_r2 ? 1 : 0;
+          keep = rank < lig_cap + 1;
+        }
+      }
       const unsigned long long mk = __ballot(keep);
       if (FILL && keep) {
         const int e = base + kept + popc_below(mk, lane);
@@ -79,7 +86,6 @@ __global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, 
         gd.ll_dist[e] = n;
         reinterpret_cast<f32x4*>(gd.ll_bond4)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-      hits += __popcll(m);
       kept += __popcll(mk);
     }
     if (!FILL && lane == 0) gd.cnt_ll[node] = (nb1 - nb0) + kept;
