@@ -12,6 +12,12 @@ synthetic complexes whose tensor layout is exactly what `datasets/process_mols.p
   ['receptor'].x [Nr, 1+1280] f32     col 0 residue type, cols 1.. language-model embedding
   ['receptor'].pos [Nr,3] f32         C-alpha trace centred on its centroid
   ['receptor','receptor'].edge_index [2, 24*Nr]  kNN graph, row0 = neighbour, row1 = centre
+and, with `add_atoms()` (the all-atom schema the confidence model reads, process_mols.py:490-526):
+  ['atom'].x [Na,4] f32               categorical: residue type, atomic number idx, atom_type_2, atom_type_3
+  ['atom'].pos [Na,3] f32             heavy atoms, stored residue by residue
+  ['atom','atom_contact','atom'].edge_index [2, 8*Na]   kNN-8 graph, row0 = neighbour, row1 = centre
+  ['atom','atom_rec_contact','receptor'].edge_index [2, Na]  (atom, its residue)
+  ['receptor'].side_chain_vecs [Nr,4,3] (carried through crop_beyond, not read by the model)
 """
 from __future__ import annotations
 
@@ -239,5 +245,54 @@ def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None) -> HeteroData
     return d
 
 
-def make_workload(workload: str, seed=1234) -> HeteroData:
-    return make_complex(seed=seed, name=workload, **WORKLOADS[workload])
+REC_ATOM_FEATURE_DIMS = [38, 119, 23, 38]   # datasets/process_mols.py:114-119
+
+
+def add_atoms(d: HeteroData, seed=1234, atom_knn=8, mean_side_atoms=4.0) -> HeteroData:
+    """Adds the all-atom receptor stores to a complex made by make_complex (own RNG stream, so the coarse-grained
+    part is unchanged).  Every residue gets backbone N, CA, C, O plus 0..10 side-chain atoms placed around its C-alpha
+    with >= 1.2 A separation; atoms are stored residue by residue like the reference's featuriser."""
+    rng = np.random.default_rng([seed, 77])
+    rpos = d["receptor"].pos.numpy().astype(np.float64)
+    Nr = len(rpos)
+    res_type = d["receptor"].x[:, 0].numpy().astype(np.int64)
+    pos, feat, res_of = [], [], []
+    for r in range(Nr):
+        n_side = int(min(10, rng.poisson(mean_side_atoms)))
+        mine = [rpos[r]]                                        # CA sits on the trace point
+        for k in range(3 + n_side):
+            for _ in range(100):
+                dirn = rng.normal(size=3)
+                dirn /= np.linalg.norm(dirn)
+                base = mine[0] if k < 3 else mine[int(rng.integers(0, len(mine)))]
+                p = base + 1.5 * dirn
+                if np.min(np.linalg.norm(np.asarray(mine) - p, axis=1)) >= 1.2:
+                    mine.append(p)
+                    break
+        order = [1, 0] + list(range(2, len(mine)))              # N, CA, C, O, side chain...
+        for j, k in enumerate(order):
+            pos.append(mine[k])
+            if j < 4:
+                f = [res_type[r], (6, 5, 5, 7)[j], (8, 1, 0, 13)[j], (17, 1, 0, 26)[j]]
+            else:
+                f = [res_type[r], int(rng.choice([5, 5, 5, 6, 7, 15])), int(rng.integers(0, 23)), int(rng.integers(0, 38))]
+            feat.append(f)
+            res_of.append(r)
+    pos = np.asarray(pos)
+    Na = len(pos)
+    tree = cKDTree(pos)
+    _, nbr = tree.query(pos, k=atom_knn + 1)
+    nbr = nbr[:, 1:]
+    centre = np.repeat(np.arange(Na), atom_knn)
+    d["atom"].x = torch.from_numpy(np.asarray(feat, dtype=np.float32))
+    d["atom"].pos = torch.from_numpy(pos.astype(np.float32))
+    d["atom", "atom_contact", "atom"].edge_index = torch.from_numpy(np.stack([nbr.reshape(-1), centre]).astype(np.int64))
+    d["atom", "atom_rec_contact", "receptor"].edge_index = torch.from_numpy(
+        np.stack([np.arange(Na), np.asarray(res_of)]).astype(np.int64))
+    d["receptor"].side_chain_vecs = torch.from_numpy(rng.normal(size=(Nr, 4, 3)).astype(np.float32))
+    return d
+
+
+def make_workload(workload: str, seed=1234, all_atoms=False) -> HeteroData:
+    d = make_complex(seed=seed, name=workload, **WORKLOADS[workload])
+    return add_atoms(d, seed=seed) if all_atoms else d

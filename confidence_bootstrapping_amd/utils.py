@@ -13,6 +13,7 @@ from .diffusion_utils import get_timestep_embedding, t_to_sigma as t_to_sigma_co
 from .score_model import TensorProductScoreModel
 
 _DEFAULT_YML = os.path.join(os.path.dirname(__file__), "data", "pretrained_score_model_parameters.yml")
+_CONFIDENCE_YML = os.path.join(os.path.dirname(__file__), "data", "pretrained_confidence_model_parameters.yml")
 
 
 def load_model_args(path: str = None) -> Namespace:
@@ -33,8 +34,9 @@ def _has(args, k):
 def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False, old=False):
     if old:
         raise NotImplementedError("old score-model variants are outside the MI355X hot path")
-    if ("all_atoms" in args and args.all_atoms) or confidence_mode:
-        raise NotImplementedError("all-atom / confidence model: SURVEY.md 8f-1 (next row), not built yet")
+    all_atoms = "all_atoms" in args and args.all_atoms
+    if all_atoms != bool(confidence_mode):
+        raise NotImplementedError("the MI355X build covers the coarse-grained score model and the all-atom confidence model")
     emb_type = args.embedding_type if "embedding_type" in args else "sinusoidal"
     emb_scale = args.embedding_scale if "embedding_type" in args else 10000
     timestep_emb_func = get_timestep_embedding(emb_type, args.sigma_embed_dim, emb_scale)
@@ -45,6 +47,34 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
     if _has(args, "esm_embeddings_model"):
         lm = args.esm_embeddings_model
     g = lambda k, d: getattr(args, k) if k in args else d
+    if all_atoms:
+        from .all_atom_score_model import TensorProductScoreModel as AAScoreModel
+        n_out = lambda k: len(getattr(args, k)) + 1 if k in args and isinstance(getattr(args, k), list) else 1
+        model = AAScoreModel(
+            t_to_sigma=t_to_sigma, device=device, no_torsion=args.no_torsion, timestep_emb_func=timestep_emb_func,
+            num_conv_layers=args.num_conv_layers, lig_max_radius=args.max_radius, scale_by_sigma=args.scale_by_sigma,
+            sigma_embed_dim=args.sigma_embed_dim, norm_by_sigma=g("norm_by_sigma", False), ns=args.ns, nv=args.nv,
+            distance_embed_dim=args.distance_embed_dim, cross_distance_embed_dim=args.cross_distance_embed_dim,
+            batch_norm=not args.no_batch_norm, dropout=args.dropout, use_second_order_repr=args.use_second_order_repr,
+            cross_max_distance=args.cross_max_distance, dynamic_max_cross=args.dynamic_max_cross,
+            separate_noise_schedule=args.separate_noise_schedule, smooth_edges=g("smooth_edges", False),
+            odd_parity=g("odd_parity", False), lm_embedding_type=lm, confidence_mode=confidence_mode,
+            asyncronous_noise_schedule=g("asyncronous_noise_schedule", False),
+            affinity_prediction=g("affinity_prediction", False), parallel=g("parallel", 1),
+            num_confidence_outputs=n_out("rmsd_classification_cutoff"),
+            atom_num_confidence_outputs=n_out("atom_rmsd_classification_cutoff"),
+            parallel_aggregators=g("parallel_aggregators", ""),
+            fixed_center_conv=(not args.not_fixed_center_conv) if "not_fixed_center_conv" in args else False,
+            no_aminoacid_identities=g("no_aminoacid_identities", False),
+            include_miscellaneous_atoms=g("include_miscellaneous_atoms", False), sh_lmax=g("sh_lmax", 2),
+            differentiate_convolutions=(not args.no_differentiate_convolutions) if "no_differentiate_convolutions" in args else True,
+            tp_weights_layers=g("tp_weights_layers", 2), num_prot_emb_layers=g("num_prot_emb_layers", 0),
+            reduce_pseudoscalars=g("reduce_pseudoscalars", False), embed_also_ligand=g("embed_also_ligand", False),
+            atom_confidence=(args.atom_confidence_loss_weight > 0.0) if "atom_confidence_loss_weight" in args else False,
+            sidechain_pred=(g("sidechain_loss_weight", 0) > 0) or (g("backbone_loss_weight", 0) > 0),
+            depthwise_convolution=g("depthwise_convolution", False), embedding_scale=emb_scale)
+        model.to(device)
+        return model
     model = TensorProductScoreModel(
         t_to_sigma=t_to_sigma, device=device, no_torsion=args.no_torsion, timestep_emb_func=timestep_emb_func,
         num_conv_layers=args.num_conv_layers, lig_max_radius=args.max_radius, scale_by_sigma=args.scale_by_sigma,
@@ -69,14 +99,20 @@ def get_model(args, device, t_to_sigma, no_parallel=False, confidence_mode=False
     return model
 
 
-def make_score_model(device="cpu", seed=0, args=None, eval_mode=True):
+def make_confidence_model(device="cpu", seed=5, args=None, eval_mode=True):
+    """Random-init all-atom confidence model of the shipped architecture (see make_score_model)."""
+    return make_score_model(device, seed, args or load_model_args(_CONFIDENCE_YML), eval_mode, confidence_mode=True)
+
+
+def make_score_model(device="cpu", seed=0, args=None, eval_mode=True, confidence_mode=False):
     """Random-init score model of the shipped architecture with non-trivial BatchNorm statistics
     (checkpoints are not available offline)."""
     args = args or load_model_args()
     gen = torch.random.get_rng_state()
     torch.manual_seed(seed)
     try:
-        model = get_model(args, torch.device("cpu"), partial(t_to_sigma_compl, args=args), no_parallel=True)
+        model = get_model(args, torch.device("cpu"), partial(t_to_sigma_compl, args=args), no_parallel=True,
+                          confidence_mode=confidence_mode)
         g = torch.Generator().manual_seed(seed + 1)
         for name, buf in model.named_buffers():
             if name.endswith("running_var"):
@@ -84,7 +120,7 @@ def make_score_model(device="cpu", seed=0, args=None, eval_mode=True):
             elif name.endswith("running_mean"):
                 buf.copy_(torch.randn(buf.shape, generator=g) * 0.1)
         for name, p in model.named_parameters():
-            if "batch_norm" in name:
+            if "batch_norm" in name or "confidence_predictor.1." in name or "confidence_predictor.5." in name:
                 with torch.no_grad():
                     p.copy_(p + 0.1 * torch.randn(p.shape, generator=g))
     finally:

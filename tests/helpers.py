@@ -50,3 +50,11 @@ def load_c1_complex():
     d.original_center = torch.from_numpy(g["original_center"])[None]
     d.name = "1a0q"
     return d
+
+
+def to_aacx(d):
+    """HeteroData (single complex with the all-atom stores) -> oracle AllAtomComplex."""
+    from oracle.confidence_ref import AllAtomComplex
+    return AllAtomComplex(d["ligand"].x, d["ligand", "ligand"].edge_index, d["ligand", "ligand"].edge_attr,
+                          d["receptor"].x, d["receptor"].pos, d["receptor", "receptor"].edge_index,
+                          d["atom"].x, d["atom"].pos, d["atom", "atom"].edge_index, d["atom", "receptor"].edge_index[1])
