@@ -11,13 +11,13 @@
 #include <string>
 #include <vector>
 
-#include "../../include/cbdock.h"
+#include "host_util.h"
 #include "kernels.h"
 
 using namespace cbd;
 
 static thread_local std::string g_err;
-static int fail(int code, const char* fmt, ...) {
+int cbd_fail(int code, const char* fmt, ...) {
   char buf[1024];
   va_list ap;
   va_start(ap, fmt);
@@ -26,48 +26,8 @@ static int fail(int code, const char* fmt, ...) {
   g_err = buf;
   return code;
 }
-#define HIPCHK(x)                                                                                              \
-  do {                                                                                                         \
-    hipError_t _e = (x);                                                                                       \
-    if (_e != hipSuccess) return fail(CBD_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
-  } while (0)
-#define CHK(x)            \
-  do {                    \
-    int _r = (x);         \
-    if (_r != 0) return _r; \
-  } while (0)
 
 namespace {
-
-struct HostTensor {
-  std::vector<int64_t> shape;
-  std::vector<float> data;
-};
-
-// tracked device allocation helper
-struct DevPool {
-  std::vector<void*> ptrs;
-  template <typename T>
-  hipError_t alloc(T** p, size_t n) {
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    ptrs.push_back(q);
-    *p = reinterpret_cast<T*>(q);
-    return hipSuccess;
-  }
-  template <typename T>
-  hipError_t upload(T** p, const std::vector<T>& h) {
-    hipError_t e = alloc(p, h.size());
-    if (e != hipSuccess) return e;
-    if (!h.empty()) e = hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
-  }
-  void release() {
-    for (void* p : ptrs) (void)hipFree(p);
-    ptrs.clear();
-  }
-};
 
 struct ConvLayerDev {
   int in_level = 0, out_level = 0, n_groups = 0;

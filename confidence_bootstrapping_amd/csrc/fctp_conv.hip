@@ -1,0 +1,373 @@
+// Fused message passing of the all-atom CONFIDENCE model for gfx950 (MI355X):
+//   per edge:  h = ReLU(W1 [edge_attr | x_src[:24] | x_dst[:24]] + b1)            (FCBlock layer 1, 72 -> 72)
+//              w = W2 h + b2                                                       (FCBlock layer 2, 720..1944 wide)
+//              msg = FullyConnectedTensorProduct(x_dst, Y_{0,1,2}(edge_vec), w)    (e3nn 'uvw' paths, lmax = 2)
+//   per node:  mean -> BatchNorm -> residual in fctp_finalize_kernel
+// replacing reference models/tensor_layers.py:195-217 with `faster=False` (models/all_atom_score_model.py:170-187).
+//
+// Same mapping onto the matrix cores as tp_conv.hip (exact fp32 v_mfma_f32_32x32x2_f32, one wave = 32 edges, weights
+// streamed L2 -> registers one tile ahead, the ReLU'd accumulator of the first Linear re-used in place as the B operand of
+// the second), with K = 72: 36 k-steps, of which the last 4 come from the 8 live rows of the third hidden tile.
+// Block structure (conf_common.h): scalar blocks (24 outputs) use tiles of 4 mid indices x 8 outputs, three tiles per
+// group of 4 mids; vector blocks (6 outputs) use tiles of 5 mid indices x 6 outputs.  The Clebsch-Gordan contraction
+// runs on the VALU with canonical intermediates x, x.n, x n, x cross n and (n n^T - I/3) x; the e3nn path weights,
+// sqrt(2l+1) spherical-harmonic scales and Wigner-3j constants are folded into the packed weights.
+#include "conf_common.h"
+
+namespace cbd {
+
+__device__ __forceinline__ f32x16 cmfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], const f32x4* __restrict__ next, const float* __restrict__ bias_l,
+                                           const float (&B)[CKSTEPS], f32x16& acc, int hf) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 b = bp[2 * q + hf];
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
+#pragma unroll
+  for (int sg = 0; sg < CKSTEPS / 4; ++sg) {
+    const f32x4 w = a[sg];
+    acc = cmfma32(w.x, B[4 * sg + 0], acc);
+    acc = cmfma32(w.y, B[4 * sg + 1], acc);
+    acc = cmfma32(w.z, B[4 * sg + 2], acc);
+    acc = cmfma32(w.w, B[4 * sg + 3], acc);
+    a[sg] = next[sg * 64];
+    __builtin_amdgcn_sched_barrier(0);   // keep each refill right behind its last use (see tp_conv.hip)
+  }
+}
+
+// ---- canonical CG intermediates of edge j (xc = &xT[0][j], column stride 32; n = unit edge vector)
+__device__ __forceinline__ void ld3(const float* p, float (&x)[3]) { x[0] = p[0]; x[1] = p[32]; x[2] = p[64]; }
+__device__ __forceinline__ void cross_n(const float (&x)[3], const float (&n)[3], float (&m)[3]) {
+  m[0] = x[1] * n[2] - x[2] * n[1];
+  m[1] = x[2] * n[0] - x[0] * n[2];
+  m[2] = x[0] * n[1] - x[1] * n[0];
+}
+__device__ __forceinline__ void quad_n(const float (&x)[3], const float (&n)[3], float (&m)[3]) {   // (n n^T - I/3) x
+  const float d = x[0] * n[0] + x[1] * n[1] + x[2] * n[2];
+  m[0] = d * n[0] - x[0] * (1.0f / 3.0f);
+  m[1] = d * n[1] - x[1] * (1.0f / 3.0f);
+  m[2] = d * n[2] - x[2] * (1.0f / 3.0f);
+}
+
+template <int IN>
+__device__ __forceinline__ float cmid0e(const float* xc, int i, const float (&n)[3]) {
+  if (i < CNS) return xc[i * 32];
+  if (IN >= 1 && i < CNS + CNV) {
+    const float* p = xc + (CC_1O + 3 * (i - CNS)) * 32;
+    return p[0] * n[0] + p[32] * n[1] + p[64] * n[2];
+  }
+  return 0.f;
+}
+
+template <int IN>
+__device__ __forceinline__ void cmid1o(const float* xc, int i, const float (&n)[3], float (&m)[3]) {
+  constexpr FctpShape S = fctp_shape(IN, 3);
+  float x[3];
+  if (i < CNS) {
+    const float s = xc[i * 32];
+    m[0] = s * n[0]; m[1] = s * n[1]; m[2] = s * n[2];
+  } else if (i < CNS + S.n1o) {
+    ld3(xc + (CC_1O + 3 * (i - CNS)) * 32, m);
+  } else if (i < CNS + 2 * S.n1o) {
+    ld3(xc + (CC_1O + 3 * (i - CNS - S.n1o)) * 32, x);
+    quad_n(x, n, m);
+  } else if (i < S.fan1o) {
+    ld3(xc + (CC_1E + 3 * (i - CNS - 2 * S.n1o)) * 32, x);
+    cross_n(x, n, m);
+  } else {
+    m[0] = m[1] = m[2] = 0.f;
+  }
+}
+
+template <int IN>
+__device__ __forceinline__ void cmid1e(const float* xc, int i, const float (&n)[3], float (&m)[3]) {
+  constexpr FctpShape S = fctp_shape(IN, 3);
+  float x[3];
+  if (i < S.n1o) {
+    ld3(xc + (CC_1O + 3 * i) * 32, x);
+    cross_n(x, n, m);
+  } else if (i < S.n1o + S.n1e) {
+    ld3(xc + (CC_1E + 3 * (i - S.n1o)) * 32, m);
+  } else if (i < S.n1o + 2 * S.n1e) {
+    ld3(xc + (CC_1E + 3 * (i - S.n1o - S.n1e)) * 32, x);
+    quad_n(x, n, m);
+  } else if (i < S.fan1e) {
+    const float s = xc[(CC_0O + (i - S.n1o - 2 * S.n1e)) * 32];
+    m[0] = s * n[0]; m[1] = s * n[1]; m[2] = s * n[2];
+  } else {
+    m[0] = m[1] = m[2] = 0.f;
+  }
+}
+
+template <int IN>
+__device__ __forceinline__ float cmid0o(const float* xc, int i, const float (&n)[3]) {
+  constexpr FctpShape S = fctp_shape(IN, 3);
+  if (i < S.n1e) {
+    const float* p = xc + (CC_1E + 3 * i) * 32;
+    return p[0] * n[0] + p[32] * n[1] + p[64] * n[2];
+  }
+  if (i < S.fan0o) return xc[(CC_0O + (i - S.n1e)) * 32];
+  return 0.f;
+}
+
+constexpr int C_OUT_STRIDE = 33;
+constexpr int CXT_FLOATS = CN_STRIDE * C_OUT_STRIDE;   // gathered rows [84][32], later the message tile [84][33]
+__host__ __device__ constexpr int fctp_lds_floats(int ntiles) { return ntiles * 32 + CXT_FLOATS + 32; }
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
+  constexpr FctpShape S = fctp_shape(IN, OUT);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* bias_l = lds;
+  float* xT = lds + S.ntiles * 32;
+  int* srcl = reinterpret_cast<int*>(xT + CXT_FLOATS);
+  const int lane = threadIdx.x;
+  const int j = lane & 31, hf = lane >> 5;
+
+  int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
+  {
+    int t = blockIdx.x;
+    for (int g = 0; g < args.n_groups; ++g) {
+      const int c = *args.g[g].count;
+      const int nt = (c + WAVE_EDGES - 1) / WAVE_EDGES;
+      if (grp < 0) {
+        if (t < nt) { grp = g; e0 = t * WAVE_EDGES; cnt = c; tile_local = t; }
+        else t -= nt;
+      }
+    }
+  }
+  if (grp < 0) return;
+  const CGroup G = args.g[grp];
+
+  const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*576 + sg*64]
+  f32x4 a[CKSTEPS / 4];
+#pragma unroll
+  for (int sg = 0; sg < CKSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  {
+    const f32x4* gb = reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * CTILE_W_FLOATS);
+    constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
+    f32x4 bt[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; bt[i] = gb[k < NB4 ? k : NB4 - 1]; }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; reinterpret_cast<f32x4*>(bias_l)[k < NB4 ? k : NB4 - 1] = bt[i]; }
+  }
+
+  const int e = e0 + j;
+  const bool valid = e < cnt;
+  const int ec = valid ? e : cnt - 1;
+  const int src_r = G.src[ec], dst = G.dst[ec], aidx = G.attr_idx[ec];
+  const int src = valid ? src_r : -1;
+  const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[aidx];
+  const float n[3] = {vv.x, vv.y, vv.z};
+  if (hf == 0) srcl[j] = src;
+
+  float Bx[CKSTEPS];   // [edge_attr(24) | x_src[:24] | x_dst[:24]]; lane half hf holds columns 12hf .. 12hf+11 of each part
+  {
+    const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * CNS + 12 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)src_r * CN_STRIDE + 12 * hf);
+    const f32x4* pd = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * CN_STRIDE + 12 * hf);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const f32x4 aa = pa[q], s = ps[q], d = pd[q];
+      Bx[4 * q + 0] = aa.x; Bx[4 * q + 1] = aa.y; Bx[4 * q + 2] = aa.z; Bx[4 * q + 3] = aa.w;
+      Bx[12 + 4 * q + 0] = s.x; Bx[12 + 4 * q + 1] = s.y; Bx[12 + 4 * q + 2] = s.z; Bx[12 + 4 * q + 3] = s.w;
+      Bx[24 + 4 * q + 0] = d.x; Bx[24 + 4 * q + 1] = d.y; Bx[24 + 4 * q + 2] = d.z; Bx[24 + 4 * q + 3] = d.w;
+    }
+    // full destination row (21 float4) -> transposed LDS copy; half 0 copies float4 0..10, half 1 copies 10..20
+    const f32x4* pr = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * CN_STRIDE) + 10 * hf;
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+      const f32x4 r = pr[q];
+      float* o = xT + (40 * hf + 4 * q) * 32 + j;
+      o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
+    }
+  }
+  __syncthreads();
+
+  int T = 0;
+  f32x16 acc;
+  float h1[CKSTEPS];
+#define CBD_CTILE(BOP)                                                                             \
+  cgemm_tile(a, gp + (size_t)(T + 1) * (CTILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf);      \
+  ++T
+
+  // ---- first Linear: 72 hidden units = two full tiles + 8 live rows (registers 0..3 of both halves) of a third
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    CBD_CTILE(Bx);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+  }
+  CBD_CTILE(Bx);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) h1[32 + r] = fmaxf(acc[r], 0.f);
+
+  const float* xc = xT + j;
+  // ---- scalar blocks: group of 4 mids, three tiles (8 outputs each); register 4i+c of lane half hf = (mid 4g+i, output 8q+c+4hf)
+  float o0e[12], o0o[12];
+#pragma unroll
+  for (int r = 0; r < 12; ++r) { o0e[r] = 0.f; o0o[r] = 0.f; }
+#pragma unroll 1
+  for (int g = 0; g < S.g0e; ++g) {
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = cmid0e<IN>(xc, 4 * g + i, n);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      CBD_CTILE(h1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o0e[4 * q + c] = fmaf(m[i], acc[4 * i + c], o0e[4 * q + c]);
+    }
+  }
+
+  // ---- vector blocks: tile = 5 mids x 6 outputs; register reg < 15 of lane half hf = (mid 5t + reg/3, output 3hf + reg%3)
+  float k1o[9], k1e[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
+  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+      CBD_CTILE(h1);
+#pragma unroll
+      for (int q = 0; q < C_VEC_TILE_I; ++q) {
+        float m[3];
+        mid_fn(xc, C_VEC_TILE_I * t + q, n, m);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+          const float w = acc[3 * q + o];
+          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
+          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
+          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
+        }
+      }
+    }
+  };
+  vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1o<IN>(x, i, nn, m); }, S.t1o, k1o);
+  if constexpr (OUT >= 2)
+    vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1e<IN>(x, i, nn, m); }, S.t1e, k1e);
+  if constexpr (OUT >= 3) {
+#pragma unroll 1
+    for (int g = 0; g < S.g0o; ++g) {
+      float m[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        CBD_CTILE(h1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o0o[4 * q + c] = fmaf(m[i], acc[4 * i + c], o0o[4 * q + c]);
+      }
+    }
+  }
+#undef CBD_CTILE
+
+  // ---- messages -> LDS, run-length sums per aggregating node (deterministic, see tp_conv.hip)
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      xT[(8 * q + c + 4 * hf) * C_OUT_STRIDE + j] = o0e[4 * q + c];
+      if constexpr (OUT >= 3) xT[(CC_0O + 8 * q + c + 4 * hf) * C_OUT_STRIDE + j] = o0o[4 * q + c];
+    }
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      xT[(CC_1O + 3 * (3 * hf + o) + c) * C_OUT_STRIDE + j] = k1o[3 * o + c];
+      if constexpr (OUT >= 2) xT[(CC_1E + 3 * (3 * hf + o) + c) * C_OUT_STRIDE + j] = k1e[3 * o + c];
+    }
+  __syncthreads();
+  float* const fs = G.first_sum + (size_t)tile_local * CN_STRIDE;
+  float* const ls = G.last_sum + (size_t)tile_local * CN_STRIDE;
+  for (int col = lane; col < S.out_dim; col += 64) {
+    const float* oc = xT + col * C_OUT_STRIDE;
+    float sum = 0.f;
+    int cur = srcl[0], a0 = 0;
+    for (int jj = 0; jj < 32; ++jj) {
+      const int sj = srcl[jj];
+      if (sj != cur) {
+        float* d = a0 == 0 ? fs : G.run_acc + (size_t)cur * CN_STRIDE;
+        d[col] = sum;
+        sum = 0.f;
+        a0 = jj;
+        cur = sj;
+      }
+      sum += oc[jj];
+    }
+    if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;
+  }
+}
+
+// mean over all incoming edge types -> e3nn BatchNorm (eval) -> residual (reference tensor_layers.py:206-216)
+__global__ void fctp_finalize_kernel(CFinArgs fa, const float* __restrict__ node_in, float* __restrict__ node_out,
+                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_mean,
+                                     const float* __restrict__ bn_bias, int n_nodes, int in_dim, int out_dim, int node_off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = idx / CN_STRIDE, c = idx % CN_STRIDE;
+  if (i >= n_nodes) return;
+  const size_t o = (size_t)(i + node_off) * CN_STRIDE + c;
+  float r = 0.f;
+  if (c < out_dim) {
+    float sum = 0.f;
+    int deg = 0;
+    for (int g = 0; g < fa.n_groups; ++g) {
+      const CFinGroup& G = fa.g[g];
+      const int s = G.start[i], n = G.cnt[i];
+      deg += n;
+      if (n <= 0) continue;
+      const int e = s + n, t0 = s / WAVE_EDGES, t1 = (e - 1) / WAVE_EDGES;
+      const bool at_start = (s % WAVE_EDGES) == 0;
+      if (t0 == t1) {
+        if (at_start) sum += G.first_sum[(size_t)t0 * CN_STRIDE + c];
+        else if ((e % WAVE_EDGES) == 0) sum += G.last_sum[(size_t)t0 * CN_STRIDE + c];
+        else sum += G.run_acc[(size_t)(i + node_off) * CN_STRIDE + c];
+      } else {
+        sum += (at_start ? G.first_sum : G.last_sum)[(size_t)t0 * CN_STRIDE + c];
+        for (int t = t0 + 1; t <= t1; ++t) sum += G.first_sum[(size_t)t * CN_STRIDE + c];
+      }
+    }
+    float m = sum / (float)(deg > 1 ? deg : 1);
+    m = (m - bn_mean[c]) * bn_scale[c] + bn_bias[c];
+    r = m + (c < in_dim ? node_in[o] : 0.f);
+  }
+  node_out[o] = r;
+}
+
+template <int IN, int OUT>
+static hipError_t launch_fctp_one(const CArgs& a, int grid, hipStream_t s) {
+  constexpr int lds_bytes = fctp_lds_floats(fctp_shape(IN, OUT).ntiles) * 4;
+  hipLaunchKernelGGL((fctp_conv_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_fctp_conv(int in_level, int out_level, const CArgs& a, int grid, hipStream_t s) {
+  if (grid <= 0) return hipSuccess;
+  if (in_level == 0 && out_level == 1) return launch_fctp_one<0, 1>(a, grid, s);
+  if (in_level == 1 && out_level == 2) return launch_fctp_one<1, 2>(a, grid, s);
+  if (in_level == 2 && out_level == 3) return launch_fctp_one<2, 3>(a, grid, s);
+  if (in_level == 3 && out_level == 3) return launch_fctp_one<3, 3>(a, grid, s);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_fctp_finalize(const CFinArgs& fa, const float* node_in, float* node_out, const float* bn_scale,
+                                const float* bn_mean, const float* bn_bias, int n_nodes, int in_dim, int out_dim,
+                                int node_off, hipStream_t s) {
+  if (n_nodes <= 0) return hipSuccess;
+  const int total = n_nodes * CN_STRIDE;
+  hipLaunchKernelGGL(fctp_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, fa, node_in, node_out, bn_scale,
+                     bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off);
+  return hipGetLastError();
+}
+
+}  // namespace cbd

@@ -33,6 +33,12 @@ class cbd_step(C.Structure):
                 ("tor_noise_coef", C.c_float), ("sigma_emb", C.c_float * 32)]
 
 
+class cbd_conf_config(C.Structure):
+    _fields_ = [("ns", C.c_int32), ("nv", C.c_int32), ("num_conv_layers", C.c_int32), ("lm_embedding_dim", C.c_int32),
+                ("lig_max_radius", C.c_float), ("cross_cutoff", C.c_float), ("lig_radius_cap", C.c_int32),
+                ("max_batch", C.c_int32), ("device", C.c_int32)]
+
+
 # every symbol include/cbdock.h declares: name -> (restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = {
@@ -55,6 +61,19 @@ SYMBOLS = {
     "cbd_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cbd_conv_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_pack_conv_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_conf_create": (C.c_int, [C.POINTER(cbd_conf_config), C.POINTER(_P)]),
+    "cbd_conf_destroy": (C.c_int, [_P]),
+    "cbd_conf_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
+    "cbd_conf_finalize_weights": (C.c_int, [_P]),
+    "cbd_conf_set_complex": (C.c_int, [_P] + [C.c_int32] * 6 + [_P] * 10),
+    "cbd_conf_score": (C.c_int, [_P, C.c_int32, _P, C.c_float, _P, _P, _P]),
+    "cbd_conf_check": (C.c_int, [_P]),
+    "cbd_conf_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "cbd_conf_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
+    "cbd_conf_last_edge_counts": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "cbd_conf_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    "cbd_conf_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
+    "cbd_conf_pack_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
 }
 
 
@@ -366,6 +385,156 @@ def pack_conv_stream(in_level, out_level, w1, b1, w2, b2):
     arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (w1, b1, w2, b2)]
     _check(lib.cbd_pack_conv_stream(in_level, out_level, *[_hptr(a) for a in arrs], _hptr(out)))
     return out
+
+
+def pack_fctp_stream(in_level, out_level, w1, b1, w2, b2):
+    """Host-only: the MFMA weight-tile stream of one FCBlock of a confidence-model layer (CPU emulation tests)."""
+    lib = load_library()
+    n = lib.cbd_conf_stream_floats(in_level, out_level)
+    out = np.empty(n, dtype=np.float32)
+    arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (w1, b1, w2, b2)]
+    _check(lib.cbd_conf_pack_stream(in_level, out_level, *[_hptr(a) for a in arrs], _hptr(out)))
+    return out
+
+
+CONF_GROUPS = ("ll", "lr", "la", "rr", "rl", "ra", "aa", "al", "ar")
+
+
+class ConfidenceEngine:
+    """All-atom confidence model on one GPU (cbd_conf_* of include/cbdock.h).  One engine per (weights, device)."""
+
+    def __init__(self, device, max_batch: int = 64, lm_embedding_dim: int = 1280, lig_max_radius=5.0, cross_cutoff=20.0):
+        self.lib = load_library()
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("the confidence engine runs on an MI355X (device type 'cuda' under ROCm); got " + str(device))
+        self.device = device
+        self.cfg = cbd_conf_config(24, 6, 5, lm_embedding_dim, lig_max_radius, cross_cutoff, 32, max_batch, device.index or 0)
+        h = C.c_void_p()
+        _check(self.lib.cbd_conf_create(C.byref(self.cfg), C.byref(h)))
+        self.h = h
+        self.max_batch = max_batch
+        self.complex_key = None
+        self.Nl = self.Nr = self.Na = 0
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.cbd_conf_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def load_state_dict(self, sd):
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            a = np.ascontiguousarray(v.detach().cpu().float().numpy())
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape) if a.ndim else (C.c_int64 * 1)(1)
+            _check(self.lib.cbd_conf_load_weight(self.h, k.encode(), _hptr(a), shape, a.ndim))
+        _check(self.lib.cbd_conf_finalize_weights(self.h))
+        self.complex_key = None
+
+    @classmethod
+    def from_model(cls, model, device, max_batch: int = 64):
+        # dynamic_max_cross at t = 0: cutoff = 3 * 0 + 20 (models/all_atom_score_model.py:388)
+        eng = cls(device, max_batch=max_batch, lm_embedding_dim=1280 if model.lm_embedding_type == "precomputed" else 0,
+                  lig_max_radius=model.lig_max_radius, cross_cutoff=20.0)
+        eng.load_state_dict(model.state_dict())
+        return eng
+
+    def set_complex(self, graph, key=None):
+        """graph: one un-cropped complex carrying the all-atom stores (un-batched or a 1-graph Batch)."""
+        f32 = lambda t: np.ascontiguousarray(t.cpu().float().numpy())
+        i64 = lambda t: np.ascontiguousarray(t.cpu().numpy().astype(np.int64))
+        lig_x, battr = f32(graph["ligand"].x), f32(graph["ligand", "ligand"].edge_attr)
+        bidx = i64(graph["ligand", "ligand"].edge_index)
+        rec_x, rec_pos, ridx = f32(graph["receptor"].x), f32(graph["receptor"].pos), i64(graph["receptor", "receptor"].edge_index)
+        atom_x, atom_pos, aidx = f32(graph["atom"].x), f32(graph["atom"].pos), i64(graph["atom", "atom"].edge_index)
+        ar = i64(graph["atom", "receptor"].edge_index)
+        Nl, Nr, Na = lig_x.shape[0], rec_x.shape[0], atom_x.shape[0]
+        if not np.array_equal(ar[0], np.arange(Na)):
+            raise RuntimeError("('atom','atom_rec_contact','receptor').edge_index[0] must be arange(num_atoms)")
+        if rec_x.shape[1] != 1 + self.cfg.lm_embedding_dim:
+            raise RuntimeError(f"receptor features have {rec_x.shape[1]} columns, expected {1 + self.cfg.lm_embedding_dim}")
+        if lig_x.shape[1] != 16 or atom_x.shape[1] != 4:
+            raise RuntimeError("ligand / atom feature widths must be 16 / 4")
+        ares = np.ascontiguousarray(ar[1])
+        _check(self.lib.cbd_conf_set_complex(self.h, Nl, Nr, Na, bidx.shape[1], ridx.shape[1], aidx.shape[1], _hptr(lig_x), _hptr(bidx),
+                                             _hptr(battr), _hptr(rec_x), _hptr(rec_pos), _hptr(ridx), _hptr(atom_x), _hptr(atom_pos),
+                                             _hptr(aidx), _hptr(ares)))
+        self.Nl, self.Nr, self.Na = Nl, Nr, Na
+        self.complex_key = key
+
+    def score(self, pos: torch.Tensor, crop_beyond=None, check=True):
+        """pos [B,Nl,3] -> (confidence [B], atom_confidence [B*Nl, 1]) device tensors."""
+        B = pos.shape[0]
+        pos = pos.to(self.device, torch.float32).contiguous()
+        conf = torch.empty(B, device=self.device)
+        atom = torch.empty(B * self.Nl, device=self.device)
+        with torch.cuda.device(self.device):
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _check(self.lib.cbd_conf_score(self.h, B, _dptr(pos), float(crop_beyond or 0.0), _dptr(conf), _dptr(atom), stream))
+            if check:
+                _check(self.lib.cbd_conf_check(self.h))
+        return conf, atom.unsqueeze(1)
+
+    def set_option(self, name: str, value: int):
+        _check(self.lib.cbd_conf_set_option(self.h, name.encode(), int(value)))
+
+    def fetch(self, name: str, capacity: int = 1 << 24):
+        buf = np.empty(capacity, dtype=np.float32)
+        n = self.lib.cbd_conf_debug_fetch(self.h, name.encode(), _hptr(buf), capacity)
+        if n < 0:
+            raise RuntimeError(self.lib.cbd_last_error().decode())
+        return buf[:n].copy()
+
+    def edge_counts(self):
+        c = (C.c_int64 * 9)()
+        _check(self.lib.cbd_conf_last_edge_counts(self.h, c))
+        return dict(zip(CONF_GROUPS, list(c)))
+
+    def kernel_timing(self, enable=True, reset=False):
+        avg, n, tot = C.c_double(), C.c_int64(), C.c_double()
+        _check(self.lib.cbd_conf_kernel_timing(self.h, int(enable), int(reset), C.byref(avg), C.byref(n), C.byref(tot)))
+        return avg.value, n.value, tot.value
+
+
+def _single_all_atom_complex(data):
+    """Un-batched view of the (identical, un-cropped) all-atom complexes in a batch."""
+    g, B, Nl = _single_complex(data) if "mask_rotate" in data["ligand"] else (None, data.num_graphs, data["ligand"].num_nodes // data.num_graphs)
+    from .hetero import HeteroData
+    if g is None:
+        g = HeteroData()
+        lig, rec = data["ligand"], data["receptor"]
+        Nr = rec.num_nodes // B
+        M, Err = data["ligand", "ligand"].num_edges // B, data["receptor", "receptor"].num_edges // B
+        g["ligand"].x, g["ligand"].pos = lig.x[:Nl], lig.pos[:Nl]
+        g["ligand", "ligand"].edge_index = data["ligand", "ligand"].edge_index[:, :M]
+        g["ligand", "ligand"].edge_attr = data["ligand", "ligand"].edge_attr[:M]
+        g["receptor"].x, g["receptor"].pos = rec.x[:Nr], rec.pos[:Nr]
+        g["receptor", "receptor"].edge_index = data["receptor", "receptor"].edge_index[:, :Err]
+    atom = data["atom"]
+    Na = atom.num_nodes // B
+    g["atom"].x, g["atom"].pos = atom.x[:Na], atom.pos[:Na]
+    g["atom", "atom"].edge_index = data["atom", "atom"].edge_index[:, :data["atom", "atom"].num_edges // B]
+    g["atom", "receptor"].edge_index = data["atom", "receptor"].edge_index[:, :Na]
+    return g, B, Nl
+
+
+def confidence_batch(model, data, crop_beyond=None):
+    """All-atom TensorProductScoreModel.forward(batch) in confidence mode: (confidence [B], atom_confidence [B*Nl,1]).
+    `data` holds B poses of ONE un-cropped complex; the crop (model.crop_beyond or the argument) runs on the GPU."""
+    ct = getattr(data, "complex_t", None)
+    if ct is not None and float(torch.as_tensor(ct["tr"]).abs().max()) != 0.0:
+        raise NotImplementedError("the confidence engine evaluates at t = 0 (utils/sampling.py:253)")
+    eng = model.engine(max_batch=max(64, data.num_graphs))
+    g, B, Nl = _single_all_atom_complex(data)
+    key = complex_fingerprint(data) + (g["atom"].pos.shape[0],)
+    if eng.complex_key != key:
+        eng.set_complex(g, key)
+    crop = crop_beyond if crop_beyond is not None else getattr(model, "crop_beyond", None)
+    return eng.score(data["ligand"].pos.reshape(B, Nl, 3), crop)
 
 
 def _single_complex(data):

@@ -148,6 +148,57 @@ int64_t cbd_conv_stream_floats(int32_t in_level, int32_t out_level);
 int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host,
                          const float* w2_host, const float* b2_host, float* out_host);
 
+
+/* ============================ all-atom CONFIDENCE model ===========================================
+ * Replaces, for the shipped workdir/pretrained_confidence architecture, the confidence branch of
+ * utils/sampling.py:240-261: crop_beyond (utils/utils.py:395-420) + set_time(0) + the all-atom
+ * TensorProductScoreModel.forward in confidence mode (models/all_atom_score_model.py:363-454).
+ * One engine per GPU and model; weights are loaded by state-dict name like cbd_load_weight. */
+typedef struct cbd_conf_engine cbd_conf_engine;
+
+typedef struct cbd_conf_config {
+  int32_t ns, nv;                   /* 24, 6 (the only supported values)                       */
+  int32_t num_conv_layers;          /* 5                                                       */
+  int32_t lm_embedding_dim;         /* 1280 ('precomputed' ESM block) or 0                     */
+  float lig_max_radius;             /* 5   : ligand radius graph, lig->atom edges              */
+  float cross_cutoff;               /* 20  : lig->residue edges at t = 0 (dynamic_max_cross)   */
+  int32_t lig_radius_cap;           /* 32  : torch_cluster max_num_neighbors                   */
+  int32_t max_batch;                /* capacity: poses per cbd_conf_score call                 */
+  int32_t device;                   /* HIP device ordinal                                      */
+} cbd_conf_config;
+
+int cbd_conf_create(const cbd_conf_config* cfg, cbd_conf_engine** out);
+int cbd_conf_destroy(cbd_conf_engine* e);
+/* One call per state_dict tensor of the confidence model (fp32, host), then finalize. */
+int cbd_conf_load_weight(cbd_conf_engine* e, const char* name, const float* data_host, const int64_t* shape, int32_t ndim);
+int cbd_conf_finalize_weights(cbd_conf_engine* e);
+/* The un-cropped complex in the all-atom schema (datasets/process_mols.py:448-526), host pointers, copied.
+ * lig_x [Nl][16] / atom_x [Na][4] categorical features as floats; rec_x [Nr][1 + lm_embedding_dim];
+ * edge lists are [2][E] int64 rows (edge_index[0] = aggregating node); atom_res [Na] = residue of each atom. */
+int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na, int32_t n_bond_dir, int32_t Err, int32_t Eaa,
+                         const float* lig_x, const int64_t* bond_index, const float* bond_attr,
+                         const float* rec_x, const float* rec_pos, const int64_t* rec_edge_index,
+                         const float* atom_x, const float* atom_pos, const int64_t* atom_edge_index, const int64_t* atom_res);
+/* Confidence of B poses of the current complex.  pos_dev [B][Nl][3] device fp32.  crop_beyond <= 0 disables the crop.
+ * Outputs (device fp32): confidence_dev [B], atom_confidence_dev [B*Nl] (may be NULL).  Asynchronous on `stream`. */
+int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float crop_beyond, float* confidence_dev,
+                   float* atom_confidence_dev, void* stream);
+/* After the work of the last cbd_conf_score has completed: 0 if it was valid, CBD_ERR_CAPACITY if a per-atom edge
+ * capacity was exceeded (results must be discarded).  Synchronises the stream of that call. */
+int cbd_conf_check(cbd_conf_engine* e);
+/* Options: "debug" (0/1) keeps per-layer ligand features of the next calls for cbd_conf_debug_fetch (synchronises). */
+int cbd_conf_set_option(cbd_conf_engine* e, const char* name, int64_t value);
+/* Introspection for parity tests / benchmark: named intermediate of the last call (see cbd_debug_fetch);
+ * edge counts of the 9 groups (ll, lr, la, rr, rl, ra, aa, al, ar); HIP-event timing of the fused conv kernel. */
+int64_t cbd_conf_debug_fetch(cbd_conf_engine* e, const char* name, float* out_host, int64_t capacity);
+int cbd_conf_last_edge_counts(cbd_conf_engine* e, int64_t counts_host[9]);
+int cbd_conf_kernel_timing(cbd_conf_engine* e, int32_t enable, int32_t reset, double* avg_ms_out, int64_t* n_launches_out,
+                           double* total_ms_out);
+/* Weight-stream packer of one FCBlock of a confidence conv layer (exposed for the CPU pack-emulation test). */
+int64_t cbd_conf_stream_floats(int32_t in_level, int32_t out_level);
+int cbd_conf_pack_stream(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host,
+                         const float* w2_host, const float* b2_host, float* out_host);
+
 #ifdef __cplusplus
 }
 #endif
