@@ -76,6 +76,35 @@ def cpu_baseline(model, cplx, args, sched):
                       f"oracle PyTorch-CPU fp32, {t_steps + t_rec:.1f}s measured, extrapolated to 20 steps/pose"}
 
 
+def confidence_leg(cplx_seed, final_pos, dev):
+    """All-atom confidence scoring of the 40 final poses of the last complex, measured OUTSIDE the timed
+    region of the headline metric: ms per 40-pose batch and the fused conv kernel's algorithmic TFLOP/s (HIP events)."""
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.utils import make_confidence_model
+    from tools.conf_bench import flops_per_edge as cflops
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    ceng = cmodel.engine(max_batch=SAMPLES)
+    ceng.set_complex(make_workload(WORKLOAD, seed=cplx_seed, all_atoms=True))
+    for _ in range(2):
+        ceng.score(final_pos, cargs.crop_beyond)
+    counts = ceng.edge_counts()
+    torch.cuda.synchronize()
+    ceng.kernel_timing(enable=True, reset=True)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ceng.score(final_pos, cargs.crop_beyond, check=False)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    _, n, tot_ms = ceng.kernel_timing(enable=False)
+    e_all, e_last = sum(counts.values()), counts["ll"] + counts["lr"] + counts["la"]
+    fl = e_all * (cflops(0, 1) + cflops(1, 2) + cflops(2, 3) + cflops(3, 3)) + e_last * cflops(3, 3)
+    tf = fl * reps / (tot_ms * 1e-3) / 1e12
+    return {"what": "all-atom confidence model on the 40 final poses (crop 20 A, t=0), not part of `value`", "ms_per_40_poses": round(dt * 1e3, 3),
+            "edges_per_layer": e_all, "kernel": "fctp_conv_kernel", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +208,8 @@ def main():
                          "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
                          "pose_steps_per_s": round(poses * DENOISE_STEPS / elapsed, 1)},
         }
+        if world == 1:
+            out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev)
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
         print(json.dumps(out), flush=True)

@@ -11,8 +11,12 @@ Differences from the reference that are deliberate and documented (SURVEY.md 8a 
     rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
   * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
     rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
-  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond, asynchronous schedules raise
+  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model), asynchronous schedules raise
     NotImplementedError (the first three also raise in the reference).
+Confidence scoring (reference utils/sampling.py:240-261): with `confidence_model` set, the final poses of every batch
+are scored by the all-atom confidence engine (cbd_conf_score) -- crop_beyond per pose, t = 0 -- on the all-atom graphs
+of `filtering_data_list` (or of `data_list` itself when it carries the 'atom' stores); returns the concatenated
+confidences with NaN -> -1000 like the reference.
 """
 from __future__ import annotations
 
@@ -20,7 +24,7 @@ import numpy as np
 import torch
 from scipy.spatial.transform import Rotation as R
 
-from .engine import make_steps, complex_fingerprint, _single_complex
+from .engine import make_steps, complex_fingerprint, _single_complex, _single_all_atom_complex
 from .hetero import DataLoader
 
 
@@ -92,8 +96,12 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         raise NotImplementedError("asynchronous noise schedules are outside the MI355X hot path")
     if getattr(model_args, "crop_beyond", None) is not None:
         raise NotImplementedError("crop_beyond is only used by the all-atom / confidence model (SURVEY.md 8f-1)")
-    if confidence_model is not None:
-        raise NotImplementedError("confidence model scoring: SURVEY.md 8f-1 (next row)")
+    conf_model = getattr(confidence_model, "module", confidence_model)
+    if conf_model is not None and not hasattr(conf_model, "atom_confidence_predictor"):
+        raise NotImplementedError("confidence scoring runs on the all-atom confidence engine (all_atom_score_model)")
+    if filtering_data_list is not None and len(filtering_data_list) != N:
+        raise ValueError("filtering_data_list must have one graph per pose")
+    confidence = []
     tr_schedule, rot_schedule, tor_schedule = (np.asarray(s, dtype=np.float64) for s in (tr_schedule, rot_schedule, tor_schedule))
     if not (np.array_equal(tr_schedule, rot_schedule) and np.array_equal(tr_schedule, tor_schedule)):
         raise NotImplementedError("--different_schedules: the engine takes one diffusion time per step")
@@ -140,9 +148,26 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             flat = pos.reshape(b * Nl, 3)
             for i in range(b):
                 data_list[batch_id * batch_size + i]["ligand"].pos = flat[i * Nl:(i + 1) * Nl]
+            if conf_model is not None:
+                if filtering_data_list is not None:
+                    fbatch = DataLoader(filtering_data_list[offset:offset + b], batch_size=b).__iter__().__next__()
+                    crop = getattr(filtering_model_args, "crop_beyond", None)
+                else:
+                    fbatch, crop = batch, None
+                fg, _, fNl = _single_all_atom_complex(fbatch)
+                if fNl != Nl:
+                    raise RuntimeError("filtering graphs hold a different ligand than the sampled ones")
+                ceng = conf_model.engine(max_batch=max(int(batch_size), 1))
+                ckey = complex_fingerprint(fbatch) + (fg["atom"].pos.shape[0],)
+                if ceng.complex_key != ckey:
+                    ceng.set_complex(fg, ckey)
+                confidence.append(ceng.score(pos, crop)[0])
             offset += b
             if visualization_list is not None:
                 for idx, visualization in enumerate(visualization_list):
                     visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),
                                       part=1, order=2)
+    if conf_model is not None:
+        confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
+        return data_list, confidence
     return data_list, None
