@@ -454,8 +454,8 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
   e->complex_ready = false;
-  e->cpool.release();
-  e->bpool.release();
+  e->cpool.reset();
+  e->bpool.reset();
   const int B = e->cfg.max_batch;
   for (int k = 0; k < 2 * nbd; ++k)
     if (bond_index[k] < 0 || bond_index[k] >= Nl) return fail(CBD_ERR_ARG, "ligand bond index out of range");

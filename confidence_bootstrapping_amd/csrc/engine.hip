@@ -525,7 +525,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(hipDeviceSynchronize());
   if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
   e->graph_key.clear(); e->g_pos = nullptr; e->g_S_cap = 0;
-  e->cpool.release(); e->bpool.release();
+  e->cpool.reset(); e->bpool.reset();
   e->complex_ready = false;
   const int Bm = e->cfg.max_batch, lm = e->cfg.lm_embedding_dim;
   GraphStatic& gs = e->gs;

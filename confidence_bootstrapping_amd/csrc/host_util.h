@@ -32,17 +32,40 @@ struct HostTensor {
   std::vector<float> data;
 };
 
-// tracked device allocation helper
+// Device arena: bump allocation out of large hipMalloc'd chunks.  reset() rewinds without freeing, so the per-complex and
+// per-batch workspaces of successive complexes re-use the same memory (a hipMalloc/hipFree pair per buffer costs more than
+// the kernels of a small complex's set-up); release() returns everything to the runtime.
 struct DevPool {
-  std::vector<void*> ptrs;
+  struct Chunk { char* base; size_t size, used; };
+  std::vector<Chunk> chunks;
+  size_t cur = 0;
+  static constexpr size_t kChunk = size_t(64) << 20, kAlign = 256;
+
+  hipError_t raw(void** out, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 1) + kAlign - 1) / kAlign * kAlign;
+    for (; cur < chunks.size(); ++cur) {
+      Chunk& c = chunks[cur];
+      if (c.size - c.used >= bytes) {
+        *out = c.base + c.used;
+        c.used += bytes;
+        return hipSuccess;
+      }
+    }
+    void* q = nullptr;
+    const size_t sz = std::max(bytes, kChunk);
+    hipError_t e = hipMalloc(&q, sz);
+    if (e != hipSuccess) return e;
+    chunks.push_back(Chunk{static_cast<char*>(q), sz, bytes});
+    cur = chunks.size() - 1;
+    *out = q;
+    return hipSuccess;
+  }
   template <typename T>
   hipError_t alloc(T** p, size_t n) {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(T));
-    if (e != hipSuccess) return e;
-    ptrs.push_back(q);
-    *p = reinterpret_cast<T*>(q);
-    return hipSuccess;
+    hipError_t e = raw(&q, n * sizeof(T));
+    if (e == hipSuccess) *p = reinterpret_cast<T*>(q);
+    return e;
   }
   template <typename T>
   hipError_t upload(T** p, const std::vector<T>& h) {
@@ -51,9 +74,14 @@ struct DevPool {
     if (!h.empty()) e = hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
     return e;
   }
+  void reset() {
+    for (Chunk& c : chunks) c.used = 0;
+    cur = 0;
+  }
   void release() {
-    for (void* p : ptrs) (void)hipFree(p);
-    ptrs.clear();
+    for (Chunk& c : chunks) (void)hipFree(c.base);
+    chunks.clear();
+    cur = 0;
   }
 };
 
