@@ -32,6 +32,7 @@ namespace {
 struct ConvLayerDev {
   int in_level = 0, out_level = 0, n_groups = 0;
   float* wstream[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* wstream_bf16[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16-operand variant (tp_conv_bf16.hip)
   float *bn_scale = nullptr, *bn_mean = nullptr, *bn_bias = nullptr;   // [NODE_STRIDE]
 };
 
@@ -67,6 +68,7 @@ struct cbd_engine {
   int* rr_count_dev = nullptr;
   float *d_rec_x = nullptr, *d_vec0 = nullptr, *d_dist0 = nullptr;
   int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
+  bool use_bf16 = false;            // cbd_set_option("bf16", 1): FCBlock GEMMs on bf16 MFMA (fp32 accumulate)
   // hipGraph of the step loop (optional)
   bool use_graph = false;
   hipGraphExec_t graph_exec = nullptr;
@@ -125,51 +127,30 @@ static int need(cbd_engine* e, const std::string& k, std::initializer_list<int64
 
 // Re-pack one FCBlock (Linear 96->96, ReLU, Linear 96->W) into the tile stream consumed by tp_conv_kernel.
 // See the layout notes at the top of tp_conv.hip.  W2's k order follows the C/D register layout of the first GEMM.
-static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+// Row description of every 32-row weight tile of a layer: which row of W1 / W2 (or none) each MFMA row carries and the
+// folded coefficient (1/sqrt(fan_in), sqrt(3) of sh_1, 1/sqrt(2) of the cross paths).  Shared by the fp32 and bf16 packers.
+struct TileRow { int row; float scale; };          // row < 0: zero row
+struct TileRows { std::vector<TileRow> rows; int ntiles; };   // rows[T*32 + r]; tiles 0..2 index W1/b1, the rest W2/b2
+
+static TileRows conv_tile_rows(int IN, int OUT) {
   const ConvShape S = conv_shape(IN, OUT);
-  std::vector<float> out(conv_stream_floats(S.ntiles), 0.f);
-  float* const bias_tab = out.data() + (size_t)(S.ntiles + 1) * TILE_W_FLOATS;
-  auto widx = [](int s, int lane) { return ((s >> 2) * 64 + lane) * 4 + (s & 3); };
+  TileRows tr;
+  tr.ntiles = S.ntiles;
+  tr.rows.assign((size_t)S.ntiles * 32, TileRow{-1, 0.f});
   int T = 0;
-  for (int m = 0; m < 3; ++m, ++T) {
-    float* tile = out.data() + (size_t)T * TILE_W_FLOATS;
-    for (int s = 0; s < KSTEPS; ++s)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int i = lane & 31, h = lane >> 5;
-        const int f = 32 * (s / 16) + 16 * h + (s % 16);
-        tile[widx(s, lane)] = W1[(size_t)(32 * m + i) * KDIM + f];
-      }
-    for (int r = 0; r < 32; ++r) bias_tab[(size_t)T * 32 + r] = b1[32 * m + r];
-  }
-  auto kperm = [](int s, int h) { return 32 * (s / 16) + ((s % 16) & 3) + 8 * ((s % 16) >> 2) + 4 * h; };
-  auto fill_tile = [&](int Tt, const int* wc, const float* scale) {   // wc[r] < 0 => zero row
-    float* tile = out.data() + (size_t)Tt * TILE_W_FLOATS;
-    for (int s = 0; s < KSTEPS; ++s)
-      for (int lane = 0; lane < 64; ++lane) {
-        const int r = lane & 31, h = lane >> 5;
-        tile[widx(s, lane)] = wc[r] < 0 ? 0.f : scale[r] * W2[(size_t)wc[r] * KDIM + kperm(s, h)];
-      }
-    for (int r = 0; r < 32; ++r) bias_tab[(size_t)Tt * 32 + r] = wc[r] < 0 ? 0.f : scale[r] * b2[wc[r]];
-  };
+  for (int m = 0; m < 3; ++m, ++T)
+    for (int r = 0; r < 32; ++r) tr.rows[(size_t)T * 32 + r] = TileRow{32 * m + r, 1.0f};
   const float s3 = std::sqrt(3.0f), s15 = std::sqrt(1.5f);
-  int wc[32];
-  float sc[32];
-  // block 0e
-  for (int i = 0; i < S.fan0e; ++i, ++T) {
-    for (int r = 0; r < 32; ++r) { wc[r] = i * NS + r; sc[r] = 1.0f / std::sqrt((float)S.fan0e); }
-    fill_tile(T, wc, sc);
-  }
+  for (int i = 0; i < S.fan0e; ++i, ++T)
+    for (int r = 0; r < 32; ++r) tr.rows[(size_t)T * 32 + r] = TileRow{i * NS + r, 1.0f / std::sqrt((float)S.fan0e)};
   auto vec_tiles = [&](int off, int fan, int ntile, auto mid_factor) {
-    for (int t = 0; t < ntile; ++t, ++T) {
+    for (int t = 0; t < ntile; ++t, ++T)
       for (int r = 0; r < 32; ++r) {
         // row r = (reg&3) + 8*(reg>>2) + 4*hf  <->  reg = (r&3) + 4*(r>>3), hf = (r>>2)&1
         const int reg = (r & 3) + 4 * (r >> 3), hf = (r >> 2) & 1;
         const int i = VEC_TILE_I * t + reg / 3, o = 3 * hf + reg % 3;
-        if (reg < 15 && i < fan) { wc[r] = off + i * NV + o; sc[r] = mid_factor(i) / std::sqrt((float)fan); }
-        else { wc[r] = -1; sc[r] = 0.f; }
+        if (reg < 15 && i < fan) tr.rows[(size_t)T * 32 + r] = TileRow{off + i * NV + o, mid_factor(i) / std::sqrt((float)fan)};
       }
-      fill_tile(T, wc, sc);
-    }
   };
   int off = S.fan0e * NS;
   vec_tiles(off, S.fan1o, S.t1o, [&](int i) { return i < NS ? s3 : (i < NS + S.n1o ? 1.0f : s15); });
@@ -179,6 +160,70 @@ static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, con
     off += S.fan1e * NV;
   }
   if (OUT >= 3) vec_tiles(off, S.fan0o, S.t0o, [&](int) { return 1.0f; });
+  return tr;
+}
+
+static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+  const TileRows tr = conv_tile_rows(IN, OUT);
+  std::vector<float> out(conv_stream_floats(tr.ntiles), 0.f);
+  float* const bias_tab = out.data() + (size_t)(tr.ntiles + 1) * TILE_W_FLOATS;
+  auto widx = [](int s, int lane) { return ((s >> 2) * 64 + lane) * 4 + (s & 3); };
+  auto kperm = [](int s, int h) { return 32 * (s / 16) + ((s % 16) & 3) + 8 * ((s % 16) >> 2) + 4 * h; };
+  for (int T = 0; T < tr.ntiles; ++T) {
+    float* tile = out.data() + (size_t)T * TILE_W_FLOATS;
+    const bool first = T < 3;
+    for (int s = 0; s < KSTEPS; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        const TileRow& R = tr.rows[(size_t)T * 32 + r];
+        if (R.row < 0) { tile[widx(s, lane)] = 0.f; continue; }
+        // first Linear: lane half h holds input columns 16h..16h+15 of each 32-wide part; second Linear: C/D register order
+        const int k = first ? 32 * (s / 16) + 16 * h + (s % 16) : kperm(s, h);
+        tile[widx(s, lane)] = R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
+      }
+    for (int r = 0; r < 32; ++r) {
+      const TileRow& R = tr.rows[(size_t)T * 32 + r];
+      bias_tab[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
+    }
+  }
+  return out;
+}
+
+// bf16 stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] (6 KB), then the fp32 bias table.
+static uint16_t f32_to_bf16_rne(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+  const TileRows tr = conv_tile_rows(IN, OUT);
+  constexpr int TILE_BF16 = 32 * KDIM;   // 3072 bf16 = 6 KB
+  std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + (size_t)tr.ntiles * 32 * 4) / 4, 0.f);
+  uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
+  float* const bias_tab = reinterpret_cast<float*>(w + (size_t)(tr.ntiles + 1) * TILE_BF16);
+  for (int T = 0; T < tr.ntiles; ++T) {
+    uint16_t* tile = w + (size_t)T * TILE_BF16;
+    const bool first = T < 3;
+    for (int q = 0; q < KDIM / 16; ++q)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        const TileRow& R = tr.rows[(size_t)T * 32 + r];
+        for (int j = 0; j < 8; ++j) {
+          // first Linear: k-step q = 2*part + sub covers input columns 16h + 8sub + j of the 32-wide part;
+          // second Linear: registers 8s..8s+7 of hidden tile m = q/2, s = q%2: unit 32m + 16s + 8(j>>2) + 4h + (j&3)
+          const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+          const float v = R.row < 0 ? 0.f : R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
+          tile[((size_t)q * 64 + lane) * 8 + j] = f32_to_bf16_rne(v);
+        }
+      }
+    for (int r = 0; r < 32; ++r) {
+      const TileRow& R = tr.rows[(size_t)T * 32 + r];
+      bias_tab[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
+    }
+  }
   return out;
 }
 
@@ -197,6 +242,7 @@ static int build_conv_layer(cbd_engine* e, const std::string& prefix, int IN, in
     CHK(need(e, fc + ".3.bias", {S.weight_numel}, &b1));
     std::vector<float> st = pack_conv_stream(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data());
     HIPCHK(e->wpool.upload(&L->wstream[g], st));
+    HIPCHK(e->wpool.upload(&L->wstream_bf16[g], pack_conv_stream_bf16(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
   }
   // e3nn BatchNorm (eval) per output column
   const int nf = NS + NV + (OUT >= 2 ? NV : 0) + (OUT >= 3 ? NV : 0);
@@ -448,7 +494,7 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
   int grid = 0;
   for (int g = 0; g < n_groups; ++g) {
     a.g[g] = groups[g];
-    a.g[g].wstream = L.wstream[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
+    a.g[g].wstream = (e->use_bf16 ? L.wstream_bf16 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
     grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
   }
   a.node_in = node_in;
@@ -464,7 +510,8 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     ++e->ev_used;
     HIPCHK(hipEventRecord(e0, s));
   }
-  HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
+  if (e->use_bf16) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) HIPCHK(hipEventRecord(e1, s));
   return 0;
 }
@@ -935,6 +982,11 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
   if (k == "graph") {
     e->use_graph = value != 0;
     if (!e->use_graph && e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    return 0;
+  }
+  if (k == "bf16") {   // captured graphs bake the kernel choice in: drop them
+    e->use_bf16 = value != 0;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
     return 0;
   }
   return fail(CBD_ERR_ARG, "unknown option '%s'", name);

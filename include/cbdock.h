@@ -113,7 +113,9 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, 
                float* scores_out_dev, void* stream);
 
 /* Engine options.  "graph" (0/1): capture the S-step loop of cbd_sample into a hipGraph that is instantiated once per
- * (batch size, schedule) and replayed with one launch per batch (inputs are staged into engine-owned buffers). */
+ * (batch size, schedule) and replayed with one launch per batch (inputs are staged into engine-owned buffers).
+ * "bf16" (0/1): run the two Linears of every tensor-product layer's radial MLP on bf16 matrix cores (bf16 operands, fp32
+ * accumulate; everything else stays fp32) -- BASELINE.json configs[3]; results differ from the fp32 path at the 1e-2 level. */
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value);
 
 /* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
