@@ -55,6 +55,7 @@ struct cbd_engine {
   StepWeights sw{};
   CenterHead ch{};
   BondHead bh{};
+  float* bond_stream = nullptr;     // tor_bond_conv FCBlock as an MFMA tile stream (bond_conv_kernel)
   float *rec_emb_table = nullptr, *rec_node_w = nullptr, *rec_node_b = nullptr;
   std::vector<float> lig_node_w_host;   // additional_features_embedder [32][64]
   std::vector<std::vector<float>> lig_emb_tables;
@@ -95,7 +96,7 @@ struct cbd_engine {
   float* sigma_emb_dev = nullptr;   // [S_max][32]
   int sigma_cap = 0;
   float *tr_out = nullptr, *rot_out = nullptr, *tor_out = nullptr, *dbg_global = nullptr, *dbg_torfeat = nullptr;
-  float *center_msg = nullptr, *tor_msg = nullptr;
+  float* center_msg = nullptr;
   int *tor_nb = nullptr, *tor_nb_cnt = nullptr;
   int n_nodes_cap = 0;
   int last_B = 0;
@@ -163,8 +164,25 @@ static TileRows conv_tile_rows(int IN, int OUT) {
   return tr;
 }
 
+static std::vector<float> pack_rows_f32(const TileRows& tr, const float* W1, const float* b1, const float* W2, const float* b2);
 static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
-  const TileRows tr = conv_tile_rows(IN, OUT);
+  return pack_rows_f32(conv_tile_rows(IN, OUT), W1, b1, W2, b2);
+}
+
+// tor_bond_conv (e3nn FCTP with two live paths): 3 tiles of W1, then one tile per mid index u of path A (1o x T1 -> 32x0e,
+// weight block [6][32] at offset 0) and of path B (1e x T1 -> 32x0o, offset 192); constants live in the kernel's mids.
+static TileRows bond_tile_rows() {
+  TileRows tr;
+  tr.ntiles = BOND_CONV_TILES;
+  tr.rows.assign((size_t)tr.ntiles * 32, TileRow{-1, 0.f});
+  for (int m = 0; m < 3; ++m)
+    for (int r = 0; r < 32; ++r) tr.rows[(size_t)m * 32 + r] = TileRow{32 * m + r, 1.0f};
+  for (int q = 0; q < 12; ++q)
+    for (int r = 0; r < 32; ++r) tr.rows[(size_t)(3 + q) * 32 + r] = TileRow{(q < 6 ? q * 32 : 192 + (q - 6) * 32) + r, 1.0f};
+  return tr;
+}
+
+static std::vector<float> pack_rows_f32(const TileRows& tr, const float* W1, const float* b1, const float* W2, const float* b2) {
   std::vector<float> out(conv_stream_floats(tr.ntiles), 0.f);
   float* const bias_tab = out.data() + (size_t)(tr.ntiles + 1) * TILE_W_FLOATS;
   auto widx = [](int s, int lane) { return ((s >> 2) * 64 + lane) * 4 + (s & 3); };
@@ -457,6 +475,12 @@ int cbd_finalize_weights(cbd_engine* e) {
     CHK(upload_named(e, "tor_bond_conv.fc.0.bias", {96}, &bh.fc_b0));
     CHK(upload_named(e, "tor_bond_conv.fc.3.weight", {384, 96}, &bh.fc_w1));
     CHK(upload_named(e, "tor_bond_conv.fc.3.bias", {384}, &bh.fc_b1));
+    {
+      const HostTensor *w0, *b0, *w1, *b1;
+      CHK(need(e, "tor_bond_conv.fc.0.weight", {96, 96}, &w0)); CHK(need(e, "tor_bond_conv.fc.0.bias", {96}, &b0));
+      CHK(need(e, "tor_bond_conv.fc.3.weight", {384, 96}, &w1)); CHK(need(e, "tor_bond_conv.fc.3.bias", {384}, &b1));
+      HIPCHK(e->wpool.upload(&e->bond_stream, pack_rows_f32(bond_tile_rows(), w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
+    }
     const HostTensor *bw, *bb, *bm, *bv;
     CHK(need(e, "tor_bond_conv.batch_norm.weight", {64}, &bw));
     CHK(need(e, "tor_bond_conv.batch_norm.bias", {32}, &bb));
@@ -530,6 +554,17 @@ static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_
   for (int g = 0; g < n_groups; ++g) fa.g[g] = groups[g];
   HIPCHK(launch_conv_finalize(fa, node_in, node_out, L.bn_scale, L.bn_mean, L.bn_bias, n_nodes, in_level_dim(L.in_level),
                               out_level_dim(L.out_level), node_off, s));
+  return 0;
+}
+
+static int run_finalize2(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const FinGroup* g0, int ng0,
+                         int n0, int off0, const FinGroup* g1, int ng1, int n1, int off1, hipStream_t s) {
+  FinArgs f0{}, f1{};
+  f0.n_groups = ng0; f1.n_groups = ng1;
+  for (int g = 0; g < ng0; ++g) f0.g[g] = g0[g];
+  for (int g = 0; g < ng1; ++g) f1.g[g] = g1[g];
+  HIPCHK(launch_conv_finalize2(f0, n0, off0, f1, n1, off1, node_in, node_out, L.bn_scale, L.bn_mean, L.bn_bias,
+                               in_level_dim(L.in_level), out_level_dim(L.out_level), s));
   return 0;
 }
 
@@ -665,7 +700,6 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&gd.start_ll, (size_t)Bm * Nl)); HIPCHK(e->bpool.alloc(&gd.start_lr, (size_t)Bm * Nl));
   HIPCHK(e->bpool.alloc(&gd.start_rl, (size_t)Bm * Nr));
   HIPCHK(e->bpool.alloc(&gd.counts, 8));
-  HIPCHK(e->bpool.alloc(&gd.deg_embed, (size_t)N)); HIPCHK(e->bpool.alloc(&gd.deg_full, (size_t)N));
   HIPCHK(e->bpool.alloc(&gd.ll_src, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_dst, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_aidx, cap_ll));
   HIPCHK(e->bpool.alloc(&gd.ll_vec, cap_ll * 4)); HIPCHK(e->bpool.alloc(&gd.ll_dist, cap_ll)); HIPCHK(e->bpool.alloc(&gd.ll_bond4, cap_ll * 4));
   HIPCHK(e->bpool.alloc(&gd.lr_src, cap_x)); HIPCHK(e->bpool.alloc(&gd.lr_dst, cap_x)); HIPCHK(e->bpool.alloc(&gd.lr_aidx, cap_x));
@@ -684,7 +718,6 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&e->tr_out, (size_t)Bm * 3)); HIPCHK(e->bpool.alloc(&e->rot_out, (size_t)Bm * 3));
   HIPCHK(e->bpool.alloc(&e->tor_out, (size_t)Bm * std::max(R, 1)));
   HIPCHK(e->bpool.alloc(&e->center_msg, (size_t)Bm * Nl * 12));
-  HIPCHK(e->bpool.alloc(&e->tor_msg, (size_t)Bm * std::max(R, 1) * 32 * 64));
   HIPCHK(e->bpool.alloc(&e->tor_nb, (size_t)Bm * std::max(R, 1) * 32)); HIPCHK(e->bpool.alloc(&e->tor_nb_cnt, (size_t)Bm * std::max(R, 1)));
   HIPCHK(e->bpool.alloc(&e->dbg_global, (size_t)Bm * 12)); HIPCHK(e->bpool.alloc(&e->dbg_torfeat, (size_t)Bm * std::max(R, 1) * 64));
   // batched receptor edges (independent of B: receptor rows start at rec_off)
@@ -816,14 +849,12 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
       const ConvGroup g3[3] = {gll, glr, grl};
       const int caps[3] = {cap_ll, cap_x, cap_x}, widx[3] = {0, 1, 3};
       CHK(run_conv(e, e->conv[l], g3, 3, caps, in, s, widx));
-      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));
-      CHK(run_finalize(e, e->conv[l], in, out, rec2_shared, 2, nR, gs.rec_off, s));
+      CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2_shared, 2, nR, gs.rec_off, s));
     } else if (l < 4) {
       const ConvGroup g4[4] = {gll, glr, grr, grl};
       const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
       CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
-      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));
-      CHK(run_finalize(e, e->conv[l], in, out, rec2, 2, nR, gs.rec_off, s));
+      CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2, 2, nR, gs.rec_off, s));
     } else {
       const ConvGroup g2[2] = {gll, glr};
       const int caps[2] = {cap_ll, cap_x};
@@ -836,9 +867,11 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   }
   const float* lig_node = in;
   HIPCHK(launch_center_head(e->ch, e->sv, pos_dev, lig_node, B, Nl, st.tr_sigma, st.rot_score_norm, tr_dev, rot_dev, e->dbg_global, e->center_msg, s));
-  if (!e->cfg.no_torsion && R > 0)
-    HIPCHK(launch_bond_head(e->bh, gs, pos_dev, lig_node, B, e->cfg.lig_max_radius, 32, st.tor_score_norm_sqrt, tor_dev,
-                            gd.counts + 4, e->dbg_torfeat, e->tor_nb, e->tor_nb_cnt, e->tor_msg, s));
+  if (!e->cfg.no_torsion && R > 0) {
+    HIPCHK(launch_bond_nb(gs, pos_dev, B, e->cfg.lig_max_radius, 32, e->tor_nb, e->tor_nb_cnt, gd.counts + 4, s));
+    HIPCHK(launch_bond_conv(e->bh, gs, pos_dev, lig_node, B, e->tor_nb, e->tor_nb_cnt, e->bond_stream, st.tor_score_norm_sqrt, tor_dev,
+                            e->dbg_torfeat, s));
+  }
   e->dbg.clear();
   e->dbg["center_mean"] = {e->dbg_global, (size_t)B * 12};
   e->dbg["tor_feat"] = {e->dbg_torfeat, (size_t)B * R * 64};
@@ -1002,7 +1035,7 @@ int cbd_share_weights(cbd_engine* dst, cbd_engine* src) {
   for (int l = 0; l < 5; ++l) dst->conv[l] = src->conv[l];
   dst->m_lig_edge = src->m_lig_edge; dst->m_cross = src->m_cross; dst->m_rec_edge = src->m_rec_edge;
   dst->m_final_edge = src->m_final_edge; dst->m_center = src->m_center;
-  dst->sw = src->sw; dst->ch = src->ch; dst->bh = src->bh;
+  dst->sw = src->sw; dst->ch = src->ch; dst->bh = src->bh; dst->bond_stream = src->bond_stream;
   dst->rec_emb_table = src->rec_emb_table; dst->rec_node_w = src->rec_node_w; dst->rec_node_b = src->rec_node_b;
   dst->lig_node_w_host = src->lig_node_w_host; dst->lig_emb_tables = src->lig_emb_tables;
   dst->weights_ready = true;

@@ -33,7 +33,6 @@ struct GraphDyn {        // per forward pass, device pointers (capacity sized)
   int* cnt_ll; int* cnt_lr; int* cnt_rl;        // per node counts   [B*Nl], [B*Nl], [B*Nr]
   int* start_ll; int* start_lr; int* start_rl;  // exclusive scans
   int* counts;                   // [8]: ll, lr, rr, rl, tor, ...
-  int* deg_embed; int* deg_full; // [N]
   int *ll_src, *ll_dst, *ll_aidx; float* ll_vec; float* ll_dist; float* ll_bond4;
   int *lr_src, *lr_dst, *lr_aidx; float* lr_vec; float* lr_dist;
   int *rl_src, *rl_dst, *rl_aidx; float* rl_vec;
@@ -79,10 +78,6 @@ struct BondHead {
   const float *bn_scale, *bn_mean, *bn_bias;                         // [64] per output column
   const float *tf_w0, *tf_w1;                                        // tor_final_layer [32][64], [32]
 };
-hipError_t launch_bond_head(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, float lig_r,
-                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, int* nb_ws,
-                            int* nb_cnt_ws, float* msg_ws, hipStream_t s);   // nb_ws [B*R][32], nb_cnt_ws [B*R], msg_ws [B*R*32][64]
-
 struct SdeCoefs { float tr_s, tr_n, rot_s, rot_n, tor_s, tor_n; };
 // perturbation (if scores != null) + modify_conformer_batch.  If coefs == null the tr/rot/tor inputs are the updates.
 hipError_t launch_pose_update(const GraphStatic& gs, float* pos, int B, const float* tr, const float* rot, const float* tor,
@@ -94,7 +89,15 @@ hipError_t launch_edge_geom(const float* pos, const int* src, const int* dst, in
 hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t s);
 
 // tp_conv.hip
+// torsion head on the matrix cores (replaces the msg/final stages of launch_bond_head); nb/nb_cnt from launch_bond_nb
+hipError_t launch_bond_nb(const GraphStatic& gs, const float* pos, int B, float lig_r, int cap, int* nb_ws, int* nb_cnt_ws, int* tor_edge_count, hipStream_t s);
+hipError_t launch_bond_conv(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, const int* nb,
+                            const int* nb_cnt, const float* wstream, float tor_norm_sqrt, float* tor_out, float* dbg_feat, hipStream_t s);
+constexpr int BOND_CONV_TILES = 15;
 hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);
+hipError_t launch_conv_finalize2(const FinArgs& fa0, int n0, int off0, const FinArgs& fa1, int n1, int off1, const float* node_in,
+                                 float* node_out, const float* bn_scale, const float* bn_mean, const float* bn_bias, int in_dim,
+                                 int out_dim, hipStream_t s);
 hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);   // bf16 weight streams
 hipError_t launch_conv_finalize(const FinArgs& fa, const float* node_in, float* node_out, const float* bn_scale,
                                 const float* bn_mean, const float* bn_bias, int n_nodes, int in_dim, int out_dim,

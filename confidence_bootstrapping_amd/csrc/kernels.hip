@@ -152,56 +152,52 @@ hipError_t launch_graph_fill(const GraphStatic& gs, const GraphDyn& gd, int B, f
   return hipGetLastError();
 }
 
-// Exclusive scans of the three per-node count arrays (single workgroup; <= ~1e5 entries) + in-degree tables.
+// Exclusive scans of the three per-node count arrays, one 1024-thread workgroup per array (wave-shuffle scan over
+// coalesced 1024-entry chunks), edge totals -> counts[], algorithmic work accounting -> stats[] (bench.py).
 __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphDyn gd, int B, unsigned long long* stats) {
-  __shared__ int part[1024];
-  __shared__ int carry;
-  const int tid = threadIdx.x;
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int which = blockIdx.x;
   const int nL = B * gs.Nl, nR = B * gs.Nr;
-  for (int which = 0; which < 3; ++which) {
-    const int* cnt = which == 0 ? gd.cnt_ll : which == 1 ? gd.cnt_lr : gd.cnt_rl;
-    int* start = which == 0 ? gd.start_ll : which == 1 ? gd.start_lr : gd.start_rl;
-    const int n = which == 2 ? nR : nL;
-    const int per = (n + 1023) / 1024;
-    const int i0 = tid * per, i1 = min(n, i0 + per);
-    int s = 0;
-    for (int i = i0; i < i1; ++i) s += cnt[i];
-    part[tid] = s;
-    __syncthreads();
-    // Hillis-Steele inclusive scan over 1024 partial sums
-    for (int off = 1; off < 1024; off <<= 1) {
-      int v = tid >= off ? part[tid - off] : 0;
-      __syncthreads();
-      part[tid] += v;
-      __syncthreads();
+  const int* cnt = which == 0 ? gd.cnt_ll : which == 1 ? gd.cnt_lr : gd.cnt_rl;
+  int* start = which == 0 ? gd.start_ll : which == 1 ? gd.start_lr : gd.start_rl;
+  const int n = which == 2 ? nR : nL;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + tid;
+    const int v = i < n ? cnt[i] : 0;
+    int x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
     }
-    int run = tid == 0 ? 0 : part[tid - 1];
-    for (int i = i0; i < i1; ++i) { start[i] = run; run += cnt[i]; }
-    if (tid == 1023) gd.counts[which == 0 ? 0 : which == 1 ? 1 : 3] = part[1023];
+    if (lane == 63) wsum[wid] = x;
+    __syncthreads();
+    int woff = 0;
+    for (int w = 0; w < wid; ++w) woff += wsum[w];
+    const int carry = carry_s;
+    if (i < n) start[i] = carry + woff + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
     __syncthreads();
   }
   if (tid == 0) {
-    gd.counts[2] = B * gs.Err;
-    if (stats) {   // edge-layer visits of this forward pass (algorithmic work accounting for bench.py)
-      const unsigned long long ll = gd.counts[0], lr = gd.counts[1], rr = B * gs.Err, rl = gd.counts[3];
-      stats[0] += ll;                                  // each of the 3 ligand embedding layers visits ll edges
-      stats[1] += 4ull * (ll + lr + rr + rl) + (ll + lr);   // 4 full interaction layers + the ligand-only last one
-      stats[2] += 1ull;
+    const unsigned long long total = (unsigned long long)carry_s;
+    gd.counts[which == 0 ? 0 : which == 1 ? 1 : 3] = (int)total;
+    if (which == 2) gd.counts[2] = B * gs.Err;
+    if (stats) {   // edge-layer visits: 3 ligand embedding layers visit ll; 4 joint layers visit all groups, the last one ll + lr
+      if (which == 0) { atomicAdd(&stats[0], total); atomicAdd(&stats[1], 5ull * total); atomicAdd(&stats[2], 1ull); }
+      if (which == 1) atomicAdd(&stats[1], 5ull * total);
+      if (which == 2) atomicAdd(&stats[1], 4ull * total + 4ull * (unsigned long long)(B * gs.Err));
     }
   }
-  for (int n = tid; n < nL; n += 1024) {
-    gd.deg_embed[n] = gd.cnt_ll[n];
-    gd.deg_full[n] = gd.cnt_ll[n] + gd.cnt_lr[n];
-  }
-  for (int n = tid; n < nR; n += 1024) {
-    gd.deg_embed[gs.rec_off + n] = 0;
-    gd.deg_full[gs.rec_off + n] = gs.rr_deg0[n % gs.Nr] + gd.cnt_rl[n];
-  }
-  (void)carry;
 }
 
 hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, unsigned long long* stats, hipStream_t s) {
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(1), dim3(1024), 0, s, gs, gd, B, stats);
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(3), dim3(1024), 0, s, gs, gd, B, stats);
   return hipGetLastError();
 }
 
@@ -464,8 +460,8 @@ hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const f
 // tor_bond_conv.tp has two live paths (6x1o x T1 -> 32x0e, 6x1e x T1 -> 32x0o) where T1 is the 1o block of
 // FullTensorProduct(sh(edge), Y2(bond)) = (3/sqrt2)(b b^T - I/3)(sqrt3 v)  (tests/test_kernel_math.py::tor_t1).
 // Stage 1: one wave per (sample, bond): radius(lig_pos, bond_pos, 5) -> first `cap` atoms in index order.
-// Stage 2: one workgroup per (sample, bond, neighbour slot): edge MLPs + tensor product -> 64-value message.
-// Stage 3: one wave per (sample, bond): mean over slots in order, BatchNorm, tor_final_layer.
+// Stage 2 (tp_conv.hip::bond_conv_kernel): one wave per (sample, bond) on the matrix cores: edge MLPs + tensor product for
+// its <= 32 neighbour slots, mean over slots, BatchNorm, tor_final_layer.
 constexpr int TOR_SLOTS = 32;
 
 __global__ __launch_bounds__(64) void bond_nb_kernel(GraphStatic gs, const float* __restrict__ pos, float lig_r2, int cap,
@@ -492,96 +488,10 @@ __global__ __launch_bounds__(64) void bond_nb_kernel(GraphStatic gs, const float
   }
 }
 
-__global__ __launch_bounds__(128) void bond_msg_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
-                                                       const float* __restrict__ node, const int* __restrict__ nb,
-                                                       const int* __restrict__ nb_cnt, float* __restrict__ msg) {
-  __shared__ float s_in[96], s_hid[96], s_w[384], s_da[6], s_db[6];
-  const int tid = threadIdx.x;
-  const int bond = blockIdx.x / TOR_SLOTS, slot = blockIdx.x % TOR_SLOTS;
-  if (slot >= nb_cnt[bond]) return;
-  const int b = bond / gs.R, rho = bond % gs.R, Nl = gs.Nl;
-  const float* P = pos + (size_t)b * Nl * 3;
-  const int u = gs.rot_u[rho], v = gs.rot_v[rho];   // bonds = edge_index[:, edge_mask]; [0] = u, [1] = v
-  const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
-  float bux, buy, buz, bn;
-  unit_vec(P[3 * v] - P[3 * u], P[3 * v + 1] - P[3 * u + 1], P[3 * v + 2] - P[3 * u + 2], bux, buy, buz, bn);
-  const float* xu = node + (size_t)(b * Nl + u) * NODE_STRIDE;
-  const float* xv = node + (size_t)(b * Nl + v) * NODE_STRIDE;
-  const float is3 = 0.57735026918962576f, pw = 0.40824829046386302f /* sqrt(1/6) */;
-  const int a = nb[(size_t)bond * TOR_SLOTS + slot];
-  const float* x = node + (size_t)(b * Nl + a) * NODE_STRIDE;
-  float ux, uy, uz, d;
-  unit_vec(P[3 * a] - bx, P[3 * a + 1] - by, P[3 * a + 2] - bz, ux, uy, uz, d);
-  // final_edge_embedding on the gaussian-expanded distance (wave 0), node / bond scalars
-  if (tid < 64) {
-    const float e = edge_mlp_eval(h.fe, d, nullptr, tid & 31, tid & 32);
-    if (tid < 32) s_in[tid] = e;
-  } else if (tid < 96) {
-    s_in[tid - 32] = x[tid - 64];                       // lig_node_attr[atom, :ns]
-  } else {
-    s_in[tid - 32] = xu[tid - 96] + xv[tid - 96];       // tor_bond_attr[bond, :ns]
-  }
-  if (tid < 12) {
-    const float bv = bux * ux + buy * uy + buz * uz;
-    const float c = 3.6742346141747673f;   // (3/sqrt2) * sqrt3
-    const float t1[3] = {c * (bux * bv - ux / 3.f), c * (buy * bv - uy / 3.f), c * (buz * bv - uz / 3.f)};
-    const int uu = tid % 6;
-    const float* p = x + (tid < 6 ? COL_1O : COL_1E) + 3 * uu;
-    const float dd = (p[0] * t1[0] + p[1] * t1[1] + p[2] * t1[2]) * is3 * pw;
-    if (tid < 6) s_da[uu] = dd; else s_db[uu] = dd;
-  }
-  __syncthreads();
-  if (tid < 96) {
-    float acc = h.fc_b0[tid];
-    for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w0[tid * 96 + q], s_in[q], acc);
-    s_hid[tid] = fmaxf(acc, 0.f);
-  }
-  __syncthreads();
-  for (int r = tid; r < 384; r += 128) {
-    float acc = h.fc_b1[r];
-    for (int q = 0; q < 96; ++q) acc = fmaf(h.fc_w1[r * 96 + q], s_hid[q], acc);
-    s_w[r] = acc;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    // output columns: [32x0o (path B: 1e x T1) | 32x0e (path A: 1o x T1)]; weights: path A first, each [u=6][w=32]
-    const int wcol = tid & 31;
-    float r = 0.f;
-    if (tid < 32) { for (int q = 0; q < 6; ++q) r = fmaf(s_w[192 + q * 32 + wcol], s_db[q], r); }
-    else          { for (int q = 0; q < 6; ++q) r = fmaf(s_w[q * 32 + wcol], s_da[q], r); }
-    msg[(size_t)blockIdx.x * 64 + tid] = r;
-  }
-}
-
-__global__ __launch_bounds__(64) void bond_final_kernel(BondHead h, const int* __restrict__ nb_cnt, const float* __restrict__ msg,
-                                                        float tor_norm_sqrt, float* __restrict__ tor_out, float* __restrict__ dbg_feat) {
-  __shared__ float s_feat[64];
-  const int tid = threadIdx.x, bond = blockIdx.x;
-  const int ne = nb_cnt[bond];
-  float a = 0.f;
-  for (int k = 0; k < ne; ++k) a += msg[((size_t)bond * TOR_SLOTS + k) * 64 + tid];
-  const float mean = a / (float)(ne > 1 ? ne : 1);
-  const float f = (mean - h.bn_mean[tid]) * h.bn_scale[tid] + h.bn_bias[tid];
-  s_feat[tid] = f;
-  if (dbg_feat) dbg_feat[(size_t)bond * 64 + tid] = f;
-  __syncthreads();
-  if (tid < 32) {
-    float acc = 0.f;
-    for (int q = 0; q < 64; ++q) acc = fmaf(h.tf_w0[tid * 64 + q], s_feat[q], acc);
-    float t = tanhf(acc) * h.tf_w1[tid];
-    for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
-    if (tid == 0) tor_out[bond] = t * tor_norm_sqrt;
-  }
-}
-
-hipError_t launch_bond_head(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, float lig_r,
-                            int cap, float tor_norm_sqrt, float* tor_out, int* tor_edge_count, float* dbg_feat, int* nb_ws,
-                            int* nb_cnt_ws, float* msg_ws, hipStream_t s) {
+hipError_t launch_bond_nb(const GraphStatic& gs, const float* pos, int B, float lig_r, int cap, int* nb_ws, int* nb_cnt_ws, int* tor_edge_count,
+                          hipStream_t s) {
   if (gs.R <= 0) return hipSuccess;
-  const int nbond = B * gs.R;
-  hipLaunchKernelGGL(bond_nb_kernel, dim3(nbond), dim3(64), 0, s, gs, pos, lig_r * lig_r, cap, nb_ws, nb_cnt_ws, tor_edge_count);
-  hipLaunchKernelGGL(bond_msg_kernel, dim3(nbond * TOR_SLOTS), dim3(128), 0, s, h, gs, pos, node, nb_ws, nb_cnt_ws, msg_ws);
-  hipLaunchKernelGGL(bond_final_kernel, dim3(nbond), dim3(64), 0, s, h, nb_cnt_ws, msg_ws, tor_norm_sqrt, tor_out, dbg_feat);
+  hipLaunchKernelGGL(bond_nb_kernel, dim3(B * gs.R), dim3(64), 0, s, gs, pos, lig_r * lig_r, cap, nb_ws, nb_cnt_ws, tor_edge_count);
   return hipGetLastError();
 }
 

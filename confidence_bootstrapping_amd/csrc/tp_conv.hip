@@ -28,7 +28,7 @@
 //     in a fixed order -> bitwise reproducible results.
 #include <cstdlib>
 
-#include "common.h"
+#include "kernels.h"
 
 namespace cbd {
 
@@ -346,12 +346,9 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 // The message sums were left by tp_conv as per-tile pieces (see the end of tp_conv_kernel); they are combined here group by
 // group, tile by tile -- a fixed order, so results are bitwise reproducible.  bn_scale[c] = weight * rsqrt(running_var +
 // eps) per column; bn_mean / bn_bias are zero outside the 0e columns.
-__global__ void conv_finalize_kernel(FinArgs fa, const float* __restrict__ node_in, float* __restrict__ node_out,
-                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_mean,
-                                     const float* __restrict__ bn_bias, int n_nodes, int in_dim, int out_dim, int node_off) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
-  if (i >= n_nodes) return;
+__device__ __forceinline__ void finalize_one(const FinArgs& fa, const float* __restrict__ node_in, float* __restrict__ node_out,
+                                             const float* __restrict__ bn_scale, const float* __restrict__ bn_mean,
+                                             const float* __restrict__ bn_bias, int i, int c, int in_dim, int out_dim, int node_off) {
   const size_t o = (size_t)(i + node_off) * NODE_STRIDE + c;
   float r = 0.f;
   if (c < out_dim) {
@@ -381,6 +378,180 @@ __global__ void conv_finalize_kernel(FinArgs fa, const float* __restrict__ node_
   node_out[o] = r;
 }
 
+__global__ void conv_finalize_kernel(FinArgs fa, const float* __restrict__ node_in, float* __restrict__ node_out,
+                                     const float* __restrict__ bn_scale, const float* __restrict__ bn_mean,
+                                     const float* __restrict__ bn_bias, int n_nodes, int in_dim, int out_dim, int node_off) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  if (i >= n_nodes) return;
+  finalize_one(fa, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, node_off);
+}
+
+// both node types of a joint layer in one launch: nodes [0, n0) use the ligand-side groups, [n0, n0 + n1) the receptor-side
+__global__ void conv_finalize2_kernel(FinArgs fa0, int n0, int off0, FinArgs fa1, int n1, int off1, const float* __restrict__ node_in,
+                                      float* __restrict__ node_out, const float* __restrict__ bn_scale,
+                                      const float* __restrict__ bn_mean, const float* __restrict__ bn_bias, int in_dim, int out_dim) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  if (i >= n0 + n1) return;
+  if (i < n0) finalize_one(fa0, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, off0);
+  else finalize_one(fa1, node_in, node_out, bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim, off1);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Torsion head on the matrix cores (reference models/score_model.py:431-448, 650-664): one wave per (sample, rotatable
+// bond); its <= 32 neighbour atoms (radius(lig_pos, bond_pos, 5), bond_nb_kernel) are the 32 MFMA columns.
+//   per edge: attr = final_edge_embedding(gauss(d)); h = ReLU(W1 [attr | x_atom[:32] | (x_u + x_v)[:32]] + b1); w = W2 h + b2
+//             msg[0:32] (0o) = sum_u w_B[u][.] d_B[u],  msg[32:64] (0e) = sum_u w_A[u][.] d_A[u]
+//             d_A[u] = x1o[u] . T1 / sqrt(3) / sqrt(6), d_B[u] = x1e[u] . T1 / sqrt(3) / sqrt(6),
+//             T1 = (3/sqrt2)(b b^T - I/3)(sqrt3 v)  (the two live e3nn paths, tests/test_kernel_math.py::tor_t1)
+//   per bond: mean over its edges -> BatchNorm -> tor_final_layer -> * sqrt(torus score norm)
+// Weight stream: 3 tiles of W1, then one tile per mid index (6 of path A, 6 of path B), 32 outputs each.
+constexpr int BOND_TILES = 15;
+__global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
+                                                       const float* __restrict__ node, const int* __restrict__ nb,
+                                                       const int* __restrict__ nb_cnt, const float* __restrict__ wstream,
+                                                       float tor_norm_sqrt, float* __restrict__ tor_out, float* __restrict__ dbg_feat) {
+  __shared__ __attribute__((aligned(16))) float bias_l[BOND_TILES * 32];
+  __shared__ float msg_l[64 * 33];
+  __shared__ float s_feat[64];
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int bond = blockIdx.x;
+  const int ne = nb_cnt[bond];
+  const int b = bond / gs.R, rho = bond % gs.R, Nl = gs.Nl;
+  const float* P = pos + (size_t)b * Nl * 3;
+  const int u = gs.rot_u[rho], v = gs.rot_v[rho];
+
+  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
+  f32x4 a[KSTEPS / 4];
+#pragma unroll
+  for (int sg = 0; sg < KSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  {
+    const f32x4* gb = reinterpret_cast<const f32x4*>(wstream + (size_t)(BOND_TILES + 1) * TILE_W_FLOATS);
+    constexpr int NB4 = BOND_TILES * 8, NBI = (NB4 + 63) / 64;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; reinterpret_cast<f32x4*>(bias_l)[k < NB4 ? k : NB4 - 1] = gb[k < NB4 ? k : NB4 - 1]; }
+  }
+  const bool valid = j < ne;
+  const int at = valid ? nb[(size_t)bond * 32 + j] : u;
+  const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
+  float bux, buy, buz, bn, ux, uy, uz, d;
+  {
+    float x = P[3 * v] - P[3 * u], y = P[3 * v + 1] - P[3 * u + 1], z = P[3 * v + 2] - P[3 * u + 2];
+    bn = sqrtf(x * x + y * y + z * z);
+    const float inv = 1.0f / fmaxf(bn, 1e-12f);
+    bux = x * inv; buy = y * inv; buz = z * inv;
+    x = P[3 * at] - bx; y = P[3 * at + 1] - by; z = P[3 * at + 2] - bz;
+    d = sqrtf(x * x + y * y + z * z);
+    const float inv2 = 1.0f / fmaxf(d, 1e-12f);
+    ux = x * inv2; uy = y * inv2; uz = z * inv2;
+  }
+  const float* xa = node + (size_t)(b * Nl + at) * NODE_STRIDE;
+  const float* xu = node + (size_t)(b * Nl + u) * NODE_STRIDE;
+  const float* xv = node + (size_t)(b * Nl + v) * NODE_STRIDE;
+  // the 12 CG intermediates of this edge (zero for empty slots)
+  float md[12];
+  {
+    const float bv = bux * ux + buy * uy + buz * uz;
+    const float c = 3.6742346141747673f;   // (3/sqrt2) * sqrt3
+    const float t1[3] = {c * (bux * bv - ux / 3.f), c * (buy * bv - uy / 3.f), c * (buz * bv - uz / 3.f)};
+    const float k = valid ? 0.57735026918962576f * 0.40824829046386302f : 0.f;   // 1/sqrt3 * sqrt(1/6)
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+      const float* p = xa + (q < 6 ? COL_1O + 3 * q : COL_1E + 3 * (q - 6));
+      md[q] = (p[0] * t1[0] + p[1] * t1[1] + p[2] * t1[2]) * k;
+    }
+  }
+  // first-Linear input, lane half hf holds columns 16hf..16hf+15 of each part
+  float Bx[KSTEPS];
+  {
+    // final_edge_embedding(GaussianSmearing(d)): every lane evaluates the hidden layer, then its 16 outputs
+    float hid[32];
+#pragma unroll
+    for (int o = 0; o < 32; ++o) hid[o] = h.fe.part[o];
+    for (int k = 0; k < 32; ++k) {
+      const float t = d - h.fe.offset[k];
+      const float gk = expf(h.fe.coeff * (t * t));
+#pragma unroll
+      for (int o = 0; o < 32; ++o) hid[o] = fmaf(h.fe.WgT[k * 32 + o], gk, hid[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < 16; ++o) Bx[o] = h.fe.b1[16 * hf + o];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {
+      const float hk = fmaxf(hid[k], 0.f);
+#pragma unroll
+      for (int o = 0; o < 16; ++o) Bx[o] = fmaf(h.fe.W1T[k * 32 + 16 * hf + o], hk, Bx[o]);
+    }
+    const f32x4* pa = reinterpret_cast<const f32x4*>(xa + 16 * hf);
+    const f32x4* pu = reinterpret_cast<const f32x4*>(xu + 16 * hf);
+    const f32x4* pv = reinterpret_cast<const f32x4*>(xv + 16 * hf);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 s = pa[q], c0 = pu[q], c1 = pv[q];
+      Bx[16 + 4 * q + 0] = s.x; Bx[16 + 4 * q + 1] = s.y; Bx[16 + 4 * q + 2] = s.z; Bx[16 + 4 * q + 3] = s.w;
+      Bx[32 + 4 * q + 0] = c0.x + c1.x; Bx[32 + 4 * q + 1] = c0.y + c1.y; Bx[32 + 4 * q + 2] = c0.z + c1.z; Bx[32 + 4 * q + 3] = c0.w + c1.w;
+    }
+  }
+  __syncthreads();
+  int T = 0;
+  f32x16 acc;
+  float h1[KSTEPS];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    gemm_tile<0>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, Bx, acc, hf);
+    ++T;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+  }
+  float oA[16], oB[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { oA[r] = 0.f; oB[r] = 0.f; }
+#pragma unroll
+  for (int q = 0; q < 12; ++q) {
+    gemm_tile<0>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, h1, acc, hf);
+    ++T;
+    if (q < 6) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oA[r] = fmaf(md[q], acc[r], oA[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oB[r] = fmaf(md[q], acc[r], oB[r]);
+    }
+  }
+  // feature order of the reference layer output: [32x0o (path B) | 32x0e (path A)]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int w = (r & 3) + 8 * (r >> 2) + 4 * hf;
+    msg_l[w * 33 + j] = oB[r];
+    msg_l[(32 + w) * 33 + j] = oA[r];
+  }
+  __syncthreads();
+  {
+    float sum = 0.f;
+    for (int k = 0; k < 32; ++k) sum += msg_l[lane * 33 + k];   // empty slots hold exact zeros
+    const float mean = sum / (float)(ne > 1 ? ne : 1);
+    const float f = (mean - h.bn_mean[lane]) * h.bn_scale[lane] + h.bn_bias[lane];
+    s_feat[lane] = f;
+    if (dbg_feat) dbg_feat[(size_t)bond * 64 + lane] = f;
+  }
+  __syncthreads();
+  if (lane < 32) {
+    float t = 0.f;
+    for (int q = 0; q < 64; ++q) t = fmaf(h.tf_w0[lane * 64 + q], s_feat[q], t);
+    t = tanhf(t) * h.tf_w1[lane];
+    for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
+    if (lane == 0) tor_out[bond] = t * tor_norm_sqrt;
+  }
+}
+
+hipError_t launch_bond_conv(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, const int* nb,
+                            const int* nb_cnt, const float* wstream, float tor_norm_sqrt, float* tor_out, float* dbg_feat, hipStream_t s) {
+  if (gs.R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bond_conv_kernel, dim3(B * gs.R), dim3(64), 0, s, h, gs, pos, node, nb, nb_cnt, wstream, tor_norm_sqrt, tor_out, dbg_feat);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------- host launchers
 template <int IN, int OUT>
 static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
@@ -408,6 +579,16 @@ hipError_t launch_conv_finalize(const FinArgs& fa, const float* node_in, float* 
   const int total = n_nodes * NODE_STRIDE;
   hipLaunchKernelGGL(conv_finalize_kernel, dim3((total + 255) / 256), dim3(256), 0, s, fa, node_in, node_out, bn_scale,
                      bn_mean, bn_bias, n_nodes, in_dim, out_dim, node_off);
+  return hipGetLastError();
+}
+
+hipError_t launch_conv_finalize2(const FinArgs& fa0, int n0, int off0, const FinArgs& fa1, int n1, int off1, const float* node_in,
+                                 float* node_out, const float* bn_scale, const float* bn_mean, const float* bn_bias, int in_dim,
+                                 int out_dim, hipStream_t s) {
+  const int total = (n0 + n1) * NODE_STRIDE;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(conv_finalize2_kernel, dim3((total + 255) / 256), dim3(256), 0, s, fa0, n0, off0, fa1, n1, off1, node_in, node_out,
+                     bn_scale, bn_mean, bn_bias, in_dim, out_dim);
   return hipGetLastError();
 }
 
