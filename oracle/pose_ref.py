@@ -113,7 +113,8 @@ def sde_coefficients(t_idx, schedule, cfg: ScoreConfig):
 
 @torch.no_grad()
 def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreConfig, so3_table, torus_table,
-                 noise=None, no_final_step_noise=False, ode=False, record=False):
+                 noise=None, no_final_step_noise=False, ode=False, record=False, temp_sampling=1.0, temp_psi=0.0,
+                 temp_sigma_data=0.5):
     """Reverse diffusion for b poses of ONE complex: pos0 [b,N,3] -> final pos [b,N,3].
     noise: dict of 'tr' [S,b,3], 'rot' [S,b,3], 'tor' [S,b*R] (explicit, lifted out of the reference's
     unseeded torch.normal calls, drawn in the reference's order) or None => zeros (no_random)."""
@@ -140,6 +141,20 @@ def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreCon
         if not cfg.no_torsion and R > 0:
             z_tor = torch.zeros(b * R) if zero else noise["tor"][s]
             tor_p = 0.5 * g[2] ** 2 * dt * tor_s if ode else g[2] ** 2 * dt * tor_s + g[2] * np.sqrt(dt) * z_tor
+        # low-temperature sampling (utils/sampling.py:146-167): overrides the perturbation of every component whose
+        # temperature differs from 1
+        ts = list(temp_sampling) if np.iterable(temp_sampling) else [temp_sampling] * 3
+        tp = list(temp_psi) if np.iterable(temp_psi) else [temp_psi] * 3
+        lims = [(cfg.tr_sigma_min, cfg.tr_sigma_max), (cfg.rot_sigma_min, cfg.rot_sigma_max), (cfg.tor_sigma_min, cfg.tor_sigma_max)]
+        scores, zs = [tr_s, rot_s, tor_s], [z_tr, z_rot, None if tor_p is None else z_tor]
+        new = [tr_p, rot_p, tor_p]
+        for k in range(3):
+            if ts[k] != 1.0 and new[k] is not None and not ode:
+                lo, hi = lims[k]
+                sigma_data = np.exp(temp_sigma_data * np.log(hi) + (1 - temp_sigma_data) * np.log(lo))
+                lam = (sigma_data + sig[k]) / (sigma_data + sig[k] / ts[k])
+                new[k] = g[k] ** 2 * dt * (lam + ts[k] * tp[k] / 2) * scores[k] + g[k] * np.sqrt(dt * (1 + tp[k])) * zs[k]
+        tr_p, rot_p, tor_p = new
         pos = modify_conformer_batch(pos, cx, tr_p.float(), rot_p.float(), None if tor_p is None else tor_p.float())
         if record:
             trace.append({"tr": tr_s.clone(), "rot": rot_s.clone(), "tor": tor_s.clone(), "pos": pos.clone()})

@@ -142,3 +142,8 @@ def test_ragged_last_batch_and_sampling_modes(dev, score_model, tables):
     got = run(noise=noise, no_final_step_noise=True)
     ref = pr.sampling_ref(sd, cx, pos0, sched, sr.ScoreConfig(), so3, torus, noise=noise, no_final_step_noise=True)
     assert float(rmsd(got, ref).max()) < 1e-3
+    # low-temperature sampling (inference.py passes temp_sampling_* / temp_psi_* / temp_sigma_data_*; utils/sampling.py:146-167)
+    temps = dict(temp_sampling=[1.17, 2.06, 7.04], temp_psi=[0.73, 0.90, 0.59], temp_sigma_data=0.48)
+    got = run(noise=noise, **temps)
+    ref = pr.sampling_ref(sd, cx, pos0, sched, sr.ScoreConfig(), so3, torus, noise=noise, **temps)
+    assert float(rmsd(got, ref).max()) < 1e-3
