@@ -465,6 +465,25 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
     if (atom_ei[k] < 0 || atom_ei[k] >= Na) return fail(CBD_ERR_ARG, "atom edge index out of range");
   for (int k = 0; k < Na; ++k)
     if (atom_res[k] < 0 || atom_res[k] >= Nr) return fail(CBD_ERR_ARG, "atom -> residue index out of range");
+  {  // categorical features index embedding tables on the device: validate them here
+    static const int lig_dims[LIG_N_CAT] = {119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2};
+    static const int atom_dims[ATOM_N_CAT] = {38, 119, 23, 38};
+    for (int a = 0; a < Nl; ++a)
+      for (int f = 0; f < LIG_N_CAT; ++f) {
+        const float v = lig_x[(size_t)a * LIG_N_CAT + f];
+        if (!(v >= 0 && v < lig_dims[f]) || v != (float)(int)v) return fail(CBD_ERR_ARG, "ligand feature %d of atom %d out of range", f, a);
+      }
+    for (int a = 0; a < Na; ++a)
+      for (int f = 0; f < ATOM_N_CAT; ++f) {
+        const float v = atom_x[(size_t)a * ATOM_N_CAT + f];
+        if (!(v >= 0 && v < atom_dims[f]) || v != (float)(int)v) return fail(CBD_ERR_ARG, "receptor-atom feature %d of atom %d out of range", f, a);
+      }
+    const int stride = 1 + e->cfg.lm_embedding_dim;
+    for (int r = 0; r < Nr; ++r) {
+      const float v = rec_x[(size_t)r * stride];
+      if (!(v >= 0 && v < 38) || v != (float)(int)v) return fail(CBD_ERR_ARG, "residue type of residue %d out of range", r);
+    }
+  }
 
   ConfStatic& cs = e->cs;
   cs = ConfStatic{};

@@ -112,6 +112,12 @@ def test_confidence_edge_cases(conf_model):
     assert (conf_nc.cpu() - ref_nc["confidence"]).abs().max() < 2e-5
     with pytest.raises(RuntimeError):
         eng.score(torch.zeros(eng.max_batch + 1, eng.Nl, 3).cuda())
+    bad = copy.deepcopy(cplx)
+    bad["atom"].x = bad["atom"].x.clone()
+    bad["atom"].x[3, 2] = 23.0          # atom_type_2 has 23 classes: index 23 is out of range
+    with pytest.raises(RuntimeError, match="out of range"):
+        eng.set_complex(bad)
+    eng.set_complex(cplx)
 
 
 def test_confidence_forward_api(conf_model):
