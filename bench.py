@@ -197,7 +197,7 @@ def main():
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
         flops_per_launch = total_flops / max(n_launch, 1)
         traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tp = os.path.join(ROOT, "profiles", "r01_b_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
         if os.path.exists(tp):
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
