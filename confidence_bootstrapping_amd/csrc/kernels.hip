@@ -202,27 +202,9 @@ hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, u
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Edge embedding MLP (GaussianSmearing + Linear/ReLU/Linear), 32 lanes per edge:
+// Edge embedding MLP (GaussianSmearing + Linear/ReLU/Linear):
 // lig_edge_embedding / cross_edge_embedding / rec_edge_embedding / final_edge_embedding,
 // score_model.py:111,114,123,259-264 applied at :286,311,352,660 on the features built at :504-518,534-535,578-580,658.
-CBD_DEV float edge_mlp_eval(const EdgeMlp& m, float d, const float* bond4, int o, int sub_base) {
-  // gaussian k for this lane, then hidden pre-activation for output o
-  const float t = d - m.offset[o];
-  const float gk = expf(m.coeff * (t * t));
-  float h = m.part[o];
-#pragma unroll 8
-  for (int k = 0; k < 32; ++k) h = fmaf(m.WgT[k * 32 + o], __shfl(gk, sub_base + k), h);
-  if (m.WbT && bond4) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c) h = fmaf(m.WbT[c * 32 + o], bond4[c], h);
-  }
-  h = fmaxf(h, 0.f);
-  float out = m.b1[o];
-#pragma unroll 8
-  for (int k = 0; k < 32; ++k) out = fmaf(m.W1T[k * 32 + o], __shfl(h, sub_base + k), out);
-  return out;
-}
-
 // One lane per edge: all weight addresses are wave-uniform (scalar loads), the 2 x 32x32 products are straight-line
 // FMAs on register arrays, no cross-lane traffic; each lane writes its own 128-B row.
 __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlp m, const float* __restrict__ dist, const float* __restrict__ bond4,
