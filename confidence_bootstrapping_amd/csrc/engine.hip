@@ -1141,4 +1141,11 @@ int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1, c
   return 0;
 }
 
+int cbd_symm_rmsd(int32_t B, int32_t N, int32_t K, const float* pos_dev, const float* ref_dev, const int32_t* idx_ref_dev,
+                  const int32_t* idx_pos_dev, float* rmsd_out_dev, int32_t* argmin_out_dev, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || !pos_dev || !ref_dev || !idx_ref_dev || !idx_pos_dev || !rmsd_out_dev) return fail(CBD_ERR_ARG, "bad argument");
+  HIPCHK(launch_symm_rmsd(B, N, K, pos_dev, ref_dev, idx_ref_dev, idx_pos_dev, rmsd_out_dev, argmin_out_dev, reinterpret_cast<hipStream_t>(stream)));
+  return 0;
+}
+
 }  // extern "C"

@@ -86,6 +86,8 @@ hipError_t launch_pose_update(const GraphStatic& gs, float* pos, int B, const fl
 hipError_t launch_rec_node_embed(const float* rec_x, int Nr, int lm_dim, const float* emb_table, const float* w, const float* b,
                                  float* node, hipStream_t s);
 hipError_t launch_edge_geom(const float* pos, const int* src, const int* dst, int n, float* vec4, float* dist, hipStream_t s);
+hipError_t launch_symm_rmsd(int B, int N, int K, const float* pos, const float* ref, const int* idx_ref, const int* idx_pos, float* out,
+                            int* argmin, hipStream_t s);
 hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t s);
 
 // tp_conv.hip

@@ -689,4 +689,39 @@ hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Symmetry-corrected RMSD (reference utils/molecules_utils.py:3-18 -> spyrmsd/rmsd.py:116-203 with center=False,
+// minimize=False): for pose b the minimum over graph isomorphisms k of sum_i |ref[idx_ref[k][i]] - pos[b][idx_pos[k][i]]|^2,
+// rmsd = sqrt(min / n).  One wave per pose, lanes over atoms, fp64 accumulation; the first minimum wins (strict <).
+__global__ __launch_bounds__(64) void symm_rmsd_kernel(int N, int K, const float* __restrict__ pos, const float* __restrict__ ref,
+                                                       const int* __restrict__ idx_ref, const int* __restrict__ idx_pos,
+                                                       float* __restrict__ out, int* __restrict__ argmin) {
+  const int b = blockIdx.x, lane = lane_id();
+  const float* P = pos + (size_t)b * N * 3;
+  double best = 1.0e300;
+  int best_k = 0;
+  for (int k = 0; k < K; ++k) {
+    double s = 0.0;
+    for (int i = lane; i < N; i += 64) {
+      const int ir = idx_ref[(size_t)k * N + i], ip = idx_pos[(size_t)k * N + i];
+      const double dx = (double)ref[3 * ir] - (double)P[3 * ip], dy = (double)ref[3 * ir + 1] - (double)P[3 * ip + 1],
+                   dz = (double)ref[3 * ir + 2] - (double)P[3 * ip + 2];
+      s += dx * dx + dy * dy + dz * dz;
+    }
+    s = wave_sum_d(s);
+    if (s < best) { best = s; best_k = k; }
+  }
+  if (lane == 0) {
+    out[b] = (float)sqrt(best / (double)N);
+    if (argmin) argmin[b] = best_k;
+  }
+}
+
+hipError_t launch_symm_rmsd(int B, int N, int K, const float* pos, const float* ref, const int* idx_ref, const int* idx_pos, float* out,
+                            int* argmin, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL(symm_rmsd_kernel, dim3(B), dim3(64), 0, s, N, K, pos, ref, idx_ref, idx_pos, out, argmin);
+  return hipGetLastError();
+}
+
 }  // namespace cbd

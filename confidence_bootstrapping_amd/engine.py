@@ -61,6 +61,7 @@ SYMBOLS = {
     "cbd_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cbd_conv_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_pack_conv_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_symm_rmsd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_conf_create": (C.c_int, [C.POINTER(cbd_conf_config), C.POINTER(_P)]),
     "cbd_conf_destroy": (C.c_int, [_P]),
     "cbd_conf_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),

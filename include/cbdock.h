@@ -151,6 +151,13 @@ int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1_ho
                          const float* w2_host, const float* b2_host, float* out_host);
 
 
+/* Symmetry-corrected ligand RMSD of B poses against one reference pose: replaces the loop over graph
+ * isomorphisms of the reference's vendored spyrmsd (utils/molecules_utils.py:3-18 -> spyrmsd/rmsd.py:116-203, center=False,
+ * minimize=False).  idx_ref / idx_pos [K][N] int32: isomorphism k maps reference atom idx_ref[k][i] to pose atom idx_pos[k][i]
+ * (enumerated on the host).  Outputs: rmsd [B] and (optional) the index of the minimising isomorphism.  Device pointers. */
+int cbd_symm_rmsd(int32_t B, int32_t N, int32_t K, const float* pos_dev, const float* ref_dev, const int32_t* idx_ref_dev,
+                  const int32_t* idx_pos_dev, float* rmsd_out_dev, int32_t* argmin_out_dev, void* stream);
+
 /* ============================ all-atom CONFIDENCE model ===========================================
  * Replaces, for the shipped workdir/pretrained_confidence architecture, the confidence branch of
  * utils/sampling.py:240-261: crop_beyond (utils/utils.py:395-420) + set_time(0) + the all-atom
