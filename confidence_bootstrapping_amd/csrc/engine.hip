@@ -1076,7 +1076,7 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     if (!e->stamps_dev || capacity < 3) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_CONV_VARIANT=8)");
     std::vector<unsigned long long> h(8192 * 8);
     if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
-    std::vector<double> ghz, dur, pro, g1, tiles, fin;
+    std::vector<double> ghz, dur, pro, g1, tiles, fin, g1a;
     for (int i = 0; i < 8192; ++i) {
       const unsigned long long* q = h.data() + 8 * i;
       const double dt = (double)(q[2] - q[0]), dr = (double)(q[3] - q[1]);
@@ -1084,14 +1084,16 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
         ghz.push_back(dt / dr * 0.1); dur.push_back(dr * 10.0);   // memrealtime ticks at 100 MHz
         pro.push_back((double)(q[4] - q[0])); g1.push_back((double)(q[5] - q[4])); tiles.push_back((double)(q[6] - q[5]));
         fin.push_back((double)(q[2] - q[6]));
+        g1a.push_back((double)(q[7] - q[4]));
       }
     }
     if (ghz.empty()) return fail(CBD_ERR_STATE, "no stamps recorded");
     auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
     if (capacity >= 7) { out[3] = (float)med(pro); out[4] = (float)med(g1); out[5] = (float)med(tiles); out[6] = (float)med(fin); }
+    if (capacity >= 8) out[7] = (float)med(g1a);
     std::sort(ghz.begin(), ghz.end()); std::sort(dur.begin(), dur.end());
     out[0] = (float)ghz[ghz.size() / 2]; out[1] = (float)dur[dur.size() / 2]; out[2] = (float)ghz.size();
-    return capacity >= 7 ? 7 : 3;
+    return capacity >= 8 ? 8 : capacity >= 7 ? 7 : 3;
   }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
   if (grp < 0) return;
   const ConvGroup G = args.g[grp];
-  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_g0 = 0;
   if constexpr (VAR == 8) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
@@ -231,6 +231,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     CBD_TILE(Bx);
 #pragma unroll
     for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+    if constexpr (VAR == 8) { if (m == 0) st_g0 = stamp(); }
   }
 
   if constexpr (VAR == 8) st_t2 = stamp();
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
       unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
       o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
-      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = 0;
+      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = st_g0;
     }
   }
 }

@@ -20,7 +20,7 @@ noise = [torch.randn(20, B, 3, generator=g), torch.randn(20, B, 3, generator=g),
 t0 = time.time()
 while time.time() - t0 < 4.0:
     p = pos0.clone(); eng.sample(p, steps, *noise); torch.cuda.synchronize()
-ghz, dur_ns, n, pro, g1, tiles, fin = eng.fetch("conv_clock_ghz", 16)
+ghz, dur_ns, n, pro, g1, tiles, fin, g1a = eng.fetch("conv_clock_ghz", 16)
 print(f"in-kernel clock of tp_conv<3,3>: median {ghz:.3f} GHz over {int(n)} workgroups, median workgroup lifetime {dur_ns/1e3:.1f} us")
 print(f"median cycles: prologue(gather+bias) {pro:.0f}, first Linear (3 tiles) {g1:.0f}, 54 weight tiles {tiles:.0f} ({tiles/54:.0f}/tile), "
-      f"message reduce+atomics {fin:.0f}; total {pro+g1+tiles+fin:.0f}")
+      f"message reduce {fin:.0f}; total {pro+g1+tiles+fin:.0f}; first tile of the first Linear alone {g1a:.0f}")
