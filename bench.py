@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3])")
+    ap.add_argument("--pair", type=int, default=1, help="1: co-schedule consecutive complexes two at a time (cbd_sample_pair: one "
+                    "tensor-product launch covers both 40-pose batches); 0: one complex at a time")
     a = ap.parse_args()
     WORKLOAD, SAMPLES, DENOISE_STEPS = a.workload, a.samples, a.denoise_steps
 
@@ -155,6 +157,12 @@ def main():
     eng.set_complex(cplx)
     eng.set_option("graph", a.graph)
     eng.set_option("bf16", int(a.dtype == "bf16"))
+    pair = bool(a.pair) and a.streams == 1 and not a.graph
+    eng2 = None
+    if pair:   # second engine (own workspace, same device-resident weights) for the complex that is co-scheduled
+        eng2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
+        eng2.set_complex(cplx)
+        eng2.set_option("bf16", int(a.dtype == "bf16"))
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
     steps = make_steps(sched, margs, model.timestep_emb_func)
     R = eng.R
@@ -174,17 +182,31 @@ def main():
         eng.recompute_receptor()
         eng.sample(pos0[k], steps, *noise[k])
 
-    for k in range(a.warmup):
-        one_complex(k)
+    def run(lo, hi):
+        """complexes lo..hi-1, two at a time when pairing is on (each complex still gets its own receptor embedding pass)"""
+        k = lo
+        while k < hi:
+            if pair and k + 1 < hi:
+                eng.recompute_receptor()
+                eng2.recompute_receptor()
+                eng.engines[0].sample_pair(eng2.engines[0], pos0[k], steps, noise[k], pos0[k + 1], noise[k + 1])
+                k += 2
+            else:
+                one_complex(k)
+                k += 1
+
+    run(0, a.warmup)
     torch.cuda.synchronize()
     eng.kernel_timing(enable=not a.graph, reset=True)
     eng.stats(reset=True)
+    if eng2 is not None:
+        eng2.kernel_timing(enable=True, reset=True)
+        eng2.stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(a.warmup, n_runs):
-        one_complex(k)
+    run(a.warmup, n_runs)
     final = gather_poses(pos0[n_runs - 1], world, rank)
     torch.cuda.synchronize()
     if world > 1:
@@ -197,6 +219,11 @@ def main():
         elapsed = float(tmax.item())
     avg_ms, n_launch, total_ms = eng.kernel_timing(enable=False)
     st = eng.stats()
+    if eng2 is not None:   # merged launches are timed by whichever engine arrived second at the rendezvous
+        _, n2, t2 = eng2.kernel_timing(enable=False)
+        n_launch, total_ms = n_launch + n2, total_ms + t2
+        avg_ms = total_ms / max(n_launch, 1)
+        st = {k: st[k] + v for k, v in eng2.stats().items()}
     assert torch.isfinite(pos0[n_runs - 1]).all(), "non-finite poses"
 
     if rank == 0:
@@ -221,6 +248,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS, "streams": a.streams,
+                       "co_scheduled_complexes": 2 if pair else 1,
                        "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel" if a.dtype == "f32" else "tp_conv_bf16_kernel",

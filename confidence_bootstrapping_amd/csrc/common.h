@@ -75,12 +75,15 @@ struct ConvGroup {
   float* first_sum;      // [tiles][NODE_STRIDE]
   float* last_sum;       // [tiles][NODE_STRIDE]
   float* run_acc;        // [N][NODE_STRIDE], row = aggregating node
+  const float* node_in;  // [N][NODE_STRIDE] node features this group's src / dst indices refer to
 };
 
+// Up to 8 groups per launch: the 4 edge groups of one batch, or of TWO batches (two engines working on different complexes
+// co-scheduled by cbd_sample_pair so that one launch carries twice the waves -- the per-launch drain is amortised).
+constexpr int CONV_MAX_GROUPS = 8;
 struct ConvArgs {
-  ConvGroup g[4];
+  ConvGroup g[CONV_MAX_GROUPS];
   int n_groups;
-  const float* node_in;  // [N][NODE_STRIDE]
   unsigned long long* stamps;   // diagnostic build only (CBD_CONV_VARIANT=8): [grid][4] s_memtime/s_memrealtime at start/end
 };
 

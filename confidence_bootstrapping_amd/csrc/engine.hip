@@ -8,7 +8,10 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "host_util.h"
@@ -43,8 +46,23 @@ struct MlpDev {   // 2-layer edge MLP pieces
 
 }  // namespace
 
+// Rendezvous of two engines whose step loops run in lockstep (cbd_sample_pair): at every tensor-product launch both hand in
+// their edge groups and the later one launches ONE kernel covering both batches.
+struct PairCtx {
+  std::mutex m;
+  std::condition_variable cv;
+  int arrived = 0;
+  unsigned gen = 0;
+  bool abort = false;
+  ConvArgs args[2];
+  int grid[2] = {0, 0};
+  int rc = 0;
+};
+
 struct cbd_engine {
   cbd_config cfg{};
+  PairCtx* pair = nullptr;          // non-null while cbd_sample_pair drives this engine
+  int pair_rank = 0;
   std::map<std::string, HostTensor> host_w;
   bool weights_ready = false, complex_ready = false;
   DevPool wpool, cpool, bpool;   // weights / complex / batch workspace
@@ -511,18 +529,7 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
   return r;
 }
 
-static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
-                    const float* node_in, hipStream_t s, const int* widx = nullptr) {
-  ConvArgs a{};
-  a.n_groups = n_groups;
-  int grid = 0;
-  for (int g = 0; g < n_groups; ++g) {
-    a.g[g] = groups[g];
-    a.g[g].wstream = (e->use_bf16 ? L.wstream_bf16 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
-    grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
-  }
-  a.node_in = node_in;
-  a.stamps = e->stamps_dev;
+static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
     if (e->ev_used == e->ev_pool.size()) {
@@ -538,6 +545,47 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) HIPCHK(hipEventRecord(e1, s));
   return 0;
+}
+
+static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
+                    const float* node_in, hipStream_t s, const int* widx = nullptr) {
+  ConvArgs a{};
+  a.n_groups = n_groups;
+  int grid = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    a.g[g] = groups[g];
+    a.g[g].wstream = (e->use_bf16 ? L.wstream_bf16 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
+    a.g[g].node_in = node_in;
+    grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
+  }
+  a.stamps = e->stamps_dev;
+  if (e->pair && s != e->side) {
+    // lockstep with the partner engine: the second to arrive launches one kernel over both batches' groups (same layer,
+    // hence the same weight streams); both continue only after that launch has been enqueued on the shared stream
+    PairCtx& P = *e->pair;
+    std::unique_lock<std::mutex> lk(P.m);
+    if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
+    P.args[e->pair_rank] = a;
+    P.grid[e->pair_rank] = grid;
+    if (++P.arrived == 2) {
+      ConvArgs m = P.args[0];
+      for (int g = 0; g < P.args[1].n_groups; ++g) m.g[m.n_groups + g] = P.args[1].g[g];
+      m.n_groups += P.args[1].n_groups;
+      P.rc = launch_conv_timed(e, L, m, P.grid[0] + P.grid[1], s);
+      if (P.rc != 0) P.abort = true;
+      P.arrived = 0;
+      ++P.gen;
+      const int rc = P.rc;
+      lk.unlock();
+      P.cv.notify_all();
+      return rc;
+    }
+    const unsigned my = P.gen;
+    P.cv.wait(lk, [&] { return P.gen != my || P.abort; });
+    if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
+    return P.rc;
+  }
+  return launch_conv_timed(e, L, a, grid, s);
 }
 
 static FinGroup fin_group(const ConvGroup& g, const int* start, const int* cnt, int node_mod = 0) {
@@ -959,7 +1007,7 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
     }
     return 0;
   };
-  if (e->use_graph && !e->timing && !scores_out && !e->keep_debug) {
+  if (e->use_graph && !e->timing && !scores_out && !e->keep_debug && !e->pair) {
     hipStream_t user = s;
     if (!user) {   // the legacy default stream cannot be captured: run on the engine's own stream, ordered after/before it
       HIPCHK(hipEventRecord(e->ev_a, user));
@@ -1007,6 +1055,42 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
   }
   CHK(run_steps(pos_dev, noise_tr, noise_rot, noise_tor, scores_out));
   return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
+}
+
+int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int32_t S, const cbd_step* steps, float* pos0_dev,
+                    const float* noise_tr0, const float* noise_rot0, const float* noise_tor0, float* pos1_dev,
+                    const float* noise_tr1, const float* noise_rot1, const float* noise_tor1, void* stream) {
+  if (!e0 || !e1 || e0 == e1) return fail(CBD_ERR_ARG, "two distinct engines are required");
+  if (e0->cfg.device != e1->cfg.device) return fail(CBD_ERR_ARG, "paired engines must live on the same device");
+  if (e0->use_bf16 != e1->use_bf16) return fail(CBD_ERR_ARG, "paired engines must use the same operand precision");
+  if (e0->conv[0].wstream[0] != e1->conv[0].wstream[0]) return fail(CBD_ERR_ARG, "paired engines must share one set of weights (cbd_share_weights)");
+  CHK(check_batch(e0, B0));
+  CHK(check_batch(e1, B1));
+  PairCtx ctx;
+  e0->pair = e1->pair = &ctx;
+  e0->pair_rank = 0; e1->pair_rank = 1;
+  int rc1 = 0;
+  std::string err1;
+  std::thread partner([&] {
+    rc1 = cbd_sample(e1, B1, S, steps, pos1_dev, noise_tr1, noise_rot1, noise_tor1, nullptr, stream);
+    if (rc1 != 0) {
+      err1 = cbd_last_error();
+      std::lock_guard<std::mutex> lk(ctx.m);
+      ctx.abort = true;
+      ctx.cv.notify_all();
+    }
+  });
+  const int rc0 = cbd_sample(e0, B0, S, steps, pos0_dev, noise_tr0, noise_rot0, noise_tor0, nullptr, stream);
+  if (rc0 != 0) {
+    std::lock_guard<std::mutex> lk(ctx.m);
+    ctx.abort = true;
+    ctx.cv.notify_all();
+  }
+  partner.join();
+  e0->pair = e1->pair = nullptr;
+  if (rc0 != 0) return rc0;
+  if (rc1 != 0) return fail(rc1, "%s", err1.c_str());
+  return 0;
 }
 
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {

@@ -196,8 +196,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   float Bx[KSTEPS];  // first-Linear input: [edge_attr(32) | x_src[:32] | x_dst[:32]], lane half hf holds cols 16hf..16hf+15
   {
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
-    const f32x4* pd = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
+    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 aa = pa[q], s = ps[q], d = pd[q];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
       Bx[32 + 4 * q + 0] = d.x; Bx[32 + 4 * q + 1] = d.y; Bx[32 + 4 * q + 2] = d.z; Bx[32 + 4 * q + 3] = d.w;
     }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
-    const f32x4* pr = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
+    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
       const f32x4 r = pr[q];

@@ -164,8 +164,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
   bf16x8 Bx[BQ];  // first-Linear input [edge_attr(32) | x_src[:32] | x_dst[:32]]: k-step 2*seg+sub = cols 16hf+8sub .. +7 of segment seg
   {
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
-    const f32x4* pd = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
+    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const f32x4 aa = pa[q], s = ps[q], d = pd[q];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
       Bx[4 + qq][o + 0] = (__bf16)d.x; Bx[4 + qq][o + 1] = (__bf16)d.y; Bx[4 + qq][o + 2] = (__bf16)d.z; Bx[4 + qq][o + 3] = (__bf16)d.w;
     }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
-    const f32x4* pr = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
+    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
       const f32x4 r = pr[q];

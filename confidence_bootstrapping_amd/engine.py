@@ -52,6 +52,7 @@ SYMBOLS = {
     "cbd_score": (C.c_int, [_P, C.c_int32, _P, C.POINTER(cbd_step), _P, _P, _P, _P]),
     "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
+    "cbd_sample_pair": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(cbd_step)] + [_P] * 9),
     "cbd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cbd_share_weights": (C.c_int, [_P, _P]),
     "cbd_recompute_receptor": (C.c_int, [_P, _P]),
@@ -258,6 +259,23 @@ class DockEngine:
                                        _dptr(scores), self._stream()))
         return scores
 
+    def share_weights_from(self, other: "DockEngine"):
+        """Use `other`'s device-resident weights (one copy in HBM/L2) instead of uploading this engine's own."""
+        _check(self.lib.cbd_share_weights(self.h, other.h))
+
+    def sample_pair(self, other: "DockEngine", pos, steps, noise, other_pos, other_noise):
+        """In-place reverse diffusion of two batches (two complexes) in lockstep with merged tensor-product launches
+        (cbd_sample_pair).  noise / other_noise: (tr, rot, tor) device tensors or None."""
+        f = lambda x: None if x is None else x.to(self.device, torch.float32).contiguous()
+        n0 = [f(x) for x in (noise or (None, None, None))]
+        n1 = [f(x) for x in (other_noise or (None, None, None))]
+        for p in (pos, other_pos):
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_sample_pair(self.h, other.h, pos.shape[0], other_pos.shape[0], len(steps), steps, _dptr(pos),
+                                            _dptr(n0[0]), _dptr(n0[1]), _dptr(n0[2]), _dptr(other_pos), _dptr(n1[0]), _dptr(n1[1]),
+                                            _dptr(n1[2]), self._stream()))
+
     def recompute_receptor(self):
         with torch.cuda.device(self.device):
             _check(self.lib.cbd_recompute_receptor(self.h, self._stream()))
@@ -298,12 +316,15 @@ class DockEnginePool:
     one chunk's tensor-product launches overlap with the other chunk's matrix-core work.  Results are identical to a
     single engine (samples never interact)."""
 
-    def __init__(self, state_dict, device, n: int = 1, max_batch: int = 64, **engine_kw):
+    def __init__(self, state_dict, device, n: int = 1, max_batch: int = 64, share_from=None, **engine_kw):
         self.device = torch.device(device)
         self.n = max(1, int(n))
         per = (max_batch + self.n - 1) // self.n
         self.engines = [DockEngine(self.device, max_batch=per, **engine_kw) for _ in range(self.n)]
-        self.engines[0].load_state_dict(state_dict)
+        if share_from is not None:     # reuse the weights another pool already holds on this device
+            self.engines[0].share_weights_from(share_from.engines[0])
+        else:
+            self.engines[0].load_state_dict(state_dict)
         for e in self.engines[1:]:     # one copy of the weights in HBM/L2, shared by all streams
             _check(e.lib.cbd_share_weights(e.h, self.engines[0].h))
         self.streams = [torch.cuda.Stream(self.device) for _ in range(self.n)]
@@ -311,8 +332,8 @@ class DockEnginePool:
         self.complex_key = None
 
     @classmethod
-    def from_model(cls, model, device, n=1, max_batch=64):
-        return cls(model.state_dict(), device, n=n, max_batch=max_batch,
+    def from_model(cls, model, device, n=1, max_batch=64, share_from=None):
+        return cls(model.state_dict(), device, n=n, max_batch=max_batch, share_from=share_from,
                    lm_embedding_dim=1280 if model.lm_embedding_type == "precomputed" else 0, no_torsion=model.no_torsion,
                    lig_max_radius=model.lig_max_radius, rec_max_radius=model.rec_max_radius,
                    cross_max_distance=model.cross_max_distance, center_max_distance=model.center_max_distance)

@@ -112,6 +112,14 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps_host, 
                const float* noise_tr_dev, const float* noise_rot_dev, const float* noise_tor_dev,
                float* scores_out_dev, void* stream);
 
+/* Two batches (normally the pose batches of two different complexes) advanced through the same S steps in lockstep: every
+ * tensor-product launch covers the edge groups of BOTH engines (twice the waves per launch; the per-launch drain of the
+ * long-lived waves is amortised).  e0 and e1 must live on the same device and share one set of weights
+ * (cbd_share_weights).  Results are identical to two cbd_sample calls.  Not captured into a hipGraph. */
+int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int32_t S, const cbd_step* steps_host, float* pos0_dev,
+                    const float* noise_tr0_dev, const float* noise_rot0_dev, const float* noise_tor0_dev, float* pos1_dev,
+                    const float* noise_tr1_dev, const float* noise_rot1_dev, const float* noise_tor1_dev, void* stream);
+
 /* Engine options.  "graph" (0/1): capture the S-step loop of cbd_sample into a hipGraph that is instantiated once per
  * (batch size, schedule) and replayed with one launch per batch (inputs are staged into engine-owned buffers).
  * "bf16" (0/1): run the two Linears of every tensor-product layer's radial MLP on bf16 matrix cores (bf16 operands, fp32

@@ -315,3 +315,42 @@ def test_errors_are_raised_not_swallowed(engine_tiny, dev, score_model):
 def test_smoke_entry():
     import __graft_entry__ as ge
     ge.smoke()
+
+
+def test_sample_pair_equals_two_samples():
+    """cbd_sample_pair (two complexes in lockstep, merged tensor-product launches) == two separate cbd_sample calls, bitwise."""
+    import copy
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, make_complex
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    dev = torch.device("cuda:0")
+    model, args = make_score_model(device=dev, seed=0)
+    ca, cb = make_workload("tiny"), make_complex(Nl=17, Nr=60, R=3, knn=10, seed=77)      # two DIFFERENT complexes
+    S = 4
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    e0 = DockEngine.from_model(model, dev, max_batch=8)
+    e1 = DockEngine(dev, max_batch=8)
+    e1.share_weights_from(e0)
+    e0.set_complex(ca)
+    e1.set_complex(cb)
+    g = torch.Generator().manual_seed(2)
+    inputs = []
+    for cplx, B in ((ca, 5), (cb, 3)):
+        torch.manual_seed(B); np.random.seed(B)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        R = int(cplx["ligand"].edge_mask.sum())
+        inputs.append((torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous(),
+                       [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * R, generator=g).to(dev)]))
+    ref = []
+    for e, (p, nz) in zip((e0, e1), inputs):
+        q = p.clone()
+        e.sample(q, steps, *nz)
+        ref.append(q)
+    pa, pb = inputs[0][0].clone(), inputs[1][0].clone()
+    e0.sample_pair(e1, pa, steps, inputs[0][1], pb, inputs[1][1])
+    torch.cuda.synchronize()
+    assert torch.equal(pa, ref[0]) and torch.equal(pb, ref[1])
