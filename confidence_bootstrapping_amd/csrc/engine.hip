@@ -57,6 +57,10 @@ struct PairCtx {
   ConvArgs args[2];
   int grid[2] = {0, 0};
   int rc = 0;
+  // each engine enqueues on its own stream (their small kernels overlap); the merged launch is ordered after both streams
+  // through `ready[rank]` and both streams continue after `done`
+  hipEvent_t ready[2] = {nullptr, nullptr};
+  hipEvent_t done = nullptr;
 };
 
 struct cbd_engine {
@@ -561,21 +565,26 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
   a.stamps = e->stamps_dev;
   if (e->pair && s != e->side) {
     // lockstep with the partner engine: the second to arrive launches one kernel over both batches' groups (same layer,
-    // hence the same weight streams); both continue only after that launch has been enqueued on the shared stream
+    // hence the same weight streams) on its own stream, ordered after the partner's stream; both streams continue after it
     PairCtx& P = *e->pair;
+    const int me = e->pair_rank;
+    HIPCHK(hipEventRecord(P.ready[me], s));
     std::unique_lock<std::mutex> lk(P.m);
     if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
-    P.args[e->pair_rank] = a;
-    P.grid[e->pair_rank] = grid;
+    P.args[me] = a;
+    P.grid[me] = grid;
     if (++P.arrived == 2) {
       ConvArgs m = P.args[0];
       for (int g = 0; g < P.args[1].n_groups; ++g) m.g[m.n_groups + g] = P.args[1].g[g];
       m.n_groups += P.args[1].n_groups;
-      P.rc = launch_conv_timed(e, L, m, P.grid[0] + P.grid[1], s);
-      if (P.rc != 0) P.abort = true;
+      int rc = 0;
+      if (hipStreamWaitEvent(s, P.ready[1 - me], 0) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipStreamWaitEvent failed");
+      if (rc == 0) rc = launch_conv_timed(e, L, m, P.grid[0] + P.grid[1], s);
+      if (rc == 0 && hipEventRecord(P.done, s) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipEventRecord failed");
+      P.rc = rc;
+      if (rc != 0) P.abort = true;
       P.arrived = 0;
       ++P.gen;
-      const int rc = P.rc;
       lk.unlock();
       P.cv.notify_all();
       return rc;
@@ -583,7 +592,10 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     const unsigned my = P.gen;
     P.cv.wait(lk, [&] { return P.gen != my || P.abort; });
     if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
-    return P.rc;
+    const int rc = P.rc;
+    lk.unlock();
+    if (rc == 0) HIPCHK(hipStreamWaitEvent(s, P.done, 0));   // `done` is re-recorded only at the next rendezvous, which needs this thread
+    return rc;
   }
   return launch_conv_timed(e, L, a, grid, s);
 }
@@ -1066,13 +1078,21 @@ int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int3
   if (e0->conv[0].wstream[0] != e1->conv[0].wstream[0]) return fail(CBD_ERR_ARG, "paired engines must share one set of weights (cbd_share_weights)");
   CHK(check_batch(e0, B0));
   CHK(check_batch(e1, B1));
+  HIPCHK(hipSetDevice(e0->cfg.device));
+  hipStream_t s0 = reinterpret_cast<hipStream_t>(stream), s1 = e1->own;
   PairCtx ctx;
+  HIPCHK(hipEventCreateWithFlags(&ctx.ready[0], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx.ready[1], hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ctx.done, hipEventDisableTiming));
+  // engine 1 works on its own stream, ordered after the caller's stream now and joined back at the end
+  HIPCHK(hipEventRecord(e1->ev_a, s0));
+  HIPCHK(hipStreamWaitEvent(s1, e1->ev_a, 0));
   e0->pair = e1->pair = &ctx;
   e0->pair_rank = 0; e1->pair_rank = 1;
   int rc1 = 0;
   std::string err1;
   std::thread partner([&] {
-    rc1 = cbd_sample(e1, B1, S, steps, pos1_dev, noise_tr1, noise_rot1, noise_tor1, nullptr, stream);
+    rc1 = cbd_sample(e1, B1, S, steps, pos1_dev, noise_tr1, noise_rot1, noise_tor1, nullptr, s1);
     if (rc1 != 0) {
       err1 = cbd_last_error();
       std::lock_guard<std::mutex> lk(ctx.m);
@@ -1080,7 +1100,7 @@ int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int3
       ctx.cv.notify_all();
     }
   });
-  const int rc0 = cbd_sample(e0, B0, S, steps, pos0_dev, noise_tr0, noise_rot0, noise_tor0, nullptr, stream);
+  const int rc0 = cbd_sample(e0, B0, S, steps, pos0_dev, noise_tr0, noise_rot0, noise_tor0, nullptr, s0);
   if (rc0 != 0) {
     std::lock_guard<std::mutex> lk(ctx.m);
     ctx.abort = true;
@@ -1088,8 +1108,13 @@ int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int3
   }
   partner.join();
   e0->pair = e1->pair = nullptr;
+  hipError_t je = hipEventRecord(e1->ev_b, s1);
+  if (je == hipSuccess) je = hipStreamWaitEvent(s0, e1->ev_b, 0);
+  // the events may still be referenced by enqueued work: destroying an event with pending work is deferred by the runtime
+  (void)hipEventDestroy(ctx.ready[0]); (void)hipEventDestroy(ctx.ready[1]); (void)hipEventDestroy(ctx.done);
   if (rc0 != 0) return rc0;
   if (rc1 != 0) return fail(rc1, "%s", err1.c_str());
+  HIPCHK(je);
   return 0;
 }
 
