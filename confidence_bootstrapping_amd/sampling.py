@@ -1,6 +1,10 @@
 """`sampling()` and `randomize_position()` with the reference's signatures and semantics
 (reference utils/sampling.py:15-48, 59-274), driving the MI355X engine.
 
+`batch_size` keeps its meaning for the order and sizes of the random draws, but consecutive loader batches of the same
+complex are executed as ONE engine batch (up to the engine capacity, 64 poses): pose samples never interact, results are
+unchanged, and e.g. the reference's default of 10 poses per batch no longer turns into four small GPU launches per layer.
+
 What stays on the host (as in the reference): batching the data list, the schedule scalars of every step
 (engine.make_steps), drawing the N(0,1) noise in the reference's order, writing poses back into `data_list`.
 What moves to the GPU as ONE call per batch: the whole step loop (score model + perturbation + pose update),
@@ -117,16 +121,58 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     use_noise = not (no_random or ode)
     loader = DataLoader(data_list, batch_size=batch_size)
     offset = 0
+    # `batch_size` keeps its reference meaning for the ORDER of the random draws (tr (b,3), rot (b,3), tor (b*R) per step
+    # and per loader batch), but consecutive loader batches of the same complex are executed together as one engine batch
+    # of up to `eng.max_batch` poses: pose samples never interact, so results are unchanged and the GPU sees large launches.
+    pending = []          # (first pose index, b, pos [b,Nl,3] CPU, z_tr, z_rot, z_tor, loader batch)
+    pending_key = None
+
+    def flush():
+        nonlocal pending, pending_key
+        if not pending:
+            return
+        first = pending[0][0]
+        B = sum(p[1] for p in pending)
+        Nl = pending[0][2].shape[1]
+        batch0 = pending[0][6]
+        g, _, _ = _single_complex(batch0)
+        if eng.complex_key != pending_key:
+            eng.set_complex(g, pending_key)
+        R_ = eng.R if not model_args.no_torsion else 0
+        pos = torch.cat([p[2] for p in pending], dim=0).to(device, torch.float32).contiguous()
+        cat = lambda k, dim: None if pending[0][k] is None else torch.cat([p[k] for p in pending], dim=dim)
+        z_tr, z_rot = cat(3, 1), cat(4, 1)
+        z_tor = cat(5, 1) if R_ > 0 else None
+        eng.sample(pos, steps, z_tr, z_rot, z_tor)
+        flat = pos.reshape(B * Nl, 3)
+        for i in range(B):
+            data_list[first + i]["ligand"].pos = flat[i * Nl:(i + 1) * Nl]
+        if conf_model is not None:
+            if filtering_data_list is not None:
+                fbatch = next(iter(DataLoader(filtering_data_list[first:first + 1], batch_size=1)))
+                crop = getattr(filtering_model_args, "crop_beyond", None)
+            else:
+                fbatch, crop = batch0, None
+            fg, _, fNl = _single_all_atom_complex(fbatch)
+            if fNl != Nl:
+                raise RuntimeError("filtering graphs hold a different ligand than the sampled ones")
+            ceng = conf_model.engine(max_batch=eng.max_batch)
+            ckey = complex_fingerprint(fbatch) + (fg["atom"].pos.shape[0],)
+            if ceng.complex_key != ckey:
+                ceng.set_complex(fg, ckey)
+            confidence.append(ceng.score(pos, crop)[0])
+        pending, pending_key = [], None
+
     with torch.no_grad():
         for batch_id, batch in enumerate(loader):
             b = batch.num_graphs
             if b > eng.max_batch:
                 raise RuntimeError(f"batch of {b} exceeds the engine capacity {eng.max_batch}")
-            g, _, Nl = _single_complex(batch)
+            _, _, Nl = _single_complex(batch)
             key = complex_fingerprint(batch)
-            if eng.complex_key != key:
-                eng.set_complex(g, key)
-            R_ = eng.R if not model_args.no_torsion else 0
+            if pending and (key != pending_key or sum(p[1] for p in pending) + b > eng.max_batch):
+                flush()
+            R_ = int(batch["ligand"].edge_mask.sum()) // b if not model_args.no_torsion else 0
             z_tr = z_rot = z_tor = None
             if use_noise:
                 if noise is not None:
@@ -143,30 +189,14 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                             tor_l.append(torch.zeros(b * R_) if last_quiet else torch.normal(mean=0, std=1, size=(b * R_,)))
                     z_tr, z_rot = torch.stack(tr_l), torch.stack(rot_l)
                     z_tor = torch.stack(tor_l) if R_ > 0 else None
-            pos = batch["ligand"].pos.reshape(b, Nl, 3).to(device, torch.float32).contiguous()
-            eng.sample(pos, steps, z_tr, z_rot, z_tor)
-            flat = pos.reshape(b * Nl, 3)
-            for i in range(b):
-                data_list[batch_id * batch_size + i]["ligand"].pos = flat[i * Nl:(i + 1) * Nl]
-            if conf_model is not None:
-                if filtering_data_list is not None:
-                    fbatch = DataLoader(filtering_data_list[offset:offset + b], batch_size=b).__iter__().__next__()
-                    crop = getattr(filtering_model_args, "crop_beyond", None)
-                else:
-                    fbatch, crop = batch, None
-                fg, _, fNl = _single_all_atom_complex(fbatch)
-                if fNl != Nl:
-                    raise RuntimeError("filtering graphs hold a different ligand than the sampled ones")
-                ceng = conf_model.engine(max_batch=max(int(batch_size), 1))
-                ckey = complex_fingerprint(fbatch) + (fg["atom"].pos.shape[0],)
-                if ceng.complex_key != ckey:
-                    ceng.set_complex(fg, ckey)
-                confidence.append(ceng.score(pos, crop)[0])
+            pending.append((offset, b, batch["ligand"].pos.reshape(b, Nl, 3).cpu().float(), z_tr, z_rot, z_tor, batch))
+            pending_key = key
             offset += b
-            if visualization_list is not None:
-                for idx, visualization in enumerate(visualization_list):
-                    visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),
-                                      part=1, order=2)
+        flush()
+        if visualization_list is not None:
+            for idx, visualization in enumerate(visualization_list):
+                visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),
+                                  part=1, order=2)
     if conf_model is not None:
         confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
         return data_list, confidence
