@@ -76,6 +76,9 @@ struct ConvGroup {
   float* last_sum;       // [tiles][NODE_STRIDE]
   float* run_acc;        // [N][NODE_STRIDE], row = aggregating node
   const float* node_in;  // [N][NODE_STRIDE] node features this group's src / dst indices refer to
+  // weight-tile slice executed for this group (run_conv fills the full range): 0e tiles [i0e_lo, i0e_hi) and, if vec_on, the
+  // 1o/1e/0o blocks.  Virtual slices of one edge group write their own piece buffers; the finalize kernel adds them.
+  int i0e_lo, i0e_hi, vec_on;
 };
 
 // Up to 8 groups per launch: the 4 edge groups of one batch, or of TWO batches (two engines working on different complexes
@@ -96,9 +99,10 @@ struct FinGroup {
   const float* last_sum;
   const float* run_acc;
   int node_mod;            // > 0: the group is shared by all samples, node k = i % node_mod (layer-0 receptor edges)
+  int deg_weight;          // 1: its edges count towards the node's in-degree; 0: a further slice of an already counted group
 };
 struct FinArgs {
-  FinGroup g[2];
+  FinGroup g[4];
   int n_groups;
 };
 

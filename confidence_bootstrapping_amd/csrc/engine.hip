@@ -101,6 +101,7 @@ struct cbd_engine {
   // per edge group (ll, lr, rr, rl, rr0 = single-copy receptor graph): pieces of the deterministic segmented reduction
   float *fsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *lsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* racc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float *fsum_x[2] = {nullptr, nullptr}, *lsum_x[2] = {nullptr, nullptr}, *racc_x[2] = {nullptr, nullptr};   // extra slices of ll (embedding layers)
   int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
   int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges
   hipStream_t own = nullptr;        // used instead of the legacy default stream for graph capture (which cannot be captured)
@@ -560,6 +561,9 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     a.g[g] = groups[g];
     a.g[g].wstream = (e->use_bf16 ? L.wstream_bf16 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
     a.g[g].node_in = node_in;
+    if (a.g[g].i0e_hi == 0 && a.g[g].vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
+      a.g[g].i0e_lo = 0; a.g[g].i0e_hi = conv_shape(L.in_level, L.out_level).t0e; a.g[g].vec_on = 1;
+    }
     grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
   }
   a.stamps = e->stamps_dev;
@@ -604,6 +608,7 @@ static FinGroup fin_group(const ConvGroup& g, const int* start, const int* cnt, 
   FinGroup f{};
   f.start = start; f.cnt = cnt; f.total = g.count; f.first_sum = g.first_sum; f.last_sum = g.last_sum; f.run_acc = g.run_acc;
   f.node_mod = node_mod;
+  f.deg_weight = 1;
   return f;
 }
 
@@ -799,6 +804,12 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
       HIPCHK(e->bpool.alloc(&e->lsum[g], tiles * NODE_STRIDE));
       HIPCHK(e->bpool.alloc(&e->racc[g], (size_t)(g == 4 ? Nr : N) * NODE_STRIDE));
     }
+    for (int k = 0; k < 2; ++k) {
+      const size_t tiles = (cap_ll + CONV_WG_EDGES - 1) / CONV_WG_EDGES + 1;
+      HIPCHK(e->bpool.alloc(&e->fsum_x[k], tiles * NODE_STRIDE));
+      HIPCHK(e->bpool.alloc(&e->lsum_x[k], tiles * NODE_STRIDE));
+      HIPCHK(e->bpool.alloc(&e->racc_x[k], (size_t)Bm * Nl * NODE_STRIDE));
+    }
     std::vector<int> row0(Nr + 1, 0);
     for (int r = 0; r < Nr; ++r) row0[r + 1] = row0[r] + deg0[r];
     std::vector<int> bstart((size_t)Bm * Nr), bcnt((size_t)Bm * Nr);
@@ -896,8 +907,28 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   float* out = Xb;
   static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
   for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
-    CHK(run_conv(e, e->lig_emb[l], &gll, 1, &cap_ll, in, s));
-    CHK(run_finalize(e, e->lig_emb[l], in, out, &f_ll, 1, nL, 0, s));
+    // These launches hold only ~10 edge tiles per pose (a fraction of one round of waves) and are bound by the length of a
+    // wave's weight-tile chain: split the chain over 2-3 waves per edge tile (virtual slices of the ll group, own pieces).
+    const ConvShape ES = conv_shape(e->lig_emb[l].in_level, e->lig_emb[l].out_level);
+    const int tvec = ES.t1o + ES.t1e + ES.t0o, nsl = 2;   // the same slicing with and without a partner engine: identical results
+    const int per = (ES.t0e + tvec + nsl - 1) / nsl;
+    const int c_lo = ES.t0e - std::max(0, std::min(ES.t0e, per - tvec));   // 0e tiles the vector slice also takes
+    ConvGroup sl[3];
+    FinGroup fsl[3];
+    int caps_sl[3];
+    for (int k = 0; k < nsl; ++k) {
+      sl[k] = gll;
+      if (k > 0) { sl[k].first_sum = e->fsum_x[k - 1]; sl[k].last_sum = e->lsum_x[k - 1]; sl[k].run_acc = e->racc_x[k - 1]; }
+      if (k == nsl - 1) { sl[k].i0e_lo = c_lo; sl[k].i0e_hi = ES.t0e; sl[k].vec_on = 1; }
+      else { sl[k].i0e_lo = c_lo * k / (nsl - 1); sl[k].i0e_hi = c_lo * (k + 1) / (nsl - 1); sl[k].vec_on = 0; }
+      if (sl[k].i0e_hi == 0 && sl[k].vec_on == 0) sl[k].i0e_hi = sl[k].i0e_lo = 0, sl[k].vec_on = 0;
+      fsl[k] = fin_group(sl[k], gd.start_ll, gd.cnt_ll);
+      fsl[k].deg_weight = k == 0 ? 1 : 0;
+      caps_sl[k] = cap_ll;
+    }
+    const int widx_sl[3] = {0, 0, 0};
+    CHK(run_conv(e, e->lig_emb[l], sl, nsl, caps_sl, in, s, widx_sl));
+    CHK(run_finalize(e, e->lig_emb[l], in, out, fsl, nsl, nL, 0, s));
     std::swap(in, out);
     snap(e, emb_names[l], in, (size_t)nL * NODE_STRIDE, s);
   }

@@ -189,14 +189,22 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
   f32x16 acc;
   bf16x8 h1[BQ];
   // the stream carries one zero tile after the last real one, so the prefetch of tile T+1 is always in bounds
-#define CBD_TILE(BOP)                                                                  \
-  gemm_tile_b(a, gp + (size_t)(T + 1) * BTILE_FRAGS, bias_l + T * 32, BOP, acc, hf); \
-  ++T
+#define CBD_TILE(BOP, NEXT)                                                           \
+  {                                                                                   \
+    const int tn_ = (NEXT);                                                           \
+    gemm_tile_b(a, gp + (size_t)tn_ * BTILE_FRAGS, bias_l + T * 32, BOP, acc, hf);    \
+    T = tn_;                                                                          \
+  }
 
   // ---- first Linear (3 tiles): h1 = ReLU(W1 x + b1), kept in the C/D register layout
+  // A group may be a VIRTUAL slice of an edge group (ConvGroup::i0e_lo/hi, vec_on): the same edges, but only the 0e tiles
+  // [lo, hi) and/or the vector blocks -- several waves then share one 32-edge tile's weight-tile chain (short launches)
+  const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
+  const bool vec_on = G.vec_on != 0;
+  const int T_vec = 3 + S.t0e;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    CBD_TILE(Bx);
+    CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
 #pragma unroll
     for (int r = 0; r < 16; ++r) h1[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
   }
@@ -207,8 +215,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
 #pragma unroll 1
-  for (int i = 0; i < S.t0e; ++i) {
-    CBD_TILE(h1);
+  for (int i = i_lo; i < i_hi; ++i) {
+    CBD_TILE(h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
     const float m = mid0e<IN>(xc, i, v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
   auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
-      CBD_TILE(h1);
+      CBD_TILE(h1, T + 1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
         float m[3];
@@ -240,13 +248,14 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
     }
   };
 
+  if (vec_on) {
   vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); }, S.t1o, k1o);
   if constexpr (OUT >= 2)
     vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); }, S.t1e, k1e);
   if constexpr (OUT >= 3) {
 #pragma unroll 1
     for (int t = 0; t < S.t0o; ++t) {
-      CBD_TILE(h1);
+      CBD_TILE(h1, T + 1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
         const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
@@ -254,6 +263,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_bf16_kernel(ConvArgs args) {
         for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
       }
     }
+  }
   }
 
 #undef CBD_TILE
