@@ -354,3 +354,13 @@ def test_sample_pair_equals_two_samples():
     e0.sample_pair(e1, pa, steps, inputs[0][1], pb, inputs[1][1])
     torch.cuda.synchronize()
     assert torch.equal(pa, ref[0]) and torch.equal(pb, ref[1])
+    # error paths: a failing partner (batch over capacity) must not leave the other engine waiting at the rendezvous
+    too_many = torch.zeros(9, inputs[1][0].shape[1], 3, device=dev)
+    with pytest.raises(RuntimeError):
+        e0.sample_pair(e1, pa, steps, inputs[0][1], too_many, None)
+    with pytest.raises(RuntimeError):
+        e0.sample_pair(e0, pa, steps, inputs[0][1], pa, inputs[0][1])
+    # and the engines stay usable afterwards
+    q = inputs[0][0].clone()
+    e0.sample(q, steps, *inputs[0][1])
+    assert torch.equal(q, ref[0])
