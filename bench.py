@@ -128,8 +128,8 @@ def main():
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3])")
-    ap.add_argument("--pair", type=int, default=1, help="1: co-schedule consecutive complexes two at a time (cbd_sample_pair: one "
-                    "tensor-product launch covers both 40-pose batches); 0: one complex at a time")
+    ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
+                    "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..4 = that many")
     a = ap.parse_args()
     WORKLOAD, SAMPLES, DENOISE_STEPS = a.workload, a.samples, a.denoise_steps
 
@@ -145,7 +145,7 @@ def main():
 
     from confidence_bootstrapping_amd.synthetic import make_workload
     from confidence_bootstrapping_amd.utils import make_score_model
-    from confidence_bootstrapping_amd.engine import DockEnginePool, make_steps
+    from confidence_bootstrapping_amd.engine import DockEngine, DockEnginePool, make_steps
     from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
     from confidence_bootstrapping_amd.sampling import randomize_position
     from confidence_bootstrapping_amd import Batch
@@ -157,12 +157,15 @@ def main():
     eng.set_complex(cplx)
     eng.set_option("graph", a.graph)
     eng.set_option("bf16", int(a.dtype == "bf16"))
-    pair = bool(a.pair) and a.streams == 1 and not a.graph
-    eng2 = None
-    if pair:   # second engine (own workspace, same device-resident weights) for the complex that is co-scheduled
-        eng2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
-        eng2.set_complex(cplx)
-        eng2.set_option("bf16", int(a.dtype == "bf16"))
+    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 4))) if (a.pair and a.streams == 1 and not a.graph) else 1
+    pair = cosched > 1
+    extra = []   # further engines (own workspace, same device-resident weights) for the complexes that are co-scheduled
+    for _ in range(cosched - 1):
+        e2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
+        e2.set_complex(cplx)
+        e2.set_option("bf16", int(a.dtype == "bf16"))
+        extra.append(e2)
+    eng2 = extra[0] if extra else None
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
     steps = make_steps(sched, margs, model.timestep_emb_func)
     R = eng.R
@@ -187,10 +190,13 @@ def main():
         k = lo
         while k < hi:
             if pair and k + 1 < hi:
-                eng.recompute_receptor()
-                eng2.recompute_receptor()
-                eng.engines[0].sample_pair(eng2.engines[0], pos0[k], steps, noise[k], pos0[k + 1], noise[k + 1])
-                k += 2
+                m = min(cosched, hi - k)
+                pools = [eng] + extra[:m - 1]
+                for p_ in pools:
+                    p_.recompute_receptor()
+                DockEngine.sample_multi([p_.engines[0] for p_ in pools], [pos0[k + q] for q in range(m)], steps,
+                                        [noise[k + q] for q in range(m)])
+                k += m
             else:
                 one_complex(k)
                 k += 1
@@ -199,9 +205,9 @@ def main():
     torch.cuda.synchronize()
     eng.kernel_timing(enable=not a.graph, reset=True)
     eng.stats(reset=True)
-    if eng2 is not None:
-        eng2.kernel_timing(enable=True, reset=True)
-        eng2.stats(reset=True)
+    for e2 in extra:
+        e2.kernel_timing(enable=True, reset=True)
+        e2.stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -219,11 +225,11 @@ def main():
         elapsed = float(tmax.item())
     avg_ms, n_launch, total_ms = eng.kernel_timing(enable=False)
     st = eng.stats()
-    if eng2 is not None:   # merged launches are timed by whichever engine arrived second at the rendezvous
-        _, n2, t2 = eng2.kernel_timing(enable=False)
+    for e2 in extra:   # merged launches are timed by whichever engine arrived last at the rendezvous
+        _, n2, t2 = e2.kernel_timing(enable=False)
         n_launch, total_ms = n_launch + n2, total_ms + t2
         avg_ms = total_ms / max(n_launch, 1)
-        st = {k: st[k] + v for k, v in eng2.stats().items()}
+        st = {k: st[k] + v for k, v in e2.stats().items()}
     assert torch.isfinite(pos0[n_runs - 1]).all(), "non-finite poses"
 
     if rank == 0:
@@ -248,7 +254,7 @@ def main():
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS, "streams": a.streams,
-                       "co_scheduled_complexes": 2 if pair else 1,
+                       "co_scheduled_complexes": cosched,
                        "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel" if a.dtype == "f32" else "tp_conv_bf16_kernel",

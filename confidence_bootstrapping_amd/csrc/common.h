@@ -81,9 +81,11 @@ struct ConvGroup {
   int i0e_lo, i0e_hi, vec_on;
 };
 
-// Up to 8 groups per launch: the 4 edge groups of one batch, or of TWO batches (two engines working on different complexes
-// co-scheduled by cbd_sample_pair so that one launch carries twice the waves -- the per-launch drain is amortised).
-constexpr int CONV_MAX_GROUPS = 8;
+// Up to 16 groups per launch: the 4 edge groups of one batch, or of up to FOUR batches (engines working on different
+// complexes co-scheduled by cbd_sample_multi so that one launch carries several times the waves -- the per-launch drain is
+// amortised).
+constexpr int CONV_MAX_GROUPS = 16;
+constexpr int CONV_MAX_COSCHED = 4;
 struct ConvArgs {
   ConvGroup g[CONV_MAX_GROUPS];
   int n_groups;

@@ -54,12 +54,13 @@ struct PairCtx {
   int arrived = 0;
   unsigned gen = 0;
   bool abort = false;
-  ConvArgs args[2];
-  int grid[2] = {0, 0};
+  int n = 2;                        // engines taking part
+  ConvArgs args[CONV_MAX_COSCHED];
+  int grid[CONV_MAX_COSCHED] = {0, 0, 0, 0};
   int rc = 0;
   // each engine enqueues on its own stream (their small kernels overlap); the merged launch is ordered after both streams
   // through `ready[rank]` and both streams continue after `done`
-  hipEvent_t ready[2] = {nullptr, nullptr};
+  hipEvent_t ready[CONV_MAX_COSCHED] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t done = nullptr;
 };
 
@@ -577,13 +578,17 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
     P.args[me] = a;
     P.grid[me] = grid;
-    if (++P.arrived == 2) {
+    if (++P.arrived == P.n) {
       ConvArgs m = P.args[0];
-      for (int g = 0; g < P.args[1].n_groups; ++g) m.g[m.n_groups + g] = P.args[1].g[g];
-      m.n_groups += P.args[1].n_groups;
-      int rc = 0;
-      if (hipStreamWaitEvent(s, P.ready[1 - me], 0) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipStreamWaitEvent failed");
-      if (rc == 0) rc = launch_conv_timed(e, L, m, P.grid[0] + P.grid[1], s);
+      int grid_all = P.grid[0], rc = 0;
+      for (int k = 1; k < P.n; ++k) {
+        for (int g = 0; g < P.args[k].n_groups; ++g) m.g[m.n_groups + g] = P.args[k].g[g];
+        m.n_groups += P.args[k].n_groups;
+        grid_all += P.grid[k];
+      }
+      for (int k = 0; k < P.n && rc == 0; ++k)
+        if (k != me && hipStreamWaitEvent(s, P.ready[k], 0) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipStreamWaitEvent failed");
+      if (rc == 0) rc = launch_conv_timed(e, L, m, grid_all, s);
       if (rc == 0 && hipEventRecord(P.done, s) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipEventRecord failed");
       P.rc = rc;
       if (rc != 0) P.abort = true;
@@ -1100,53 +1105,77 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
   return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
 }
 
-int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int32_t S, const cbd_step* steps, float* pos0_dev,
-                    const float* noise_tr0, const float* noise_rot0, const float* noise_tor0, float* pos1_dev,
-                    const float* noise_tr1, const float* noise_rot1, const float* noise_tor1, void* stream) {
-  if (!e0 || !e1 || e0 == e1) return fail(CBD_ERR_ARG, "two distinct engines are required");
-  if (e0->cfg.device != e1->cfg.device) return fail(CBD_ERR_ARG, "paired engines must live on the same device");
-  if (e0->use_bf16 != e1->use_bf16) return fail(CBD_ERR_ARG, "paired engines must use the same operand precision");
-  if (e0->conv[0].wstream[0] != e1->conv[0].wstream[0]) return fail(CBD_ERR_ARG, "paired engines must share one set of weights (cbd_share_weights)");
-  CHK(check_batch(e0, B0));
-  CHK(check_batch(e1, B1));
+int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, int32_t S, const cbd_step* steps, float* const* pos_dev,
+                     const float* const* noise_tr, const float* const* noise_rot, const float* const* noise_tor, void* stream) {
+  if (n < 1 || n > CONV_MAX_COSCHED || !engines || !B || !pos_dev) return fail(CBD_ERR_ARG, "1..%d engines are required", CONV_MAX_COSCHED);
+  auto nz = [](const float* const* a, int k) { return a ? a[k] : nullptr; };
+  if (n == 1) return cbd_sample(engines[0], B[0], S, steps, pos_dev[0], nz(noise_tr, 0), nz(noise_rot, 0), nz(noise_tor, 0), nullptr, stream);
+  cbd_engine* e0 = engines[0];
+  for (int k = 0; k < n; ++k) {
+    cbd_engine* e = engines[k];
+    if (!e) return fail(CBD_ERR_ARG, "null engine");
+    for (int q = 0; q < k; ++q)
+      if (engines[q] == e) return fail(CBD_ERR_ARG, "distinct engines are required");
+    if (e->cfg.device != e0->cfg.device) return fail(CBD_ERR_ARG, "co-scheduled engines must live on the same device");
+    if (e->use_bf16 != e0->use_bf16) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
+    if (!e->weights_ready || !e0->weights_ready || e->conv[0].wstream[0] != e0->conv[0].wstream[0])
+      return fail(CBD_ERR_ARG, "co-scheduled engines must share one set of weights (cbd_share_weights)");
+    CHK(check_batch(e, B[k]));
+  }
   HIPCHK(hipSetDevice(e0->cfg.device));
-  hipStream_t s0 = reinterpret_cast<hipStream_t>(stream), s1 = e1->own;
+  hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
   PairCtx ctx;
-  HIPCHK(hipEventCreateWithFlags(&ctx.ready[0], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&ctx.ready[1], hipEventDisableTiming));
+  ctx.n = n;
+  for (int k = 0; k < n; ++k) HIPCHK(hipEventCreateWithFlags(&ctx.ready[k], hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ctx.done, hipEventDisableTiming));
-  // engine 1 works on its own stream, ordered after the caller's stream now and joined back at the end
-  HIPCHK(hipEventRecord(e1->ev_a, s0));
-  HIPCHK(hipStreamWaitEvent(s1, e1->ev_a, 0));
-  e0->pair = e1->pair = &ctx;
-  e0->pair_rank = 0; e1->pair_rank = 1;
-  int rc1 = 0;
-  std::string err1;
-  std::thread partner([&] {
-    rc1 = cbd_sample(e1, B1, S, steps, pos1_dev, noise_tr1, noise_rot1, noise_tor1, nullptr, s1);
-    if (rc1 != 0) {
-      err1 = cbd_last_error();
+  // engines 1.. work on their own streams, ordered after the caller's stream now and joined back at the end
+  for (int k = 1; k < n; ++k) {
+    HIPCHK(hipEventRecord(engines[k]->ev_a, s0));
+    HIPCHK(hipStreamWaitEvent(engines[k]->own, engines[k]->ev_a, 0));
+  }
+  for (int k = 0; k < n; ++k) { engines[k]->pair = &ctx; engines[k]->pair_rank = k; }
+  int rc[CONV_MAX_COSCHED] = {0, 0, 0, 0};
+  std::string err[CONV_MAX_COSCHED];
+  auto body = [&](int k) {
+    rc[k] = cbd_sample(engines[k], B[k], S, steps, pos_dev[k], nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), nullptr,
+                       k == 0 ? s0 : engines[k]->own);
+    if (rc[k] != 0) {
+      err[k] = cbd_last_error();
       std::lock_guard<std::mutex> lk(ctx.m);
       ctx.abort = true;
       ctx.cv.notify_all();
     }
-  });
-  const int rc0 = cbd_sample(e0, B0, S, steps, pos0_dev, noise_tr0, noise_rot0, noise_tor0, nullptr, s0);
-  if (rc0 != 0) {
-    std::lock_guard<std::mutex> lk(ctx.m);
-    ctx.abort = true;
-    ctx.cv.notify_all();
+  };
+  std::vector<std::thread> partners;
+  for (int k = 1; k < n; ++k) partners.emplace_back(body, k);
+  body(0);
+  for (auto& t : partners) t.join();
+  hipError_t je = hipSuccess;
+  for (int k = 0; k < n; ++k) engines[k]->pair = nullptr;
+  for (int k = 1; k < n && je == hipSuccess; ++k) {
+    je = hipEventRecord(engines[k]->ev_b, engines[k]->own);
+    if (je == hipSuccess) je = hipStreamWaitEvent(s0, engines[k]->ev_b, 0);
   }
-  partner.join();
-  e0->pair = e1->pair = nullptr;
-  hipError_t je = hipEventRecord(e1->ev_b, s1);
-  if (je == hipSuccess) je = hipStreamWaitEvent(s0, e1->ev_b, 0);
   // the events may still be referenced by enqueued work: destroying an event with pending work is deferred by the runtime
-  (void)hipEventDestroy(ctx.ready[0]); (void)hipEventDestroy(ctx.ready[1]); (void)hipEventDestroy(ctx.done);
-  if (rc0 != 0) return rc0;
-  if (rc1 != 0) return fail(rc1, "%s", err1.c_str());
+  for (int k = 0; k < n; ++k) (void)hipEventDestroy(ctx.ready[k]);
+  (void)hipEventDestroy(ctx.done);
+  for (int k = 0; k < n; ++k)
+    if (rc[k] != 0) return fail(rc[k], "%s", err[k].c_str());
   HIPCHK(je);
   return 0;
+}
+
+int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int32_t S, const cbd_step* steps, float* pos0_dev,
+                    const float* noise_tr0, const float* noise_rot0, const float* noise_tor0, float* pos1_dev,
+                    const float* noise_tr1, const float* noise_rot1, const float* noise_tor1, void* stream) {
+  cbd_engine* es[2] = {e0, e1};
+  const int32_t Bs[2] = {B0, B1};
+  float* ps[2] = {pos0_dev, pos1_dev};
+  const float* tr[2] = {noise_tr0, noise_tr1};
+  const float* rot[2] = {noise_rot0, noise_rot1};
+  const float* tor[2] = {noise_tor0, noise_tor1};
+  if (!e0 || !e1 || e0 == e1) return fail(CBD_ERR_ARG, "two distinct engines are required");
+  return cbd_sample_multi(2, es, Bs, S, steps, ps, tr, rot, tor, stream);
 }
 
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {

@@ -53,6 +53,7 @@ SYMBOLS = {
     "cbd_modify_conformer": (C.c_int, [_P, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_sample": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P, _P]),
     "cbd_sample_pair": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(cbd_step)] + [_P] * 9),
+    "cbd_sample_multi": (C.c_int, [C.c_int32, _P, C.POINTER(C.c_int32), C.c_int32, C.POINTER(cbd_step), _P, _P, _P, _P, _P]),
     "cbd_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cbd_share_weights": (C.c_int, [_P, _P]),
     "cbd_recompute_receptor": (C.c_int, [_P, _P]),
@@ -275,6 +276,23 @@ class DockEngine:
             _check(self.lib.cbd_sample_pair(self.h, other.h, pos.shape[0], other_pos.shape[0], len(steps), steps, _dptr(pos),
                                             _dptr(n0[0]), _dptr(n0[1]), _dptr(n0[2]), _dptr(other_pos), _dptr(n1[0]), _dptr(n1[1]),
                                             _dptr(n1[2]), self._stream()))
+
+    @staticmethod
+    def sample_multi(engines, poses, steps, noises):
+        """cbd_sample_multi: up to 4 engines (sharing weights, each with its own complex) advanced in lockstep with merged
+        tensor-product launches.  poses: list of [b,Nl,3] device tensors (updated in place); noises: list of (tr, rot, tor) or None."""
+        n = len(engines)
+        e0 = engines[0]
+        f = lambda x: None if x is None else x.to(e0.device, torch.float32).contiguous()
+        nz = [[f(x) for x in (nn or (None, None, None))] for nn in noises]
+        for p in poses:
+            assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()
+        arr = lambda vals: (C.c_void_p * n)(*[None if v is None else v.data_ptr() for v in vals])
+        hs = (C.c_void_p * n)(*[e.h.value for e in engines])
+        Bs = (C.c_int32 * n)(*[p.shape[0] for p in poses])
+        with torch.cuda.device(e0.device):
+            _check(e0.lib.cbd_sample_multi(n, hs, Bs, len(steps), steps, arr(poses), arr([z[0] for z in nz]), arr([z[1] for z in nz]),
+                                           arr([z[2] for z in nz]), e0._stream()))
 
     def recompute_receptor(self):
         with torch.cuda.device(self.device):

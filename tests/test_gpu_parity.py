@@ -354,6 +354,17 @@ def test_sample_pair_equals_two_samples():
     e0.sample_pair(e1, pa, steps, inputs[0][1], pb, inputs[1][1])
     torch.cuda.synchronize()
     assert torch.equal(pa, ref[0]) and torch.equal(pb, ref[1])
+    # three engines (third = a second copy of complex A with its own poses) through cbd_sample_multi
+    e2 = DockEngine(dev, max_batch=8)
+    e2.share_weights_from(e0)
+    e2.set_complex(ca)
+    pc_in = inputs[0][0].flip(0).contiguous()
+    pc_ref = pc_in.clone()
+    e2.sample(pc_ref, steps, *inputs[0][1])
+    pa, pb, pc = inputs[0][0].clone(), inputs[1][0].clone(), pc_in.clone()
+    DockEngine.sample_multi([e0, e1, e2], [pa, pb, pc], steps, [inputs[0][1], inputs[1][1], inputs[0][1]])
+    torch.cuda.synchronize()
+    assert torch.equal(pa, ref[0]) and torch.equal(pb, ref[1]) and torch.equal(pc, pc_ref)
     # error paths: a failing partner (batch over capacity) must not leave the other engine waiting at the rendezvous
     too_many = torch.zeros(9, inputs[1][0].shape[1], 3, device=dev)
     with pytest.raises(RuntimeError):
