@@ -239,9 +239,9 @@ def main():
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
         flops_per_launch = total_flops / max(n_launch, 1)
         traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tp = os.path.join(ROOT, "profiles", "r01_d_traffic.json")
+        tp = os.path.join(ROOT, "profiles", "r01_f_traffic.json")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
         if os.path.exists(tp):
-            traffic = round(json.load(open(tp))["hbm_bytes_per_launch"])
+            traffic = round(json.load(open(tp))["hbm_bytes_per_launch_all_tp_conv"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         headline = (WORKLOAD, SAMPLES, DENOISE_STEPS, a.dtype) == ("c2_dockgen_median", 40, 20, "f32")
         peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS

@@ -20,6 +20,7 @@ def load(path):
 
 def main():
     root, tag = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[3] if len(sys.argv) > 3 else "bench.py"
     out_rows, per = [], {}
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
         rows = load(os.path.join(root, c, "p_counter_collection.csv"))
@@ -38,9 +39,12 @@ def main():
     m = {(n, c): mean for n, c, _, mean, _, _ in out_rows}
     fetch, write = m[("tp_conv<3,3>", "FETCH_SIZE")], m[("tp_conv<3,3>", "WRITE_SIZE")]
     busy = sum(per[("tp_conv<3,3>", "SQ_VALU_MFMA_BUSY_CYCLES")]) / (sum(per[("tp_conv<3,3>", "GRBM_GUI_ACTIVE")]) / 8 * 1024)
+    allf = per[("tp_conv<3,3>", "FETCH_SIZE")] + per.get(("tp_conv<embedding layers>", "FETCH_SIZE"), [])
+    allw = per[("tp_conv<3,3>", "WRITE_SIZE")] + per.get(("tp_conv<embedding layers>", "WRITE_SIZE"), [])
     j = {"kernel": "tp_conv_kernel<3,3>", "hbm_bytes_per_launch": (2 * fetch + write) * 1024, "fetch_size_kb": fetch, "write_size_kb": write,
+         "hbm_bytes_per_launch_all_tp_conv": (2 * sum(allf) / len(allf) + sum(allw) / len(allw)) * 1024, "launches_all_tp_conv": len(allf),
          "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE in separate passes over "
-                 "`bench.py --steps 1 --warmup 0`; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section); mean over the "
+                 f"`{cmd}`; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section); mean over the "
                  f"{len(per[('tp_conv<3,3>', 'FETCH_SIZE')])} tp_conv<3,3> launches", "mfma_busy_frac": busy}
     json.dump(j, open(os.path.join(prof, f"{tag}_traffic.json"), "w"), indent=1)
     print(json.dumps(j))
