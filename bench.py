@@ -257,7 +257,7 @@ def main():
                        "co_scheduled_complexes": cosched,
                        "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel" if a.dtype == "f32" else "tp_conv_bf16_kernel",
+            "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel<OpsF32>" if a.dtype == "f32" else "tp_conv_kernel<OpsBf16>",
                          "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,

@@ -35,7 +35,7 @@ namespace {
 struct ConvLayerDev {
   int in_level = 0, out_level = 0, n_groups = 0;
   float* wstream[4] = {nullptr, nullptr, nullptr, nullptr};
-  float* wstream_bf16[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16-operand variant (tp_conv_bf16.hip)
+  float* wstream_bf16[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16-operand policy (tp_conv.hip::OpsBf16)
   float *bn_scale = nullptr, *bn_mean = nullptr, *bn_bias = nullptr;   // [NODE_STRIDE]
 };
 
@@ -231,7 +231,7 @@ static std::vector<float> pack_rows_f32(const TileRows& tr, const float* W1, con
   return out;
 }
 
-// bf16 stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] (6 KB), then the fp32 bias table.
+// bf16 stream of tp_conv.hip::OpsBf16: (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] (6 KB), then the fp32 bias table.
 static uint16_t f32_to_bf16_rne(float f) {
   uint32_t u;
   memcpy(&u, &f, 4);

@@ -6,7 +6,8 @@
 // replacing reference models/tensor_layers.py:195-206 (FCBlock -> FasterTensorProduct.forward:66-117 ->
 // torch_scatter.scatter) without ever materialising the [E, W] per-edge weight tensor in HBM.
 //
-// Mapping onto the matrix cores (exact fp32, v_mfma_f32_32x32x2_f32):
+// Mapping onto the matrix cores (described for the exact-fp32 policy OpsF32, v_mfma_f32_32x32x2_f32; OpsBf16 below is the
+// bf16-operand policy of the same kernel):
 //   D[row = weight column, col = edge] = sum_k  A[row][k] * B[k][edge]
 //   * B (activations) lives in registers for the whole tile: lane (j = lane&31, hf = lane>>5) holds
 //     act[edge j][k(s, hf)] for the 48 k-steps s.  The accumulator of the first Linear (after bias+ReLU) IS the
@@ -41,35 +42,81 @@ __device__ __forceinline__ unsigned long long stamp() {
   return t;
 }
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
+// ---- operand policies: how the two Linears of the radial MLP run on the matrix cores ------------------------------------
+// One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers, loaded one tile ahead
+// straight from global/L2 in MFMA operand order; each fragment register is refilled with the NEXT tile's data right after its
+// last use, so the loads have a whole tile of MFMA time to land and no barrier or LDS staging is involved.
+//
+// OpsF32: exact fp32, v_mfma_f32_32x32x2_f32, 48 k-steps, 12 float4 fragments (12 KB tile).
+struct OpsF32 {
+  using Frag = f32x4;
+  static constexpr int NFRAG = KSTEPS / 4;                 // 12
+  static constexpr int TILE_FRAGS = TILE_W_FLOATS / 4;     // 768 fragments of 16 B per tile
+  struct Act { float v[KSTEPS]; };                         // B operand: lane (j, hf) holds act[edge j][k(s, hf)] for the 48 k-steps
+  // gathered input columns 16hf + 4q .. +3 of part `seg` (edge_attr | x_src | x_dst)
+  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
+    B.v[16 * seg + 4 * q + 0] = x.x; B.v[16 * seg + 4 * q + 1] = x.y; B.v[16 * seg + 4 * q + 2] = x.z; B.v[16 * seg + 4 * q + 3] = x.w;
+  }
+  // ReLU'd accumulator of hidden tile m IS the B operand of the second Linear (W2's k order follows the C/D layout)
+  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h.v[16 * m + r] = fmaxf(acc[r], 0.f);
+  }
+  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int sg = 0; sg < NFRAG; ++sg) {
+      const f32x4 w = a[sg];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * sg + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * sg + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * sg + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * sg + 3], acc, 0, 0, 0);
+      a[sg] = next[sg * 64];
+      // keep the refill right behind its last use: without this hipcc sinks all 12 loads to the end of the tile and the
+      // next tile then starts by waiting a full L2 round trip
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
 
-// One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers (a[12], 48 VGPRs,
-// loaded one tile ahead straight from global/L2 in MFMA operand order: 12 fully coalesced 1 KB wave loads per tile);
-// each fragment register is refilled with the NEXT tile's data right after its last use, so the loads have a whole
-// tile of MFMA time (~3000 cycles) to land and no barrier or LDS staging is involved.
-template <int VAR>
-__device__ __forceinline__ void gemm_tile(f32x4 (&a)[KSTEPS / 4], const f32x4* __restrict__ next, const float* __restrict__ bias_l,
-                                          const float (&B)[KSTEPS], f32x16& acc, int hf) {
+// OpsBf16: bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16, 6 k-steps of 16, 6 fragments of 8 bf16 (6 KB tile).
+// Lane (r = lane&31, h = lane>>5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7 (cdna_hip_programming.md
+// section 3).  Registers 8s..8s+7 of hidden tile m are the fragment of k-step 2m+s: element j of lane half h is hidden unit
+// 32m + 16s + 8(j>>2) + 4h + (j&3); W2's k order is permuted to match at pack time (pack_conv_stream_bf16).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+struct OpsBf16 {
+  using Frag = bf16x8;
+  static constexpr int NFRAG = KDIM / 16;                  // 6
+  static constexpr int TILE_FRAGS = NFRAG * 64;            // 384 fragments of 16 B per tile
+  struct Act { bf16x8 v[NFRAG]; };
+  // k-step 2*seg + sub covers input columns 16hf + 8sub .. +7 of part seg; q = 2*sub + half
+  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
+    const int k = 2 * seg + (q >> 1), o = 4 * (q & 1);
+    B.v[k][o + 0] = (__bf16)x.x; B.v[k][o + 1] = (__bf16)x.y; B.v[k][o + 2] = (__bf16)x.z; B.v[k][o + 3] = (__bf16)x.w;
+  }
+  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
+  }
+  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < NFRAG; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B.v[q], acc, 0, 0, 0);
+      a[q] = next[q * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+template <class Ops>
+__device__ __forceinline__ void gemm_tile(typename Ops::Frag (&a)[Ops::NFRAG], const typename Ops::Frag* __restrict__ next,
+                                          const float* __restrict__ bias_l, const typename Ops::Act& B, f32x16& acc, int hf) {
   const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     f32x4 b = bp[2 * q + hf];
     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
   }
-#pragma unroll
-  for (int sg = 0; sg < KSTEPS / 4; ++sg) {
-    const f32x4 w = a[sg];
-    acc = mfma32(w.x, B[4 * sg + 0], acc);
-    acc = mfma32(w.y, B[4 * sg + 1], acc);
-    acc = mfma32(w.z, B[4 * sg + 2], acc);
-    acc = mfma32(w.w, B[4 * sg + 3], acc);
-    a[sg] = next[sg * 64];
-    // keep the refill right behind its last use: without this hipcc sinks all 12 loads to the end of the tile and the
-    // next tile then starts by waiting a full L2 round trip
-    __builtin_amdgcn_sched_barrier(0);
-  }
+  Ops::gemm(a, next, B, acc);
 }
 
 // "mid" evaluators: value of the CG intermediate with index i for edge j (xc = &xT[0][j], column stride 32).
@@ -138,7 +185,7 @@ constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed 
 constexpr int OUT_STRIDE = 33;                           // message tile stride (conflict-free column reads)
 __host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
-template <int IN, int OUT, int VAR>
+template <int IN, int OUT, int VAR, class Ops>
 __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -167,12 +214,13 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   if constexpr (VAR == 8) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
-  const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*768 + sg*64]
-  f32x4 a[KSTEPS / 4];
+  using Frag = typename Ops::Frag;
+  const Frag* gp = reinterpret_cast<const Frag*>(G.wstream) + lane;   // tile T fragment sg: gp[T * TILE_FRAGS + sg * 64]
+  Frag a[Ops::NFRAG];
 #pragma unroll
-  for (int sg = 0; sg < KSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  for (int sg = 0; sg < Ops::NFRAG; ++sg) a[sg] = gp[sg * 64];
   {  // bias table -> LDS: fixed number of unconditional, clamped loads (a counted loop compiles to a load/wait waterfall)
-    const f32x4* gb = reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * TILE_W_FLOATS);
+    const f32x4* gb = reinterpret_cast<const f32x4*>(reinterpret_cast<const Frag*>(G.wstream) + (size_t)(S.ntiles + 1) * Ops::TILE_FRAGS);
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
     f32x4 bt[NBI];
 #pragma unroll
@@ -193,17 +241,16 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const float v[3] = {vv.x, vv.y, vv.z};
   if (hf == 0) srcl[j] = src;
 
-  float Bx[KSTEPS];  // first-Linear input: [edge_attr(32) | x_src[:32] | x_dst[:32]], lane half hf holds cols 16hf..16hf+15
+  typename Ops::Act Bx;  // first-Linear input: [edge_attr(32) | x_src[:32] | x_dst[:32]], lane half hf holds cols 16hf..16hf+15
   {
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
     const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
     const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const f32x4 aa = pa[q], s = ps[q], d = pd[q];
-      Bx[4 * q + 0] = aa.x; Bx[4 * q + 1] = aa.y; Bx[4 * q + 2] = aa.z; Bx[4 * q + 3] = aa.w;
-      Bx[16 + 4 * q + 0] = s.x; Bx[16 + 4 * q + 1] = s.y; Bx[16 + 4 * q + 2] = s.z; Bx[16 + 4 * q + 3] = s.w;
-      Bx[32 + 4 * q + 0] = d.x; Bx[32 + 4 * q + 1] = d.y; Bx[32 + 4 * q + 2] = d.z; Bx[32 + 4 * q + 3] = d.w;
+      Ops::set_in(Bx, 0, q, pa[q]);
+      Ops::set_in(Bx, 1, q, ps[q]);
+      Ops::set_in(Bx, 2, q, pd[q]);
     }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
     const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
@@ -219,12 +266,12 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 
   int T = 0;
   f32x16 acc;
-  float h1[KSTEPS];
+  typename Ops::Act h1;
   // the stream carries one zero tile after the last real one, so the prefetch of tile T+1 is always in bounds
 #define CBD_TILE(BOP, NEXT)                                                                         \
   {                                                                                                 \
     const int tn_ = (NEXT);                                                                         \
-    gemm_tile<VAR>(a, gp + (size_t)tn_ * (TILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf);       \
+    gemm_tile<Ops>(a, gp + (size_t)tn_ * Ops::TILE_FRAGS, bias_l + T * 32, BOP, acc, hf);          \
     T = tn_;                                                                                        \
   }
 
@@ -237,8 +284,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+    Ops::set_hidden(h1, m, acc);
     if constexpr (VAR == 8) { if (m == 0) st_g0 = stamp(); }
   }
 
@@ -474,7 +520,8 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, GraphStatic g
     }
   }
   // first-Linear input, lane half hf holds columns 16hf..16hf+15 of each part
-  float Bx[KSTEPS];
+  OpsF32::Act BxA;
+  float (&Bx)[KSTEPS] = BxA.v;
   {
     // final_edge_embedding(GaussianSmearing(d)): every lane evaluates the hidden layer, then its 16 outputs
     float hid[32];
@@ -507,20 +554,19 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, GraphStatic g
   __syncthreads();
   int T = 0;
   f32x16 acc;
-  float h1[KSTEPS];
+  OpsF32::Act h1;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    gemm_tile<0>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, Bx, acc, hf);
+    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, BxA, acc, hf);
     ++T;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+    OpsF32::set_hidden(h1, m, acc);
   }
   float oA[16], oB[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { oA[r] = 0.f; oB[r] = 0.f; }
 #pragma unroll
   for (int q = 0; q < 12; ++q) {
-    gemm_tile<0>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, h1, acc, hf);
+    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, h1, acc, hf);
     ++T;
     if (q < 6) {
 #pragma unroll
@@ -569,9 +615,28 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
   // CBD_CONV_VARIANT=8 selects the diagnostic build of the 74->74 kernel that stamps s_memtime/s_memrealtime
   static const int var = getenv("CBD_CONV_VARIANT") ? atoi(getenv("CBD_CONV_VARIANT")) : 0;
-  if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0>), dim3(grid), dim3(64), lds_bytes, s, a);
+  if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
+}
+
+// bf16-operand variant (cbd_set_option("bf16", 1), BASELINE.json configs[3]): the same kernel with OpsBf16 -- weights packed as
+// bf16 (pack_conv_stream_bf16), gathered inputs / hidden activations converted in registers (v_cvt_pk_bf16_f32); node features,
+// CG contraction, messages and the segmented reduction stay fp32.  Tolerance vs the fp32 path: tests/test_gpu_bf16.py.
+template <int IN, int OUT>
+static hipError_t launch_one_bf16(const ConvArgs& a, int grid, hipStream_t s) {
+  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
+  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsBf16>), dim3(grid), dim3(64), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s) {
+  if (grid <= 0) return hipSuccess;
+  if (in_level == 0 && out_level == 1) return launch_one_bf16<0, 1>(a, grid, s);
+  if (in_level == 1 && out_level == 2) return launch_one_bf16<1, 2>(a, grid, s);
+  if (in_level == 2 && out_level == 3) return launch_one_bf16<2, 3>(a, grid, s);
+  if (in_level == 3 && out_level == 3) return launch_one_bf16<3, 3>(a, grid, s);
+  return hipErrorInvalidValue;
 }
 
 hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s) {
