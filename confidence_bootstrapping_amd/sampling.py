@@ -29,7 +29,7 @@ import torch
 from scipy.spatial.transform import Rotation as R
 
 from .engine import make_steps, complex_fingerprint, _single_complex, _single_all_atom_complex
-from .hetero import DataLoader
+
 
 
 def _mask_rotate_of(graph):
@@ -119,11 +119,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                        temp_sigma_data=temp_sigma_data)
     S = inference_steps
     use_noise = not (no_random or ode)
-    loader = DataLoader(data_list, batch_size=batch_size)
     offset = 0
-    # `batch_size` keeps its reference meaning for the ORDER of the random draws (tr (b,3), rot (b,3), tor (b*R) per step
-    # and per loader batch), but consecutive loader batches of the same complex are executed together as one engine batch
-    # of up to `eng.max_batch` poses: pose samples never interact, so results are unchanged and the GPU sees large launches.
     pending = []          # (first pose index, b, pos [b,Nl,3] CPU, z_tr, z_rot, z_tor, loader batch)
     pending_key = None
 
@@ -134,7 +130,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         first = pending[0][0]
         B = sum(p[1] for p in pending)
         Nl = pending[0][2].shape[1]
-        batch0 = pending[0][6]
+        batch0 = pending[0][6]            # first graph of the group: all of them are poses of the same complex
         g, _, _ = _single_complex(batch0)
         if eng.complex_key != pending_key:
             eng.set_complex(g, pending_key)
@@ -149,7 +145,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             data_list[first + i]["ligand"].pos = flat[i * Nl:(i + 1) * Nl]
         if conf_model is not None:
             if filtering_data_list is not None:
-                fbatch = next(iter(DataLoader(filtering_data_list[first:first + 1], batch_size=1)))
+                fbatch = filtering_data_list[first]
                 crop = getattr(filtering_model_args, "crop_beyond", None)
             else:
                 fbatch, crop = batch0, None
@@ -164,15 +160,25 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         pending, pending_key = [], None
 
     with torch.no_grad():
-        for batch_id, batch in enumerate(loader):
-            b = batch.num_graphs
+        # The reference collates every chunk with torch_geometric's Batch (utils/sampling.py:78); only the ligand coordinates of
+        # the poses and ONE copy of the complex are needed here, so the chunks are walked without collating (for a 40-pose
+        # complex the collation of the 1281-wide receptor features alone costs more host time than the GPU work).
+        for start in range(0, N, max(int(batch_size), 1)):
+            chunk = data_list[start:start + max(int(batch_size), 1)]
+            b = len(chunk)
             if b > eng.max_batch:
                 raise RuntimeError(f"batch of {b} exceeds the engine capacity {eng.max_batch}")
-            _, _, Nl = _single_complex(batch)
+            if any(getattr(d, "num_graphs", 1) != 1 for d in chunk):
+                raise ValueError("data_list elements must be single graphs (as inference.py builds them)")
+            batch = chunk[0]
+            Nl = batch["ligand"].pos.shape[0]
             key = complex_fingerprint(batch)
+            for d in chunk[1:]:
+                if complex_fingerprint(d) != key:
+                    raise NotImplementedError("all poses of one batch must belong to the same complex (as modify_conformer_batch assumes)")
             if pending and (key != pending_key or sum(p[1] for p in pending) + b > eng.max_batch):
                 flush()
-            R_ = int(batch["ligand"].edge_mask.sum()) // b if not model_args.no_torsion else 0
+            R_ = int(batch["ligand"].edge_mask.sum()) if not model_args.no_torsion else 0
             z_tr = z_rot = z_tor = None
             if use_noise:
                 if noise is not None:
@@ -189,7 +195,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                             tor_l.append(torch.zeros(b * R_) if last_quiet else torch.normal(mean=0, std=1, size=(b * R_,)))
                     z_tr, z_rot = torch.stack(tr_l), torch.stack(rot_l)
                     z_tor = torch.stack(tor_l) if R_ > 0 else None
-            pending.append((offset, b, batch["ligand"].pos.reshape(b, Nl, 3).cpu().float(), z_tr, z_rot, z_tor, batch))
+            lig_pos = torch.stack([d["ligand"].pos.detach().cpu().float().reshape(Nl, 3) for d in chunk])
+            pending.append((offset, b, lig_pos, z_tr, z_rot, z_tor, batch))
             pending_key = key
             offset += b
         flush()

@@ -165,3 +165,10 @@ def test_sampling_returns_confidence(conf_model):
     final = torch.stack([d["ligand"].pos.cpu() for d in out])
     ref = _oracle(cmodel, cplx, final)
     assert (conf.cpu() - ref["confidence"]).abs().max() < 2e-5
+
+
+def test_end_to_end_demo_runs():
+    """tools/dock_demo.py: randomize -> sampling with confidence -> ranking -> symmetric RMSD, on the tiny complex."""
+    from tools.dock_demo import main
+    conf, rmsds = main(["--samples", "6", "--steps", "3", "--workload", "tiny", "--batch-size", "4"])
+    assert conf.shape == (6,) and torch.isfinite(conf).all() and torch.isfinite(rmsds).all()
