@@ -62,19 +62,36 @@ def cpu_baseline(model, cplx, args, sched):
     cfg = sr.ScoreConfig()
     # time `steps` of the 20 schedule points spread over the schedule (the cross graph shrinks with t)
     idx = np.linspace(0, len(sched) - 1, steps).round().astype(int)
-    t0 = time.perf_counter()
-    rec_cache = sr.receptor_embedding(sd, cx, cfg)
-    t_rec = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    for i in idx:
-        t = sched[i]
-        out = sr.score_forward(sd, cx, pos, t, t, t, cfg, so3, torus, rec_cache=rec_cache)
-        pos = pr.modify_conformer_batch(pos, cx, 0.01 * out["tr_pred"], 0.01 * out["rot_pred"], 0.01 * out["tor_pred"])
-    t_steps = time.perf_counter() - t0
-    per_pose = (t_steps / steps / b) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
-    return {"value": round(1.0 / per_pose, 5), "unit": "poses/s", "cores": torch.get_num_threads(), "kind": "port",
+
+    def timed():
+        p = pos.clone()
+        t0 = time.perf_counter()
+        rec_cache = sr.receptor_embedding(sd, cx, cfg)
+        t_rec = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for i in idx:
+            t = sched[i]
+            out = sr.score_forward(sd, cx, p, t, t, t, cfg, so3, torus, rec_cache=rec_cache)
+            p = pr.modify_conformer_batch(p, cx, 0.01 * out["tr_pred"], 0.01 * out["rot_pred"], 0.01 * out["tor_pred"])
+        t_steps = time.perf_counter() - t0
+        per_pose = (t_steps / steps / b) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
+        return 1.0 / per_pose, t_steps + t_rec
+
+    all_threads = torch.get_num_threads()
+    v_all, t_all = timed()
+    # the reference's own --restrict_cpu setting (inference.py:225-234) is 16 threads: report that figure too
+    torch.set_num_threads(min(16, all_threads))
+    try:
+        v16, t16 = timed()
+    finally:
+        torch.set_num_threads(all_threads)
+    n16 = min(16, all_threads)
+    best, cores = (v16, n16) if v16 >= v_all else (v_all, all_threads)
+    return {"value": round(best, 5), "unit": "poses/s", "cores": cores, "kind": "port",
+            "by_threads": {str(all_threads): round(v_all, 5), str(n16): round(v16, 5)},
             "sample": f"{b} poses x {steps} of {DENOISE_STEPS} denoise steps (+ receptor embedding) of {WORKLOAD}, "
-                      f"oracle PyTorch-CPU fp32, {t_steps + t_rec:.1f}s measured, extrapolated to 20 steps/pose"}
+                      f"oracle PyTorch-CPU fp32, {t_all:.1f}s measured with {all_threads} threads and {t16:.1f}s with 16, "
+                      f"extrapolated to 20 steps/pose"}
 
 
 def hbm_secondary(st, eng, poses, elapsed):
