@@ -144,7 +144,8 @@ def main():
     ap.add_argument("--workload", default=WORKLOAD, help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3])")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_split"],
+                    help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3]); f32_split: fp32 operands as three bf16 planes on the bf16 MFMA")
     ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
                     "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..4 = that many")
     a = ap.parse_args()
@@ -174,6 +175,8 @@ def main():
     eng.set_complex(cplx)
     eng.set_option("graph", a.graph)
     eng.set_option("bf16", int(a.dtype == "bf16"))
+    if a.dtype == "f32_split":
+        eng.set_option("f32_split", 1)
     cosched = (2 if a.pair == 1 else max(1, min(a.pair, 4))) if (a.pair and a.streams == 1 and not a.graph) else 1
     pair = cosched > 1
     extra = []   # further engines (own workspace, same device-resident weights) for the complexes that are co-scheduled
@@ -181,6 +184,8 @@ def main():
         e2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
         e2.set_complex(cplx)
         e2.set_option("bf16", int(a.dtype == "bf16"))
+        if a.dtype == "f32_split":
+            e2.set_option("f32_split", 1)
         extra.append(e2)
     eng2 = extra[0] if extra else None
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
@@ -220,6 +225,8 @@ def main():
 
     run(0, a.warmup)
     torch.cuda.synchronize()
+    alt_k = list(range(max(a.warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
+    alt_init = {k: pos0[k].clone() for k in alt_k}
     eng.kernel_timing(enable=not a.graph, reset=True)
     eng.stats(reset=True)
     for e2 in extra:
@@ -260,6 +267,9 @@ def main():
         if os.path.exists(tp):
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch_all_tp_conv"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        algorithmic = achieved
+        if a.dtype == "f32_split":
+            achieved *= 6.0     # every fp32 product is issued as 6 bf16 plane products; price the ISSUED flops against the bf16 peak
         headline = (WORKLOAD, SAMPLES, DENOISE_STEPS, a.dtype) == ("c2_dockgen_median", 40, 20, "f32")
         peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
         if not headline:
@@ -274,11 +284,12 @@ def main():
                        "co_scheduled_complexes": cosched,
                        "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel<OpsF32>" if a.dtype == "f32" else "tp_conv_kernel<OpsBf16>",
+            "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": "tp_conv_kernel<OpsBf16>", "f32_split": "tp_conv_kernel<OpsBf16x3>"}[a.dtype],
                          "achieved": round(achieved, 3), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
+                         "algorithmic_tflops": round(algorithmic, 3),
                          "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
                          "pose_steps_per_s": round(poses * DENOISE_STEPS / elapsed, 1),
                          # secondary: fused-ideal algorithmic bytes = 432 B per edge-layer visit + 592 B per
@@ -287,6 +298,26 @@ def main():
         }
         if world == 1 and headline:
             out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev)
+        if world == 1 and headline and pair:
+            # The same complexes in the two other operand modes of the same kernel (NOT part of `value`): f32_split = fp32 operands as
+            # three exact bf16 planes on the bf16 matrix cores (fp32-grade results, tests/test_gpu_bf16.py); bf16 = configs[3].
+            out["other_operand_modes"] = {}
+            for mode in ("f32_split", "bf16"):
+                for p_ in [eng] + extra:
+                    p_.set_option("bf16", int(mode == "bf16"))
+                    p_.set_option("f32_split", int(mode == "f32_split"))
+                for timed in (False, True):
+                    for k in alt_k:
+                        pos0[k].copy_(alt_init[k])
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    run(alt_k[0], n_runs)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter() - t1
+                out["other_operand_modes"][mode] = {"value": round(SAMPLES * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k)}
+            for p_ in [eng] + extra:
+                p_.set_option("bf16", 0)
+                p_.set_option("f32_split", 0)
         if world == 1 and headline and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
         print(json.dumps(out), flush=True)

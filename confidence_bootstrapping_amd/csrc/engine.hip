@@ -36,6 +36,7 @@ struct ConvLayerDev {
   int in_level = 0, out_level = 0, n_groups = 0;
   float* wstream[4] = {nullptr, nullptr, nullptr, nullptr};
   float* wstream_bf16[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16-operand policy (tp_conv.hip::OpsBf16)
+  float* wstream_x3[4] = {nullptr, nullptr, nullptr, nullptr};          // bf16x3 fp32-emulation policy (OpsBf16x3)
   float *bn_scale = nullptr, *bn_mean = nullptr, *bn_bias = nullptr;   // [NODE_STRIDE]
 };
 
@@ -92,7 +93,8 @@ struct cbd_engine {
   int* rr_count_dev = nullptr;
   float *d_rec_x = nullptr, *d_vec0 = nullptr, *d_dist0 = nullptr;
   int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
-  bool use_bf16 = false;            // cbd_set_option("bf16", 1): FCBlock GEMMs on bf16 MFMA (fp32 accumulate)
+  int use_bf16 = 0;                 // operand policy of the tensor-product kernel: 0 exact fp32 MFMA, 1 bf16 ("bf16" option),
+                                    // 2 fp32 emulated by three bf16 planes ("f32_split" option)
   // hipGraph of the step loop (optional)
   bool use_graph = false;
   hipGraphExec_t graph_exec = nullptr;
@@ -269,6 +271,42 @@ static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1
   return out;
 }
 
+// bf16x3 stream (tp_conv.hip::OpsBf16x3): every weight as the exact sum of three bf16 planes; (ntiles + 1) tiles of
+// [6 k-steps x 3 planes][64 lanes][8 bf16] (18 KB, same k order as the bf16 stream), then the fp32 bias table.
+static std::vector<float> pack_conv_stream_bf16x3(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+  const TileRows tr = conv_tile_rows(IN, OUT);
+  constexpr int TILE_BF16 = 3 * 32 * KDIM;   // 9216 bf16 = 18 KB
+  std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + (size_t)tr.ntiles * 32 * 4) / 4, 0.f);
+  uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
+  float* const bias_tab = reinterpret_cast<float*>(w + (size_t)(tr.ntiles + 1) * TILE_BF16);
+  auto bf2f = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+  for (int T = 0; T < tr.ntiles; ++T) {
+    uint16_t* tile = w + (size_t)T * TILE_BF16;
+    const bool first = T < 3;
+    for (int q = 0; q < KDIM / 16; ++q)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int r = lane & 31, h = lane >> 5;
+        const TileRow& R = tr.rows[(size_t)T * 32 + r];
+        for (int j = 0; j < 8; ++j) {
+          const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+          const float v = R.row < 0 ? 0.f : R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
+          const uint16_t hi = f32_to_bf16_rne(v);
+          const float r1 = v - bf2f(hi);
+          const uint16_t mid = f32_to_bf16_rne(r1);
+          const uint16_t lo = f32_to_bf16_rne(r1 - bf2f(mid));
+          tile[((size_t)(3 * q + 0) * 64 + lane) * 8 + j] = hi;
+          tile[((size_t)(3 * q + 1) * 64 + lane) * 8 + j] = mid;
+          tile[((size_t)(3 * q + 2) * 64 + lane) * 8 + j] = lo;
+        }
+      }
+    for (int r = 0; r < 32; ++r) {
+      const TileRow& R = tr.rows[(size_t)T * 32 + r];
+      bias_tab[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
+    }
+  }
+  return out;
+}
+
 static int out_level_dim(int level) { return conv_shape(0, level).out_dim; }
 static int in_level_dim(int level) { return conv_shape(level, 3).in_dim; }
 
@@ -285,6 +323,7 @@ static int build_conv_layer(cbd_engine* e, const std::string& prefix, int IN, in
     std::vector<float> st = pack_conv_stream(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data());
     HIPCHK(e->wpool.upload(&L->wstream[g], st));
     HIPCHK(e->wpool.upload(&L->wstream_bf16[g], pack_conv_stream_bf16(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
+    HIPCHK(e->wpool.upload(&L->wstream_x3[g], pack_conv_stream_bf16x3(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
   }
   // e3nn BatchNorm (eval) per output column
   const int nf = NS + NV + (OUT >= 2 ? NV : 0) + (OUT >= 3 ? NV : 0);
@@ -364,6 +403,7 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   HIPCHK(hipSetDevice(cfg->device));
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
+  if (const char* p = getenv("CBD_PRECISION")) e->use_bf16 = std::max(0, std::min(2, atoi(p)));   // test hook: default operand policy
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
@@ -547,7 +587,8 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++e->ev_used;
     HIPCHK(hipEventRecord(e0, s));
   }
-  if (e->use_bf16) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) HIPCHK(hipEventRecord(e1, s));
   return 0;
@@ -560,7 +601,7 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
   int grid = 0;
   for (int g = 0; g < n_groups; ++g) {
     a.g[g] = groups[g];
-    a.g[g].wstream = (e->use_bf16 ? L.wstream_bf16 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
+    a.g[g].wstream = (e->use_bf16 == 1 ? L.wstream_bf16 : e->use_bf16 == 2 ? L.wstream_x3 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
     a.g[g].node_in = node_in;
     if (a.g[g].i0e_hi == 0 && a.g[g].vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
       a.g[g].i0e_lo = 0; a.g[g].i0e_hi = conv_shape(L.in_level, L.out_level).t0e; a.g[g].vec_on = 1;
@@ -876,7 +917,8 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   HIPCHK(hipEventRecord(e->ev_fork, s));
   HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
   {
-    hipStream_t ss = e->side;
+    static const bool no_side = getenv("CBD_NO_SIDE") != nullptr;   // diagnostic: keep the time-only work on the main stream
+    hipStream_t ss = no_side ? s : e->side;
     HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, ss));
     HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, Xb, B, gs.rec_off, Nr, ss));
     const int cap0 = gs.Err, w_rr = 2;
@@ -1187,7 +1229,12 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
     return 0;
   }
   if (k == "bf16") {   // captured graphs bake the kernel choice in: drop them
-    e->use_bf16 = value != 0;
+    if (value != 0) e->use_bf16 = 1; else if (e->use_bf16 == 1) e->use_bf16 = 0;
+    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    return 0;
+  }
+  if (k == "f32_split") {   // fp32 operands as three bf16 planes on the bf16 matrix cores (OpsBf16x3)
+    if (value != 0) e->use_bf16 = 2; else if (e->use_bf16 == 2) e->use_bf16 = 0;
     if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
     return 0;
   }

@@ -101,6 +101,7 @@ hipError_t launch_conv_finalize2(const FinArgs& fa0, int n0, int off0, const Fin
                                  float* node_out, const float* bn_scale, const float* bn_mean, const float* bn_bias, int in_dim,
                                  int out_dim, hipStream_t s);
 hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);   // bf16 weight streams
+hipError_t launch_tp_conv_x3(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);     // bf16x3 weight streams
 hipError_t launch_conv_finalize(const FinArgs& fa, const float* node_in, float* node_out, const float* bn_scale,
                                 const float* bn_mean, const float* bn_bias, int n_nodes, int in_dim, int out_dim,
                                 int node_off, hipStream_t s);

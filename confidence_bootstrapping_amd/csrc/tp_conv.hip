@@ -49,6 +49,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 //
 // OpsF32: exact fp32, v_mfma_f32_32x32x2_f32, 48 k-steps, 12 float4 fragments (12 KB tile).
 struct OpsF32 {
+  static constexpr bool EXACT_F32 = true;
   using Frag = f32x4;
   static constexpr int NFRAG = KSTEPS / 4;                 // 12
   static constexpr int TILE_FRAGS = TILE_W_FLOATS / 4;     // 768 fragments of 16 B per tile
@@ -78,12 +79,30 @@ struct OpsF32 {
   }
 };
 
+// Measured on gfx950 (ROCm 7.2 hipcc): a VALU write into a VGPR that an already-issued v_mfma_f32_32x32x16_bf16 has not yet read
+// as its A/B operand corrupts that operand.  The MFMA reads its operands when it starts executing, which with two waves sharing
+// the matrix pipe can be tens of cycles after issue; hipcc re-uses the registers of a fragment that died at its last MFMA for
+// the address arithmetic of the refill loads and pads nothing in between (seen as run-to-run differences of ~1e-4 relative in
+// single output columns of the OpsBf16x3 kernel; 8 wait states were not enough, 64 were).  The bf16 policies therefore
+//   * compute the refill address of a group BEFORE its MFMAs and pin it (no VALU instruction sits between the MFMAs and the
+//     refill loads, and while the loads are in flight their destination registers are not free for re-use), and
+//   * close the one group whose operands die without a refill (end of the first Linear) with mfma_operand_guard().
+// tests/test_gpu_parity.py / test_gpu_bf16.py compare repeated trajectories bitwise in all three modes as the tripwire.
+__device__ __forceinline__ void mfma_operand_guard() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+  __builtin_amdgcn_sched_barrier(0);
+}
+template <class P>
+__device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
+
 // OpsBf16: bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16, 6 k-steps of 16, 6 fragments of 8 bf16 (6 KB tile).
 // Lane (r = lane&31, h = lane>>5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7 (cdna_hip_programming.md
 // section 3).  Registers 8s..8s+7 of hidden tile m are the fragment of k-step 2m+s: element j of lane half h is hidden unit
 // 32m + 16s + 8(j>>2) + 4h + (j&3); W2's k order is permuted to match at pack time (pack_conv_stream_bf16).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct OpsBf16 {
+  static constexpr bool EXACT_F32 = false;
   using Frag = bf16x8;
   static constexpr int NFRAG = KDIM / 16;                  // 6
   static constexpr int TILE_FRAGS = NFRAG * 64;            // 384 fragments of 16 B per tile
@@ -100,8 +119,72 @@ struct OpsBf16 {
   static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
 #pragma unroll
     for (int q = 0; q < NFRAG; ++q) {
+      const Frag* p = next + q * 64;
+      pin(p);
+      __builtin_amdgcn_sched_barrier(0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B.v[q], acc, 0, 0, 0);
-      a[q] = next[q * 64];
+      __builtin_amdgcn_sched_barrier(0);
+      a[q] = *p;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+};
+
+// OpsBf16x3: fp32 operands represented EXACTLY as the sum of three bf16 planes (hi + mid + lo = 3 x 8 significand bits) and
+// multiplied on the bf16 matrix cores with fp32 accumulation: of the nine plane products the six largest are kept
+// (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi); the dropped ones are <= 2^-24 relative each, i.e. at the level of one fp32
+// rounding.  36 bf16 MFMAs per tile (1152 cycles) instead of 48 fp32 ones (3072): the "fp32 emulation on low-precision matrix
+// cores" scheme (cf. the BF16x9 mode of vendor BLAS libraries), selected by cbd_set_option("f32_split", 1); accuracy against
+// the exact-fp32 policy is measured in tests/test_gpu_bf16.py.  Fragment 3q + p = plane p of k-step q (18 KB tile).
+struct OpsBf16x3 {
+  static constexpr bool EXACT_F32 = false;
+  using Frag = bf16x8;
+  static constexpr int NFRAG = 3 * (KDIM / 16);            // 18
+  static constexpr int TILE_FRAGS = NFRAG * 64;            // 1152 fragments of 16 B per tile
+  struct Act { bf16x8 v[NFRAG]; };
+  static __device__ __forceinline__ void split(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    float r = x - (float)h;      // exact
+    m = (__bf16)r;
+    r -= (float)m;               // exact
+    l = (__bf16)r;
+  }
+  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
+    const int k = 3 * (2 * seg + (q >> 1)), o = 4 * (q & 1);
+    const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      __bf16 h, m, l;
+      split(xs[c], h, m, l);
+      B.v[k][o + c] = h; B.v[k + 1][o + c] = m; B.v[k + 2][o + c] = l;
+    }
+  }
+  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = 3 * (2 * m + (r >> 3));
+      __bf16 hh, mm, ll;
+      split(fmaxf(acc[r], 0.f), hh, mm, ll);
+      h.v[k][r & 7] = hh; h.v[k + 1][r & 7] = mm; h.v[k + 2][r & 7] = ll;
+    }
+  }
+  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < NFRAG / 3; ++q) {
+      const int k = 3 * q;   // smallest terms first
+      const Frag* p = next + k * 64;
+      pin(p);
+      __builtin_amdgcn_sched_barrier(0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 2], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a[k + 0] = p[0];
+      a[k + 1] = p[64];
+      a[k + 2] = p[128];
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -284,6 +367,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
     CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
+    if constexpr (!Ops::EXACT_F32) { if (m == 2) mfma_operand_guard(); }   // the first-Linear operands die here without a refill
     Ops::set_hidden(h1, m, acc);
     if constexpr (VAR == 8) { if (m == 0) st_g0 = stamp(); }
   }
@@ -636,6 +720,22 @@ hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, i
   if (in_level == 1 && out_level == 2) return launch_one_bf16<1, 2>(a, grid, s);
   if (in_level == 2 && out_level == 3) return launch_one_bf16<2, 3>(a, grid, s);
   if (in_level == 3 && out_level == 3) return launch_one_bf16<3, 3>(a, grid, s);
+  return hipErrorInvalidValue;
+}
+
+template <int IN, int OUT>
+static hipError_t launch_one_x3(const ConvArgs& a, int grid, hipStream_t s) {
+  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
+  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsBf16x3>), dim3(grid), dim3(64), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tp_conv_x3(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s) {
+  if (grid <= 0) return hipSuccess;
+  if (in_level == 0 && out_level == 1) return launch_one_x3<0, 1>(a, grid, s);
+  if (in_level == 1 && out_level == 2) return launch_one_x3<1, 2>(a, grid, s);
+  if (in_level == 2 && out_level == 3) return launch_one_x3<2, 3>(a, grid, s);
+  if (in_level == 3 && out_level == 3) return launch_one_x3<3, 3>(a, grid, s);
   return hipErrorInvalidValue;
 }
 

@@ -128,7 +128,12 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
 /* Engine options.  "graph" (0/1): capture the S-step loop of cbd_sample into a hipGraph that is instantiated once per
  * (batch size, schedule) and replayed with one launch per batch (inputs are staged into engine-owned buffers).
  * "bf16" (0/1): run the two Linears of every tensor-product layer's radial MLP on bf16 matrix cores (bf16 operands, fp32
- * accumulate; everything else stays fp32) -- BASELINE.json configs[3]; results differ from the fp32 path at the 1e-2 level. */
+ * accumulate; everything else stays fp32) -- BASELINE.json configs[3]; results differ from the fp32 path at the 1e-2 level.
+ * "f32_split" (0/1): the same two Linears with every fp32 operand held as the exact sum of three bf16 planes (hi+mid+lo) and
+ * the six plane products down to 2^-24 relative issued on the bf16 matrix cores with fp32 accumulate: results agree with the
+ * fp32 kernel to fp32 rounding level (scores 2e-7..2e-6 relative, 20-step trajectories within 1e-4 A) at ~1.5x its
+ * throughput.  "bf16" and "f32_split" are mutually exclusive: switching one on replaces the other, switching one off only
+ * clears itself.  Default: both off = v_mfma_f32_32x32x2_f32 (exact fp32 products). */
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value);
 
 /* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
