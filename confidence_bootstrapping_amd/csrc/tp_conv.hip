@@ -30,243 +30,10 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "tp_conv_dev.h"
 
 namespace cbd {
 
-// diagnostic stamp (CBD_CONV_VARIANT=8 build only): s_memtime pinned in place (cdna_hip_programming.md section 7)
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  __builtin_amdgcn_sched_barrier(0);
-  return t;
-}
-
-// ---- operand policies: how the two Linears of the radial MLP run on the matrix cores ------------------------------------
-// One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers, loaded one tile ahead
-// straight from global/L2 in MFMA operand order; each fragment register is refilled with the NEXT tile's data right after its
-// last use, so the loads have a whole tile of MFMA time to land and no barrier or LDS staging is involved.
-//
-// OpsF32: exact fp32, v_mfma_f32_32x32x2_f32, 48 k-steps, 12 float4 fragments (12 KB tile).
-struct OpsF32 {
-  static constexpr bool EXACT_F32 = true;
-  using Frag = f32x4;
-  static constexpr int NFRAG = KSTEPS / 4;                 // 12
-  static constexpr int TILE_FRAGS = TILE_W_FLOATS / 4;     // 768 fragments of 16 B per tile
-  struct Act { float v[KSTEPS]; };                         // B operand: lane (j, hf) holds act[edge j][k(s, hf)] for the 48 k-steps
-  // gathered input columns 16hf + 4q .. +3 of part `seg` (edge_attr | x_src | x_dst)
-  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
-    B.v[16 * seg + 4 * q + 0] = x.x; B.v[16 * seg + 4 * q + 1] = x.y; B.v[16 * seg + 4 * q + 2] = x.z; B.v[16 * seg + 4 * q + 3] = x.w;
-  }
-  // ReLU'd accumulator of hidden tile m IS the B operand of the second Linear (W2's k order follows the C/D layout)
-  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h.v[16 * m + r] = fmaxf(acc[r], 0.f);
-  }
-  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
-#pragma unroll
-    for (int sg = 0; sg < NFRAG; ++sg) {
-      const f32x4 w = a[sg];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * sg + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * sg + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * sg + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * sg + 3], acc, 0, 0, 0);
-      a[sg] = next[sg * 64];
-      // keep the refill right behind its last use: without this hipcc sinks all 12 loads to the end of the tile and the
-      // next tile then starts by waiting a full L2 round trip
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-};
-
-// Measured on gfx950 (ROCm 7.2 hipcc): a VALU write into a VGPR that an already-issued v_mfma_f32_32x32x16_bf16 has not yet read
-// as its A/B operand corrupts that operand.  The MFMA reads its operands when it starts executing, which with two waves sharing
-// the matrix pipe can be tens of cycles after issue; hipcc re-uses the registers of a fragment that died at its last MFMA for
-// the address arithmetic of the refill loads and pads nothing in between (seen as run-to-run differences of ~1e-4 relative in
-// single output columns of the OpsBf16x3 kernel; 8 wait states were not enough, 64 were).  The bf16 policies therefore
-//   * compute the refill address of a group BEFORE its MFMAs and pin it (no VALU instruction sits between the MFMAs and the
-//     refill loads, and while the loads are in flight their destination registers are not free for re-use), and
-//   * close the one group whose operands die without a refill (end of the first Linear) with mfma_operand_guard().
-// tests/test_gpu_parity.py / test_gpu_bf16.py compare repeated trajectories bitwise in all three modes as the tripwire.
-__device__ __forceinline__ void mfma_operand_guard() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
-  __builtin_amdgcn_sched_barrier(0);
-}
-template <class P>
-__device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
-
-// OpsBf16: bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16, 6 k-steps of 16, 6 fragments of 8 bf16 (6 KB tile).
-// Lane (r = lane&31, h = lane>>5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7 (cdna_hip_programming.md
-// section 3).  Registers 8s..8s+7 of hidden tile m are the fragment of k-step 2m+s: element j of lane half h is hidden unit
-// 32m + 16s + 8(j>>2) + 4h + (j&3); W2's k order is permuted to match at pack time (pack_conv_stream_bf16).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-struct OpsBf16 {
-  static constexpr bool EXACT_F32 = false;
-  using Frag = bf16x8;
-  static constexpr int NFRAG = KDIM / 16;                  // 6
-  static constexpr int TILE_FRAGS = NFRAG * 64;            // 384 fragments of 16 B per tile
-  struct Act { bf16x8 v[NFRAG]; };
-  // k-step 2*seg + sub covers input columns 16hf + 8sub .. +7 of part seg; q = 2*sub + half
-  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
-    const int k = 2 * seg + (q >> 1), o = 4 * (q & 1);
-    B.v[k][o + 0] = (__bf16)x.x; B.v[k][o + 1] = (__bf16)x.y; B.v[k][o + 2] = (__bf16)x.z; B.v[k][o + 3] = (__bf16)x.w;
-  }
-  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
-  }
-  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
-#pragma unroll
-    for (int q = 0; q < NFRAG; ++q) {
-      const Frag* p = next + q * 64;
-      pin(p);
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B.v[q], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a[q] = *p;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-};
-
-// OpsBf16x3: fp32 operands represented EXACTLY as the sum of three bf16 planes (hi + mid + lo = 3 x 8 significand bits) and
-// multiplied on the bf16 matrix cores with fp32 accumulation: of the nine plane products the six largest are kept
-// (hi*hi, hi*mid, mid*hi, hi*lo, mid*mid, lo*hi); the dropped ones are <= 2^-24 relative each, i.e. at the level of one fp32
-// rounding.  36 bf16 MFMAs per tile (1152 cycles) instead of 48 fp32 ones (3072): the "fp32 emulation on low-precision matrix
-// cores" scheme (cf. the BF16x9 mode of vendor BLAS libraries), selected by cbd_set_option("f32_split", 1); accuracy against
-// the exact-fp32 policy is measured in tests/test_gpu_bf16.py.  Fragment 3q + p = plane p of k-step q (18 KB tile).
-struct OpsBf16x3 {
-  static constexpr bool EXACT_F32 = false;
-  using Frag = bf16x8;
-  static constexpr int NFRAG = 3 * (KDIM / 16);            // 18
-  static constexpr int TILE_FRAGS = NFRAG * 64;            // 1152 fragments of 16 B per tile
-  struct Act { bf16x8 v[NFRAG]; };
-  static __device__ __forceinline__ void split(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    float r = x - (float)h;      // exact
-    m = (__bf16)r;
-    r -= (float)m;               // exact
-    l = (__bf16)r;
-  }
-  static __device__ __forceinline__ void set_in(Act& B, int seg, int q, f32x4 x) {
-    const int k = 3 * (2 * seg + (q >> 1)), o = 4 * (q & 1);
-    const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      __bf16 h, m, l;
-      split(xs[c], h, m, l);
-      B.v[k][o + c] = h; B.v[k + 1][o + c] = m; B.v[k + 2][o + c] = l;
-    }
-  }
-  static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = 3 * (2 * m + (r >> 3));
-      __bf16 hh, mm, ll;
-      split(fmaxf(acc[r], 0.f), hh, mm, ll);
-      h.v[k][r & 7] = hh; h.v[k + 1][r & 7] = mm; h.v[k + 2][r & 7] = ll;
-    }
-  }
-  static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
-#pragma unroll
-    for (int q = 0; q < NFRAG / 3; ++q) {
-      const int k = 3 * q;   // smallest terms first
-      const Frag* p = next + k * 64;
-      pin(p);
-      __builtin_amdgcn_sched_barrier(0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 2], B.v[k + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 2], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a[k + 0] = p[0];
-      a[k + 1] = p[64];
-      a[k + 2] = p[128];
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-};
-
-template <class Ops>
-__device__ __forceinline__ void gemm_tile(typename Ops::Frag (&a)[Ops::NFRAG], const typename Ops::Frag* __restrict__ next,
-                                          const float* __restrict__ bias_l, const typename Ops::Act& B, f32x16& acc, int hf) {
-  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    f32x4 b = bp[2 * q + hf];
-    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
-  }
-  Ops::gemm(a, next, B, acc);
-}
-
-// "mid" evaluators: value of the CG intermediate with index i for edge j (xc = &xT[0][j], column stride 32).
-// Index spaces follow reference tensor_layers.py:72-85 (concatenation order of out_dict[...] lists).
-template <int IN>
-__device__ __forceinline__ float mid0e(const float* xc, int i, const float (&v)[3]) {
-  if (i < NS) return xc[i * 32];
-  if (IN >= 1) {
-    const float* p = xc + (COL_1O + 3 * (i - NS)) * 32;
-    return p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
-  }
-  return 0.f;
-}
-
-__device__ __forceinline__ void cross3(const float* p, const float (&v)[3], float (&m)[3]) {
-  const float a0 = p[0], a1 = p[32], a2 = p[64];
-  m[0] = a1 * v[2] - a2 * v[1];
-  m[1] = a2 * v[0] - a0 * v[2];
-  m[2] = a0 * v[1] - a1 * v[0];
-}
-
-template <int IN>
-__device__ __forceinline__ void mid1o(const float* xc, int i, const float (&v)[3], float (&m)[3]) {
-  constexpr ConvShape S = conv_shape(IN, 3);
-  if (i < NS) {
-    const float s = xc[i * 32];
-    m[0] = s * v[0]; m[1] = s * v[1]; m[2] = s * v[2];
-  } else if (i < NS + S.n1o) {
-    const float* p = xc + (COL_1O + 3 * (i - NS)) * 32;
-    m[0] = p[0]; m[1] = p[32]; m[2] = p[64];
-  } else if (i < S.fan1o) {
-    cross3(xc + (COL_1E + 3 * (i - NS - S.n1o)) * 32, v, m);
-  } else {
-    m[0] = m[1] = m[2] = 0.f;
-  }
-}
-
-template <int IN>
-__device__ __forceinline__ void mid1e(const float* xc, int i, const float (&v)[3], float (&m)[3]) {
-  constexpr ConvShape S = conv_shape(IN, 3);
-  if (i < S.n1o) {
-    cross3(xc + (COL_1O + 3 * i) * 32, v, m);
-  } else if (i < S.n1o + S.n1e) {
-    const float* p = xc + (COL_1E + 3 * (i - S.n1o)) * 32;
-    m[0] = p[0]; m[1] = p[32]; m[2] = p[64];
-  } else if (i < S.fan1e) {
-    const float s = xc[(COL_0O + (i - S.n1o - S.n1e)) * 32];
-    m[0] = s * v[0]; m[1] = s * v[1]; m[2] = s * v[2];
-  } else {
-    m[0] = m[1] = m[2] = 0.f;
-  }
-}
-
-template <int IN>
-__device__ __forceinline__ float mid0o(const float* xc, int i, const float (&v)[3]) {
-  constexpr ConvShape S = conv_shape(IN, 3);
-  if (i < S.n1e) {
-    const float* p = xc + (COL_1E + 3 * i) * 32;
-    return p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
-  }
-  if (i < S.fan0o) return xc[(COL_0O + (i - S.n1e)) * 32];
-  return 0.f;
-}
-
-constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed copy of the gathered rows
-constexpr int OUT_STRIDE = 33;                           // message tile stride (conflict-free column reads)
-__host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
 template <int IN, int OUT, int VAR, class Ops>
 __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {

@@ -1,0 +1,383 @@
+// Training-side tensor-product kernels for gfx950 (MI355X): forward and backward of
+//   msg[e] = FasterTensorProduct(x[e], sh(vec[e]), w[e]),   w[e] = W2 h[e] + b2
+// (reference models/tensor_layers.py:66-117 fed by the last Linear of the FCBlock, models/layers.py:8-15) for the
+// confidence-bootstrapping fine-tuning step (reference finetune_train.py:330 -> utils/training.py:184-233), where autograd needs
+// d msg / d{x, h, W2, b2}.  As in the inference kernel (tp_conv.hip) the [E, W] per-edge weight tensor never exists in the
+// forward pass: one wave owns 32 edges, the hidden activations h are the B operand in registers, the packed W2 tiles stream from
+// L2 into registers one tile ahead, and every finished 32x32 tile of w is consumed at once by the CG contraction on the VALU.
+//
+// What differs from inference:
+//   * the first Linear + ReLU + Dropout of the FCBlock stay in PyTorch (rocBLAS GEMM + torch's own dropout RNG), so h[E, 96]
+//     is an input and its gradient an output of the op -- dropout masks are then exactly torch's and the first Linear's
+//     gradients are ordinary autograd;
+//   * all tensors are per edge and dense (x rows already gathered, messages not yet reduced): gathers, the scatter-mean over
+//     edge groups and BatchNorm in training mode are autograd-visible torch ops around the kernel;
+//   * backward re-computes each w tile on the matrix cores (same 48 MFMAs as forward) instead of loading a saved [E, W]
+//     tensor, forms   g_w[row] = mid . g_msg[out(row)]   and   g_mid = sum_out w[row] g_msg[out(row)]   on the VALU, folds
+//     g_mid through the transposed CG "mid" maps into g_x (per-wave LDS tile), and writes g_w[E, Wp] (packed-row order, the
+//     only [E, W]-sized tensor of the step: 6.6 KB/edge written once, read twice by the two rocBLAS GEMMs
+//     g_h = g_w W2p and dW2p = g_w^T h that finish the FCBlock's backward).
+//
+// Weight stream: the inference layout (cbd_pack_conv_stream: 3 tiles of W1 that this kernel skips, then the W2 tiles
+// regrouped per output irrep block with 1/sqrt(fan_in), sqrt(3), sqrt(1.5) folded, then the bias table); g_w columns are
+// (tile - 3) * 32 + row of that stream.  The Python side maps them back to the reference parameter layout
+// (confidence_bootstrapping_amd/train_ops.py).
+#include "host_util.h"
+#include "kernels.h"
+#include "tp_conv_dev.h"
+
+namespace cbd {
+
+struct TrainTpArgs {
+  const float* xrow;     // [E][NODE_STRIDE] features of the node every edge reads (node_attr[edge_dst]), zero padded
+  const float* vec;      // [E][4] unit edge vector (xyz, 0)
+  const float* h;        // [E][96] hidden activations of the radial MLP
+  const float* wstream;  // packed FCBlock stream (fp32 policy)
+  int E;
+  float* msg;            // forward out  [E][NODE_STRIDE]
+  const float* gmsg;     // backward in  [E][NODE_STRIDE]  d loss / d msg
+  float* gx;             // backward out [E][NODE_STRIDE]  d loss / d xrow
+  float* gw;             // backward out [E][Wp]           d loss / d (packed w)
+};
+
+constexpr int GX_STRIDE = 33;
+__host__ __device__ constexpr int train_lds_floats(int ntiles, bool bwd) {
+  return ntiles * 32 + XT_FLOATS + (bwd ? NODE_STRIDE * GX_STRIDE : 0);
+}
+
+// common prologue: weight stream start (tile 3), bias table, gathered row tile, hidden activations as the MFMA B operand
+template <int IN, int OUT>
+__device__ __forceinline__ void train_prologue(const TrainTpArgs& A, float* bias_l, float* xT, int lane, int ec, const f32x4* gp,
+                                               f32x4 (&a)[OpsF32::NFRAG], OpsF32::Act& h1) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+  for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[(size_t)3 * OpsF32::TILE_FRAGS + sg * 64];
+  {
+    const f32x4* gb = reinterpret_cast<const f32x4*>(A.wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS;
+    constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
+    f32x4 bt[NBI];
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; bt[i] = gb[k < NB4 ? k : NB4 - 1]; }
+#pragma unroll
+    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; reinterpret_cast<f32x4*>(bias_l)[k < NB4 ? k : NB4 - 1] = bt[i]; }
+  }
+  // k-step s = 16m + r of lane half hf is hidden unit 32m + (r&3) + 8(r>>2) + 4hf (the C/D layout the stream's W2 follows)
+  const f32x4* ph = reinterpret_cast<const f32x4*>(A.h + (size_t)ec * KDIM + 4 * hf);
+#pragma unroll
+  for (int m = 0; m < 3; ++m)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 x = ph[8 * m + 2 * q];
+      h1.v[16 * m + 4 * q + 0] = x.x; h1.v[16 * m + 4 * q + 1] = x.y; h1.v[16 * m + 4 * q + 2] = x.z; h1.v[16 * m + 4 * q + 3] = x.w;
+    }
+  const f32x4* pr = reinterpret_cast<const f32x4*>(A.xrow + (size_t)ec * NODE_STRIDE + 40 * hf);
+#pragma unroll
+  for (int q = 0; q < 10; ++q) {
+    const f32x4 r = pr[q];
+    float* o = xT + (40 * hf + 4 * q) * 32 + j;
+    o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
+  }
+}
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* bias_l = lds;
+  float* xT = lds + S.ntiles * 32;
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int e0 = blockIdx.x * WAVE_EDGES, e = e0 + j;
+  const int ec = e < A.E ? e : A.E - 1;
+  const f32x4* gp = reinterpret_cast<const f32x4*>(A.wstream) + lane;
+  f32x4 a[OpsF32::NFRAG];
+  OpsF32::Act h1;
+  train_prologue<IN, OUT>(A, bias_l, xT, lane, ec, gp, a, h1);
+  const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
+  const float v[3] = {vv.x, vv.y, vv.z};
+  __syncthreads();
+
+  int T = 3;
+  f32x16 acc;
+#define CBD_TT()                                                                                              \
+  {                                                                                                           \
+    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, bias_l + T * 32, h1, acc, hf);            \
+    ++T;                                                                                                      \
+  }
+  const float* xc = xT + j;
+  float o0e[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
+#pragma unroll 1
+  for (int i = 0; i < S.t0e; ++i) {
+    CBD_TT();
+    const float m = mid0e<IN>(xc, i, v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
+  }
+  float k1o[9], k1e[9], k0o[3];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
+  k0o[0] = k0o[1] = k0o[2] = 0.f;
+  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+      CBD_TT();
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        float m[3];
+        mid_fn(xc, VEC_TILE_I * t + q, v, m);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+          const float w = acc[3 * q + o];
+          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
+          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
+          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
+        }
+      }
+    }
+  };
+  vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, u, m); }, S.t1o, k1o);
+  if constexpr (OUT >= 2)
+    vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, u, m); }, S.t1e, k1e);
+  if constexpr (OUT >= 3) {
+#pragma unroll 1
+    for (int t = 0; t < S.t0o; ++t) {
+      CBD_TT();
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
+      }
+    }
+  }
+#undef CBD_TT
+  // messages -> LDS tile -> coalesced rows of msg (columns >= out_dim are written as zeros)
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xT[((r & 3) + 8 * (r >> 2) + 4 * hf) * OUT_STRIDE + j] = o0e[r];
+#pragma unroll
+  for (int o = 0; o < 3; ++o)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      xT[(COL_1O + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1o[3 * o + c];
+      if constexpr (OUT >= 2) xT[(COL_1E + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1e[3 * o + c];
+    }
+  if constexpr (OUT >= 3) {
+#pragma unroll
+    for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
+  }
+  __syncthreads();
+  const int nrow = A.E - e0 < WAVE_EDGES ? A.E - e0 : WAVE_EDGES;
+  for (int col = lane; col < NODE_STRIDE; col += 64) {
+    const bool live = col < S.out_dim;
+    for (int jj = 0; jj < nrow; ++jj) A.msg[(size_t)(e0 + jj) * NODE_STRIDE + col] = live ? xT[col * OUT_STRIDE + jj] : 0.f;
+  }
+}
+
+__device__ __forceinline__ float half_sum(float x) { return x + __shfl_xor(x, 32, 64); }
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  constexpr int WP = (S.ntiles - 3) * 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* bias_l = lds;
+  float* xT = lds + S.ntiles * 32;
+  float* gxT = xT + XT_FLOATS;   // [NODE_STRIDE][GX_STRIDE] gradient wrt the gathered row, column-major per edge
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  const int e0 = blockIdx.x * WAVE_EDGES, e = e0 + j;
+  const bool valid = e < A.E;
+  const int ec = valid ? e : A.E - 1;
+  const f32x4* gp = reinterpret_cast<const f32x4*>(A.wstream) + lane;
+  f32x4 a[OpsF32::NFRAG];
+  OpsF32::Act h1;
+  train_prologue<IN, OUT>(A, bias_l, xT, lane, ec, gp, a, h1);
+  const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
+  const float v[3] = {vv.x, vv.y, vv.z};
+  // this lane's slice of d loss / d msg in the accumulator layout: 0e rows (r&3) + 8(r>>2) + 4hf; vector outputs 3hf..3hf+2
+  const float* gm = A.gmsg + (size_t)ec * NODE_STRIDE;
+  float g0e[16], g1o[9], g1e[9], g0o[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(gm + 4 * hf)[2 * q];
+    g0e[4 * q + 0] = x.x; g0e[4 * q + 1] = x.y; g0e[4 * q + 2] = x.z; g0e[4 * q + 3] = x.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    g1o[k] = gm[COL_1O + 9 * hf + k];
+    g1e[k] = OUT >= 2 ? gm[COL_1E + 9 * hf + k] : 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) g0o[o] = OUT >= 3 ? gm[COL_0O + 3 * hf + o] : 0.f;
+  for (int k = lane; k < NODE_STRIDE * GX_STRIDE; k += 64) gxT[k] = 0.f;
+  __syncthreads();
+
+  int T = 3;
+  f32x16 acc;
+#define CBD_TT()                                                                                              \
+  {                                                                                                           \
+    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, bias_l + T * 32, h1, acc, hf);            \
+    ++T;                                                                                                      \
+  }
+  const float* xc = xT + j;
+  float* gxc = gxT + j;                                   // gxc[col * GX_STRIDE]
+  float* const gwrow = A.gw + (size_t)ec * WP + 4 * hf;   // + (tile - 3) * 32 + 8q: the 4 rows (r&3) of register quad q
+  auto store_gw = [&](int tile, const float (&gw)[16]) __attribute__((always_inline)) {
+    if (valid) {
+      f32x4* o = reinterpret_cast<f32x4*>(gwrow + (size_t)(tile - 3) * 32);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[2 * q] = f32x4{gw[4 * q], gw[4 * q + 1], gw[4 * q + 2], gw[4 * q + 3]};
+    }
+  };
+  // transposed mid maps: add g (gradient wrt mid i of a block) into the gradient of the gathered row.  Only lane half 0
+  // updates the LDS tile (both halves hold the same, already half-summed g).
+  auto add_s = [&](int col, float g) __attribute__((always_inline)) { gxc[col * GX_STRIDE] += g; };
+  auto add_v = [&](int col, float g0, float g1, float g2) __attribute__((always_inline)) {
+    gxc[col * GX_STRIDE] += g0; gxc[(col + 1) * GX_STRIDE] += g1; gxc[(col + 2) * GX_STRIDE] += g2;
+  };
+
+  // ---- block 0e
+#pragma unroll 1
+  for (int i = 0; i < S.t0e; ++i) {
+    const int Tc = T;
+    CBD_TT();
+    const float m = mid0e<IN>(xc, i, v);
+    float gw[16], part = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { gw[r] = m * g0e[r]; part = fmaf(acc[r], g0e[r], part); }
+    store_gw(Tc, gw);
+    const float g = half_sum(part);
+    if (hf == 0) {
+      if (i < NS) add_s(i, g);
+      else if (IN >= 1) add_v(COL_1O + 3 * (i - NS), g * v[0], g * v[1], g * v[2]);
+    }
+  }
+  // ---- vector blocks
+  auto vec_block = [&](auto mid_fn, auto back_fn, int ntile, const float (&gk)[9]) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+      const int Tc = T;
+      CBD_TT();
+      float gw[16];
+      gw[15] = 0.f;
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        float m[3];
+        mid_fn(xc, VEC_TILE_I * t + q, v, m);
+        float gmid[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+          const float w = acc[3 * q + o];
+          gw[3 * q + o] = m[0] * gk[3 * o + 0] + m[1] * gk[3 * o + 1] + m[2] * gk[3 * o + 2];
+          gmid[0] = fmaf(w, gk[3 * o + 0], gmid[0]);
+          gmid[1] = fmaf(w, gk[3 * o + 1], gmid[1]);
+          gmid[2] = fmaf(w, gk[3 * o + 2], gmid[2]);
+        }
+        gmid[0] = half_sum(gmid[0]); gmid[1] = half_sum(gmid[1]); gmid[2] = half_sum(gmid[2]);
+        if (hf == 0) back_fn(VEC_TILE_I * t + q, gmid);
+      }
+      store_gw(Tc, gw);
+    }
+  };
+  // d/da of g . (a x v) is v x g
+  auto vxg = [&](const float (&g)[3], float (&o)[3]) __attribute__((always_inline)) {
+    o[0] = v[1] * g[2] - v[2] * g[1];
+    o[1] = v[2] * g[0] - v[0] * g[2];
+    o[2] = v[0] * g[1] - v[1] * g[0];
+  };
+  vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, u, m); },
+            [&](int i, const float (&g)[3]) __attribute__((always_inline)) {
+              if (i < NS) add_s(i, g[0] * v[0] + g[1] * v[1] + g[2] * v[2]);
+              else if (i < NS + S.n1o) add_v(COL_1O + 3 * (i - NS), g[0], g[1], g[2]);
+              else if (i < S.fan1o) { float o[3]; vxg(g, o); add_v(COL_1E + 3 * (i - NS - S.n1o), o[0], o[1], o[2]); }
+            },
+            S.t1o, g1o);
+  if constexpr (OUT >= 2)
+    vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, u, m); },
+              [&](int i, const float (&g)[3]) __attribute__((always_inline)) {
+                if (i < S.n1o) { float o[3]; vxg(g, o); add_v(COL_1O + 3 * i, o[0], o[1], o[2]); }
+                else if (i < S.n1o + S.n1e) add_v(COL_1E + 3 * (i - S.n1o), g[0], g[1], g[2]);
+                else if (i < S.fan1e) add_s(COL_0O + (i - S.n1o - S.n1e), g[0] * v[0] + g[1] * v[1] + g[2] * v[2]);
+              },
+              S.t1e, g1e);
+  if constexpr (OUT >= 3) {
+#pragma unroll 1
+    for (int t = 0; t < S.t0o; ++t) {
+      const int Tc = T;
+      CBD_TT();
+      float gw[16];
+      gw[15] = 0.f;
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const int i = VEC_TILE_I * t + q;
+        const float m = mid0o<IN>(xc, i, v);
+        float part = 0.f;
+#pragma unroll
+        for (int o = 0; o < 3; ++o) { gw[3 * q + o] = m * g0o[o]; part = fmaf(acc[3 * q + o], g0o[o], part); }
+        const float g = half_sum(part);
+        if (hf == 0) {
+          if (i < S.n1e) add_v(COL_1E + 3 * i, g * v[0], g * v[1], g * v[2]);
+          else if (i < S.fan0o) add_s(COL_0O + (i - S.n1e), g);
+        }
+      }
+      store_gw(Tc, gw);
+    }
+  }
+#undef CBD_TT
+  __syncthreads();
+  const int nrow = A.E - e0 < WAVE_EDGES ? A.E - e0 : WAVE_EDGES;
+  for (int col = lane; col < NODE_STRIDE; col += 64)
+    for (int jj = 0; jj < nrow; ++jj) A.gx[(size_t)(e0 + jj) * NODE_STRIDE + col] = gxT[col * GX_STRIDE + jj];
+}
+
+template <int IN, int OUT>
+static hipError_t launch_train(bool bwd, const TrainTpArgs& a, hipStream_t s) {
+  const int grid = (a.E + WAVE_EDGES - 1) / WAVE_EDGES;
+  const int lds_bytes = train_lds_floats(conv_shape(IN, OUT).ntiles, bwd) * 4;
+  if (bwd) hipLaunchKernelGGL((tp_train_bwd_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else hipLaunchKernelGGL((tp_train_fwd_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_train_any(int in_level, int out_level, bool bwd, const TrainTpArgs& a, hipStream_t s) {
+  if (in_level == 0 && out_level == 1) return launch_train<0, 1>(bwd, a, s);
+  if (in_level == 1 && out_level == 2) return launch_train<1, 2>(bwd, a, s);
+  if (in_level == 2 && out_level == 3) return launch_train<2, 3>(bwd, a, s);
+  if (in_level == 3 && out_level == 3) return launch_train<3, 3>(bwd, a, s);
+  return hipErrorInvalidValue;
+}
+
+}  // namespace cbd
+
+extern "C" {
+
+int64_t cbd_tp_packed_width(int32_t in_level, int32_t out_level) {
+  if (in_level < 0 || in_level > 3 || out_level < 1 || out_level > 3) return -1;
+  return (int64_t)(cbd::conv_shape(in_level, out_level).ntiles - 3) * 32;
+}
+
+int cbd_tp_forward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
+                   const float* wstream_dev, float* msg_dev, void* stream) {
+  if (E < 0 || E > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "bad edge count");
+  if (E == 0) return 0;
+  if (!xrow_dev || !vec4_dev || !h_dev || !wstream_dev || !msg_dev) return fail(CBD_ERR_ARG, "null argument");
+  cbd::TrainTpArgs a{xrow_dev, vec4_dev, h_dev, wstream_dev, (int)E, msg_dev, nullptr, nullptr, nullptr};
+  const hipError_t r = cbd::launch_train_any(in_level, out_level, false, a, reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_forward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_tp_backward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
+                    const float* wstream_dev, const float* gmsg_dev, float* gx_dev, float* gw_dev, void* stream) {
+  if (E < 0 || E > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "bad edge count");
+  if (E == 0) return 0;
+  if (!xrow_dev || !vec4_dev || !h_dev || !wstream_dev || !gmsg_dev || !gx_dev || !gw_dev) return fail(CBD_ERR_ARG, "null argument");
+  cbd::TrainTpArgs a{xrow_dev, vec4_dev, h_dev, wstream_dev, (int)E, nullptr, gmsg_dev, gx_dev, gw_dev};
+  const hipError_t r = cbd::launch_train_any(in_level, out_level, true, a, reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""Autograd op for the fine-tuning step: `FasterTensorProduct` fed by the last Linear of its FCBlock, forward and backward
+on hand-written gfx950 kernels (csrc/tp_train.hip through the C ABI `cbd_tp_forward` / `cbd_tp_backward`).
+
+Replaces, inside `TensorProductConvLayer.forward` (reference models/tensor_layers.py:195-206),
+    tp(node_attr[edge_dst], edge_sh, fc[-1](h))        with h = Dropout(ReLU(fc[0](edge_attr)))
+and its autograd graph.  The per-edge [E, weight_numel] tensor is never built in the forward pass; backward writes its
+gradient once (packed-row order) and finishes the Linear's backward with two rocBLAS GEMMs.
+
+There is no PyTorch fallback: without the HIP library (or on CPU tensors) the op raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import lru_cache
+
+import numpy as np
+import torch
+
+from .engine import load_library, _check
+
+NODE_STRIDE = 80      # csrc/common.h
+KDIM = 96
+TILE_W_FLOATS = 48 * 64
+LEVEL_DIMS = [32, 50, 68, 74]
+
+
+def _bind(lib):   # symbols are bound (and checked against include/cbdock.h) by engine.load_library
+    return lib
+
+
+class StreamMap:
+    """How one FCBlock's parameters (reference layout) land in the MFMA tile stream of level (IN, OUT):
+       stream[i] = scale[i] * flat[src[i]],  flat = [fc.0.weight (96x96) | fc.0.bias | fc.3.weight (W x 96) | fc.3.bias]
+    obtained by probing the library's own packer (`cbd_pack_conv_stream`, host only), plus the positions of the logical
+    second-Linear matrix W2p[(tile-3)*32 + row][hidden unit] and bias b2p inside the stream."""
+
+    def __init__(self, in_level: int, out_level: int):
+        lib = _bind(load_library())
+        self.in_level, self.out_level = in_level, out_level
+        n = int(lib.cbd_conv_stream_floats(in_level, out_level))
+        self.wp = int(lib.cbd_tp_packed_width(in_level, out_level))
+        self.ntiles = self.wp // 32 + 3
+        from .score_model import faster_tp_weight_numel, get_irrep_seq
+        seq = get_irrep_seq(32, 6, False, True)
+        self.weight_numel = W = faster_tp_weight_numel(seq[in_level], seq[out_level])
+        sizes = [KDIM * KDIM, KDIM, W * KDIM, W]
+        offs = np.concatenate([[0], np.cumsum(sizes)])
+
+        def pack(parts):
+            out = np.zeros(n, dtype=np.float32)
+            arrs = [np.ascontiguousarray(p, dtype=np.float32) for p in parts]
+            _check(lib.cbd_pack_conv_stream(in_level, out_level, *[a.ctypes.data_as(C.c_void_p) for a in arrs],
+                                            out.ctypes.data_as(C.c_void_p)))
+            return out
+
+        scale = pack([np.ones(s, dtype=np.float32) for s in sizes])
+        idx = pack([np.arange(offs[k] + 1, offs[k + 1] + 1, dtype=np.float32) for k in range(4)])
+        live = scale != 0
+        src = np.zeros(n, dtype=np.int64)
+        src[live] = np.rint(idx[live].astype(np.float64) / scale[live].astype(np.float64)).astype(np.int64) - 1
+        assert src.min() >= 0 and src.max() < offs[-1]
+        self.n, self.scale_np, self.src_np = n, scale, src
+        # physical position of (tile T, row r, k-step s, lane half hf) (csrc/engine.hip::pack_rows_f32) and the hidden unit the
+        # second Linear's k-step addresses (C/D register layout of the first GEMM)
+        T, r, s, hf = np.meshgrid(np.arange(3, self.ntiles), np.arange(32), np.arange(48), np.arange(2), indexing="ij")
+        phys = T * TILE_W_FLOATS + ((s >> 2) * 64 + hf * 32 + r) * 4 + (s & 3)
+        hidden = 32 * (s // 16) + ((s % 16) & 3) + 8 * ((s % 16) >> 2) + 4 * hf
+        w2p = np.zeros((self.wp, KDIM), dtype=np.int64)
+        w2p[((T - 3) * 32 + r).ravel(), hidden.ravel()] = phys.ravel()
+        self.w2p_np = w2p
+        self.b2p_np = (self.ntiles + 1) * TILE_W_FLOATS + 96 + np.arange(self.wp)
+        self._dev = {}
+
+    def on(self, device):
+        d = self._dev.get(str(device))
+        if d is None:
+            d = {"src": torch.from_numpy(self.src_np).to(device), "scale": torch.from_numpy(self.scale_np).to(device),
+                 "w2p": torch.from_numpy(self.w2p_np.ravel()).to(device), "b2p": torch.from_numpy(self.b2p_np).to(device)}
+            self._dev[str(device)] = d
+        return d
+
+    def stream(self, fc) -> torch.Tensor:
+        """Differentiable tile stream of an FCBlock `nn.Sequential(Linear, ReLU, Dropout, Linear)`."""
+        w1, w2 = fc[0], fc[3]
+        flat = torch.cat([w1.weight.reshape(-1), w1.bias, w2.weight.reshape(-1), w2.bias])
+        d = self.on(flat.device)
+        return flat[d["src"]] * d["scale"]
+
+
+@lru_cache(maxsize=None)
+def stream_map(in_level: int, out_level: int) -> StreamMap:
+    return StreamMap(in_level, out_level)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream_handle():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class TensorProductFn(torch.autograd.Function):
+    """msg[E, 80] = FasterTensorProduct(xrow[E, 80], [1, sqrt3 vec[E, :3]], W2 h + b2) with (W2, b2) inside `stream`."""
+
+    @staticmethod
+    def forward(ctx, xrow, vec4, h, stream, in_level, out_level):
+        if not xrow.is_cuda:
+            raise RuntimeError("TensorProductFn runs on the MI355X HIP kernels only (no CPU fallback)")
+        lib = _bind(load_library())
+        xrow, vec4, h, stream = xrow.contiguous().float(), vec4.contiguous().float(), h.contiguous().float(), stream.contiguous().float()
+        E = xrow.shape[0]
+        assert xrow.shape == (E, NODE_STRIDE) and vec4.shape == (E, 4) and h.shape == (E, KDIM)
+        msg = torch.empty(E, NODE_STRIDE, device=xrow.device, dtype=torch.float32)
+        _check(lib.cbd_tp_forward(in_level, out_level, E, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(stream), _ptr(msg), _stream_handle()))
+        ctx.save_for_backward(xrow, vec4, h, stream)
+        ctx.levels = (in_level, out_level)
+        return msg
+
+    @staticmethod
+    def backward(ctx, gmsg):
+        xrow, vec4, h, stream = ctx.saved_tensors
+        in_level, out_level = ctx.levels
+        lib = _bind(load_library())
+        sm = stream_map(in_level, out_level)
+        d = sm.on(xrow.device)
+        E = xrow.shape[0]
+        gmsg = gmsg.contiguous().float()
+        gx = torch.empty_like(xrow)
+        gw = torch.empty(E, sm.wp, device=xrow.device, dtype=torch.float32)
+        _check(lib.cbd_tp_backward(in_level, out_level, E, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(stream), _ptr(gmsg), _ptr(gx), _ptr(gw),
+                                   _stream_handle()))
+        gstream = gh = None
+        if ctx.needs_input_grad[2]:
+            w2p = stream[d["w2p"]].view(sm.wp, KDIM)
+            gh = gw @ w2p
+        if ctx.needs_input_grad[3]:
+            gstream = torch.zeros_like(stream)
+            gstream[d["w2p"]] = (gw.t() @ h).reshape(-1)
+            gstream[d["b2p"]] = gw.sum(0)
+        return (gx if ctx.needs_input_grad[0] else None), None, gh, gstream, None, None
+
+
+def tensor_product(xrow, vec4, h, stream, in_level, out_level):
+    return TensorProductFn.apply(xrow, vec4, h, stream, in_level, out_level)

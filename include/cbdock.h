@@ -226,6 +226,27 @@ int64_t cbd_conf_stream_floats(int32_t in_level, int32_t out_level);
 int cbd_conf_pack_stream(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host,
                          const float* w2_host, const float* b2_host, float* out_host);
 
+/* ---- training-side tensor product (fine-tuning step) ------------------------------------------------
+ * Forward / backward of  msg[e] = FasterTensorProduct(x[e], [1, sqrt3 vec[e]], W2 h[e] + b2)
+ * (reference models/tensor_layers.py:66-117 fed by the last Linear of the FCBlock, models/layers.py:8-15, inside
+ * TensorProductConvLayer.forward models/tensor_layers.py:195-206), the op autograd differentiates in
+ * utils/training.py:184-233 (train_epoch: loss.backward()).  All pointers are device pointers, all tensors fp32 and per edge:
+ *   xrow [E][80]  features of the node the edge reads (node_attr[edge_dst]; columns >= the level's width are zero)
+ *   vec4 [E][4]   unit edge vector (x, y, z, 0)
+ *   h    [E][96]  hidden activations of the radial MLP (after ReLU and Dropout)
+ *   wstream       the FCBlock's tile stream (cbd_pack_conv_stream layout, cbd_conv_stream_floats(in, out) floats)
+ *   msg  [E][80]  out: messages (columns >= out width are zero)
+ *   gmsg [E][80]  in:  d loss / d msg
+ *   gx   [E][80]  out: d loss / d xrow
+ *   gw   [E][Wp]  out: d loss / d (packed per-edge weights), Wp = cbd_tp_packed_width(in, out); column (tile-3)*32 + row of the
+ *                 stream's second-Linear tiles.  The caller finishes the Linear's backward: g_h = gw W2p, dW2p = gw^T h.
+ * (in_level, out_level) in {(0,1), (1,2), (2,3), (3,3)} = node widths 32/50/68/74 of get_irrep_seq (tensor_layers.py:12-27). */
+int64_t cbd_tp_packed_width(int32_t in_level, int32_t out_level);
+int cbd_tp_forward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
+                   const float* wstream_dev, float* msg_dev, void* stream);
+int cbd_tp_backward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
+                    const float* wstream_dev, const float* gmsg_dev, float* gx_dev, float* gw_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
