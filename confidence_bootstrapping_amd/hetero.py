@@ -95,6 +95,12 @@ class HeteroData:
                 self.__dict__[k] = {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
         return self
 
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None):
+        return self.to("cuda" if device is None else device)
+
     def clone(self):
         return copy.deepcopy(self)
 

@@ -267,6 +267,14 @@ class TensorProductScoreModel(nn.Module):
 
     def forward(self, data):
         """Same contract as the reference forward (models/score_model.py:333-449):
-        returns (tr_pred [B,3], rot_pred [B,3], tor_pred [B*R], None)."""
+        returns (tr_pred [B,3], rot_pred [B,3], tor_pred [B*R], None).  eval mode: the fused inference engine (no autograd);
+        training mode: the differentiable path of train_forward.py (HIP tensor-product op + autograd) for fine-tuning."""
+        if self.training:
+            return self.forward_train(data)
         from .engine import score_batch
         return score_batch(self, data)
+
+    def forward_train(self, data):
+        """Differentiable forward (list of HeteroData or a collated Batch with per-graph complex_t), any mode."""
+        from .train_forward import forward as _fwd
+        return _fwd(self, data)

@@ -1,0 +1,300 @@
+"""Differentiable forward pass of `TensorProductScoreModel` for the fine-tuning step (reference
+models/score_model.py:282-449 under `model.train()`, called from utils/training.py:198 `model(data)`).
+
+Heterogeneous batches (different complexes, one diffusion time each), training-mode e3nn BatchNorm (batch statistics, running
+averages updated), Dropout where the reference has it.  Every FasterTensorProduct layer -- > 99 % of the FLOPs -- runs on the
+hand-written gfx950 kernels of csrc/tp_train.hip through `train_ops.tensor_product`; the surrounding small ops (embeddings,
+radius graphs, scatter-mean, BatchNorm, the two e3nn heads) are autograd-visible torch ops on the same device.  The inference
+path (`model.eval()` + sampling) does not come through here: it runs on the fused engine (engine.py).
+
+Works in eval mode too (running statistics, no dropout), which the tests use to cross-check this path against the engine.
+"""
+from __future__ import annotations
+
+import math
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import so3, torus
+from .hetero import Batch, HeteroData
+from .score_model import parse_irreps
+from .train_ops import LEVEL_DIMS, NODE_STRIDE, stream_map, tensor_product
+
+SQ3 = math.sqrt(3.0)
+
+
+# ----------------------------------------------------------------------------- batching
+def collate(data_list: List[HeteroData], device) -> Batch:
+    """`Batch.from_data_list` + per-graph diffusion times as tensors (what PyG's collate gives the reference for
+    `complex_t` dicts, utils/diffusion_utils.py:150-179)."""
+    if isinstance(data_list, Batch):
+        return data_list.to(device)
+    ts = {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list])
+          for k in ("tr", "rot", "tor")}
+    keep = []
+    for d in data_list:
+        c = d.clone()
+        for k in ("complex_t",):
+            c.__dict__.pop(k, None)
+        for nt in ("ligand", "receptor"):
+            c[nt].__dict__.pop("node_t", None)
+        keep.append(c)
+    b = Batch.from_data_list(keep).to(device)
+    b.complex_t = {k: v.to(device) for k, v in ts.items()}
+    return b
+
+
+# ----------------------------------------------------------------------------- graph ops (torch_cluster / torch_scatter semantics)
+def radius(x, y, r, batch_x, batch_y, max_num_neighbors=32):
+    """For every y the x's of the same graph with |x - y|^2 < r^2, first `max_num_neighbors` in index order
+    (torch_cluster.radius; row 0 = index into y, row 1 = index into x)."""
+    d2 = torch.zeros(y.shape[0], x.shape[0], dtype=x.dtype, device=x.device)
+    for k in range(x.shape[1]):
+        diff = x[None, :, k] - y[:, None, k]
+        d2 = d2 + diff * diff
+    ok = (d2 < r * r) & (batch_y[:, None] == batch_x[None, :])
+    rank = torch.cumsum(ok.to(torch.int32), dim=1)
+    ok = ok & (rank <= max_num_neighbors)
+    row, col = torch.nonzero(ok, as_tuple=True)
+    return torch.stack([row, col], dim=0)
+
+
+def radius_graph(x, r, batch, max_num_neighbors=32):
+    ei = radius(x, x, r, batch, batch, max_num_neighbors + 1)
+    keep = ei[0] != ei[1]
+    return torch.stack([ei[1][keep], ei[0][keep]], dim=0)   # [neighbour; centre]
+
+
+def scatter_mean(src, index, dim_size):
+    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    out = out.index_add(0, index, src)
+    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(index, dtype=src.dtype))
+    return out / cnt.clamp(min=1).reshape((dim_size,) + (1,) * (src.dim() - 1))
+
+
+def gaussian_smearing(mod, dist):
+    d = dist.view(-1, 1) - mod.offset.view(1, -1)
+    return torch.exp(mod.coeff * torch.pow(d, 2))
+
+
+def unit4(vec):
+    """unit edge vector padded to 4 floats: the kernels' `vec` operand (sh = [1, sqrt3 * unit])."""
+    return F.pad(F.normalize(vec, dim=-1), (0, 1))
+
+
+def atom_encoder(enc, x_cat, extra):
+    emb = 0
+    for i, table in enumerate(enc.atom_embedding_list):
+        emb = emb + table(x_cat[:, i].long())
+    if enc.additional_features_dim > 0:
+        emb = enc.additional_features_embedder(torch.cat([emb, extra], dim=1))
+    return emb
+
+
+def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1):
+    """e3nn.nn.BatchNorm (0.5.0: affine, normalization='component', reduce='mean').  Training: per-channel batch mean of the 0e
+    fields and batch mean of the squared (centred) components of every field, running averages updated with `momentum`;
+    eval: running statistics."""
+    outs, ix, iw, ib = [], 0, 0, 0
+    new_mean, new_var = [], []
+    for m, l, p in parse_irreps(bn.irreps):
+        d = 2 * l + 1
+        f = x[:, ix:ix + m * d].reshape(-1, m, d)
+        ix += m * d
+        scalar = l == 0 and p == 1
+        if scalar:
+            mean = f.mean(dim=(0, 2)) if bn.training else bn.running_mean[ib:ib + m]
+            if bn.training:
+                new_mean.append(mean.detach())
+            f = f - mean.reshape(1, m, 1)
+        var = f.pow(2).mean(dim=2).mean(dim=0) if bn.training else bn.running_var[iw:iw + m]
+        if bn.training:
+            new_var.append(var.detach())
+        f = f * ((var + eps).pow(-0.5) * bn.weight[iw:iw + m]).reshape(1, m, 1)
+        if scalar:
+            f = f + bn.bias[ib:ib + m].reshape(1, m, 1)
+            ib += m
+        iw += m
+        outs.append(f.reshape(-1, m * d))
+    if bn.training:
+        with torch.no_grad():
+            if new_mean:
+                bn.running_mean.mul_(1 - momentum).add_(momentum * torch.cat(new_mean))
+            bn.running_var.mul_(1 - momentum).add_(momentum * torch.cat(new_var))
+    return torch.cat(outs, dim=-1)
+
+
+# ----------------------------------------------------------------------------- layers
+def _fc_hidden(fc, x):
+    return fc[2](fc[1](fc[0](x)))   # Linear -> ReLU -> Dropout; the last Linear lives inside the HIP op
+
+
+def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, out_level):
+    """TensorProductConvLayer.forward (models/tensor_layers.py:195-217) with FasterTensorProduct on the HIP op."""
+    n, din = node_attr.shape
+    dout = LEVEL_DIMS[out_level]
+    if edge_index.shape[1] == 0:
+        out = torch.zeros(n, dout, dtype=node_attr.dtype, device=node_attr.device)
+    else:
+        src, dst = edge_index[0], edge_index[1]
+        xpad = F.pad(node_attr, (0, NODE_STRIDE - din))
+        sm = stream_map(in_level, out_level)
+        groups = edge_attr_groups if isinstance(edge_attr_groups, (list, tuple)) else [edge_attr_groups]
+        fcs = [layer.fc] if layer.edge_groups == 1 else list(layer.fc)
+        msgs, lo = [], 0
+        for fc, ea in zip(fcs, groups):
+            hi = lo + ea.shape[0]
+            if hi > lo:
+                msgs.append(tensor_product(xpad[dst[lo:hi]], vec4[lo:hi], _fc_hidden(fc, ea), sm.stream(fc), in_level, out_level)[:, :dout])
+            lo = hi
+        out = scatter_mean(torch.cat(msgs, dim=0), src, n)
+        out = irreps_batch_norm(layer.batch_norm, out)
+    return out + F.pad(node_attr, (0, dout - din))
+
+
+def center_tensor_product(x, vec, w):
+    """o3.FullyConnectedTensorProduct(74-irreps, '1x0e+1x1o', '2x1o+2x1e') with per-edge weights (final_conv.tp,
+    models/tensor_layers.py:185): instruction-major weights [0e*1o->1o | 1o*0e->1o | 1o*1o->1e | 1e*0e->1e | 1e*1o->1o | 0o*1o->1e]."""
+    E = x.shape[0]
+    v = SQ3 * F.normalize(vec, dim=-1)
+    x0e, x1o, x1e, x0o = x[:, :32], x[:, 32:50].reshape(E, 6, 3), x[:, 50:68].reshape(E, 6, 3), x[:, 68:74]
+    wa, wb = w[:, 0:64].reshape(E, 32, 2), w[:, 64:76].reshape(E, 6, 2)
+    wc, wd = w[:, 76:88].reshape(E, 6, 2), w[:, 88:100].reshape(E, 6, 2)
+    we, wf = w[:, 100:112].reshape(E, 6, 2), w[:, 112:124].reshape(E, 6, 2)
+    vb = v[:, None, :].expand(E, 6, 3)
+    s2 = 1.0 / math.sqrt(2.0)
+    out1o = (torch.einsum("euw,eu,ek->ewk", wa, x0e, v) + torch.einsum("euw,euk->ewk", wb, x1o)
+             + s2 * torch.einsum("euw,euk->ewk", we, torch.linalg.cross(x1e, vb, dim=-1))) / math.sqrt(44.0)
+    out1e = (s2 * torch.einsum("euw,euk->ewk", wc, torch.linalg.cross(x1o, vb, dim=-1)) + torch.einsum("euw,euk->ewk", wd, x1e)
+             + torch.einsum("euw,eu,ek->ewk", wf, x0o, v)) / math.sqrt(18.0)
+    return torch.cat([out1o.reshape(E, 6), out1e.reshape(E, 6)], dim=1)
+
+
+def bond_tensor_product(x, edge_vec, bond_vec, w):
+    """final_tp_tor (o3.FullTensorProduct('1x0e+1x1o', '2e')) followed by tor_bond_conv.tp (FCTP with two live paths):
+    1o x T1 -> 32x0e (weights [0:192]) and 1e x T1 -> 32x0o ([192:384]); output order [0o | 0e].  T1 is the 1o block of the
+    full product: (3/sqrt2)(b b^T - I/3)(sqrt3 v) for unit bond direction b and unit edge direction v (score_model.py:431-441)."""
+    E = x.shape[0]
+    v = SQ3 * F.normalize(edge_vec, dim=-1)
+    b = F.normalize(bond_vec, dim=-1)
+    t1 = (3.0 / math.sqrt(2.0)) * (b * (b * v).sum(-1, keepdim=True) - v / 3.0)
+    x1o, x1e = x[:, 32:50].reshape(E, 6, 3), x[:, 50:68].reshape(E, 6, 3)
+    c = 1.0 / math.sqrt(6.0) / SQ3
+    out0e = c * torch.einsum("euw,eu->ew", w[:, :192].reshape(E, 6, 32), (x1o * t1[:, None, :]).sum(-1))
+    out0o = c * torch.einsum("euw,eu->ew", w[:, 192:].reshape(E, 6, 32), (x1e * t1[:, None, :]).sum(-1))
+    return torch.cat([out0o, out0e], dim=1)
+
+
+# ----------------------------------------------------------------------------- the model
+def forward(model, data):
+    """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449)."""
+    dev = next(model.parameters()).device
+    if dev.type != "cuda":
+        raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
+    data = collate(data, dev)
+    ns = model.ns
+    lig, rec = data["ligand"], data["receptor"]
+    B = data.num_graphs
+    ct = data.complex_t
+    tr_sigma, rot_sigma, tor_sigma = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
+    lig_batch, rec_batch = lig.batch, rec.batch
+    lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
+
+    # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
+    r_ei = data["receptor", "receptor"].edge_index.long()
+    r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
+    rec_edge_attr = model.rec_edge_embedding(gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1)))
+    r_vec4 = unit4(r_vec)
+    rec_node = atom_encoder(model.rec_node_embedding, rec.x[:, :1], rec.x[:, 1:].float())
+    for l, layer in enumerate(model.rec_emb_layers):
+        ea = torch.cat([rec_edge_attr, rec_node[r_ei[0], :ns], rec_node[r_ei[1], :ns]], -1)
+        rec_node = conv_layer(layer, rec_node, r_ei, ea, r_vec4, min(l, 3), min(l + 1, 3))
+    graph_sigma_emb = model.timestep_emb_func(ct["tr"])
+    rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
+    rec_node = torch.cat([rec_node[:, :ns] + rec_sigma_emb[rec_batch], rec_node[:, ns:]], dim=1)
+    rec_edge_attr = rec_edge_attr + rec_sigma_emb[rec_batch[r_ei[0]]]
+
+    # ---- ligand graph + embedding (score_model.py:492-522, 282-295)
+    node_sigma_emb = graph_sigma_emb[lig_batch]
+    bond_ei = data["ligand", "ligand"].edge_index.long()
+    radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
+    l_ei = torch.cat([bond_ei, radius_edges], 1)
+    l_attr = torch.cat([data["ligand", "ligand"].edge_attr.float(),
+                        torch.zeros(radius_edges.shape[1], model.in_lig_edge_features, device=dev)], 0)
+    l_vec = lig_pos[l_ei[1]] - lig_pos[l_ei[0]]
+    l_attr = torch.cat([l_attr, node_sigma_emb[l_ei[0]], gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))], 1)
+    l_vec4 = unit4(l_vec)
+    lig_node = atom_encoder(model.lig_node_embedding, lig.x, node_sigma_emb)
+    lig_edge_attr = model.lig_edge_embedding(l_attr)
+    for l, layer in enumerate(model.lig_emb_layers):
+        ea = torch.cat([lig_edge_attr, lig_node[l_ei[0], :ns], lig_node[l_ei[1], :ns]], -1)
+        lig_node = conv_layer(layer, lig_node, l_ei, ea, l_vec4, min(l, 3), min(l + 1, 3))
+
+    # ---- cross graph (score_model.py:345-352, 564-587)
+    cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
+    lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
+    c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
+    lr_attr = torch.cat([node_sigma_emb[lr[0]], gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))], 1)
+    lr_edge_attr = model.cross_edge_embedding(lr_attr)
+    lr_vec4 = unit4(c_vec)
+
+    # ---- joint graph, interaction layers (score_model.py:354-376)
+    nL = lig_node.shape[0]
+    node = torch.cat([lig_node, rec_node], 0)
+    lr_j = torch.stack([lr[0], lr[1] + nL], 0)
+    edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.flip(lr_j, dims=[0])], 1)
+    edge_attr = torch.cat([lig_edge_attr, lr_edge_attr, rec_edge_attr, lr_edge_attr], 0)
+    vec4 = torch.cat([l_vec4, lr_vec4, r_vec4, -lr_vec4], 0)
+    s1 = l_ei.shape[1]
+    s2 = s1 + lr_j.shape[1]
+    s3 = s2 + r_ei.shape[1]
+    nconv = len(model.conv_layers)
+    for l, layer in enumerate(model.conv_layers):
+        if l < nconv - 1:
+            ea = torch.cat([edge_attr, node[edge_index[0], :ns], node[edge_index[1], :ns]], -1)
+            node = conv_layer(layer, node, edge_index, [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]], vec4, 3, 3)
+        else:
+            ea = torch.cat([edge_attr[:s2], node[edge_index[0, :s2], :ns], node[edge_index[1, :s2], :ns]], -1)
+            node = conv_layer(layer, node, edge_index[:, :s2], [ea[:s1], ea[s1:s2]], vec4[:s2], 3, 3)
+    lig_node = node[:nL]
+
+    # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
+    counts = torch.bincount(lig_batch, minlength=B).unsqueeze(1)
+    center = torch.zeros(B, 3, device=dev).index_add(0, lig_batch, lig_pos) / counts
+    c_vec2 = lig_pos - center[lig_batch]
+    c_attr = torch.cat([gaussian_smearing(model.center_distance_expansion, c_vec2.norm(dim=-1)), node_sigma_emb], 1)
+    c_attr = torch.cat([model.center_edge_embedding(c_attr), lig_node[:, :ns]], -1)
+    gp = scatter_mean(center_tensor_product(lig_node, c_vec2, model.final_conv.fc(c_attr)), lig_batch, B)
+    gp = irreps_batch_norm(model.final_conv.batch_norm, gp)
+    tr_pred = gp[:, :3] + gp[:, 6:9]
+    rot_pred = gp[:, 3:6] + gp[:, 9:]
+    tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
+    tr_pred = tr_pred / tr_norm * model.tr_final_layer(torch.cat([tr_norm, graph_sigma_emb], dim=1))
+    rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
+    rot_pred = rot_pred / rot_norm * model.rot_final_layer(torch.cat([rot_norm, graph_sigma_emb], dim=1))
+    tr_pred = tr_pred / tr_sigma.unsqueeze(1)
+    rot_pred = rot_pred * so3.score_norm(rot_sigma.detach().cpu()).unsqueeze(1).to(dev)
+
+    edge_mask = lig.edge_mask.bool()
+    if model.no_torsion or int(edge_mask.sum()) == 0:
+        return tr_pred, rot_pred, torch.empty(0, device=dev), None
+
+    # ---- torsion head (score_model.py:431-448, 650-664)
+    bonds = bond_ei[:, edge_mask]
+    bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
+    t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
+    t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
+    t_attr = model.final_edge_embedding(gaussian_smearing(model.lig_distance_expansion, t_vec.norm(dim=-1)))
+    bond_attr = lig_node[bonds[0]] + lig_node[bonds[1]]
+    t_attr = torch.cat([t_attr, lig_node[t_ei[1], :ns], bond_attr[t_ei[0], :ns]], -1)
+    bond_vec = lig_pos[bonds[1]] - lig_pos[bonds[0]]
+    msg = bond_tensor_product(lig_node[t_ei[1]], t_vec, bond_vec[t_ei[0]], model.tor_bond_conv.fc(t_attr))
+    tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
+    tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor)
+    tor_pred = model.tor_final_layer(tor).squeeze(1)
+    edge_sigma = tor_sigma[lig_batch][bond_ei[0]][edge_mask]
+    tor_pred = tor_pred * torch.sqrt(torch.tensor(torus.score_norm(edge_sigma.detach().cpu().numpy())).float().to(dev))
+    return tr_pred, rot_pred, tor_pred, None

@@ -128,3 +128,47 @@ def make_score_model(device="cpu", seed=0, args=None, eval_mode=True, confidence
     if eval_mode:
         model.eval()
     return model.to(device), args
+
+
+class ExponentialMovingAverage:
+    """Exponential moving average of the trainable parameters with the interface finetune_train.py uses (`update`, `copy_to`,
+    `store`, `restore`, `state_dict`, `load_state_dict`; reference utils/utils.py:306-392): with `use_num_updates` the decay warms
+    up as min(decay, (1 + n) / (10 + n)).  All parameters are updated by one fused multi-tensor lerp on the device."""
+
+    def __init__(self, parameters, decay, use_num_updates=True):
+        if not 0.0 <= decay <= 1.0:
+            raise ValueError("Decay must be between 0 and 1")
+        self.decay = decay
+        self.num_updates = 0 if use_num_updates else None
+        self.shadow_params = [p.detach().clone() for p in parameters if p.requires_grad]
+        self.collected_params = []
+
+    def update(self, parameters):
+        decay = self.decay
+        if self.num_updates is not None:
+            self.num_updates += 1
+            decay = min(decay, (1 + self.num_updates) / (10 + self.num_updates))
+        live = [p.detach() for p in parameters if p.requires_grad]
+        with torch.no_grad():
+            torch._foreach_lerp_(self.shadow_params, live, 1.0 - decay)   # s += (1 - decay) * (p - s)
+
+    def copy_to(self, parameters):
+        with torch.no_grad():
+            for s, p in zip(self.shadow_params, [p for p in parameters if p.requires_grad]):
+                p.copy_(s)
+
+    def store(self, parameters):
+        self.collected_params = [p.detach().clone() for p in parameters]
+
+    def restore(self, parameters):
+        with torch.no_grad():
+            for c, p in zip(self.collected_params, parameters):
+                p.copy_(c)
+
+    def state_dict(self):
+        return dict(decay=self.decay, num_updates=self.num_updates, shadow_params=self.shadow_params)
+
+    def load_state_dict(self, state_dict, device):
+        self.decay = state_dict["decay"]
+        self.num_updates = state_dict["num_updates"]
+        self.shadow_params = [t.to(device) for t in state_dict["shadow_params"]]

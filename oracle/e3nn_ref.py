@@ -275,7 +275,7 @@ class BatchNorm(torch.nn.Module):
     """e3nn.nn.BatchNorm(irreps) (eps=1e-5, affine, normalization='component', reduce='mean').
     Eval: scalars (l=0,p=+1) (x-mean)*rsqrt(var+eps)*w + b ; every other irrep x*rsqrt(var+eps)*w,
     one statistic per multiplicity channel.  state_dict: weight[F], bias[Fs], running_mean[Fs], running_var[F]
-    with F = sum of muls, Fs = sum of muls of 0e irreps.  Training mode is not restated (inference path)."""
+    with F = sum of muls, Fs = sum of muls of 0e irreps."""
 
     def __init__(self, irreps, eps=1e-5):
         super().__init__()
@@ -288,20 +288,41 @@ class BatchNorm(torch.nn.Module):
         self.register_buffer("running_mean", torch.zeros(ns))
         self.register_buffer("running_var", torch.ones(nf))
 
+    momentum = 0.1
+
     def forward(self, x):
-        assert not self.training, "oracle BatchNorm restates eval mode only"
+        """Training mode restated from e3nn 0.5.0 e3nn/nn/_batchnorm.py: 0e fields are centred on their batch mean, every
+        field is scaled by (batch mean of its squared components + eps)^-1/2, gradients flow through the statistics, and the
+        running buffers move by `momentum` towards the (detached) batch values."""
         out, ix, iw, ib = [], 0, 0, 0
+        new_mean, new_var = [], []
         for m, ir in self.irreps:
             d = ir.dim
             f = x[:, ix:ix + m * d].reshape(-1, m, d)
             ix += m * d
-            if ir.l == 0 and ir.p == 1:
-                f = f - self.running_mean[ib:ib + m].reshape(1, m, 1)
-            scale = (self.running_var[iw:iw + m] + self.eps).pow(-0.5) * self.weight[iw:iw + m]
+            scalar = ir.l == 0 and ir.p == 1
+            if scalar:
+                if self.training:
+                    mean = f.mean(dim=(0, 2))
+                    new_mean.append(mean.detach())
+                else:
+                    mean = self.running_mean[ib:ib + m]
+                f = f - mean.reshape(1, m, 1)
+            if self.training:
+                var = f.pow(2).mean(dim=2).mean(dim=0)
+                new_var.append(var.detach())
+            else:
+                var = self.running_var[iw:iw + m]
+            scale = (var + self.eps).pow(-0.5) * self.weight[iw:iw + m]
             f = f * scale.reshape(1, m, 1)
-            if ir.l == 0 and ir.p == 1:
+            if scalar:
                 f = f + self.bias[ib:ib + m].reshape(1, m, 1)
                 ib += m
             iw += m
             out.append(f.reshape(-1, m * d))
+        if self.training:
+            with torch.no_grad():
+                if new_mean:
+                    self.running_mean.copy_((1 - self.momentum) * self.running_mean + self.momentum * torch.cat(new_mean))
+                self.running_var.copy_((1 - self.momentum) * self.running_var + self.momentum * torch.cat(new_var))
         return torch.cat(out, dim=-1)

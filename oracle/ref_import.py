@@ -81,6 +81,9 @@ def install(scratch_dir="/tmp/cb_tables", torus_seed=0, load_tables=True):
     e3nn.__path__ = []
     _module("torch_scatter", scatter=gr.scatter, scatter_mean=gr.scatter_mean)
     _module("torch_cluster", radius=gr.radius, radius_graph=gr.radius_graph, knn_graph=MagicMock())
+    # base classes the reference subclasses at import time (a MagicMock base would turn the subclass into a mock)
+    _module("torch_geometric.transforms", BaseTransform=object)
+    _module("torch_geometric.data", Dataset=object, HeteroData=hetero.HeteroData, Batch=hetero.Batch, Data=object)
 
     # ---- score-normaliser tables: import the reference modules on their cached .npy files
     if load_tables:
@@ -102,7 +105,7 @@ def install(scratch_dir="/tmp/cb_tables", torus_seed=0, load_tables=True):
     return hetero
 
 
-def reference_score_model(state_dict=None):
+def reference_score_model(state_dict=None, dropout=None):
     """Construct the REFERENCE TensorProductScoreModel class with the shipped yml's kwargs
     (utils/utils.py:239-283 mapping), optionally loading a state dict produced by the build."""
     from functools import partial
@@ -111,6 +114,8 @@ def reference_score_model(state_dict=None):
     from utils.diffusion_utils import t_to_sigma as ref_t_to_sigma, get_timestep_embedding
     from models.score_model import TensorProductScoreModel as RefModel
     args = load_model_args()
+    if dropout is not None:
+        args.dropout = dropout
     emb = get_timestep_embedding(embedding_type=args.embedding_type, embedding_dim=args.sigma_embed_dim,
                                  embedding_scale=args.embedding_scale)
     model = RefModel(t_to_sigma=partial(ref_t_to_sigma, args=args), device=torch.device("cpu"), no_torsion=args.no_torsion,
