@@ -28,23 +28,59 @@ SQ3 = math.sqrt(3.0)
 
 # ----------------------------------------------------------------------------- batching
 def collate(data_list: List[HeteroData], device) -> Batch:
-    """`Batch.from_data_list` + per-graph diffusion times as tensors (what PyG's collate gives the reference for
-    `complex_t` dicts, utils/diffusion_utils.py:150-179)."""
+    """Collation of the fields the score model reads (what PyG's Batch gives the reference): node tensors concatenated,
+    edge_index offset per graph, `batch` vectors, per-graph diffusion times (utils/diffusion_utils.py:150-179) as tensors.
+    One concatenation + one host-to-device copy per field; the input graphs are not copied or modified."""
     if isinstance(data_list, Batch):
         return data_list.to(device)
-    ts = {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list])
-          for k in ("tr", "rot", "tor")}
-    keep = []
-    for d in data_list:
-        c = d.clone()
-        for k in ("complex_t",):
-            c.__dict__.pop(k, None)
-        for nt in ("ligand", "receptor"):
-            c[nt].__dict__.pop("node_t", None)
-        keep.append(c)
-    b = Batch.from_data_list(keep).to(device)
-    b.complex_t = {k: v.to(device) for k, v in ts.items()}
+    b = Batch()
+    object.__setattr__(b, "_num_graphs", len(data_list))
+    nl = [d["ligand"].num_nodes for d in data_list]
+    nr = [d["receptor"].num_nodes for d in data_list]
+    offs = lambda sizes: np.concatenate([[0], np.cumsum(sizes)[:-1]]).tolist()
+    lo, ro = offs(nl), offs(nr)
+    # host-to-device copies go through their own HIP stream: on the compute stream a copy from pageable memory would block the host
+    # until the previous step's kernels have drained (26 ms per step in the first profile)
+    side = _copy_stream(device)
+    keep_alive = []
+
+    def dv(parts, dim=0):
+        """per-graph host-to-device copies, concatenated on the device (a host-side cat of the 2 MB/complex language-model
+        features costs more than the whole GPU step on a many-core host)"""
+        with torch.cuda.stream(side):
+            out = torch.cat([p.to(device, non_blocking=True) for p in parts], dim) if len(parts) > 1 else parts[0].to(device, non_blocking=True)
+        keep_alive.append(out)
+        return out
+
+    b["ligand"].x = dv([d["ligand"].x for d in data_list])
+    b["ligand"].pos = dv([d["ligand"].pos for d in data_list])
+    b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list])
+    b["ligand"].batch = dv([torch.repeat_interleave(torch.arange(len(nl)), torch.tensor(nl))])
+    b["ligand", "ligand"].edge_index = dv([d["ligand", "ligand"].edge_index + o for d, o in zip(data_list, lo)], 1)
+    b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list])
+    b["receptor"].x = dv([d["receptor"].x for d in data_list])
+    b["receptor"].pos = dv([d["receptor"].pos for d in data_list])
+    b["receptor"].batch = dv([torch.repeat_interleave(torch.arange(len(nr)), torch.tensor(nr))])
+    b["receptor", "receptor"].edge_index = dv([d["receptor", "receptor"].edge_index + o for d, o in zip(data_list, ro)], 1)
+    b.complex_t = {k: dv([torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list])])
+                   for k in ("tr", "rot", "tor")}
+    # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
+    b.host = {"t": {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list]) for k in ("tr", "rot", "tor")},
+              "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list]}
+    torch.cuda.current_stream(device).wait_stream(side)
+    for t in keep_alive:
+        t.record_stream(torch.cuda.current_stream(device))
     return b
+
+
+_COPY_STREAMS = {}
+
+
+def _copy_stream(device):
+    key = str(device)
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _COPY_STREAMS[key]
 
 
 # ----------------------------------------------------------------------------- graph ops (torch_cluster / torch_scatter semantics)
@@ -75,6 +111,12 @@ def scatter_mean(src, index, dim_size):
     return out / cnt.clamp(min=1).reshape((dim_size,) + (1,) * (src.dim() - 1))
 
 
+def take(x, idx):
+    """x[idx] along dim 0 through index_select: its backward is one atomic index_add (torch's fancy-index backward sorts the
+    indices first -- 30 % of the step's GPU time in the first profile, profiles/r01_h_train_*)."""
+    return x.index_select(0, idx)
+
+
 def gaussian_smearing(mod, dist):
     d = dist.view(-1, 1) - mod.offset.view(1, -1)
     return torch.exp(mod.coeff * torch.pow(d, 2))
@@ -88,7 +130,7 @@ def unit4(vec):
 def atom_encoder(enc, x_cat, extra):
     emb = 0
     for i, table in enumerate(enc.atom_embedding_list):
-        emb = emb + table(x_cat[:, i].long())
+        emb = emb + take(table.weight, x_cat[:, i].long())
     if enc.additional_features_dim > 0:
         emb = enc.additional_features_embedder(torch.cat([emb, extra], dim=1))
     return emb
@@ -148,7 +190,7 @@ def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, o
         for fc, ea in zip(fcs, groups):
             hi = lo + ea.shape[0]
             if hi > lo:
-                msgs.append(tensor_product(xpad[dst[lo:hi]], vec4[lo:hi], _fc_hidden(fc, ea), sm.stream(fc), in_level, out_level)[:, :dout])
+                msgs.append(tensor_product(take(xpad, dst[lo:hi]), vec4[lo:hi], _fc_hidden(fc, ea), sm.stream(fc), in_level, out_level)[:, :dout])
             lo = hi
         out = scatter_mean(torch.cat(msgs, dim=0), src, n)
         out = irreps_batch_norm(layer.batch_norm, out)
@@ -203,6 +245,25 @@ def forward(model, data):
     lig_batch, rec_batch = lig.batch, rec.batch
     lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
 
+    # ---- everything that needs a device->host read-back (edge counts of the three radius graphs) or a host table look-up happens
+    #      first, while the GPU is still busy with the previous step: the rest of the step is enqueued without a single sync
+    host = getattr(data, "host", None)
+    t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
+    n_rot = host["n_rot"] if host else torch.bincount(lig_batch[data["ligand", "ligand"].edge_index[0][lig.edge_mask.bool()]], minlength=B).tolist()
+    _, rot_sigma_h, tor_sigma_h = model.t_to_sigma(t_host["tr"], t_host["rot"], t_host["tor"])
+    so3_norm = so3.score_norm(rot_sigma_h).unsqueeze(1).to(dev, non_blocking=True)
+    tor_sigma_edge = np.repeat(tor_sigma_h.numpy(), n_rot)
+    torus_norm = torch.sqrt(torch.tensor(torus.score_norm(tor_sigma_edge)).float()).to(dev, non_blocking=True) if sum(n_rot) else None
+    bond_ei = data["ligand", "ligand"].edge_index.long()
+    edge_mask = lig.edge_mask.bool()
+    radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
+    cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
+    lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
+    if sum(n_rot):
+        bonds = bond_ei[:, edge_mask]
+        bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
+        t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
+
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
     r_ei = data["receptor", "receptor"].edge_index.long()
     r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
@@ -210,34 +271,30 @@ def forward(model, data):
     r_vec4 = unit4(r_vec)
     rec_node = atom_encoder(model.rec_node_embedding, rec.x[:, :1], rec.x[:, 1:].float())
     for l, layer in enumerate(model.rec_emb_layers):
-        ea = torch.cat([rec_edge_attr, rec_node[r_ei[0], :ns], rec_node[r_ei[1], :ns]], -1)
+        ea = torch.cat([rec_edge_attr, take(rec_node[:, :ns], r_ei[0]), take(rec_node[:, :ns], r_ei[1])], -1)
         rec_node = conv_layer(layer, rec_node, r_ei, ea, r_vec4, min(l, 3), min(l + 1, 3))
     graph_sigma_emb = model.timestep_emb_func(ct["tr"])
     rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
-    rec_node = torch.cat([rec_node[:, :ns] + rec_sigma_emb[rec_batch], rec_node[:, ns:]], dim=1)
-    rec_edge_attr = rec_edge_attr + rec_sigma_emb[rec_batch[r_ei[0]]]
+    rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
+    rec_edge_attr = rec_edge_attr + take(rec_sigma_emb, rec_batch[r_ei[0]])
 
     # ---- ligand graph + embedding (score_model.py:492-522, 282-295)
-    node_sigma_emb = graph_sigma_emb[lig_batch]
-    bond_ei = data["ligand", "ligand"].edge_index.long()
-    radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
+    node_sigma_emb = take(graph_sigma_emb, lig_batch)
     l_ei = torch.cat([bond_ei, radius_edges], 1)
     l_attr = torch.cat([data["ligand", "ligand"].edge_attr.float(),
                         torch.zeros(radius_edges.shape[1], model.in_lig_edge_features, device=dev)], 0)
     l_vec = lig_pos[l_ei[1]] - lig_pos[l_ei[0]]
-    l_attr = torch.cat([l_attr, node_sigma_emb[l_ei[0]], gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))], 1)
+    l_attr = torch.cat([l_attr, take(node_sigma_emb, l_ei[0]), gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))], 1)
     l_vec4 = unit4(l_vec)
     lig_node = atom_encoder(model.lig_node_embedding, lig.x, node_sigma_emb)
     lig_edge_attr = model.lig_edge_embedding(l_attr)
     for l, layer in enumerate(model.lig_emb_layers):
-        ea = torch.cat([lig_edge_attr, lig_node[l_ei[0], :ns], lig_node[l_ei[1], :ns]], -1)
+        ea = torch.cat([lig_edge_attr, take(lig_node[:, :ns], l_ei[0]), take(lig_node[:, :ns], l_ei[1])], -1)
         lig_node = conv_layer(layer, lig_node, l_ei, ea, l_vec4, min(l, 3), min(l + 1, 3))
 
     # ---- cross graph (score_model.py:345-352, 564-587)
-    cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
-    lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
     c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
-    lr_attr = torch.cat([node_sigma_emb[lr[0]], gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))], 1)
+    lr_attr = torch.cat([take(node_sigma_emb, lr[0]), gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))], 1)
     lr_edge_attr = model.cross_edge_embedding(lr_attr)
     lr_vec4 = unit4(c_vec)
 
@@ -254,10 +311,10 @@ def forward(model, data):
     nconv = len(model.conv_layers)
     for l, layer in enumerate(model.conv_layers):
         if l < nconv - 1:
-            ea = torch.cat([edge_attr, node[edge_index[0], :ns], node[edge_index[1], :ns]], -1)
+            ea = torch.cat([edge_attr, take(node[:, :ns], edge_index[0]), take(node[:, :ns], edge_index[1])], -1)
             node = conv_layer(layer, node, edge_index, [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]], vec4, 3, 3)
         else:
-            ea = torch.cat([edge_attr[:s2], node[edge_index[0, :s2], :ns], node[edge_index[1, :s2], :ns]], -1)
+            ea = torch.cat([edge_attr[:s2], take(node[:, :ns], edge_index[0, :s2]), take(node[:, :ns], edge_index[1, :s2])], -1)
             node = conv_layer(layer, node, edge_index[:, :s2], [ea[:s1], ea[s1:s2]], vec4[:s2], 3, 3)
     lig_node = node[:nL]
 
@@ -276,25 +333,20 @@ def forward(model, data):
     rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
     rot_pred = rot_pred / rot_norm * model.rot_final_layer(torch.cat([rot_norm, graph_sigma_emb], dim=1))
     tr_pred = tr_pred / tr_sigma.unsqueeze(1)
-    rot_pred = rot_pred * so3.score_norm(rot_sigma.detach().cpu()).unsqueeze(1).to(dev)
+    rot_pred = rot_pred * so3_norm
 
-    edge_mask = lig.edge_mask.bool()
-    if model.no_torsion or int(edge_mask.sum()) == 0:
+    if model.no_torsion or sum(n_rot) == 0:
         return tr_pred, rot_pred, torch.empty(0, device=dev), None
 
     # ---- torsion head (score_model.py:431-448, 650-664)
-    bonds = bond_ei[:, edge_mask]
-    bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
-    t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
     t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
     t_attr = model.final_edge_embedding(gaussian_smearing(model.lig_distance_expansion, t_vec.norm(dim=-1)))
-    bond_attr = lig_node[bonds[0]] + lig_node[bonds[1]]
-    t_attr = torch.cat([t_attr, lig_node[t_ei[1], :ns], bond_attr[t_ei[0], :ns]], -1)
+    bond_attr = take(lig_node, bonds[0]) + take(lig_node, bonds[1])
+    t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
     bond_vec = lig_pos[bonds[1]] - lig_pos[bonds[0]]
-    msg = bond_tensor_product(lig_node[t_ei[1]], t_vec, bond_vec[t_ei[0]], model.tor_bond_conv.fc(t_attr))
+    msg = bond_tensor_product(take(lig_node, t_ei[1]), t_vec, bond_vec[t_ei[0]], model.tor_bond_conv.fc(t_attr))
     tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
     tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor)
     tor_pred = model.tor_final_layer(tor).squeeze(1)
-    edge_sigma = tor_sigma[lig_batch][bond_ei[0]][edge_mask]
-    tor_pred = tor_pred * torch.sqrt(torch.tensor(torus.score_norm(edge_sigma.detach().cpu().numpy())).float().to(dev))
+    tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
     return tr_pred, rot_pred, tor_pred, None

@@ -84,7 +84,7 @@ class StreamMap:
         w1, w2 = fc[0], fc[3]
         flat = torch.cat([w1.weight.reshape(-1), w1.bias, w2.weight.reshape(-1), w2.bias])
         d = self.on(flat.device)
-        return flat[d["src"]] * d["scale"]
+        return flat.index_select(0, d["src"]) * d["scale"]
 
 
 @lru_cache(maxsize=None)
