@@ -1,0 +1,59 @@
+"""One confidence-bootstrapping round trip on the MI355X (reference finetune_train.py:248-349): sample with the fused engine ->
+confidence model -> symmetry-corrected RMSD metrics -> CBBuffer -> NoiseTransform -> train_epoch on the HIP training path -> EMA ->
+sample again with the updated weights."""
+import copy
+from argparse import Namespace
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_confidence_bootstrapping_round_trip():
+    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model, load_model_args, ExponentialMovingAverage
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    from confidence_bootstrapping_amd.bootstrapping.buffer import CBBuffer
+    from confidence_bootstrapping_amd.datasets.pdbbind import NoiseTransform
+    from confidence_bootstrapping_amd.finetune_train import inference_finetune, inference_epoch
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    model, _ = make_score_model(device=dev, seed=0, args=margs)
+    conf_model, conf_args = make_confidence_model(device=dev, seed=5)
+    names = ["1abc_A_l0", "2xyz_B_l1", "3pqr_C_l2"]
+    targets = []
+    for i, n in enumerate(names):
+        g = add_atoms(make_complex(Nl=9 + i, Nr=36 + 4 * i, R=1 + i % 2, knn=8, seed=40 + i, name=n), seed=40 + i)
+        g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
+        nums = g["ligand"].x[:, 0].numpy() + 1          # synthetic atom types as "atomic numbers" (0 would be filtered as H)
+        g["ligand"].x[:, 0] = torch.from_numpy(nums)
+        ei = g["ligand", "ligand"].edge_index.numpy()
+        am = np.zeros((len(nums), len(nums)), dtype=int)
+        am[ei[0], ei[1]] = 1
+        g.mol = Namespace(atomicnums=nums, adjacency_matrix=am)
+        targets.append(g)
+    args = copy.copy(margs)
+    args.__dict__.update(inference_steps=4, inference_samples=4, inference_batch_size=4, n_epochs=2, cb_inference_freq=1,
+                         initial_iterations=1, inference_iterations=1, num_inference_complexes=3, batch_size=4, use_ema=True,
+                         tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
+    t2s = partial(t_to_sigma, args=margs)
+    torch.manual_seed(0); np.random.seed(0)
+    metrics, kept, top = inference_epoch(model, conf_model, targets, None, dev, t2s, args, conf_args, confidence_cutoff=-1e9)
+    assert len(kept) == 12 and len(top) == 3 and metrics["rmsds_lt5"] is not None and np.isfinite(metrics["avg_confidence"])
+    buf = CBBuffer(cluster_name="c", cluster_to_ligands={"c": names}, max_complexes_per_couple=6,
+                   transform=NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    w0 = model.conv_layers[0].fc[0][3].weight.detach().clone()
+    hist = inference_finetune(args, model, conf_model, conf_args, None, -1e9, opt, ema, buf, targets, t2s, dev, log=lambda s: None)
+    assert len(hist) == 2 and all(np.isfinite(h["train_loss"]) for h in hist)
+    assert hist[0]["buffer"] == 12 and hist[1]["buffer"] == 18          # 3 couples x top-6 after the second round
+    assert not torch.equal(w0, model.conv_layers[0].fc[0][3].weight)    # the fine-tuning steps moved the weights
+    assert ema.num_updates == 3 + 5
+    # the inference engine picks the updated weights up
+    model.eval()
+    m2, kept2, _ = inference_epoch(model, conf_model, targets[:1], None, dev, t2s, args, conf_args, confidence_cutoff=-1e9)
+    assert len(kept2) == 4 and np.isfinite(m2["avg_confidence"])
