@@ -36,6 +36,19 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
         raise NotImplementedError("asynchronous noise schedules are outside the MI355X hot path")
     rmsds, min_rmsds, top_rmsds, confidences_list, complexes_to_keep = [], [], [], [], []
     model.eval()
+    n = args.inference_samples
+
+    def run(items, bs):
+        """one sampling() call over the poses of all `items` (complexes): consecutive complexes are co-scheduled on the GPU"""
+        flat = [g for it in items for g in it[1]]
+        filt = [g for it in items for g in it[2]] if items[0][2] is not None else None
+        preds, conf = sampling(data_list=flat, model=model, inference_steps=args.inference_steps, tr_schedule=t_schedule,
+                               rot_schedule=t_schedule, tor_schedule=t_schedule, device=device, t_to_sigma=t_to_sigma, model_args=args,
+                               confidence_model=filtering_model, filtering_data_list=filt, filtering_model_args=filtering_args,
+                               batch_size=bs)
+        return [(preds[k * n:(k + 1) * n], None if conf is None else conf[k * n:(k + 1) * n]) for k in range(len(items))]
+
+    prepared = []
     for orig in complex_graphs:
         orig = _as_batch1(orig)
         name = orig.name[0] if isinstance(orig.name, (list, tuple)) else orig.name
@@ -44,28 +57,37 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
             if name not in filtering_complex_dict:
                 print(f"HAPPENING | The filtering dataset did not contain {name}. We are skipping this complex.")
                 continue
-            filtering_data_list = [copy.deepcopy(filtering_complex_dict[name]) for _ in range(args.inference_samples)]
-        data_list = [copy.deepcopy(orig) for _ in range(args.inference_samples)]
+            filtering_data_list = [copy.deepcopy(filtering_complex_dict[name]) for _ in range(n)]
+        data_list = [copy.deepcopy(orig) for _ in range(n)]
         randomize_position(data_list, args.no_torsion, False, args.tr_sigma_max,
                            pocket_knowledge=getattr(args, "inf_pocket_knowledge", False), pocket_cutoff=getattr(args, "inf_pocket_cutoff", 7))
-        predictions_list, confidences, failed, bs = None, None, 0, args.inference_batch_size
-        while predictions_list is None:
-            try:
-                predictions_list, confidences = sampling(data_list=data_list, model=model, inference_steps=args.inference_steps,
-                                                         tr_schedule=t_schedule, rot_schedule=t_schedule, tor_schedule=t_schedule,
-                                                         device=device, t_to_sigma=t_to_sigma, model_args=args,
-                                                         confidence_model=filtering_model, filtering_data_list=filtering_data_list,
-                                                         filtering_model_args=filtering_args, batch_size=bs)
-            except Exception as e:   # the reference's halve-and-retry protocol
-                failed += 1
-                bs = max(bs // 2, 1)
-                if failed > 5:
-                    print("failed 5 times - skipping the complex")
-                    break
-                print("Exception while running inference on complex:", e)
-                traceback.print_exc()
-        if failed > 5:
+        prepared.append((orig, data_list, filtering_data_list))
+
+    results = []
+    group = 4 if n % max(args.inference_batch_size, 1) == 0 else 1      # loader batches must not straddle complexes
+    for k in range(0, len(prepared), group):
+        items = prepared[k:k + group]
+        try:
+            results.extend(zip(items, run(items, args.inference_batch_size)))
             continue
+        except Exception as e:
+            print("Exception while running inference on a group of complexes, retrying one by one:", e)
+        for it in items:           # the reference's per-complex halve-and-retry protocol (finetune_train.py:176-196)
+            out, failed, bs = None, 0, args.inference_batch_size
+            while out is None and failed <= 5:
+                try:
+                    out = run([it], bs)[0]
+                except Exception as e:
+                    failed += 1
+                    bs = max(bs // 2, 1)
+                    print("Exception while running inference on complex:", e)
+                    traceback.print_exc()
+            if out is None:
+                print("failed 5 times - skipping the complex")
+                continue
+            results.append((it, out))
+
+    for (orig, _, _), (predictions_list, confidences) in results:
         ligand_pos = np.asarray([g["ligand"].pos.cpu().numpy() for g in predictions_list])
         if confidences is not None and isinstance(getattr(filtering_args, "rmsd_classification_cutoff", None), list):
             confidences = confidences[:, 0]

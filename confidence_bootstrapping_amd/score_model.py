@@ -250,6 +250,21 @@ class TensorProductScoreModel(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def co_engines(self, n: int, main):
+        """`n` further engines on the device of `main` that use ITS device-resident weights (cbd_share_weights) and hold their own
+        complex / workspace: the partners of `main` in cbd_sample_multi (sampling(co_schedule=...))."""
+        from .engine import DockEngine
+        if getattr(self, "_co_main", None) is not main:
+            self._co, self._co_main = [], main
+        while len(self._co) < n:
+            e = DockEngine(main.device, max_batch=main.max_batch, lm_embedding_dim=main.cfg.lm_embedding_dim,
+                           no_torsion=bool(main.cfg.no_torsion), lig_max_radius=main.cfg.lig_max_radius,
+                           rec_max_radius=main.cfg.rec_max_radius, cross_max_distance=main.cfg.cross_max_distance,
+                           center_max_distance=main.cfg.center_max_distance)
+            e.share_weights_from(main)
+            self._co.append(e)
+        return self._co[:n]
+
     def engine_pool(self, n_streams: int = 1, max_batch: int = 64):
         """n-stream engine pool used by sampling() (see engine.DockEnginePool)."""
         from .engine import DockEnginePool

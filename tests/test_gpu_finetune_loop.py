@@ -57,3 +57,30 @@ def test_confidence_bootstrapping_round_trip():
     model.eval()
     m2, kept2, _ = inference_epoch(model, conf_model, targets[:1], None, dev, t2s, args, conf_args, confidence_cutoff=-1e9)
     assert len(kept2) == 4 and np.isfinite(m2["avg_confidence"])
+
+
+def test_sampling_co_schedules_complexes_identically():
+    """sampling() over the poses of three different complexes: co_schedule=4 (cbd_sample_multi) == co_schedule=1 (one at a time)."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position
+    dev = torch.device("cuda:0")
+    model, margs = make_score_model(device=dev, seed=0)
+    conf_model, conf_args = make_confidence_model(device=dev, seed=5)
+    cps = [add_atoms(make_complex(Nl=9 + i, Nr=36 + 4 * i, R=1 + i % 2, knn=8, seed=40 + i, name=f"c{i}"), seed=40 + i) for i in range(3)]
+    torch.manual_seed(1); np.random.seed(1)
+    base = [Batch.from_data_list([copy.deepcopy(c)]) for c in cps for _ in range(4)]
+    randomize_position(base, False, False, margs.tr_sigma_max)
+    sched = get_t_schedule("expbeta", 5)
+    outs = []
+    for co in (4, 1):
+        dl = [copy.deepcopy(d) for d in base]
+        torch.manual_seed(7)
+        res, conf = sampling(data_list=dl, model=model, inference_steps=5, tr_schedule=sched, rot_schedule=sched, tor_schedule=sched,
+                             device=dev, t_to_sigma=partial(t_to_sigma, args=margs), model_args=margs, confidence_model=conf_model,
+                             filtering_model_args=conf_args, batch_size=2, co_schedule=co)
+        outs.append(([d["ligand"].pos.clone() for d in res], conf.clone()))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
+    assert torch.equal(outs[0][1], outs[1][1]) and outs[0][1].shape == (12,)
