@@ -22,6 +22,7 @@ import json
 import os
 import sys
 import time
+from functools import partial
 
 import numpy as np
 import torch
@@ -130,6 +131,42 @@ def confidence_leg(cplx_seed, final_pos, dev):
     return {"what": "all-atom confidence model on the 40 final poses (crop 20 A, t=0), not part of `value`", "ms_per_40_poses": round(dt * 1e3, 3),
             "edges_per_layer": e_all, "kernel": "fctp_conv_kernel", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
+
+
+def finetune_leg(dev, batch=8, warm=2, steps=4):
+    """One confidence-bootstrapping fine-tuning step (BASELINE.json configs[4]) measured OUTSIDE the timed region of
+    the headline metric: train-mode forward on the HIP tensor-product op, score-matching loss, HIP backward kernels, Adam, EMA on a
+    batch of `batch` different C2-sized complexes noised by NoiseTransform (same code path as tools/train_bench.py)."""
+    from confidence_bootstrapping_amd.synthetic import make_complex, WORKLOADS
+    from confidence_bootstrapping_amd.utils import make_score_model, load_model_args, ExponentialMovingAverage
+    from confidence_bootstrapping_amd.training import loss_function, train_step
+    from confidence_bootstrapping_amd.datasets.pdbbind import NoiseTransform
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    margs = load_model_args()
+    model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    t2s = partial(t_to_sigma, args=margs)
+    loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
+    base = [make_complex(name=f"cplx{i}", seed=1234 + i, **WORKLOADS["c2_dockgen_median"]) for i in range(batch)]
+    nt = NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False)
+    state = (np.random.get_state(), torch.random.get_rng_state())
+    np.random.seed(0)
+    torch.manual_seed(0)
+    batches = [[nt(copy.deepcopy(c)) for c in base] for _ in range(warm + steps)]
+    np.random.set_state(state[0])
+    torch.random.set_rng_state(state[1])
+    for k in range(warm):
+        train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(warm, warm + steps):
+        out = train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"what": "fine-tuning step (train-mode forward + HIP backward kernels + Adam + EMA), not part of `value`", "batch": batch,
+            "ms_per_step": round(dt * 1e3, 2), "complexes_per_s": round(batch / dt, 1), "loss": round(float(out[0]), 4), "dtype": "f32"}
 
 
 def main():
@@ -318,6 +355,11 @@ def main():
             for p_ in [eng] + extra:
                 p_.set_option("bf16", 0)
                 p_.set_option("f32_split", 0)
+        if world == 1 and headline:
+            try:
+                out["finetune"] = finetune_leg(dev)
+            except Exception as e:      # a secondary leg must never cost the headline line
+                out["finetune"] = {"error": repr(e)[:200]}
         if world == 1 and headline and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
         print(json.dumps(out), flush=True)
