@@ -28,11 +28,17 @@
 
 namespace cbd {
 
+constexpr int TRAIN_MAX_GROUPS = 4;
 struct TrainTpArgs {
   const float* xrow;     // [E][NODE_STRIDE] features of the node every edge reads (node_attr[edge_dst]), zero padded
   const float* vec;      // [E][4] unit edge vector (xyz, 0)
   const float* h;        // [E][96] hidden activations of the radial MLP
-  const float* wstream;  // packed FCBlock stream (fp32 policy)
+  // Edge groups of one layer (reference edge_groups / fc[g], models/tensor_layers.py:190,201): group g owns edges
+  // [e_begin[g], e_begin[g+1]) and its own FCBlock stream; one launch carries all groups, so that the small groups do not pay a
+  // launch drain of their own.  Waves never straddle groups (the grid is the sum of the groups' tile counts).
+  const float* wstream[TRAIN_MAX_GROUPS];
+  int e_begin[TRAIN_MAX_GROUPS + 1];
+  int n_groups;
   int E;
   float* msg;            // forward out  [E][NODE_STRIDE]
   const float* gmsg;     // backward in  [E][NODE_STRIDE]  d loss / d msg
@@ -45,16 +51,30 @@ __host__ __device__ constexpr int train_lds_floats(int ntiles, bool bwd) {
   return ntiles * 32 + XT_FLOATS + (bwd ? NODE_STRIDE * GX_STRIDE : 0);
 }
 
+// which group / 32-edge tile does workgroup `block` own?
+__device__ __forceinline__ void train_locate(const TrainTpArgs& A, int block, int& grp, int& e0, int& e_end) {
+  int t = block;
+  grp = 0;
+#pragma unroll
+  for (int g = 0; g < TRAIN_MAX_GROUPS; ++g) {
+    if (g < A.n_groups) {
+      const int nt = (A.e_begin[g + 1] - A.e_begin[g] + WAVE_EDGES - 1) / WAVE_EDGES;
+      if (t >= 0 && t < nt) { grp = g; e0 = A.e_begin[g] + t * WAVE_EDGES; e_end = A.e_begin[g + 1]; t = -1; }
+      else if (t >= 0) t -= nt;
+    }
+  }
+}
+
 // common prologue: weight stream start (tile 3), bias table, gathered row tile, hidden activations as the MFMA B operand
 template <int IN, int OUT>
-__device__ __forceinline__ void train_prologue(const TrainTpArgs& A, float* bias_l, float* xT, int lane, int ec, const f32x4* gp,
+__device__ __forceinline__ void train_prologue(const TrainTpArgs& A, const float* wstream, float* bias_l, float* xT, int lane, int ec, const f32x4* gp,
                                                f32x4 (&a)[OpsF32::NFRAG], OpsF32::Act& h1) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[(size_t)3 * OpsF32::TILE_FRAGS + sg * 64];
   {
-    const f32x4* gb = reinterpret_cast<const f32x4*>(A.wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS;
+    const f32x4* gb = reinterpret_cast<const f32x4*>(wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS;
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
     f32x4 bt[NBI];
 #pragma unroll
@@ -87,12 +107,15 @@ __global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
   float* bias_l = lds;
   float* xT = lds + S.ntiles * 32;
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
-  const int e0 = blockIdx.x * WAVE_EDGES, e = e0 + j;
-  const int ec = e < A.E ? e : A.E - 1;
-  const f32x4* gp = reinterpret_cast<const f32x4*>(A.wstream) + lane;
+  int grp = 0, e0 = 0, e_end = 0;
+  train_locate(A, blockIdx.x, grp, e0, e_end);
+  const int e = e0 + j;
+  const int ec = e < e_end ? e : e_end - 1;
+  const float* const wstream = A.wstream[grp];
+  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
   f32x4 a[OpsF32::NFRAG];
   OpsF32::Act h1;
-  train_prologue<IN, OUT>(A, bias_l, xT, lane, ec, gp, a, h1);
+  train_prologue<IN, OUT>(A, wstream, bias_l, xT, lane, ec, gp, a, h1);
   const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
   const float v[3] = {vv.x, vv.y, vv.z};
   __syncthreads();
@@ -169,7 +192,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
     for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
   }
   __syncthreads();
-  const int nrow = A.E - e0 < WAVE_EDGES ? A.E - e0 : WAVE_EDGES;
+  const int nrow = e_end - e0 < WAVE_EDGES ? e_end - e0 : WAVE_EDGES;
   for (int col = lane; col < NODE_STRIDE; col += 64) {
     const bool live = col < S.out_dim;
     for (int jj = 0; jj < nrow; ++jj) A.msg[(size_t)(e0 + jj) * NODE_STRIDE + col] = live ? xT[col * OUT_STRIDE + jj] : 0.f;
@@ -187,13 +210,16 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   float* xT = lds + S.ntiles * 32;
   float* gxT = xT + XT_FLOATS;   // [NODE_STRIDE][GX_STRIDE] gradient wrt the gathered row, column-major per edge
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
-  const int e0 = blockIdx.x * WAVE_EDGES, e = e0 + j;
-  const bool valid = e < A.E;
-  const int ec = valid ? e : A.E - 1;
-  const f32x4* gp = reinterpret_cast<const f32x4*>(A.wstream) + lane;
+  int grp = 0, e0 = 0, e_end = 0;
+  train_locate(A, blockIdx.x, grp, e0, e_end);
+  const int e = e0 + j;
+  const bool valid = e < e_end;
+  const int ec = valid ? e : e_end - 1;
+  const float* const wstream = A.wstream[grp];
+  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
   f32x4 a[OpsF32::NFRAG];
   OpsF32::Act h1;
-  train_prologue<IN, OUT>(A, bias_l, xT, lane, ec, gp, a, h1);
+  train_prologue<IN, OUT>(A, wstream, bias_l, xT, lane, ec, gp, a, h1);
   const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
   const float v[3] = {vv.x, vv.y, vv.z};
   // this lane's slice of d loss / d msg in the accumulator layout: 0e rows (r&3) + 8(r>>2) + 4hf; vector outputs 3hf..3hf+2
@@ -327,14 +353,16 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   }
 #undef CBD_TT
   __syncthreads();
-  const int nrow = A.E - e0 < WAVE_EDGES ? A.E - e0 : WAVE_EDGES;
+  const int nrow = e_end - e0 < WAVE_EDGES ? e_end - e0 : WAVE_EDGES;
   for (int col = lane; col < NODE_STRIDE; col += 64)
     for (int jj = 0; jj < nrow; ++jj) A.gx[(size_t)(e0 + jj) * NODE_STRIDE + col] = gxT[col * GX_STRIDE + jj];
 }
 
 template <int IN, int OUT>
 static hipError_t launch_train(bool bwd, const TrainTpArgs& a, hipStream_t s) {
-  const int grid = (a.E + WAVE_EDGES - 1) / WAVE_EDGES;
+  int grid = 0;
+  for (int g = 0; g < a.n_groups; ++g) grid += (a.e_begin[g + 1] - a.e_begin[g] + WAVE_EDGES - 1) / WAVE_EDGES;
+  if (grid == 0) return hipSuccess;
   const int lds_bytes = train_lds_floats(conv_shape(IN, OUT).ntiles, bwd) * 4;
   if (bwd) hipLaunchKernelGGL((tp_train_bwd_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
   else hipLaunchKernelGGL((tp_train_fwd_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
@@ -358,23 +386,44 @@ int64_t cbd_tp_packed_width(int32_t in_level, int32_t out_level) {
   return (int64_t)(cbd::conv_shape(in_level, out_level).ntiles - 3) * 32;
 }
 
-int cbd_tp_forward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
-                   const float* wstream_dev, float* msg_dev, void* stream) {
-  if (E < 0 || E > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "bad edge count");
-  if (E == 0) return 0;
-  if (!xrow_dev || !vec4_dev || !h_dev || !wstream_dev || !msg_dev) return fail(CBD_ERR_ARG, "null argument");
-  cbd::TrainTpArgs a{xrow_dev, vec4_dev, h_dev, wstream_dev, (int)E, msg_dev, nullptr, nullptr, nullptr};
+static int fill_groups(cbd::TrainTpArgs& a, int32_t n_groups, const int64_t* group_edges, const float* const* wstreams) {
+  if (n_groups < 1 || n_groups > cbd::TRAIN_MAX_GROUPS || !group_edges || !wstreams) return fail(CBD_ERR_ARG, "1..4 edge groups");
+  int64_t e = 0;
+  a.n_groups = n_groups;
+  for (int g = 0; g < cbd::TRAIN_MAX_GROUPS + 1; ++g) a.e_begin[g] = 0;
+  for (int g = 0; g < cbd::TRAIN_MAX_GROUPS; ++g) a.wstream[g] = nullptr;
+  for (int g = 0; g < n_groups; ++g) {
+    if (group_edges[g] < 0 || (group_edges[g] > 0 && !wstreams[g])) return fail(CBD_ERR_ARG, "bad edge group %d", g);
+    a.e_begin[g] = (int)e;
+    a.wstream[g] = wstreams[g];
+    e += group_edges[g];
+    if (e > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "too many edges");
+  }
+  for (int g = n_groups; g <= cbd::TRAIN_MAX_GROUPS; ++g) a.e_begin[g] = (int)e;
+  a.E = (int)e;
+  return 0;
+}
+
+int cbd_tp_forward(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges, const float* xrow_dev,
+                   const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, float* msg_dev, void* stream) {
+  cbd::TrainTpArgs a{};
+  CHK(fill_groups(a, n_groups, group_edges, wstreams_dev));
+  if (a.E == 0) return 0;
+  if (!xrow_dev || !vec4_dev || !h_dev || !msg_dev) return fail(CBD_ERR_ARG, "null argument");
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.msg = msg_dev;
   const hipError_t r = cbd::launch_train_any(in_level, out_level, false, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_forward: %s", hipGetErrorString(r));
   return 0;
 }
 
-int cbd_tp_backward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
-                    const float* wstream_dev, const float* gmsg_dev, float* gx_dev, float* gw_dev, void* stream) {
-  if (E < 0 || E > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "bad edge count");
-  if (E == 0) return 0;
-  if (!xrow_dev || !vec4_dev || !h_dev || !wstream_dev || !gmsg_dev || !gx_dev || !gw_dev) return fail(CBD_ERR_ARG, "null argument");
-  cbd::TrainTpArgs a{xrow_dev, vec4_dev, h_dev, wstream_dev, (int)E, nullptr, gmsg_dev, gx_dev, gw_dev};
+int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges, const float* xrow_dev,
+                    const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, const float* gmsg_dev, float* gx_dev,
+                    float* gw_dev, void* stream) {
+  cbd::TrainTpArgs a{};
+  CHK(fill_groups(a, n_groups, group_edges, wstreams_dev));
+  if (a.E == 0) return 0;
+  if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !gx_dev || !gw_dev) return fail(CBD_ERR_ARG, "null argument");
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.gx = gx_dev; a.gw = gw_dev;
   const hipError_t r = cbd::launch_train_any(in_level, out_level, true, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward: %s", hipGetErrorString(r));
   return 0;

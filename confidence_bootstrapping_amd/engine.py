@@ -78,8 +78,8 @@ SYMBOLS = {
     "cbd_conf_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_conf_pack_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_tp_packed_width": (C.c_int64, [C.c_int32, C.c_int32]),
-    "cbd_tp_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P]),
-    "cbd_tp_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_tp_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_tp_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 

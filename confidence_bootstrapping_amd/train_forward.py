@@ -186,13 +186,13 @@ def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, o
         sm = stream_map(in_level, out_level)
         groups = edge_attr_groups if isinstance(edge_attr_groups, (list, tuple)) else [edge_attr_groups]
         fcs = [layer.fc] if layer.edge_groups == 1 else list(layer.fc)
-        msgs, lo = [], 0
-        for fc, ea in zip(fcs, groups):
-            hi = lo + ea.shape[0]
-            if hi > lo:
-                msgs.append(tensor_product(take(xpad, dst[lo:hi]), vec4[lo:hi], _fc_hidden(fc, ea), sm.stream(fc), in_level, out_level)[:, :dout])
-            lo = hi
-        out = scatter_mean(torch.cat(msgs, dim=0), src, n)
+        # all edge groups of the layer in ONE launch of the HIP op (forward and backward); the first Linear of every group's
+        # FCBlock (+ ReLU + Dropout) stays a torch op
+        live = [(fc, ea) for fc, ea in zip(fcs, groups) if ea.shape[0] > 0]
+        hid = torch.cat([_fc_hidden(fc, ea) for fc, ea in live], dim=0) if len(live) > 1 else _fc_hidden(*live[0])
+        msg = tensor_product(take(xpad, dst), vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level,
+                             [ea.shape[0] for _, ea in live])[:, :dout]
+        out = scatter_mean(msg, src, n)
         out = irreps_batch_norm(layer.batch_norm, out)
     return out + F.pad(node_attr, (0, dout - din))
 

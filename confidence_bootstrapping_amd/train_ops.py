@@ -96,50 +96,112 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class KernelTimer:
+    """HIP-event timing of the two training kernels (measurement only; enabled by tools/train_bench.py).  Events are recorded on
+    the stream the kernels are launched on and read back once, in `summary()`."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []      # (kind, in_level, out_level, E, start, stop)
+
+    def wrap(self, kind, in_level, out_level, E, launch):
+        if not self.enabled:
+            return launch()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        launch()
+        b.record()
+        self.records.append((kind, in_level, out_level, E, a, b))
+
+    def summary(self):
+        """{kind: (total ms, launches, algorithmic FLOPs)}: forward = the second Linear + CG contraction (2*96*W + 2*sum fan*m*dim
+        per edge); backward = the same work re-computed plus as much again for g_w / g_mid (counted once: the MFMA part)."""
+        torch.cuda.synchronize()
+        out = {}
+        for kind, i, o, E, a, b in self.records:
+            sm = stream_map(i, o)
+            w = sm.weight_numel
+            fl = E * (2.0 * KDIM * w + 2.0 * _cg_flops(i, o))
+            ms, n, f = out.get(kind, (0.0, 0, 0.0))
+            out[kind] = (ms + a.elapsed_time(b), n + 1, f + fl)
+        self.records = []
+        return out
+
+
+def _cg_flops(in_level, out_level):
+    n1o, n1e, n0o = (6 if in_level >= 1 else 0), (6 if in_level >= 2 else 0), (6 if in_level >= 3 else 0)
+    f0e, f1o = 32 + n1o, 32 + n1o + n1e
+    f1e = n1o + n1e + n0o if out_level >= 2 else 0
+    f0o = n1e + n0o if out_level >= 3 else 0
+    return f0e * 32 + (f1o + f1e) * 6 * 3 + f0o * 6
+
+
+TIMER = KernelTimer()
+
+
 def _stream_handle():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 class TensorProductFn(torch.autograd.Function):
-    """msg[E, 80] = FasterTensorProduct(xrow[E, 80], [1, sqrt3 vec[E, :3]], W2 h + b2) with (W2, b2) inside `stream`."""
+    """msg[E, 80] = FasterTensorProduct(xrow[E, 80], [1, sqrt3 vec[E, :3]], W2_g h + b2_g): the edges are the concatenation of
+    `group_edges[g]` edges per group g, group g using (W2_g, b2_g) inside `streams[g]`; all groups run in one launch."""
 
     @staticmethod
-    def forward(ctx, xrow, vec4, h, stream, in_level, out_level):
+    def forward(ctx, xrow, vec4, h, in_level, out_level, group_edges, *streams):
         if not xrow.is_cuda:
             raise RuntimeError("TensorProductFn runs on the MI355X HIP kernels only (no CPU fallback)")
         lib = _bind(load_library())
-        xrow, vec4, h, stream = xrow.contiguous().float(), vec4.contiguous().float(), h.contiguous().float(), stream.contiguous().float()
+        xrow, vec4, h = xrow.contiguous().float(), vec4.contiguous().float(), h.contiguous().float()
+        streams = [st.contiguous().float() for st in streams]
         E = xrow.shape[0]
         assert xrow.shape == (E, NODE_STRIDE) and vec4.shape == (E, 4) and h.shape == (E, KDIM)
+        assert len(group_edges) == len(streams) and sum(group_edges) == E
+        n = len(streams)
+        ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
+        ws = (C.c_void_p * n)(*[st.data_ptr() for st in streams])
         msg = torch.empty(E, NODE_STRIDE, device=xrow.device, dtype=torch.float32)
-        _check(lib.cbd_tp_forward(in_level, out_level, E, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(stream), _ptr(msg), _stream_handle()))
-        ctx.save_for_backward(xrow, vec4, h, stream)
-        ctx.levels = (in_level, out_level)
+        TIMER.wrap("fwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_forward(
+            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(msg), _stream_handle())))
+        ctx.save_for_backward(xrow, vec4, h, *streams)
+        ctx.meta = (in_level, out_level, list(group_edges))
         return msg
 
     @staticmethod
     def backward(ctx, gmsg):
-        xrow, vec4, h, stream = ctx.saved_tensors
-        in_level, out_level = ctx.levels
+        xrow, vec4, h, *streams = ctx.saved_tensors
+        in_level, out_level, group_edges = ctx.meta
         lib = _bind(load_library())
         sm = stream_map(in_level, out_level)
         d = sm.on(xrow.device)
-        E = xrow.shape[0]
+        E, n = xrow.shape[0], len(streams)
         gmsg = gmsg.contiguous().float()
         gx = torch.empty_like(xrow)
         gw = torch.empty(E, sm.wp, device=xrow.device, dtype=torch.float32)
-        _check(lib.cbd_tp_backward(in_level, out_level, E, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(stream), _ptr(gmsg), _ptr(gx), _ptr(gw),
-                                   _stream_handle()))
-        gstream = gh = None
-        if ctx.needs_input_grad[2]:
-            w2p = stream[d["w2p"]].view(sm.wp, KDIM)
-            gh = gw @ w2p
-        if ctx.needs_input_grad[3]:
-            gstream = torch.zeros_like(stream)
-            gstream[d["w2p"]] = (gw.t() @ h).reshape(-1)
-            gstream[d["b2p"]] = gw.sum(0)
-        return (gx if ctx.needs_input_grad[0] else None), None, gh, gstream, None, None
+        ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
+        ws = (C.c_void_p * n)(*[st.data_ptr() for st in streams])
+        TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
+            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), _ptr(gw), _stream_handle())))
+        gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
+        gstreams, lo = [], 0
+        for g, (ne, stream) in enumerate(zip(group_edges, streams)):
+            hi = lo + ne
+            gwg = gw[lo:hi]
+            if gh is not None and ne:
+                torch.mm(gwg, stream[d["w2p"]].view(sm.wp, KDIM), out=gh[lo:hi])
+            gs = None
+            if ctx.needs_input_grad[6 + g]:
+                gs = torch.zeros_like(stream)
+                if ne:
+                    gs[d["w2p"]] = (gwg.t() @ h[lo:hi]).reshape(-1)
+                    gs[d["b2p"]] = gwg.sum(0)
+            gstreams.append(gs)
+            lo = hi
+        return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, *gstreams
 
 
-def tensor_product(xrow, vec4, h, stream, in_level, out_level):
-    return TensorProductFn.apply(xrow, vec4, h, stream, in_level, out_level)
+def tensor_product(xrow, vec4, h, streams, in_level, out_level, group_edges=None):
+    """`streams`: one stream tensor or a list (one per edge group, with `group_edges` = edges per group)."""
+    if torch.is_tensor(streams):
+        streams, group_edges = [streams], [xrow.shape[0]]
+    return TensorProductFn.apply(xrow, vec4, h, in_level, out_level, tuple(int(x) for x in group_edges), *streams)

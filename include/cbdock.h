@@ -234,7 +234,10 @@ int cbd_conf_pack_stream(int32_t in_level, int32_t out_level, const float* w1_ho
  *   xrow [E][80]  features of the node the edge reads (node_attr[edge_dst]; columns >= the level's width are zero)
  *   vec4 [E][4]   unit edge vector (x, y, z, 0)
  *   h    [E][96]  hidden activations of the radial MLP (after ReLU and Dropout)
- *   wstream       the FCBlock's tile stream (cbd_pack_conv_stream layout, cbd_conv_stream_floats(in, out) floats)
+ *   n_groups, group_edges_host[n_groups], wstreams_dev[n_groups] (host arrays): the layer's edge groups (reference edge_groups /
+ *                 fc[g], models/tensor_layers.py:190,201) -- consecutive edge ranges of the per-edge tensors, each with the tile
+ *                 stream of its own FCBlock (cbd_pack_conv_stream layout, cbd_conv_stream_floats(in, out) floats); E = sum of
+ *                 group_edges; 1 <= n_groups <= 4; all groups go out in ONE launch
  *   msg  [E][80]  out: messages (columns >= out width are zero)
  *   gmsg [E][80]  in:  d loss / d msg
  *   gx   [E][80]  out: d loss / d xrow
@@ -242,10 +245,11 @@ int cbd_conf_pack_stream(int32_t in_level, int32_t out_level, const float* w1_ho
  *                 stream's second-Linear tiles.  The caller finishes the Linear's backward: g_h = gw W2p, dW2p = gw^T h.
  * (in_level, out_level) in {(0,1), (1,2), (2,3), (3,3)} = node widths 32/50/68/74 of get_irrep_seq (tensor_layers.py:12-27). */
 int64_t cbd_tp_packed_width(int32_t in_level, int32_t out_level);
-int cbd_tp_forward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
-                   const float* wstream_dev, float* msg_dev, void* stream);
-int cbd_tp_backward(int32_t in_level, int32_t out_level, int64_t E, const float* xrow_dev, const float* vec4_dev, const float* h_dev,
-                    const float* wstream_dev, const float* gmsg_dev, float* gx_dev, float* gw_dev, void* stream);
+int cbd_tp_forward(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges_host, const float* xrow_dev,
+                   const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, float* msg_dev, void* stream);
+int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges_host, const float* xrow_dev,
+                    const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, const float* gmsg_dev, float* gx_dev,
+                    float* gw_dev, void* stream);
 
 #ifdef __cplusplus
 }

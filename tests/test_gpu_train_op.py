@@ -56,3 +56,49 @@ def test_tp_op_forward_backward_matches_oracle(lv, E):
     close(fcd[3].weight.grad, w2.grad, "gW2")
     close(fcd[3].bias.grad, b2.grad, "gb2")
     assert fcd[0].weight.grad is None or float(fcd[0].weight.grad.abs().max()) == 0.0
+
+
+def test_tp_op_edge_groups_in_one_launch():
+    """Three edge groups with their own FCBlocks (sizes 45 / 0 is skipped by the caller / 7 / 100) in one launch == per-group oracle."""
+    from confidence_bootstrapping_amd.score_model import FCBlock, faster_tp_weight_numel, get_irrep_seq
+    from confidence_bootstrapping_amd.train_ops import tensor_product, stream_map
+    from oracle import score_ref as sr
+    IN, OUT = 3, 3
+    seq = get_irrep_seq(32, 6, False, True)
+    W = faster_tp_weight_numel(seq[IN], seq[OUT])
+    torch.manual_seed(5)
+    sizes = [45, 7, 100]
+    fcs = [FCBlock(96, 96, W, 0.0) for _ in sizes]
+    E = sum(sizes)
+    x = torch.randn(E, 74)
+    vec = F.normalize(torch.randn(E, 3), dim=-1)
+    h = torch.relu(torch.randn(E, 96))
+    gout = torch.randn(E, 74)
+    sh = torch.cat([torch.ones(E, 1), np.sqrt(3.0) * vec], 1)
+    xo, ho = x.clone().requires_grad_(), h.clone().requires_grad_()
+    refs, lo = [], 0
+    for fc, n in zip(fcs, sizes):
+        refs.append(sr.faster_tensor_product(xo[lo:lo + n], sh[lo:lo + n], fc[3](ho[lo:lo + n]), sr.IRREP_SEQ[IN], sr.IRREP_SEQ[OUT]))
+        lo += n
+    ref = torch.cat(refs)
+    (ref * gout).sum().backward()
+    dev = torch.device("cuda:0")
+    fcd = [FCBlock(96, 96, W, 0.0).to(dev) for _ in sizes]
+    for a, b in zip(fcd, fcs):
+        a.load_state_dict(b.state_dict())
+    xd = F.pad(x, (0, 6)).to(dev).requires_grad_()
+    hd = h.to(dev).requires_grad_()
+    sm = stream_map(IN, OUT)
+    msg = tensor_product(xd, F.pad(vec, (0, 1)).to(dev), hd, [sm.stream(f) for f in fcd], IN, OUT, sizes)
+    (msg[:, :74] * gout.to(dev)).sum().backward()
+
+    def close(a, b, what):
+        a, b = a.detach().cpu(), b.detach().cpu()
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-6, what
+
+    close(msg[:, :74], ref, "msg")
+    close(xd.grad[:, :74], xo.grad, "gx")
+    close(hd.grad, ho.grad, "gh")
+    for a, b in zip(fcd, fcs):
+        close(a[3].weight.grad, b[3].weight.grad, "gW2")
+        close(a[3].bias.grad, b[3].bias.grad, "gb2")

@@ -134,3 +134,36 @@ def test_train_epoch_reduces_loss():
         last = train_epoch(model, [data], opt, dev, t2s, loss_fn, ema)
     assert np.isfinite(last["loss"]) and last["loss"] < first["loss"], (first, last)
     assert ema.num_updates == 9
+
+
+def test_training_step_edge_cases():
+    """Ragged batches the fine-tuning loop can produce: a ligand without rotatable bonds, a ligand far outside every cross
+    cutoff (empty ligand-receptor groups for that graph), and a batch whose ligands have NO rotatable bond at all."""
+    from confidence_bootstrapping_amd.synthetic import make_complex
+    from confidence_bootstrapping_amd.utils import make_score_model, load_model_args
+    from confidence_bootstrapping_amd.training import loss_function
+    from confidence_bootstrapping_amd.datasets.pdbbind import NoiseTransform
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
+    model.train()
+    t2s = partial(t_to_sigma, args=margs)
+    nt = NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False)
+    np.random.seed(3); torch.manual_seed(3)
+    a = nt(make_complex(Nl=7, Nr=30, R=0, knn=8, seed=21, name="rigid"))
+    b = nt(make_complex(Nl=11, Nr=34, R=2, knn=8, seed=22, name="far"))
+    b["ligand"].pos = b["ligand"].pos + 500.0
+    c = nt(make_complex(Nl=9, Nr=32, R=1, knn=8, seed=23, name="plain"))
+    assert a.tor_score.numel() == 0
+    for data, n_tor in (([a, b, c], 3), ([a, copy.deepcopy(a)], 0)):
+        model.zero_grad()
+        tr, rot, tor, _ = model(data)
+        assert tr.shape == (len(data), 3) and rot.shape == (len(data), 3) and tor.shape == (n_tor,)
+        out = loss_function(tr, rot, tor, None, data=data, t_to_sigma=t2s, device=dev, no_torsion=(n_tor == 0))
+        out[0].backward()
+        assert torch.isfinite(out[0]).all()
+        grads = [p.grad for p in model.parameters() if p.grad is not None]
+        assert grads and all(torch.isfinite(g).all() for g in grads)
+    per = loss_function(tr, rot, tor, None, data=data, t_to_sigma=t2s, device=dev, no_torsion=True, apply_mean=False)
+    assert per[0].shape == (2,)

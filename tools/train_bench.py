@@ -53,6 +53,8 @@ def main():
     for k in range(a.warmup):
         train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
     torch.cuda.synchronize()
+    from confidence_bootstrapping_amd.train_ops import TIMER
+    TIMER.enabled = True
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(a.steps)]
     t0 = time.perf_counter()
     for k in range(a.steps):
@@ -72,7 +74,13 @@ def main():
     f = np.mean([e[0].elapsed_time(e[1]) for e in ev])
     b = np.mean([e[1].elapsed_time(e[2]) for e in ev])
     o = np.mean([e[2].elapsed_time(e[3]) for e in ev])
-    print(json.dumps({"metric": "fine-tuning complexes/s (1 GPU)", "value": round(a.batch * a.steps / el, 2), "unit": "complexes/s",
+    ks = TIMER.summary()
+    TIMER.enabled = False
+    peak = 157.3   # fp32 MFMA dense peak, TFLOP/s (MI355X_MICROARCH.md)
+    roof = {k: {"ms_per_step": round(ms / a.steps, 3), "launches_per_step": n // a.steps, "achieved": round(fl / (ms * 1e-3) / 1e12, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4)} for k, (ms, n, fl) in ks.items()}
+    print(json.dumps({"metric": "fine-tuning complexes/s (1 GPU)", "roofline": {"bound": "mfma", "kernels": {"tp_train_fwd_kernel": roof.get("fwd"),
+                      "tp_train_bwd_kernel (matrix-core work = the forward's, re-computed)": roof.get("bwd")}}, "value": round(a.batch * a.steps / el, 2), "unit": "complexes/s",
                       "ms_per_step": round(el / a.steps * 1e3, 2), "forward_ms": round(float(f), 2), "backward_ms": round(float(b), 2),
                       "optimizer_ema_ms": round(float(o), 2), "batch": a.batch, "workload": a.workload, "dropout": margs.dropout,
                       "final_loss": float(loss)}))
