@@ -8,7 +8,8 @@ Same policy, names and argument meaning as the reference:
   * `get(idx)` returns a deep copy without the bookkeeping attributes: round-robin over the pool, or -- with `fixed_length` --
     a draw from softmax(temperature * confidence) on numpy's global generator;
   * `len()` = `len(pool) * multiplicity` or `fixed_length`.
-Differences: no torch_geometric `Dataset` base (absent here; `__len__`/`__getitem__` apply `transform` the way it does), and the
+Differences: `get` returns a copy that shares the (never written-to) tensors of the pooled graph instead of a deepcopy -- the
+transform re-binds `pos`, times and scores; no torch_geometric `Dataset` base (absent here; `__len__`/`__getitem__` apply `transform` the way it does), and the
 cluster -> ligand-names table can be passed in instead of being un-pickled from the hard-wired MOAD path.
 """
 from __future__ import annotations
@@ -63,7 +64,7 @@ class CBBuffer:
             conf = np.asarray([float(c.confidence) for c in self.complexes])
             w = np.exp(conf * self.temperature)
             pick = np.random.choice(len(self.complexes), p=w / np.sum(w))
-        g = copy.deepcopy(self.complexes[pick])
+        g = self.complexes[pick].shallow_copy() if hasattr(self.complexes[pick], "shallow_copy") else copy.deepcopy(self.complexes[pick])
         for attr in ("confidence", "iteration"):
             g.__dict__.pop(attr, None)
             for nt in ("receptor", "ligand"):

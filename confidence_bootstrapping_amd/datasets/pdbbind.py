@@ -38,14 +38,17 @@ def axis_angle_to_matrix(aa: torch.Tensor) -> torch.Tensor:
 
 
 def kabsch(A: torch.Tensor, B: torch.Tensor):
-    """R [3,3], t [3,1] minimising |R A + t - B| for 3xN point sets (reference utils/geometry.py:209-243)."""
-    ca, cb = A.mean(dim=1, keepdim=True), B.mean(dim=1, keepdim=True)
-    U, S, Vt = torch.linalg.svd((A - ca) @ (B - cb).T)
+    """R [3,3], t [3,1] minimising |R A + t - B| for 3xN point sets (reference utils/geometry.py:209-243).  The 3x3 SVD runs in
+    numpy float64: torch's CPU LAPACK path spins up the whole thread pool for it (tens of ms per call on a many-core host)."""
+    a, b_ = A.detach().cpu().numpy().astype(np.float64), B.detach().cpu().numpy().astype(np.float64)
+    ca, cb = a.mean(axis=1, keepdims=True), b_.mean(axis=1, keepdims=True)
+    U, S, Vt = np.linalg.svd((a - ca) @ (b_ - cb).T)
     R = Vt.T @ U.T
-    if torch.linalg.det(R) < 0:
-        R = (Vt.T @ torch.diag(torch.tensor([1.0, 1.0, -1.0]))) @ U.T
-    assert math.fabs(float(torch.linalg.det(R)) - 1) < 3e-3
-    return R, -R @ ca + cb
+    if np.linalg.det(R) < 0:
+        R = (Vt.T @ np.diag([1.0, 1.0, -1.0])) @ U.T
+    assert math.fabs(np.linalg.det(R) - 1) < 3e-3
+    t = -R @ ca + cb
+    return torch.from_numpy(R).to(A.dtype), torch.from_numpy(t).to(A.dtype)
 
 
 def modify_conformer(data, tr_update, rot_update, torsion_updates):

@@ -95,6 +95,21 @@ class HeteroData:
                 self.__dict__[k] = {kk: (vv.to(device) if torch.is_tensor(vv) else vv) for kk, vv in v.items()}
         return self
 
+    def shallow_copy(self):
+        """New graph object with its own attribute stores that SHARE the tensors of this one.  Everything on the sampling and
+        fine-tuning paths re-binds attributes (`g['ligand'].pos = ...`, `g.complex_t = ...`) instead of writing into tensors, so
+        a shallow copy isolates them at a fraction of a deepcopy's cost (the 1281-wide receptor features and the all-atom stores
+        are 3 MB per complex)."""
+        out = type(self)()
+        for k, st in self._stores.items():
+            out._stores[k] = Store(**st.__dict__)
+        for k, v in self.__dict__.items():
+            if not k.startswith("_"):
+                out.__dict__[k] = dict(v) if isinstance(v, dict) else v
+        if hasattr(self, "_num_graphs"):
+            object.__setattr__(out, "_num_graphs", self._num_graphs)
+        return out
+
     def cpu(self):
         return self.to("cpu")
 

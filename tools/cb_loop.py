@@ -1,0 +1,112 @@
+"""The confidence-bootstrapping loop end to end on one MI355X (BASELINE.json configs[4], C5), with the reference's command-line
+defaults for the loop shape (README.md:52 of the reference: 8 samples per complex, inference batch 4, training batch 5,
+max_complexes_per_couple 20, EMA, 20 denoising steps) on a synthetic cluster of C2-sized complexes:
+
+    python tools/cb_loop.py [--complexes 12] [--epochs 3] [--cb-inference-freq 1]
+
+Prints per-epoch logs and one JSON line with the time split (sampling + confidence + RMSD / training) and the rates."""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+from functools import partial
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--complexes", type=int, default=12)
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--cb-inference-freq", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--workload", default="c2_dockgen_median")
+    ap.add_argument("--host-threads", type=int, default=16, help="intra-op threads of the host-side numpy/torch code (the reference's "
+                    "--restrict_cpu uses 16, inference.py:225-234); tiny LAPACK/BLAS calls crawl on an unrestricted 128-thread pool")
+    a = ap.parse_args()
+    torch.set_num_threads(a.host_threads)
+    try:
+        from threadpoolctl import threadpool_limits
+        threadpool_limits(limits=a.host_threads)
+    except Exception:
+        pass
+    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms, WORKLOADS
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model, load_model_args, ExponentialMovingAverage
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    from confidence_bootstrapping_amd.bootstrapping.buffer import CBBuffer
+    from confidence_bootstrapping_amd.datasets.pdbbind import NoiseTransform
+    from confidence_bootstrapping_amd import finetune_train as ft
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    model, _ = make_score_model(device=dev, seed=0, args=margs)
+    conf_model, conf_args = make_confidence_model(device=dev, seed=5)
+    names = [f"{1000 + i}_A_lig{i}" for i in range(a.complexes)]
+    targets = []
+    for i, n in enumerate(names):
+        g = add_atoms(make_complex(seed=900 + i, name=n, **WORKLOADS[a.workload]), seed=900 + i)
+        g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
+        nums = g["ligand"].x[:, 0].numpy() + 1
+        g["ligand"].x[:, 0] = torch.from_numpy(nums)
+        ei = g["ligand", "ligand"].edge_index.numpy()
+        am = np.zeros((len(nums), len(nums)), dtype=int)
+        am[ei[0], ei[1]] = 1
+        g.mol = Namespace(atomicnums=nums, adjacency_matrix=am)
+        targets.append(g)
+    args = copy.copy(margs)
+    args.__dict__.update(inference_steps=a.steps, inference_samples=a.samples, inference_batch_size=4, n_epochs=a.epochs,
+                         cb_inference_freq=a.cb_inference_freq, initial_iterations=1, inference_iterations=1,
+                         num_inference_complexes=a.complexes, batch_size=5, use_ema=True, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
+    t2s = partial(t_to_sigma, args=margs)
+    buf = CBBuffer(cluster_name="c", cluster_to_ligands={"c": names}, max_complexes_per_couple=20,
+                   transform=NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False))
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+    # time the two phases by wrapping the module-level functions the loop calls
+    spent = {"inference": 0.0, "train": 0.0, "poses": 0, "train_items": 0}
+    inf0, tr0 = ft.inference_epoch, ft.train_epoch
+
+    def inf(*x, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        out = inf0(*x, **k)
+        torch.cuda.synchronize(); spent["inference"] += time.perf_counter() - t
+        spent["poses"] += a.samples * len(x[2])
+        return out
+
+    def tr(model_, loader, *x, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        out = tr0(model_, loader, *x, **k)
+        torch.cuda.synchronize(); spent["train"] += time.perf_counter() - t
+        spent["train_items"] += len(loader.dataset)
+        return out
+
+    ft.inference_epoch, ft.train_epoch = inf, tr
+    # warm-up round (engine creation, weight packing, allocator) outside the timed loop
+    wargs = copy.copy(args); wargs.n_epochs = 1
+    ft.inference_finetune(wargs, model, conf_model, conf_args, None, -1e9, opt, ema,
+                          CBBuffer(cluster_name="c", cluster_to_ligands={"c": names}, max_complexes_per_couple=20, transform=buf.transform),
+                          targets[:4], t2s, dev, log=lambda s: None)
+    for k in spent:
+        spent[k] = 0 if isinstance(spent[k], int) else 0.0
+    t0 = time.perf_counter()
+    hist = ft.inference_finetune(args, model, conf_model, conf_args, None, -1e9, opt, ema, buf, targets, t2s, dev)
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    print(json.dumps({"what": "confidence-bootstrapping loop, synthetic cluster", "complexes": a.complexes, "epochs": a.epochs,
+                      "samples_per_complex": a.samples, "denoise_steps": a.steps, "total_s": round(total, 2),
+                      "sampling_confidence_rmsd_s": round(spent["inference"], 2),
+                      "poses_per_s_incl_confidence_and_rmsd": round(spent["poses"] / max(spent["inference"], 1e-9), 1),
+                      "training_s": round(spent["train"], 2),
+                      "training_complexes_per_s": round(spent["train_items"] / max(spent["train"], 1e-9), 1),
+                      "buffer": len(buf.complexes), "final_train_loss": hist[-1].get("train_loss")}))
+
+
+if __name__ == "__main__":
+    main()
