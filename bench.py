@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (confidence, other operand modes, fine-tuning, "
+                    "CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the 20-step loop as one hipGraph (no per-kernel HIP events)")
     ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the 40-pose batch is split over")
     ap.add_argument("--workload", default=WORKLOAD, help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
@@ -300,7 +302,7 @@ def main():
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
         flops_per_launch = total_flops / max(n_launch, 1)
         traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tp = os.path.join(ROOT, "profiles", "r01_f_traffic.json")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
+        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r01_{t}_traffic.json") for t in "hf") if os.path.exists(q)), "")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
         if os.path.exists(tp):
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch_all_tp_conv"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -333,9 +335,10 @@ def main():
                          # node-layer visit, against the 8 TB/s HBM3E peak -- the path is far from HBM-bound
                          "hbm_secondary": hbm_secondary(st, eng, poses, elapsed)},
         }
-        if world == 1 and headline:
+        extras = world == 1 and headline and not a.headline_only
+        if extras:
             out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev)
-        if world == 1 and headline and pair:
+        if extras and pair:
             # The same complexes in the two other operand modes of the same kernel (NOT part of `value`): f32_split = fp32 operands as
             # three exact bf16 planes on the bf16 matrix cores (fp32-grade results, tests/test_gpu_bf16.py); bf16 = configs[3].
             out["other_operand_modes"] = {}
@@ -355,12 +358,12 @@ def main():
             for p_ in [eng] + extra:
                 p_.set_option("bf16", 0)
                 p_.set_option("f32_split", 0)
-        if world == 1 and headline:
+        if extras:
             try:
                 out["finetune"] = finetune_leg(dev)
             except Exception as e:      # a secondary leg must never cost the headline line
                 out["finetune"] = {"error": repr(e)[:200]}
-        if world == 1 and headline and not a.no_cpu_baseline:
+        if extras and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -25,7 +25,7 @@ def main():
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
         rows = load(os.path.join(root, c, "p_counter_collection.csv"))
         for (k, cn), v in rows.items():
-            if "cbd::tp_conv_kernel" not in k or cn != c:
+            if "cbd::tp_conv_kernel" not in k or "OpsF32" not in k or cn != c:
                 continue
             name = "tp_conv<3,3>" if "<3, 3" in k else "tp_conv<embedding layers>"
             per.setdefault((name, c), []).extend(v)
