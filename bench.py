@@ -251,7 +251,8 @@ def main():
         k = lo
         while k < hi:
             if pair and k + 1 < hi:
-                m = min(cosched, hi - k)
+                left = hi - k
+                m = -(-left // -(-left // cosched))     # balanced groups (5 -> 3 + 2 rather than 4 + 1: no complex runs alone)
                 pools = [eng] + extra[:m - 1]
                 for p_ in pools:
                     p_.recompute_receptor()
