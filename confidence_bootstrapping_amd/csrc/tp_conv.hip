@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 #define CBD_TILE(BOP, NEXT)                                                                         \
   {                                                                                                 \
     const int tn_ = (NEXT);                                                                         \
-    gemm_tile<Ops>(a, gp + (size_t)tn_ * Ops::TILE_FRAGS, bias_l + T * 32, BOP, acc, hf);          \
+    gemm_tile<Ops>(a, gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), bias_l + T * 32, BOP, acc, hf); \
     T = tn_;                                                                                        \
   }
 
@@ -467,6 +467,9 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   // CBD_CONV_VARIANT=8 selects the diagnostic build of the 74->74 kernel that stamps s_memtime/s_memrealtime
   static const int var = getenv("CBD_CONV_VARIANT") ? atoi(getenv("CBD_CONV_VARIANT")) : 0;
   if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  // CBD_CONV_VARIANT=9 (diagnostic, WRONG results): every tile re-reads weight tile 0, i.e. the L2 -> register weight stream
+  // is replaced by L1-resident loads; the speed-up, if any, is what a perfect weight-reuse scheme could gain
+  else if (IN == 3 && var == 9) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 9 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }
