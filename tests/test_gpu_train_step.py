@@ -167,3 +167,42 @@ def test_training_step_edge_cases():
         assert grads and all(torch.isfinite(g).all() for g in grads)
     per = loss_function(tr, rot, tor, None, data=data, t_to_sigma=t2s, device=dev, no_torsion=True, apply_mean=False)
     assert per[0].shape == (2,)
+
+
+def test_train_forward_full_size_properties():
+    """Size-independent properties of the differentiable path at the C2 size (no oracle run needed): SE(3) equivariance of the
+    predicted scores (tr / rot vectors rotate with the complex, torsion scores are invariant), independence of the order of the
+    graphs in the batch (eval mode), and a finite backward pass."""
+    from scipy.spatial.transform import Rotation
+    from confidence_bootstrapping_amd.synthetic import make_complex, WORKLOADS
+    from confidence_bootstrapping_amd.utils import make_score_model
+    dev = torch.device("cuda:0")
+    model, margs = make_score_model(device=dev, seed=0)
+    base = [make_complex(name=f"c{i}", seed=700 + i, **WORKLOADS["c2_dockgen_median"]) for i in range(3)]
+    rng = np.random.default_rng(1)
+    for d, t in zip(base, (0.8, 0.35, 0.1)):
+        d.complex_t = {k: torch.tensor([t], dtype=torch.float32) for k in ("tr", "rot", "tor")}
+        d["ligand"].pos = d["ligand"].pos + torch.from_numpy(rng.normal(scale=2.0, size=(1, 3)).astype(np.float32))
+
+    def moved(d, Rm, shift):
+        c = d.shallow_copy()
+        c["ligand"].pos = d["ligand"].pos @ Rm.T + shift
+        c["receptor"].pos = d["receptor"].pos @ Rm.T + shift
+        return c
+
+    with torch.no_grad():
+        tr0, rot0, tor0, _ = model.forward_train(base)
+        Rm = torch.from_numpy(Rotation.random(random_state=5).as_matrix().astype(np.float32))
+        tr1, rot1, tor1, _ = model.forward_train([moved(d, Rm, torch.tensor([[3.0, -7.0, 11.0]])) for d in base])
+        tr2, rot2, tor2, _ = model.forward_train(base[::-1])
+    Rd = Rm.to(dev)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(tr1, tr0 @ Rd.T) < 2e-3 and rel(rot1, rot0 @ Rd.T) < 2e-3 and rel(tor1, tor0) < 2e-3
+    assert rel(tr2.flip(0), tr0) < 1e-4 and rel(rot2.flip(0), rot0) < 1e-4
+    nrot = [int(d["ligand"].edge_mask.sum()) for d in base]
+    tor2_re = torch.cat(list(torch.split(tor2, nrot[::-1]))[::-1])
+    assert rel(tor2_re, tor0) < 1e-4
+    model.train()
+    tr, rot, tor, _ = model(base)
+    (tr.square().sum() + rot.square().sum() + tor.square().sum()).backward()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
