@@ -4,12 +4,14 @@ MI355X engine (csrc/, hand-written HIP) instead of PyTorch/e3nn/torch_scatter/to
 
 The module tree below exists to (a) own the parameters under the exact checkpoint key names so that
 `load_state_dict(torch.load('best_ema_inference_epoch_model.pt'), strict=True)` works unchanged
-(inference.py:298-309) and (b) hand them to the engine.  There is NO PyTorch fallback for the forward pass:
-if the HIP library is missing, `forward` raises.
+(inference.py:298-309) and (b) hand them to the engine.  `model.eval()`: forward = the fused inference engine (no autograd).
+`model.train()`: forward = the differentiable fine-tuning path (train_forward.py: the tensor-product layers on the HIP
+forward/backward kernels of csrc/tp_train.hip, the small ops around them as autograd-visible torch ops on the same GPU).
+There is NO CPU / pure-PyTorch fallback for either: if the HIP library is missing or the tensors are not on the GPU, it raises.
 
 Supported architecture = the shipped `workdir/pretrained_score/model_parameters.yml` family:
 sh_lmax=1, use_second_order_repr=False (=> FasterTensorProduct layers), reduce_pseudoscalars=True,
-embed_also_ligand=True, differentiate_convolutions=True, tp_weights_layers=2, batch_norm, eval mode,
+embed_also_ligand=True, differentiate_convolutions=True, tp_weights_layers=2, batch_norm,
 lm_embedding_type in {None,'precomputed'}.  Anything else raises NotImplementedError at construction.
 """
 from __future__ import annotations
