@@ -76,6 +76,13 @@ struct ConvGroup {
   float* last_sum;       // [tiles][NODE_STRIDE]
   float* run_acc;        // [N][NODE_STRIDE], row = aggregating node
   const float* node_in;  // [N][NODE_STRIDE] node features this group's src / dst indices refer to
+  // First Linear of the radial MLP, node part: W1 [edge_attr | x_src[:32] | x_dst[:32]] = W1a edge_attr + (W1s x_src) + (W1d x_dst).
+  // The two node terms are the same for every edge of a node, so they are projected ONCE PER NODE (node_proj_kernel, 2 x 96 x 32
+  // MACs per node instead of per edge) and enter the edge kernel through the accumulator; only the K = 32 edge-attribute part of
+  // the first Linear runs on the matrix cores per edge (2 of the 57 tiles' worth of MFMA work less: +4 % measured as a bound).
+  const float* psrc;     // [N][KDIM] W1s x[:, :32] for the rows this group uses as aggregating node
+  const float* pdst;     // [N][KDIM] W1d x[:, :32] for the rows it reads
+  int src_lo, src_n, dst_lo, dst_n;   // node-row ranges the group's src / dst indices fall in (what node_proj_kernel has to cover)
   // weight-tile slice executed for this group (run_conv fills the full range): 0e tiles [i0e_lo, i0e_hi) and, if vec_on, the
   // 1o/1e/0o blocks.  Virtual slices of one edge group write their own piece buffers; the finalize kernel adds them.
   int i0e_lo, i0e_hi, vec_on;
@@ -86,6 +93,11 @@ struct ConvGroup {
 // amortised).
 constexpr int CONV_MAX_GROUPS = 16;
 constexpr int CONV_MAX_COSCHED = 4;
+// node_proj_kernel jobs of one layer: P[row][0..95] = sum_k WT[k][.] * node[row][k] for rows [lo, lo + n)
+constexpr int PROJ_MAX_JOBS = 8;
+struct ProjJob { const float* WT; float* P; int lo, n; };
+struct ProjArgs { ProjJob job[PROJ_MAX_JOBS]; int n_jobs; const float* node_in; };
+
 struct ConvArgs {
   ConvGroup g[CONV_MAX_GROUPS];
   int n_groups;

@@ -37,6 +37,7 @@ struct ConvLayerDev {
   float* wstream[4] = {nullptr, nullptr, nullptr, nullptr};
   float* wstream_bf16[4] = {nullptr, nullptr, nullptr, nullptr};        // bf16-operand policy (tp_conv.hip::OpsBf16)
   float* wstream_x3[4] = {nullptr, nullptr, nullptr, nullptr};          // bf16x3 fp32-emulation policy (OpsBf16x3)
+  float* w1sd[4] = {nullptr, nullptr, nullptr, nullptr};                // [2][32][96]: W1[:, 32:64]^T and W1[:, 64:96]^T (node parts of the first Linear)
   float *bn_scale = nullptr, *bn_mean = nullptr, *bn_bias = nullptr;   // [NODE_STRIDE]
 };
 
@@ -117,6 +118,7 @@ struct cbd_engine {
   // ---- batch workspace
   GraphDyn gd{};
   float *X0 = nullptr, *X1 = nullptr;
+  float* proj[2 * 4 + 2] = {};   // node projections of the first Linear: (src, dst) x up to 4 FCBlocks of a layer, + one pair for the side stream
   float *ll_attr = nullptr, *lr_attr = nullptr;
   StepVectors sv{};
   float* sigma_emb_dev = nullptr;   // [S_max][32]
@@ -324,6 +326,11 @@ static int build_conv_layer(cbd_engine* e, const std::string& prefix, int IN, in
     HIPCHK(e->wpool.upload(&L->wstream[g], st));
     HIPCHK(e->wpool.upload(&L->wstream_bf16[g], pack_conv_stream_bf16(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
     HIPCHK(e->wpool.upload(&L->wstream_x3[g], pack_conv_stream_bf16x3(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
+    std::vector<float> sd((size_t)2 * NS * KDIM);   // node parts of the first Linear, k-major for node_proj_kernel
+    for (int part = 0; part < 2; ++part)
+      for (int k = 0; k < NS; ++k)
+        for (int c = 0; c < KDIM; ++c) sd[((size_t)part * NS + k) * KDIM + c] = w0->data[(size_t)c * KDIM + NS * (1 + part) + k];
+    HIPCHK(e->wpool.upload(&L->w1sd[g], sd));
   }
   // e3nn BatchNorm (eval) per output column
   const int nf = NS + NV + (OUT >= 2 ? NV : 0) + (OUT >= 3 ? NV : 0);
@@ -608,6 +615,26 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
     }
     grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
   }
+  if (e->use_bf16 != 1) {  // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual
+    ProjArgs pa{};         // slices share them.  (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)
+    pa.node_in = node_in;
+    const int base = s == e->side ? 8 : 0;
+    int slot_of[4] = {-1, -1, -1, -1}, n_slots = 0;
+    for (int g = 0; g < n_groups; ++g) {
+      const int w = widx ? widx[g] : g;
+      if (slot_of[w] < 0) {
+        slot_of[w] = n_slots++;
+        float* ps = e->proj[base + 2 * slot_of[w]];
+        float* pd = e->proj[base + 2 * slot_of[w] + 1];
+        if (base + 2 * slot_of[w] + 1 >= (int)(sizeof(e->proj) / sizeof(e->proj[0]))) return fail(CBD_ERR_STATE, "projection slots exhausted");
+        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w], ps, a.g[g].src_lo, a.g[g].src_n};
+        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w] + (size_t)NS * KDIM, pd, a.g[g].dst_lo, a.g[g].dst_n};
+      }
+      a.g[g].psrc = e->proj[base + 2 * slot_of[w]];
+      a.g[g].pdst = e->proj[base + 2 * slot_of[w] + 1];
+    }
+    HIPCHK(launch_node_proj(pa, s));
+  }
   a.stamps = e->stamps_dev;
   if (e->pair && s != e->side) {
     // lockstep with the partner engine: the second to arrive launches one kernel over both batches' groups (same layer,
@@ -694,6 +721,7 @@ static int embed_receptor(cbd_engine* e, hipStream_t s) {
     ConvGroup g{};
     g.src = e->d_src0; g.dst = e->d_dst0; g.attr_idx = e->d_ident; g.vec = e->d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
     g.first_sum = e->fsum[4]; g.last_sum = e->lsum[4]; g.run_acc = e->racc[4];
+    g.src_lo = 0; g.src_n = Nr; g.dst_lo = 0; g.dst_n = Nr;
     int cap = Err;
     CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
     const FinGroup fg = fin_group(g, e->rr0_start, e->d_deg0);
@@ -820,6 +848,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&gd.pair_eid, cap_x));
   HIPCHK(e->bpool.alloc(&e->ll_attr, cap_ll * 32)); HIPCHK(e->bpool.alloc(&e->lr_attr, cap_x * 32));
   HIPCHK(e->bpool.alloc(&e->X0, (size_t)N * NODE_STRIDE)); HIPCHK(e->bpool.alloc(&e->X1, (size_t)N * NODE_STRIDE));
+  for (float*& pbuf : e->proj) HIPCHK(e->bpool.alloc(&pbuf, (size_t)N * KDIM));
   HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
   float* vecs;
   HIPCHK(e->bpool.alloc(&vecs, 7 * 32));
@@ -912,6 +941,7 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   g_rr_shared.src = e->rr_src; g_rr_shared.dst = e->rr_dst; g_rr_shared.attr_idx = e->rr_aidx; g_rr_shared.vec = e->rr_vec;
   g_rr_shared.attr = e->rr_attr_t; g_rr_shared.count = e->rr_count_dev;
   g_rr_shared.first_sum = e->fsum[4]; g_rr_shared.last_sum = e->lsum[4]; g_rr_shared.run_acc = e->racc[2];
+  g_rr_shared.src_lo = gs.rec_off; g_rr_shared.src_n = Nr; g_rr_shared.dst_lo = gs.rec_off; g_rr_shared.dst_n = Nr;   // sample 0's rows
   float* const Xa = e->X0;          // ligand embedding ping-pong: X0 -> X1 -> X0 -> X1 ; interaction layers read X1 first
   float* const Xb = e->X1;
   HIPCHK(hipEventRecord(e->ev_fork, s));
@@ -944,6 +974,11 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   {
     ConvGroup* gg[4] = {&gll, &glr, &grr, &grl};
     for (int g = 0; g < 4; ++g) { gg[g]->first_sum = e->fsum[g]; gg[g]->last_sum = e->lsum[g]; gg[g]->run_acc = e->racc[g]; }
+    // node-row ranges of the aggregating (src) and the read (dst) side: ligand rows [0, nL), receptor rows [rec_off, rec_off + nR)
+    gll.src_lo = 0; gll.src_n = nL; gll.dst_lo = 0; gll.dst_n = nL;
+    glr.src_lo = 0; glr.src_n = nL; glr.dst_lo = gs.rec_off; glr.dst_n = nR;
+    grr.src_lo = gs.rec_off; grr.src_n = nR; grr.dst_lo = gs.rec_off; grr.dst_n = nR;
+    grl.src_lo = gs.rec_off; grl.src_n = nR; grl.dst_lo = 0; grl.dst_n = nL;
   }
   const FinGroup f_ll = fin_group(gll, gd.start_ll, gd.cnt_ll), f_lr = fin_group(glr, gd.start_lr, gd.cnt_lr);
   const FinGroup f_rl = fin_group(grl, gd.start_rl, gd.cnt_rl), f_rr = fin_group(grr, e->rr_start, e->rr_cnt);

@@ -89,6 +89,7 @@ hipError_t launch_edge_geom(const float* pos, const int* src, const int* dst, in
 hipError_t launch_symm_rmsd(int B, int N, int K, const float* pos, const float* ref, const int* idx_ref, const int* idx_pos, float* out,
                             int* argmin, hipStream_t s);
 hipError_t launch_fill_i32(int* p, int v, int n, hipStream_t s);
+hipError_t launch_node_proj(const ProjArgs& a, hipStream_t s);   // per-node part of the first Linear of a layer's FCBlocks
 
 // tp_conv.hip
 // torsion head on the matrix cores (replaces the msg/final stages of launch_bond_head); nb/nb_cnt from launch_bond_nb

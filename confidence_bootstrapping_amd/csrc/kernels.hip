@@ -724,4 +724,59 @@ hipError_t launch_symm_rmsd(int B, int N, int K, const float* pos, const float* 
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Per-node part of the first Linear of a conv layer's FCBlocks (see ConvGroup::psrc): P[row][c] = sum_{k<32} WT[k][c] x[row][k].
+// The 32 scalars of a row are the same address for 32 consecutive lanes, WT (12 KB per job) stays in L1/L2.
+constexpr int PROJ_ROWS = 32;   // rows per 256-thread block: thread (rg = tid / 32, c = tid % 32) owns rows 4 rg .. 4 rg + 3, columns c, c + 32, c + 64
+__global__ __launch_bounds__(256) void node_proj_kernel(ProjArgs a) {
+  int t = blockIdx.x;
+  int jb = -1, row0 = 0;
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const int nb = (a.job[j].n + PROJ_ROWS - 1) / PROJ_ROWS;
+    if (jb < 0) {
+      if (t < nb) { jb = j; row0 = t * PROJ_ROWS; }
+      else t -= nb;
+    }
+  }
+  if (jb < 0) return;
+  const ProjJob J = a.job[jb];
+  const int c = threadIdx.x & 31, r0 = row0 + 4 * (threadIdx.x >> 5);
+  float acc[4][3];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
+  const float* xr[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) xr[r] = a.node_in + (size_t)(J.lo + (r0 + r < J.n ? r0 + r : J.n - 1)) * NODE_STRIDE;   // clamped: no divergent loads
+#pragma unroll
+  for (int k4 = 0; k4 < NS / 4; ++k4) {
+    f32x4 x[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) x[r] = reinterpret_cast<const f32x4*>(xr[r])[k4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float* w = J.WT + (4 * k4 + kk) * KDIM + c;
+      const float w0 = w[0], w1 = w[32], w2 = w[64];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float xv = x[r][kk];
+        acc[r][0] = fmaf(xv, w0, acc[r][0]); acc[r][1] = fmaf(xv, w1, acc[r][1]); acc[r][2] = fmaf(xv, w2, acc[r][2]);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    if (r0 + r < J.n) {
+      float* o = J.P + (size_t)(J.lo + r0 + r) * KDIM + c;
+      o[0] = acc[r][0]; o[32] = acc[r][1]; o[64] = acc[r][2];
+    }
+}
+
+hipError_t launch_node_proj(const ProjArgs& a, hipStream_t s) {
+  int grid = 0;
+  for (int j = 0; j < a.n_jobs; ++j) grid += (a.job[j].n + PROJ_ROWS - 1) / PROJ_ROWS;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL(node_proj_kernel, dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace cbd

@@ -91,16 +91,20 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const float v[3] = {vv.x, vv.y, vv.z};
   if (hf == 0) srcl[j] = src;
 
-  typename Ops::Act Bx;  // first-Linear input: [edge_attr(32) | x_src[:32] | x_dst[:32]], lane half hf holds cols 16hf..16hf+15
+  typename Ops::Act Bx;  // first-Linear input on the matrix cores: edge_attr(32), lane half hf holds cols 16hf..16hf+15.  The
+                         // x_src[:32] / x_dst[:32] parts arrive as per-node projections through the accumulator (G.psrc / G.pdst)
   {
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
-    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      Ops::set_in(Bx, 0, q, pa[q]);
-      Ops::set_in(Bx, 1, q, ps[q]);
-      Ops::set_in(Bx, 2, q, pd[q]);
+    for (int q = 0; q < 4; ++q) Ops::set_in(Bx, 0, q, pa[q]);
+    if constexpr (!Ops::NODE_PROJ) {
+      const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
+      const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Ops::set_in(Bx, 1, q, ps[q]);
+        Ops::set_in(Bx, 2, q, pd[q]);
+      }
     }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
     const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
@@ -131,9 +135,24 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
   const bool vec_on = G.vec_on != 0;
   const int T_vec = 3 + S.t0e;
+  const f32x4* const p_s = reinterpret_cast<const f32x4*>(G.psrc + (size_t)src_r * KDIM + 4 * hf);
+  const f32x4* const p_d = reinterpret_cast<const f32x4*>(G.pdst + (size_t)dst * KDIM + 4 * hf);
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
+    if constexpr (!Ops::NODE_PROJ) {
+      CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
+    } else {  // acc = b1 + W1s x_src + W1d x_dst (rows 32m + (r&3) + 8(r>>2) + 4hf), then the K = 32 edge-attribute product
+      const int tn_ = m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec);
+      const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l + T * 32);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 b = bp[2 * q + hf], u = p_s[8 * m + 2 * q], w = p_d[8 * m + 2 * q];
+        acc[4 * q + 0] = b.x + u.x + w.x; acc[4 * q + 1] = b.y + u.y + w.y;
+        acc[4 * q + 2] = b.z + u.z + w.z; acc[4 * q + 3] = b.w + u.w + w.w;
+      }
+      Ops::gemm_first(a, gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), Bx, acc);
+      T = tn_;
+    }
     if constexpr (!Ops::EXACT_F32) { if (m == 2) mfma_operand_guard(); }   // the first-Linear operands die here without a refill
     Ops::set_hidden(h1, m, acc);
     if constexpr (VAR == 8) { if (m == 0) st_g0 = stamp(); }

@@ -22,6 +22,7 @@ __device__ __forceinline__ unsigned long long stamp() {
 // OpsF32: exact fp32, v_mfma_f32_32x32x2_f32, 48 k-steps, 12 float4 fragments (12 KB tile).
 struct OpsF32 {
   static constexpr bool EXACT_F32 = true;
+  static constexpr bool NODE_PROJ = true;    // node parts of the first Linear through per-node projections (ConvGroup::psrc / pdst)
   using Frag = f32x4;
   static constexpr int NFRAG = KSTEPS / 4;                 // 12
   static constexpr int TILE_FRAGS = TILE_W_FLOATS / 4;     // 768 fragments of 16 B per tile
@@ -46,6 +47,22 @@ struct OpsF32 {
       a[sg] = next[sg * 64];
       // keep the refill right behind its last use: without this hipcc sinks all 12 loads to the end of the tile and the
       // next tile then starts by waiting a full L2 round trip
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // first Linear, edge part only (K = 32: the edge_attr columns = fragments 0..3); the node parts enter through `acc`
+  // (ConvGroup::psrc / pdst).  All twelve fragments are still refilled: the next tile needs them.
+  static __device__ __forceinline__ void gemm_first(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int sg = 0; sg < NFRAG; ++sg) {
+      if (sg < NFRAG / 3) {
+        const f32x4 w = a[sg];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * sg + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * sg + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * sg + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * sg + 3], acc, 0, 0, 0);
+      }
+      a[sg] = next[sg * 64];
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -75,6 +92,8 @@ __device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct OpsBf16 {
   static constexpr bool EXACT_F32 = false;
+  static constexpr bool NODE_PROJ = false;   // the whole first Linear stays on the matrix cores: this policy is not MFMA-bound, the
+                                             // projection kernel (20 us per layer) would cost more than the two tiles it saves
   using Frag = bf16x8;
   static constexpr int NFRAG = KDIM / 16;                  // 6
   static constexpr int TILE_FRAGS = NFRAG * 64;            // 384 fragments of 16 B per tile
@@ -100,6 +119,18 @@ struct OpsBf16 {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  static __device__ __forceinline__ void gemm_first(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < NFRAG; ++q) {
+      const Frag* p = next + q * 64;
+      pin(p);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < NFRAG / 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B.v[q], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a[q] = *p;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
 };
 
 // OpsBf16x3: fp32 operands represented EXACTLY as the sum of three bf16 planes (hi + mid + lo = 3 x 8 significand bits) and
@@ -110,6 +141,7 @@ struct OpsBf16 {
 // the exact-fp32 policy is measured in tests/test_gpu_bf16.py.  Fragment 3q + p = plane p of k-step q (18 KB tile).
 struct OpsBf16x3 {
   static constexpr bool EXACT_F32 = false;
+  static constexpr bool NODE_PROJ = true;
   using Frag = bf16x8;
   static constexpr int NFRAG = 3 * (KDIM / 16);            // 18
   static constexpr int TILE_FRAGS = NFRAG * 64;            // 1152 fragments of 16 B per tile
@@ -153,6 +185,28 @@ struct OpsBf16x3 {
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a[k + 0] = p[0];
+      a[k + 1] = p[64];
+      a[k + 2] = p[128];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  static __device__ __forceinline__ void gemm_first(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
+#pragma unroll
+    for (int q = 0; q < NFRAG / 3; ++q) {
+      const int k = 3 * q;
+      const Frag* p = next + k * 64;
+      pin(p);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < NFRAG / 9) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 2], B.v[k + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 2], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
       a[k + 0] = p[0];
       a[k + 1] = p[64];
