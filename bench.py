@@ -216,7 +216,7 @@ def main():
     eng.set_option("bf16", int(a.dtype == "bf16"))
     if a.dtype == "f32_split":
         eng.set_option("f32_split", 1)
-    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 4))) if (a.pair and a.streams == 1 and not a.graph) else 1
+    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 8))) if (a.pair and a.streams == 1 and not a.graph) else 1
     pair = cosched > 1
     extra = []   # further engines (own workspace, same device-resident weights) for the complexes that are co-scheduled
     for _ in range(cosched - 1):

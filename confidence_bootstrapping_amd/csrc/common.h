@@ -82,17 +82,22 @@ struct ConvGroup {
   // the first Linear runs on the matrix cores per edge (2 of the 57 tiles' worth of MFMA work less: +4 % measured as a bound).
   const float* psrc;     // [N][KDIM] W1s x[:, :32] for the rows this group uses as aggregating node
   const float* pdst;     // [N][KDIM] W1d x[:, :32] for the rows it reads
-  int src_lo, src_n, dst_lo, dst_n;   // node-row ranges the group's src / dst indices fall in (what node_proj_kernel has to cover)
   // weight-tile slice executed for this group (run_conv fills the full range): 0e tiles [i0e_lo, i0e_hi) and, if vec_on, the
   // 1o/1e/0o blocks.  Virtual slices of one edge group write their own piece buffers; the finalize kernel adds them.
   int i0e_lo, i0e_hi, vec_on;
 };
 
-// Up to 16 groups per launch: the 4 edge groups of one batch, or of up to FOUR batches (engines working on different
+// Host-side view of a group: plus the node-row ranges its src / dst indices fall in (what node_proj_kernel has to cover).  Kept out
+// of ConvGroup so that 32 of them fit the 4 KB kernel-argument limit.
+struct ConvGroupH : ConvGroup {
+  int src_lo = 0, src_n = 0, dst_lo = 0, dst_n = 0;
+};
+
+// Up to 32 groups per launch: the 4 edge groups of one batch, or of up to EIGHT batches (engines working on different
 // complexes co-scheduled by cbd_sample_multi so that one launch carries several times the waves -- the per-launch drain is
 // amortised).
-constexpr int CONV_MAX_GROUPS = 16;
-constexpr int CONV_MAX_COSCHED = 4;
+constexpr int CONV_MAX_GROUPS = 32;
+constexpr int CONV_MAX_COSCHED = 8;
 // node_proj_kernel jobs of one layer: P[row][0..95] = sum_k WT[k][.] * node[row][k] for rows [lo, lo + n)
 constexpr int PROJ_MAX_JOBS = 8;
 struct ProjJob { const float* WT; float* P; int lo, n; };
@@ -103,6 +108,7 @@ struct ConvArgs {
   int n_groups;
   unsigned long long* stamps;   // diagnostic build only (CBD_CONV_VARIANT=8): [grid][4] s_memtime/s_memrealtime at start/end
 };
+static_assert(sizeof(ConvArgs) <= 4096, "ConvArgs is passed by value: HIP kernel arguments are limited to 4 KB");
 
 // One edge group as seen by the finalize kernel: CSR range of every node + the partial sums written by tp_conv.
 struct FinGroup {

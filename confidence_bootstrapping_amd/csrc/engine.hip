@@ -58,11 +58,11 @@ struct PairCtx {
   bool abort = false;
   int n = 2;                        // engines taking part
   ConvArgs args[CONV_MAX_COSCHED];
-  int grid[CONV_MAX_COSCHED] = {0, 0, 0, 0};
+  int grid[CONV_MAX_COSCHED] = {};
   int rc = 0;
   // each engine enqueues on its own stream (their small kernels overlap); the merged launch is ordered after both streams
   // through `ready[rank]` and both streams continue after `done`
-  hipEvent_t ready[CONV_MAX_COSCHED] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ready[CONV_MAX_COSCHED] = {};
   hipEvent_t done = nullptr;
 };
 
@@ -601,7 +601,7 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
   return 0;
 }
 
-static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* groups, int n_groups, const int* caps,
+static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroupH* groups, int n_groups, const int* caps,
                     const float* node_in, hipStream_t s, const int* widx = nullptr) {
   ConvArgs a{};
   a.n_groups = n_groups;
@@ -627,8 +627,8 @@ static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroup* group
         float* ps = e->proj[base + 2 * slot_of[w]];
         float* pd = e->proj[base + 2 * slot_of[w] + 1];
         if (base + 2 * slot_of[w] + 1 >= (int)(sizeof(e->proj) / sizeof(e->proj[0]))) return fail(CBD_ERR_STATE, "projection slots exhausted");
-        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w], ps, a.g[g].src_lo, a.g[g].src_n};
-        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w] + (size_t)NS * KDIM, pd, a.g[g].dst_lo, a.g[g].dst_n};
+        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w], ps, groups[g].src_lo, groups[g].src_n};
+        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w] + (size_t)NS * KDIM, pd, groups[g].dst_lo, groups[g].dst_n};
       }
       a.g[g].psrc = e->proj[base + 2 * slot_of[w]];
       a.g[g].pdst = e->proj[base + 2 * slot_of[w] + 1];
@@ -718,7 +718,7 @@ static int embed_receptor(cbd_engine* e, hipStream_t s) {
   float* in = e->X0;
   float* out = e->X1;
   for (int l = 0; l < 3; ++l) {
-    ConvGroup g{};
+    ConvGroupH g{};
     g.src = e->d_src0; g.dst = e->d_dst0; g.attr_idx = e->d_ident; g.vec = e->d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
     g.first_sum = e->fsum[4]; g.last_sum = e->lsum[4]; g.run_acc = e->racc[4];
     g.src_lo = 0; g.src_n = Nr; g.dst_lo = 0; g.dst_n = Nr;
@@ -937,7 +937,7 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   //      score_model.py:323-326) and the receptor->receptor messages of interaction layer 0.  Those messages read only
   //      receptor features and shared edge attributes, so they are IDENTICAL for the B samples of a complex: they are
   //      computed once (Err edges instead of B*Err) and added to every sample's sum by the finalize kernel (node_mod = Nr).
-  ConvGroup g_rr_shared{};   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
+  ConvGroupH g_rr_shared{};   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
   g_rr_shared.src = e->rr_src; g_rr_shared.dst = e->rr_dst; g_rr_shared.attr_idx = e->rr_aidx; g_rr_shared.vec = e->rr_vec;
   g_rr_shared.attr = e->rr_attr_t; g_rr_shared.count = e->rr_count_dev;
   g_rr_shared.first_sum = e->fsum[4]; g_rr_shared.last_sum = e->lsum[4]; g_rr_shared.run_acc = e->racc[2];
@@ -966,13 +966,13 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   HIPCHK(launch_lig_node_init(e->lig_static32, e->sv.lig_node_c, Xa, B, Nl, s));
   snap(e, "lig_node_emb0", Xa, (size_t)nL * NODE_STRIDE, s);
 
-  ConvGroup gll{}, glr{}, grr{}, grl{};
+  ConvGroupH gll{}, glr{}, grr{}, grl{};
   gll.src = gd.ll_src; gll.dst = gd.ll_dst; gll.attr_idx = gd.ll_aidx; gll.vec = gd.ll_vec; gll.attr = e->ll_attr; gll.count = gd.counts + 0;
   glr.src = gd.lr_src; glr.dst = gd.lr_dst; glr.attr_idx = gd.lr_aidx; glr.vec = gd.lr_vec; glr.attr = e->lr_attr; glr.count = gd.counts + 1;
   grr.src = e->rr_src; grr.dst = e->rr_dst; grr.attr_idx = e->rr_aidx; grr.vec = e->rr_vec; grr.attr = e->rr_attr_t; grr.count = gd.counts + 2;
   grl.src = gd.rl_src; grl.dst = gd.rl_dst; grl.attr_idx = gd.rl_aidx; grl.vec = gd.rl_vec; grl.attr = e->lr_attr; grl.count = gd.counts + 3;
   {
-    ConvGroup* gg[4] = {&gll, &glr, &grr, &grl};
+    ConvGroupH* gg[4] = {&gll, &glr, &grr, &grl};
     for (int g = 0; g < 4; ++g) { gg[g]->first_sum = e->fsum[g]; gg[g]->last_sum = e->lsum[g]; gg[g]->run_acc = e->racc[g]; }
     // node-row ranges of the aggregating (src) and the read (dst) side: ligand rows [0, nL), receptor rows [rec_off, rec_off + nR)
     gll.src_lo = 0; gll.src_n = nL; gll.dst_lo = 0; gll.dst_n = nL;
@@ -995,7 +995,7 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
     const int tvec = ES.t1o + ES.t1e + ES.t0o, nsl = 2;   // the same slicing with and without a partner engine: identical results
     const int per = (ES.t0e + tvec + nsl - 1) / nsl;
     const int c_lo = ES.t0e - std::max(0, std::min(ES.t0e, per - tvec));   // 0e tiles the vector slice also takes
-    ConvGroup sl[3];
+    ConvGroupH sl[3];
     FinGroup fsl[3];
     int caps_sl[3];
     for (int k = 0; k < nsl; ++k) {
@@ -1019,17 +1019,17 @@ static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& s
   static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
   for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
     if (l == 0) {
-      const ConvGroup g3[3] = {gll, glr, grl};
+      const ConvGroupH g3[3] = {gll, glr, grl};
       const int caps[3] = {cap_ll, cap_x, cap_x}, widx[3] = {0, 1, 3};
       CHK(run_conv(e, e->conv[l], g3, 3, caps, in, s, widx));
       CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2_shared, 2, nR, gs.rec_off, s));
     } else if (l < 4) {
-      const ConvGroup g4[4] = {gll, glr, grr, grl};
+      const ConvGroupH g4[4] = {gll, glr, grr, grl};
       const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
       CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
       CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2, 2, nR, gs.rec_off, s));
     } else {
-      const ConvGroup g2[2] = {gll, glr};
+      const ConvGroupH g2[2] = {gll, glr};
       const int caps[2] = {cap_ll, cap_x};
       CHK(run_conv(e, e->conv[l], g2, 2, caps, in, s));
       CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));   // receptor rows are never read again (quirk 3)
@@ -1211,7 +1211,7 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
     HIPCHK(hipStreamWaitEvent(engines[k]->own, engines[k]->ev_a, 0));
   }
   for (int k = 0; k < n; ++k) { engines[k]->pair = &ctx; engines[k]->pair_rank = k; }
-  int rc[CONV_MAX_COSCHED] = {0, 0, 0, 0};
+  int rc[CONV_MAX_COSCHED] = {};
   std::string err[CONV_MAX_COSCHED];
   auto body = [&](int k) {
     rc[k] = cbd_sample(engines[k], B[k], S, steps, pos_dev[k], nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), nullptr,

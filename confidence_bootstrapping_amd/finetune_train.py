@@ -70,7 +70,7 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
         prepared.append((orig, data_list, filtering_data_list))
 
     results = []
-    group = 4 if n % max(args.inference_batch_size, 1) == 0 else 1      # loader batches must not straddle complexes
+    group = 8 if n % max(args.inference_batch_size, 1) == 0 else 1      # loader batches must not straddle complexes
     for k in range(0, len(prepared), group):
         items = prepared[k:k + group]
         try:

@@ -88,12 +88,13 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
              temp_sigma_data=0.5, return_features=False, svgd_weight_log_0=None, svgd_repulsive_weight_log_0=None,
              svgd_weight_log_1=None, svgd_repulsive_weight_log_1=None, svgd_kernel_size_log_0=None,
              svgd_kernel_size_log_1=None, svgd_langevin_weight_log_0=None, svgd_langevin_weight_log_1=None,
-             svgd_rot_log_rel_weight=0.0, svgd_tor_log_rel_weight=0.0, svgd_use_x0=False, noise=None, n_streams=1, co_schedule=4):
+             svgd_rot_log_rel_weight=0.0, svgd_tor_log_rel_weight=0.0, svgd_use_x0=False, noise=None, n_streams=1, co_schedule=None):
     """Reverse diffusion of every pose in `data_list`; returns (data_list, confidence) like the reference.
     `noise` (optional, extension): dict of pre-drawn 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R] CPU tensors.
     `n_streams` (extension): each batch is split over this many concurrent HIP streams (identical results).
-    `co_schedule` (extension): when `data_list` holds poses of several complexes, up to this many (<= 4) complexes are advanced in
-    lockstep with merged tensor-product launches (identical results; 1 = one complex at a time like the reference)."""
+    `co_schedule` (extension): when `data_list` holds poses of several complexes, up to this many (<= 8) complexes are advanced in
+    lockstep with merged tensor-product launches (identical results; 1 = one complex at a time like the reference; default: as many
+    as bring a launch to ~160 poses)."""
     N = len(data_list)
     assert not (return_full_trajectory or return_features or pivot), "Not implemented yet in new inference version"
     if svgd_weight_log_0 is not None and svgd_weight_log_1 is not None:
@@ -121,7 +122,13 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                        temp_sigma_data=temp_sigma_data)
     S = inference_steps
     use_noise = not (no_random or ode)
-    n_co = max(1, min(int(co_schedule), 4)) if n_streams == 1 else 1
+    if co_schedule is None:
+        # aim at ~160 poses per merged launch -- 4 complexes of 40 samples, 8 of 8 (measured: 8-way is +6 % over 4-way at 8 samples per
+        # complex and -1 % at 40).  Poses per complex = the leading run of equal names (the loader batches of a complex are merged).
+        name0 = getattr(data_list[0], "name", None) if N else None
+        per = next((i for i, d in enumerate(data_list) if getattr(d, "name", None) != name0), N) if name0 is not None else int(batch_size)
+        co_schedule = -(-160 // max(per, 1))
+    n_co = max(1, min(int(co_schedule), 8)) if n_streams == 1 else 1
     offset = 0
     pending = []          # (first pose index, b, pos [b,Nl,3] CPU, z_tr, z_rot, z_tor, loader batch)
     pending_key = None
@@ -139,7 +146,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             run_groups()
 
     def run_groups():
-        """Up to four complexes advance in lockstep (cbd_sample_multi: their tensor-product launches are merged, so a launch
+        """Up to eight complexes advance in lockstep (cbd_sample_multi: their tensor-product launches are merged, so a launch
         carries several times the waves -- +24 % poses/s at 8 samples per complex); one group runs on cbd_sample.  Results are
         bitwise those of separate calls (tests/test_gpu_parity.py::test_sample_pair_equals_two_samples)."""
         if not groups:

@@ -120,7 +120,7 @@ int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int3
                     const float* noise_tr0_dev, const float* noise_rot0_dev, const float* noise_tor0_dev, float* pos1_dev,
                     const float* noise_tr1_dev, const float* noise_rot1_dev, const float* noise_tor1_dev, void* stream);
 
-/* The same for n = 1..4 engines (arrays of n entries; the noise arrays or their entries may be NULL). */
+/* The same for n = 1..8 engines (arrays of n entries; the noise arrays or their entries may be NULL). */
 int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, int32_t S, const cbd_step* steps_host,
                      float* const* pos_dev, const float* const* noise_tr_dev, const float* const* noise_rot_dev,
                      const float* const* noise_tor_dev, void* stream);
