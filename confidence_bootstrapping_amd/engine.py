@@ -282,7 +282,7 @@ class DockEngine:
 
     @staticmethod
     def sample_multi(engines, poses, steps, noises):
-        """cbd_sample_multi: up to 4 engines (sharing weights, each with its own complex) advanced in lockstep with merged
+        """cbd_sample_multi: up to 8 engines (sharing weights, each with its own complex) advanced in lockstep with merged
         tensor-product launches.  poses: list of [b,Nl,3] device tensors (updated in place); noises: list of (tr, rot, tor) or None."""
         n = len(engines)
         e0 = engines[0]
