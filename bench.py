@@ -219,7 +219,7 @@ def main():
     cosched = (2 if a.pair == 1 else max(1, min(a.pair, 8))) if (a.pair and a.streams == 1 and not a.graph) else 1
     pair = cosched > 1
     extra = []   # further engines (own workspace, same device-resident weights) for the complexes that are co-scheduled
-    for _ in range(cosched - 1):
+    for _ in range(min(cosched, 7) if pair else 0):      # one spare partner: a group may carry cosched + 1 complexes (see run())
         e2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
         e2.set_complex(cplx)
         e2.set_option("bf16", int(a.dtype == "bf16"))
@@ -252,7 +252,8 @@ def main():
         while k < hi:
             if pair and k + 1 < hi:
                 left = hi - k
-                m = -(-left // -(-left // cosched))     # balanced groups (5 -> 3 + 2 rather than 4 + 1: no complex runs alone)
+                # no complex runs alone: one more than the nominal group rides along (5 -> 5), otherwise balanced groups (9 -> 3 x 3)
+                m = left if left <= min(cosched + 1, 8) else -(-left // -(-left // cosched))
                 pools = [eng] + extra[:m - 1]
                 for p_ in pools:
                     p_.recompute_receptor()
