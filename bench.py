@@ -304,7 +304,7 @@ def main():
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
         flops_per_launch = total_flops / max(n_launch, 1)
         traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r01_{t}_traffic.json") for t in "lhf") if os.path.exists(q)), "")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
+        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r01_{t}_traffic.json") for t in "mlhf") if os.path.exists(q)), "")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
         if os.path.exists(tp):
             traffic = round(json.load(open(tp))["hbm_bytes_per_launch_all_tp_conv"])
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
