@@ -60,7 +60,8 @@ def test_confidence_bootstrapping_round_trip():
 
 
 def test_sampling_co_schedules_complexes_identically():
-    """sampling() over the poses of three different complexes: co_schedule=4 (cbd_sample_multi) == co_schedule=1 (one at a time)."""
+    """sampling() over the poses of six different complexes: any co-scheduling (cbd_sample_multi with 6 or 4 engines) gives bitwise the
+    poses and confidences of one complex at a time."""
     from confidence_bootstrapping_amd import Batch
     from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
     from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
@@ -69,18 +70,19 @@ def test_sampling_co_schedules_complexes_identically():
     dev = torch.device("cuda:0")
     model, margs = make_score_model(device=dev, seed=0)
     conf_model, conf_args = make_confidence_model(device=dev, seed=5)
-    cps = [add_atoms(make_complex(Nl=9 + i, Nr=36 + 4 * i, R=1 + i % 2, knn=8, seed=40 + i, name=f"c{i}"), seed=40 + i) for i in range(3)]
+    cps = [add_atoms(make_complex(Nl=9 + i, Nr=36 + 4 * i, R=1 + i % 2, knn=8, seed=40 + i, name=f"c{i}"), seed=40 + i) for i in range(6)]
     torch.manual_seed(1); np.random.seed(1)
-    base = [Batch.from_data_list([copy.deepcopy(c)]) for c in cps for _ in range(4)]
+    base = [Batch.from_data_list([copy.deepcopy(c)]) for c in cps for _ in range(2)]
     randomize_position(base, False, False, margs.tr_sigma_max)
     sched = get_t_schedule("expbeta", 5)
     outs = []
-    for co in (4, 1):
+    for co in (None, 4, 1):     # None: sampling() picks the group size itself (here 6 complexes of 2 poses -> one 6-engine launch group)
         dl = [copy.deepcopy(d) for d in base]
         torch.manual_seed(7)
         res, conf = sampling(data_list=dl, model=model, inference_steps=5, tr_schedule=sched, rot_schedule=sched, tor_schedule=sched,
                              device=dev, t_to_sigma=partial(t_to_sigma, args=margs), model_args=margs, confidence_model=conf_model,
                              filtering_model_args=conf_args, batch_size=2, co_schedule=co)
         outs.append(([d["ligand"].pos.clone() for d in res], conf.clone()))
-    assert all(torch.equal(a, b) for a, b in zip(outs[0][0], outs[1][0]))
-    assert torch.equal(outs[0][1], outs[1][1]) and outs[0][1].shape == (12,)
+    for other in outs[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(outs[0][0], other[0]))
+        assert torch.equal(outs[0][1], other[1]) and other[1].shape == (12,)
