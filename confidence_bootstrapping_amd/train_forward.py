@@ -30,7 +30,7 @@ SQ3 = math.sqrt(3.0)
 def collate(data_list: List[HeteroData], device) -> Batch:
     """Collation of the fields the score model reads (what PyG's Batch gives the reference): node tensors concatenated,
     edge_index offset per graph, `batch` vectors, per-graph diffusion times (utils/diffusion_utils.py:150-179) as tensors.
-    One concatenation + one host-to-device copy per field; the input graphs are not copied or modified."""
+    Per-graph host-to-device copies on a side stream, concatenated on the device; the input graphs are not copied or modified."""
     if isinstance(data_list, Batch):
         return data_list.to(device)
     b = Batch()
