@@ -377,6 +377,62 @@ static hipError_t launch_train_any(int in_level, int out_level, bool bwd, const 
   return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Weight / bias gradient of the FCBlock's FIRST Linear (96 -> 96):  dW[m][n] = sum_e G[e][m] X[e][n],  db[m] = sum_e G[e][m]
+// (G = d loss / d pre-activation, X = [edge_attr | x_src[:32] | x_dst[:32]]).  A reduction over 10^5..10^6 edges into a 96 x 96
+// output: library GEMMs run it at ~10 TFLOP/s (K huge, M = N = 96: 341 us per call in profiles/r01_h_train_b32_kernel_stats.csv),
+// it is bound by reading the two [E, 96] operands once.  Here every wave owns a contiguous chunk of edges, feeds them as the K
+// dimension of v_mfma_f32_32x32x2_f32 (two edges per k-step; lane (c = lane & 31, hf = lane >> 5) loads G[e + hf][32 i + c] and
+// X[e + hf][32 j + c]: coalesced 128-byte rows) into nine 32 x 32 accumulators, and writes one partial [96 x 96 + 96] block; the
+// caller adds the blocks (deterministic: no atomics).
+constexpr int OUTER_DIM = KDIM;
+constexpr int OUTER_PART_FLOATS = OUTER_DIM * OUTER_DIM + OUTER_DIM;
+__global__ __launch_bounds__(64, 2) void outer_accum_kernel(const float* __restrict__ G, const float* __restrict__ X, int E, int chunk,
+                                                             float* __restrict__ partial) {
+  const int lane = threadIdx.x, c = lane & 31, hf = lane >> 5;
+  const int e_lo = blockIdx.x * chunk, e_hi = min(E, e_lo + chunk);
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[3] = {0.f, 0.f, 0.f};
+  for (int e = e_lo; e < e_hi; e += 2) {
+    const int row = e + hf;
+    const bool ok = row < e_hi;
+    const size_t off = (size_t)(ok ? row : e) * OUTER_DIM + c;
+    float g[3], x[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float gv = G[off + 32 * i], xv = X[off + 32 * i];
+      g[i] = ok ? gv : 0.f;
+      x[i] = ok ? xv : 0.f;
+      colsum[i] += g[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], x[j], acc[i][j], 0, 0, 0);
+  }
+  float* out = partial + (size_t)blockIdx.x * OUTER_PART_FLOATS;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        out[(size_t)m * OUTER_DIM + 32 * j + c] = acc[i][j][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float t = colsum[i] + __shfl_xor(colsum[i], 32, 64);
+    if (hf == 0) out[OUTER_DIM * OUTER_DIM + 32 * i + c] = t;
+  }
+}
+
 }  // namespace cbd
 
 extern "C" {
@@ -426,6 +482,19 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
   a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.gx = gx_dev; a.gw = gw_dev;
   const hipError_t r = cbd::launch_train_any(in_level, out_level, true, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int64_t cbd_outer_accum_part_floats(void) { return cbd::OUTER_PART_FLOATS; }
+
+int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n_parts, float* partial_dev, void* stream) {
+  if (E <= 0 || E > (int64_t)1 << 30 || n_parts <= 0 || !g_dev || !x_dev || !partial_dev) return fail(CBD_ERR_ARG, "bad argument");
+  int chunk = (int)((E + n_parts - 1) / n_parts);
+  chunk += chunk & 1;   // even: a k-step's two edges belong to one chunk
+  hipLaunchKernelGGL(cbd::outer_accum_kernel, dim3(n_parts), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), g_dev, x_dev, (int)E,
+                     chunk, partial_dev);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_outer_accum: %s", hipGetErrorString(r));
   return 0;
 }
 

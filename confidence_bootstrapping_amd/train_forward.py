@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import LEVEL_DIMS, NODE_STRIDE, stream_map, tensor_product
+from .train_ops import LEVEL_DIMS, NODE_STRIDE, first_linear, stream_map, tensor_product
 
 SQ3 = math.sqrt(3.0)
 
@@ -189,7 +189,8 @@ def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1):
 
 # ----------------------------------------------------------------------------- layers
 def _fc_hidden(fc, x):
-    return fc[2](fc[1](fc[0](x)))   # Linear -> ReLU -> Dropout; the last Linear lives inside the HIP op
+    # Linear -> ReLU -> Dropout; the last Linear lives inside the HIP op, the first one's weight gradient on cbd_outer_accum
+    return fc[2](fc[1](first_linear(x, fc[0])))
 
 
 def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, out_level):

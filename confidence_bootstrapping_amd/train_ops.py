@@ -205,3 +205,39 @@ def tensor_product(xrow, vec4, h, streams, in_level, out_level, group_edges=None
     if torch.is_tensor(streams):
         streams, group_edges = [streams], [xrow.shape[0]]
     return TensorProductFn.apply(xrow, vec4, h, in_level, out_level, tuple(int(x) for x in group_edges), *streams)
+
+
+class FirstLinearFn(torch.autograd.Function):
+    """y = x W^T + b for the FCBlock's first Linear (96 -> 96) with the weight / bias gradient on `cbd_outer_accum`: the reduction
+    over 10^5..10^6 edges into a 96 x 96 matrix that library GEMMs run at ~10 TFLOP/s (csrc/tp_train.hip::outer_accum_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = g @ weight if ctx.needs_input_grad[0] else None
+        gw = gb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            lib = _bind(load_library())
+            E = x.shape[0]
+            g32, x32 = g.contiguous().float(), x.contiguous().float()
+            n_parts = max(1, min(1024, (E + 63) // 64))
+            pf = int(lib.cbd_outer_accum_part_floats())
+            parts = torch.empty(n_parts, pf, device=x.device, dtype=torch.float32)
+            _check(lib.cbd_outer_accum(E, _ptr(g32), _ptr(x32), n_parts, _ptr(parts), _stream_handle()))
+            tot = parts.sum(0)
+            gw, gb = tot[:KDIM * KDIM].view(KDIM, KDIM), tot[KDIM * KDIM:]
+        return gx, gw, gb
+
+
+def first_linear(x, linear):
+    """`linear(x)` for an nn.Linear(96, 96) on [E, 96] edge rows (E >= 1), HIP weight-gradient reduction."""
+    if not x.is_cuda:
+        raise RuntimeError("first_linear runs on the MI355X only (HIP weight-gradient kernel, no CPU fallback)")
+    if x.shape[0] == 0:
+        return x.new_zeros(0, linear.weight.shape[0]) + 0 * linear.bias
+    return FirstLinearFn.apply(x, linear.weight, linear.bias)

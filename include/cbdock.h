@@ -251,6 +251,13 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
                     const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, const float* gmsg_dev, float* gx_dev,
                     float* gw_dev, void* stream);
 
+/* Weight and bias gradient of the FCBlock's first Linear (96 -> 96) in the fine-tuning step (autograd of fc[0] in
+ * models/layers.py:8-15 under utils/training.py:205): partial[p] = [ sum_e g[e][m] x[e][n] (96 x 96, row-major) | sum_e g[e][m] (96) ]
+ * over the p-th of n_parts contiguous chunks of the E edges; the caller adds the n_parts blocks (cbd_outer_accum_part_floats()
+ * floats each).  g_dev, x_dev: [E][96] fp32 device pointers. */
+int64_t cbd_outer_accum_part_floats(void);
+int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n_parts, float* partial_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

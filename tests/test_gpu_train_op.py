@@ -102,3 +102,24 @@ def test_tp_op_edge_groups_in_one_launch():
     for a, b in zip(fcd, fcs):
         close(a[3].weight.grad, b[3].weight.grad, "gW2")
         close(a[3].bias.grad, b[3].bias.grad, "gb2")
+
+
+@pytest.mark.parametrize("E", [1, 63, 5001, 70000])
+def test_first_linear_weight_gradient_kernel(E):
+    """cbd_outer_accum (dW = G^T X, db = column sums of G over E edges) through FirstLinearFn against torch autograd in fp64."""
+    from confidence_bootstrapping_amd.train_ops import first_linear
+    dev = torch.device("cuda:0")
+    torch.manual_seed(E)
+    lin = torch.nn.Linear(96, 96).to(dev)
+    x = torch.randn(E, 96, device=dev, requires_grad=True)
+    gout = torch.randn(E, 96, device=dev)
+    y = first_linear(x, lin)
+    (y * gout).sum().backward()
+    lin64 = torch.nn.Linear(96, 96).double().to(dev)
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    x64 = x.detach().double().requires_grad_()
+    y64 = lin64(x64)
+    (y64 * gout.double()).sum().backward()
+    rel = lambda a, b: float((a.detach().double() - b.detach()).abs().max() / b.detach().abs().max())
+    assert rel(y, y64) < 1e-5 and rel(x.grad, x64.grad) < 1e-5
+    assert rel(lin.weight.grad, lin64.weight.grad) < 2e-5 and rel(lin.bias.grad, lin64.bias.grad) < 2e-5
