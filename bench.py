@@ -133,7 +133,7 @@ def confidence_leg(cplx_seed, final_pos, dev):
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 
-def finetune_leg(dev, batch=8, warm=2, steps=4):
+def finetune_leg(dev, batch=8, warm=3, steps=6):
     """One confidence-bootstrapping fine-tuning step (BASELINE.json configs[4]) measured OUTSIDE the timed region of
     the headline metric: train-mode forward on the HIP tensor-product op, score-matching loss, HIP backward kernels, Adam, EMA on a
     batch of `batch` different C2-sized complexes noised by NoiseTransform (same code path as tools/train_bench.py)."""
