@@ -1,0 +1,41 @@
+"""Wider fuzz campaign than tests/test_gpu_fuzz.py (run by hand on a GPU box): 150 random complexes per seed through the score engine vs
+the CPU oracle.  `python tools/fuzz_campaign.py [seed]`.  Round 1: seeds 7 and 8, 288 complexes, worst relative deviation 9.6e-6."""
+import os, sys, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tests.helpers import to_cx
+from confidence_bootstrapping_amd.utils import make_score_model
+from confidence_bootstrapping_amd.synthetic import make_complex
+from confidence_bootstrapping_amd.engine import make_steps
+from oracle import score_ref as sr
+model, args = make_score_model(device="cuda:0", seed=0)
+d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "confidence_bootstrapping_amd", "data")
+so3, torus = np.load(os.path.join(d, "so3_exp_score_norms.npy")), np.load(os.path.join(d, "torus_score_norm.npy"))
+sd = {k: v.cpu() for k, v in model.state_dict().items()}
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 7)
+eng = model.engine()
+worst, fails, n = 0.0, [], 0
+for k in range(150):
+    nl = int(rng.integers(2, 40)); nr = int(rng.integers(3, 90))
+    r = int(rng.integers(0, max(1, min(6, nl // 4)) + 1))
+    knn = int(min(24, nr - 1, rng.integers(2, 25)))
+    B = int(rng.integers(1, 7)); t = float(rng.uniform(0.02, 1.0)); spread = float(rng.choice([0.5, 2.0, 8.0, 25.0, 60.0]))
+    try:
+        cplx = make_complex(Nl=nl, Nr=nr, R=r, knn=max(knn, 1), seed=1000 + k)
+    except (RuntimeError, ValueError):
+        continue
+    g = torch.Generator().manual_seed(k)
+    pos = cplx["ligand"].pos[None].repeat(B, 1, 1) + spread * torch.randn(B, 1, 3, generator=g) + 0.2 * torch.randn(B, nl, 3, generator=g)
+    ref = sr.score_forward(sd, to_cx(cplx), pos, t, t, t, sr.ScoreConfig(), so3, torus)
+    eng.set_complex(cplx)
+    step = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+    tr, rot, tor = eng.score(pos.cuda(), step)
+    n += 1
+    for name, got, want in (("tr", tr, ref["tr_pred"]), ("rot", rot, ref["rot_pred"]), ("tor", tor, ref["tor_pred"])):
+        if want.numel() == 0: continue
+        ok = bool(torch.isfinite(got).all()) or not bool(torch.isfinite(want).all())
+        fin = torch.isfinite(want)
+        err = float((got.cpu()[fin] - want[fin]).abs().max() / max(1.0, float(want[fin].abs().max()))) if fin.any() else 0.0
+        worst = max(worst, err)
+        if err > 3e-5 or not ok:
+            fails.append((k, name, nl, nr, r, B, round(t, 3), spread, err))
+print("cases", n, "worst rel err", worst, "fails", fails[:10])
