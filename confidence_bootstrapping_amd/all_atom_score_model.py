@@ -121,7 +121,10 @@ class TensorProductScoreModel(nn.Module):
         self._engine_key = None
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        """Accept-and-ignore the persistent buffers real e3nn modules add under `conv_layers.N.tp.`."""
+        """Persistent buffers real e3nn modules add under `conv_layers.N.tp.` are dropped after their
+        Wigner-3j constants have been checked against the ones hard-wired in fctp_conv.hip (a mismatch raises)."""
+        from .e3nn_constants import check_w3j_buffers
+        check_w3j_buffers(state_dict)
         sd = {k: v for k, v in state_dict.items() if ".tp." not in k}
         out = super().load_state_dict(sd, strict=strict, **kw)
         self._engine_key = None

@@ -231,8 +231,11 @@ class TensorProductScoreModel(nn.Module):
     _IGNORED_PREFIXES = ("final_conv.tp.", "tor_bond_conv.tp.", "final_tp_tor.")
 
     def load_state_dict(self, state_dict, strict=True, **kw):
-        """Accept-and-ignore the persistent buffers real e3nn modules add (output_mask, _w3j_*):
-        their arithmetic is hard-wired in the engine."""
+        """Persistent buffers real e3nn modules add (output_mask, _w3j_*) are not parameters of this model: their arithmetic
+        is hard-wired in the engine.  The Wigner-3j constants among them are authoritative for the checkpoint:
+        they are compared with the baked ones and a mismatch raises (e3nn_constants.check_w3j_buffers); the rest is dropped."""
+        from .e3nn_constants import check_w3j_buffers
+        check_w3j_buffers(state_dict)
         sd = {k: v for k, v in state_dict.items() if not k.startswith(self._IGNORED_PREFIXES)}
         out = super().load_state_dict(sd, strict=strict, **kw)
         self._engine_key = None  # weights changed -> re-upload
