@@ -131,7 +131,11 @@ class TensorProductScoreModel(nn.Module):
         return out
 
     def _weights_version(self):
-        return sum(int(p._version) for p in self.parameters())
+        from .score_model import weights_version
+        return weights_version(self)
+
+    def invalidate_engine(self):
+        self._engine_key = None
 
     def engine(self, max_batch: int = 64):
         from .engine import ConfidenceEngine

@@ -613,8 +613,16 @@ def complex_fingerprint(data):
         while isinstance(name, (list, tuple)):
             name = name[0]
     B = data.num_graphs
-    return (name, data["ligand"].num_nodes // B, data["receptor"].num_nodes // B,
-            data["ligand", "ligand"].num_edges // B, int(data["receptor"].pos[0].sum().item() * 1e3))
+    Nl, Nr = data["ligand"].num_nodes // B, data["receptor"].num_nodes // B
+    key = (name, Nl, Nr, data["ligand", "ligand"].num_edges // B, int(data["receptor"].pos[0].sum().item() * 1e3))
+    if name is None:
+        # unnamed graphs of equal shapes must not alias a cached receptor: hash the first graph's receptor trace and atom types
+        import hashlib
+        h = hashlib.blake2b(digest_size=8)
+        h.update(np.ascontiguousarray(data["receptor"].pos[:Nr].detach().cpu().numpy()).tobytes())
+        h.update(np.ascontiguousarray(data["ligand"].x[:Nl].detach().cpu().numpy()).tobytes())
+        key += (h.hexdigest(),)
+    return key
 
 
 def score_batch(model, data):

@@ -14,7 +14,7 @@ import torch
 from .molecules_utils import get_symmetry_rmsd
 
 
-def pose_metrics(ligand_pos, orig_ligand_pos, mol=None):
+def pose_metrics(ligand_pos, orig_ligand_pos, mol=None, device=None):
     """ligand_pos [N, Nl, 3] (heavy atoms), orig_ligand_pos [Nl, 3] or [K, Nl, 3] reference pose(s), same frame.
     Returns (rmsd [N], centroid_distance [N], min_self_distance [N]) like inference.py:505-548."""
     lp = np.asarray(ligand_pos, dtype=np.float32)
@@ -22,7 +22,7 @@ def pose_metrics(ligand_pos, orig_ligand_pos, mol=None):
     ref = ref[None] if ref.ndim == 2 else ref
     if mol is not None:
         try:
-            rmsd = np.min(np.asarray([get_symmetry_rmsd(mol, r, [l for l in lp]) for r in ref]), axis=0)
+            rmsd = np.min(np.asarray([get_symmetry_rmsd(mol, r, [l for l in lp], device=device) for r in ref]), axis=0)
         except Exception as e:
             print("Using non corrected RMSD because of the error:", e)
             mol = None

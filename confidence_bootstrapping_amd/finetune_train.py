@@ -111,7 +111,7 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
             per_ref = []
             for r in ref:
                 try:
-                    per_ref.append(np.asarray(get_symmetry_rmsd(mol, r, [l for l in lp])))
+                    per_ref.append(np.asarray(get_symmetry_rmsd(mol, r, [l for l in lp], device=device)))
                 except Exception as e:
                     print("Using non corrected RMSD because of the error:", e)
                     per_ref.append(np.sqrt(((lp - r) ** 2).sum(axis=2).mean(axis=1)))

@@ -14,10 +14,27 @@ import numpy as np
 import torch
 
 
-def graph_isomorphisms(atomicnums, adjacency, atomicnums2=None, adjacency2=None) -> Tuple[np.ndarray, np.ndarray]:
+class IsomorphismLimit(RuntimeError):
+    """The enumeration of graph isomorphisms exceeded its time or count bound (highly symmetric ligand)."""
+
+
+# The reference wraps the symmetry-corrected RMSD in `time_limit(10)` and falls back to the plain RMSD when it fires
+# (inference.py:511-520, finetune_train.py:205-214).  The same bound here, plus a count cap so that the [K, N] index tables
+# handed to the GPU stay small (ligands with factorially many automorphisms would otherwise exhaust host memory first).
+MAX_ISOMORPHISMS = 100_000
+ISOMORPHISM_TIME_LIMIT_S = 10.0
+
+
+def graph_isomorphisms(atomicnums, adjacency, atomicnums2=None, adjacency2=None, max_isomorphisms=None,
+                       time_limit_s=None) -> Tuple[np.ndarray, np.ndarray]:
     """All label-preserving isomorphisms between two molecular graphs as index arrays (idx1 [K,N], idx2 [K,N]) such that atom
-    idx1[k, i] of molecule 1 corresponds to atom idx2[k, i] of molecule 2.  Raises ValueError if the graphs differ."""
+    idx1[k, i] of molecule 1 corresponds to atom idx2[k, i] of molecule 2.  Raises ValueError if the graphs differ and
+    IsomorphismLimit when more than `max_isomorphisms` exist or the enumeration takes longer than `time_limit_s` seconds
+    (the callers then use the uncorrected RMSD, like the reference after its time_limit)."""
+    import time
     import networkx as nx
+    max_isomorphisms = MAX_ISOMORPHISMS if max_isomorphisms is None else max_isomorphisms
+    time_limit_s = ISOMORPHISM_TIME_LIMIT_S if time_limit_s is None else time_limit_s
     a1, m1 = np.asarray(atomicnums), np.asarray(adjacency)
     a2 = a1 if atomicnums2 is None else np.asarray(atomicnums2)
     m2 = m1 if adjacency2 is None else np.asarray(adjacency2)
@@ -27,7 +44,13 @@ def graph_isomorphisms(atomicnums, adjacency, atomicnums2=None, adjacency2=None)
     gm = nx.algorithms.isomorphism.GraphMatcher(G1, G2, lambda x, y: x["aprops"] == y["aprops"])
     if not gm.is_isomorphic():
         raise ValueError("Graphs are not isomorphic.")
-    iso = [(list(m.keys()), list(m.values())) for m in gm.isomorphisms_iter()]
+    iso, t0 = [], time.monotonic()
+    for m in gm.isomorphisms_iter():
+        iso.append((list(m.keys()), list(m.values())))
+        if len(iso) > max_isomorphisms:
+            raise IsomorphismLimit(f"more than {max_isomorphisms} graph isomorphisms")
+        if (len(iso) & 63) == 0 and time.monotonic() - t0 > time_limit_s:
+            raise IsomorphismLimit(f"graph isomorphism enumeration exceeded {time_limit_s} s ({len(iso)} found)")
     idx1 = np.asarray([i for i, _ in iso], dtype=np.int32)
     idx2 = np.asarray([j for _, j in iso], dtype=np.int32)
     return idx1, idx2
@@ -40,7 +63,9 @@ def symmetry_rmsd(coords_ref, coords, atomicnums, adjacency, atomicnums2=None, a
     from .engine import load_library, _check, _dptr
     lib = load_library()
     single = not isinstance(coords, (list, tuple)) and np.asarray(coords if not torch.is_tensor(coords) else coords.cpu()).ndim == 2
-    dev = torch.device(device) if device is not None else (coords.device if torch.is_tensor(coords) and coords.is_cuda else torch.device("cuda:0"))
+    # default device: the tensors' own, else this process's CURRENT device (one process per GPU: never everybody's cuda:0)
+    dev = torch.device(device) if device is not None else (coords.device if torch.is_tensor(coords) and coords.is_cuda
+                                                            else torch.device("cuda", torch.cuda.current_device()))
     if dev.type != "cuda":
         raise RuntimeError("symmetry_rmsd runs on an MI355X (device type 'cuda' under ROCm)")
     to_t = lambda x: x.to(dev, torch.float32) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x), dtype=torch.float32, device=dev)
@@ -83,8 +108,9 @@ def _graph_of(mol):
     raise TypeError("mol must provide atomicnums/adjacency_matrix (spyrmsd Molecule) or the rdkit Mol API")
 
 
-def get_symmetry_rmsd(mol, coords1, coords2, mol2=None, return_permutation=False):
-    """Same call as the reference (utils/molecules_utils.py:3): coords1 = reference pose, coords2 = pose or list of poses."""
+def get_symmetry_rmsd(mol, coords1, coords2, mol2=None, return_permutation=False, device=None):
+    """Same call as the reference (utils/molecules_utils.py:3): coords1 = reference pose, coords2 = pose or list of poses.
+    `device` (extension): the GPU to reduce on; default = the poses' device or the process's current device."""
     n1, a1 = _graph_of(mol)
     n2, a2 = _graph_of(mol2) if mol2 is not None else (n1, a1)
-    return symmetry_rmsd(coords1, coords2, n1, a1, n2, a2, return_permutation=return_permutation)
+    return symmetry_rmsd(coords1, coords2, n1, a1, n2, a2, device=device, return_permutation=return_permutation)

@@ -81,6 +81,29 @@ def randomize_position(data_list, no_torsion, no_random, tr_sigma_max, pocket_kn
             g["ligand"].pos += torch.normal(mean=0, std=tr_sigma_max, size=(1, 3))
 
 
+def _draw_chunk_noise(b, R_, S, no_final_step_noise=False):
+    """N(0,1) draws of one loader batch of b poses: per step tr (b,3), rot (b,3), tor (b*R) from the global CPU generator -- the
+    order and sizes of the reference's torch.normal calls (utils/sampling.py:122-141)."""
+    tr_l, rot_l, tor_l = [], [], []
+    for s in range(S):
+        last_quiet = no_final_step_noise and s == S - 1
+        tr_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
+        rot_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
+        if R_ > 0:
+            tor_l.append(torch.zeros(b * R_) if last_quiet else torch.normal(mean=0, std=1, size=(b * R_,)))
+    return torch.stack(tr_l), torch.stack(rot_l), (torch.stack(tor_l) if R_ > 0 else None)
+
+
+def draw_noise_like_reference(N, R_, S, batch_size, no_final_step_noise=False):
+    """The noise `sampling()` would draw for N poses of one complex (R_ rotatable bonds) walked in loader batches of `batch_size`,
+    as a dict of 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R_] (None if R_ == 0) CPU tensors: `sampling(..., noise=this)` then equals
+    `sampling(...)` under the same seed.  `sampling_distributed` draws it on every rank and slices, so results do not depend
+    on the number of ranks."""
+    parts = [_draw_chunk_noise(min(int(batch_size), N - start), R_, S, no_final_step_noise) for start in range(0, N, max(int(batch_size), 1))]
+    return {"tr": torch.cat([p[0] for p in parts], 1), "rot": torch.cat([p[1] for p in parts], 1),
+            "tor": torch.cat([p[2] for p in parts], 1) if R_ > 0 else None}
+
+
 def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
              no_random=False, ode=False, visualization_list=None, confidence_model=None, filtering_data_list=None,
              filtering_model_args=None, asyncronous_noise_schedule=False, t_schedule=None, batch_size=32,
@@ -214,15 +237,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                     z_rot = noise["rot"][:, offset:offset + b]
                     z_tor = noise["tor"][:, offset * R_:(offset + b) * R_] if R_ > 0 else None
                 else:
-                    tr_l, rot_l, tor_l = [], [], []
-                    for s in range(S):   # same order and sizes as the reference's torch.normal calls
-                        last_quiet = no_final_step_noise and s == S - 1
-                        tr_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
-                        rot_l.append(torch.zeros(b, 3) if last_quiet else torch.normal(mean=0, std=1, size=(b, 3)))
-                        if R_ > 0:
-                            tor_l.append(torch.zeros(b * R_) if last_quiet else torch.normal(mean=0, std=1, size=(b * R_,)))
-                    z_tr, z_rot = torch.stack(tr_l), torch.stack(rot_l)
-                    z_tor = torch.stack(tor_l) if R_ > 0 else None
+                    z_tr, z_rot, z_tor = _draw_chunk_noise(b, R_, S, no_final_step_noise)
             lig_pos = torch.stack([d["ligand"].pos.detach().cpu().float().reshape(Nl, 3) for d in chunk])
             pending.append((offset, b, lig_pos, z_tr, z_rot, z_tor, batch))
             pending_key = key

@@ -128,6 +128,18 @@ class TensorProductConvLayer(nn.Module):
         self.batch_norm = IrrepsBatchNorm(out_irreps) if batch_norm else None
 
 
+def weights_version(module):
+    """Identity of a module's weights for the engine cache: autograd version counters of parameters AND buffers (in-place
+    optimiser / BatchNorm updates bump them) plus a checksum over a handful of tensors, which also catches writes through
+    `.data` (the idiom of torch-ema style `copy_to` / `restore`), which leave `_version` untouched."""
+    ts = list(module.parameters()) + [b for b in module.buffers() if b.is_floating_point()]
+    v = sum(int(t._version) for t in ts)
+    pick = [t for t in (ts[:2] + ts[len(ts) // 2:len(ts) // 2 + 2] + ts[-2:]) if t.numel() > 0]
+    with torch.no_grad():
+        chk = float(torch.stack([t.detach().double().sum() + t.detach().double().abs().sum() for t in pick]).sum()) if pick else 0.0
+    return (v, len(ts), chk)
+
+
 class TensorProductScoreModel(nn.Module):
     def __init__(self, t_to_sigma, device, timestep_emb_func, in_lig_edge_features=4, sigma_embed_dim=32, sh_lmax=2,
                  ns=16, nv=4, num_conv_layers=2, lig_max_radius=5, rec_max_radius=30, cross_max_distance=250,
@@ -283,7 +295,18 @@ class TensorProductScoreModel(nn.Module):
         return self._pool
 
     def _weights_version(self):
-        return sum(int(p._version) for p in self.parameters())
+        return weights_version(self)
+
+    def invalidate_engine(self):
+        """Force the next engine() / engine_pool() call to re-upload the weights (after out-of-band updates of parameters or
+        BatchNorm buffers that autograd's version counters do not see)."""
+        self._engine_key = None
+        self._pool_key = None
+
+    def train(self, mode: bool = True):
+        if self.training and not mode:
+            self.invalidate_engine()      # leaving training mode: parameters and running statistics have (very likely) moved
+        return super().train(mode)
 
     def forward(self, data):
         """Same contract as the reference forward (models/score_model.py:333-449):

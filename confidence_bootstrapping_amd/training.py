@@ -93,56 +93,123 @@ _METRICS = ["loss", "tr_loss", "rot_loss", "tor_loss", "backbone_loss", "sidecha
             "tor_base_loss", "backbone_base_loss", "sidechain_base_loss"]
 
 
-def allreduce_gradients(model, world_size=None):
-    """Average the gradients over ranks with one flat all-reduce (RCCL when the process group is 'nccl'; 4 084 564 floats =
-    16.3 MB for the shipped model -- a single bucket, so the ring runs once per step at full message size)."""
+def _dist_world():
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return
-    world_size = world_size or dist.get_world_size()
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size()
+    return 1
+
+
+def allreduce_gradients(model, world_size=None, skip=False):
+    """Average the gradients over ranks with one flat all-reduce (RCCL when the process group is 'nccl'; 4 084 564 floats =
+    16.3 MB for the shipped model -- a single bucket, so the ring runs once per step at full message size).
+
+    The buffer carries one extra element, this rank's `skip` flag: a rank whose batch is unusable (NaN loss, batch of one)
+    still ENTERS the collective with zero gradients, and every rank learns whether anybody skipped.  Returns True when the
+    step is good on all ranks.  (Deciding to skip on one rank alone would leave the others blocked in the all-reduce.)"""
+    import torch.distributed as dist
+    world_size = world_size or _dist_world()
     if world_size == 1:
-        return
+        return not skip
     params = [p for p in model.parameters() if p.requires_grad]
-    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
+    dev = params[0].device
+    grads = [torch.zeros_like(p).reshape(-1) if (skip or p.grad is None) else p.grad.reshape(-1) for p in params]
+    flat = torch.cat(grads + [torch.full((1,), 1.0 if skip else 0.0, device=dev, dtype=grads[0].dtype)])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    n_skipped = float(flat[-1])
+    if n_skipped > 0 or not bool(torch.isfinite(flat).all()):      # non-finite gradients anywhere count as a skipped step everywhere
+        return False
     flat /= world_size
     off = 0
     for p in params:
         n = p.numel()
         p.grad = flat[off:off + n].view_as(p).clone() if p.grad is None else p.grad.copy_(flat[off:off + n].view_as(p))
         off += n
+    return True
 
 
-def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=None):
-    """One optimisation step on a list of noised graphs (body of the reference loop, utils/training.py:195-211)."""
-    from .train_forward import forward as forward_train
+def sync_batchnorm_buffers(model):
+    """Average the BatchNorm running statistics over ranks (one flat all-reduce).  Each rank's train-mode forward updates its
+    own running_mean / running_var from its own batches (DataParallel in the reference keeps a single copy on GPU 0); without
+    this the inference engines of the ranks drift apart.  Called at the end of every epoch."""
+    import torch.distributed as dist
+    world = _dist_world()
+    if world == 1:
+        return
+    bufs = [b for n, b in model.named_buffers() if n.endswith(("running_mean", "running_var")) and b.numel() > 0]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1).float() for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    with torch.no_grad():
+        for b in bufs:
+            b.copy_(flat[off:off + b.numel()].view_as(b))
+            off += b.numel()
+    if hasattr(model, "invalidate_engine"):
+        model.invalidate_engine()
+
+
+def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=None, forward_fn=None, skip=False):
+    """One optimisation step on a list of noised graphs (body of the reference loop, utils/training.py:195-211).
+    Returns None when the step was skipped -- on ANY rank: the skip decision (NaN loss, `skip=True` for an unusable batch) is
+    made collectively inside the gradient all-reduce, so no rank is left waiting in a collective the others never enter."""
+    if forward_fn is None:
+        from .train_forward import forward as forward_fn
     optimizer.zero_grad()
-    tr_pred, rot_pred, tor_pred, sc = forward_train(model, data)
-    loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sc, data=data, t_to_sigma=t_to_sigma, device=device)
-    loss = loss_tuple[0]
-    if torch.any(torch.isnan(loss)):
+    loss_tuple = None
+    if not skip:
+        tr_pred, rot_pred, tor_pred, sc = forward_fn(model, data)
+        loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sc, data=data, t_to_sigma=t_to_sigma, device=device)
+        loss = loss_tuple[0]
+        if torch.any(torch.isnan(loss)):
+            skip = True
+        else:
+            loss.backward()
+    if not allreduce_gradients(model, skip=skip):
+        optimizer.zero_grad()
         return None
-    loss.backward()
-    allreduce_gradients(model)
     optimizer.step()
     if ema_weights is not None:
         ema_weights.update(model.parameters())
     return (loss.detach(),) + tuple(loss_tuple[1:])
 
 
-def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False):
+def uniform_step_count(loader):
+    """Number of batches every rank runs this epoch: the minimum of the ranks' loader lengths (each rank's buffer / loader has its
+    own length; the surplus batches of longer loaders are dropped, like drop_last over ranks)."""
+    import torch.distributed as dist
+    n = len(loader)
+    if _dist_world() == 1:
+        return n
+    t = torch.tensor([n], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
+
+
+def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None):
     if torsional:
         raise NotImplementedError("torsional-only training is outside the score-model fine-tuning path")
     model.train()
     meter = AverageMeter(_METRICS)
-    for data in loader:
+    distributed = _dist_world() > 1
+    n_steps = uniform_step_count(loader) if distributed else None
+    for i, data in enumerate(loader):
+        if n_steps is not None and i >= n_steps:
+            break
         n = len(data) if isinstance(data, (list, tuple)) else data.num_graphs
         if n == 1:
             print("Skipping batch of size 1 since otherwise batchnorm would not work.")
+            if distributed:     # the other ranks are inside this step's all-reduce: take part with zero gradients
+                train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn, skip=True)
             continue
-        out = train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights)
+        out = train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn)
         if out is None:
-            print("Nan loss, skipping batch")
+            print("Nan loss, skipping batch" + (" (on some rank)" if distributed else ""))
             continue
         meter.add(out)
+    sync_batchnorm_buffers(model)
     return meter.summary()

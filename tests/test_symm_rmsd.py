@@ -46,3 +46,21 @@ def test_symmetry_rmsd_matches_spyrmsd():
             atomicnums, adjacency_matrix = nums, am
         single = get_symmetry_rmsd(Mol, ref, poses[1])
         assert isinstance(single, float) and abs(single - float(g[f"{name}_rmsd"][1])) < 2e-5
+
+
+def test_isomorphism_enumeration_is_bounded():
+    """A highly symmetric ligand (factorially many automorphisms) must raise quickly instead of stalling / exhausting the host: the
+    callers then fall back to the uncorrected RMSD like the reference after its time_limit(10) (inference.py:511-520)."""
+    import time
+    from confidence_bootstrapping_amd.molecules_utils import graph_isomorphisms, IsomorphismLimit
+    n = 9
+    adj = np.ones((n, n), dtype=int) - np.eye(n, dtype=int)          # K9, one element: 9! = 362 880 automorphisms
+    nums = np.full(n, 6)
+    t0 = time.monotonic()
+    with pytest.raises(IsomorphismLimit):
+        graph_isomorphisms(nums, adj, max_isomorphisms=500)
+    with pytest.raises(IsomorphismLimit):
+        graph_isomorphisms(nums, adj, time_limit_s=0.05)
+    assert time.monotonic() - t0 < 5.0
+    i1, i2 = graph_isomorphisms(np.array([6, 6, 8]), np.array([[0, 1, 0], [1, 0, 1], [0, 1, 0]]))      # C-C-O: only the identity
+    assert i1.shape == (1, 3) and (i1 == i2).all()
