@@ -1,7 +1,10 @@
 """Benchmark of the hot path: reverse-diffusion docking sampler on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+  N > 1: run bare, this process starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N ...`, before any
+  GPU call is made here) and exits with their status; launched under torch.distributed.run (RANK / WORLD_SIZE set, as the
+  driver does) it is one of the ranks.  Fails loudly -- non-zero exit, no JSON line -- when fewer than N GPUs are visible or
+  WORLD_SIZE disagrees with --gpus.
 
 One "step" = one complex of the named workload: 40 poses x 20 denoise steps (BASELINE.json configs[1],
 synthetic DockGen-median complex: Nl=28, Nr=384, R=6), i.e. the time-independent receptor embedding +
@@ -9,6 +12,17 @@ synthetic DockGen-median complex: Nl=28, Nr=384, R=6), i.e. the time-independent
 Inputs (weights, complex, initial poses, pre-drawn noise) are resident in HBM before the timed region.
 Multi-GPU: complexes are independent -> every rank runs K complexes of its own (weak scaling), no collective in
 the data path; the only exchange is the final gather of poses to rank 0 (kept inside the timed region).
+
+Workload geometry (SURVEY.md 8 table / BASELINE.md section 4: 32.8 GFLOP per pose-step at a step-mean of ~6 200 cross edges per
+pose).  With random-init weights the score carries no information about the pocket, so a free-running reverse SDE is a random
+walk that leaves the protein and the cross graph collapses to a third of the blueprint's size (round 1 measured 22 GFLOP per
+pose-step).  The default `--poses ideal` therefore drives the poses along the path a trained model produces: the centroid of
+pose b at step i sits at pocket + sigma_tr(t_i) * eps_b (the probability-flow path of the reverse process for a point-mass
+data distribution), realised through the PRE-DRAWN translation noise z_tr (an input of the sampler) with the translation
+head's last layer scaled by 0.02 so that its random drift stays below 1 A; the receptor is a globular 384-residue trace at
+folded-protein density (135 A^3 per residue) with the pocket at 0.7 of the surface radius.  Every kernel runs exactly as
+in production; only the DATA differ.  The measured edge counts and FLOPs per pose-step are printed in `roofline`.
+`--poses free --geometry loose` reproduces the round-1 workload.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = tp_conv,
 fp32 MFMA bound, duration from HIP events on the launch stream) and `cpu_baseline` (the oracle's PyTorch-CPU
@@ -34,6 +48,10 @@ WORKLOAD = "c2_dockgen_median"
 SAMPLES, DENOISE_STEPS = 40, 20
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (~2.5 PF)
+# PMC traffic summaries (tools/pmc_summary.py) of the default command line per (workload, dtype, geometry, poses), newest first
+TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r02_a_traffic.json"],
+                    ("c2_dockgen_median", "f32", "loose", "free"): ["r01_m_traffic.json"],
+                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r02_c4_bf16_traffic.json"]}
 
 
 def flops_per_edge(in_level: int, out_level: int) -> float:
@@ -49,62 +67,82 @@ def flops_per_edge(in_level: int, out_level: int) -> float:
 
 
 def cpu_baseline(model, cplx, args, sched):
-    """Oracle (PyTorch-CPU port of the reference arithmetic) on a bounded sample of the same workload."""
-    from oracle import score_ref as sr, pose_ref as pr
+    """Oracle (PyTorch-CPU port of the reference arithmetic) on a bounded sample of the same workload, with the split BASELINE.md
+    section 3 asks for: score-model forward / graph construction (radius_graph + the two radius searches, re-run on the same poses
+    and timed on their own; contained in the forward figure) / pose update."""
+    from oracle import score_ref as sr, pose_ref as pr, graph_ref as gr
     from tests.helpers import to_cx
     d = os.path.join(ROOT, "confidence_bootstrapping_amd", "data")
     so3, torus = np.load(os.path.join(d, "so3_exp_score_norms.npy")), np.load(os.path.join(d, "torus_score_norm.npy"))
     cx = to_cx(cplx)
-    b, steps = 2, 4
+    b, steps = 4, 4
     g = torch.Generator().manual_seed(0)
-    pos = cplx["ligand"].pos[None].repeat(b, 1, 1) - cplx["ligand"].pos.mean(0) + cplx["receptor"].pos.mean(0) \
-        + 10 * torch.randn(b, 1, 3, generator=g)
+    pocket = cplx["ligand"].pos.mean(0)
+    eps = torch.randn(b, 1, 3, generator=g)
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     cfg = sr.ScoreConfig()
-    # time `steps` of the 20 schedule points spread over the schedule (the cross graph shrinks with t)
+    # time `steps` of the schedule points spread over the schedule (the cross graph shrinks with t); poses on the ideal path
     idx = np.linspace(0, len(sched) - 1, steps).round().astype(int)
+    Nl, Nr = cplx["ligand"].pos.shape[0], cplx["receptor"].pos.shape[0]
+    lig_batch, rec_batch = torch.arange(b).repeat_interleave(Nl), torch.arange(b).repeat_interleave(Nr)
+    rec_pos = cplx["receptor"].pos.repeat(b, 1)
 
     def timed():
-        p = pos.clone()
         t0 = time.perf_counter()
         rec_cache = sr.receptor_embedding(sd, cx, cfg)
         t_rec = time.perf_counter() - t0
-        t0 = time.perf_counter()
+        t_fwd = t_pose = t_graph = 0.0
         for i in idx:
-            t = sched[i]
+            t = float(sched[i])
+            sig = float(args.tr_sigma_min ** (1 - t) * args.tr_sigma_max ** t)
+            p = cplx["ligand"].pos[None] + sig * eps
+            t0 = time.perf_counter()
             out = sr.score_forward(sd, cx, p, t, t, t, cfg, so3, torus, rec_cache=rec_cache)
-            p = pr.modify_conformer_batch(p, cx, 0.01 * out["tr_pred"], 0.01 * out["rot_pred"], 0.01 * out["tor_pred"])
-        t_steps = time.perf_counter() - t0
-        per_pose = (t_steps / steps / b) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
-        return 1.0 / per_pose, t_steps + t_rec
+            t1 = time.perf_counter()
+            pr.modify_conformer_batch(p, cx, 0.01 * out["tr_pred"], 0.01 * out["rot_pred"], 0.01 * out["tor_pred"])
+            t2 = time.perf_counter()
+            flat = p.reshape(-1, 3)
+            gr.radius_graph(flat, cfg.lig_max_radius, lig_batch)
+            cut = 3 * sig + 20
+            gr.radius(rec_pos / cut, flat / cut, 1, rec_batch, lig_batch, max_num_neighbors=10000)
+            t3 = time.perf_counter()
+            t_fwd, t_pose, t_graph = t_fwd + (t1 - t0), t_pose + (t2 - t1), t_graph + (t3 - t2)
+        n = steps * b
+        per_pose = ((t_fwd + t_pose) / n) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
+        split = {"forward_s_per_pose_step": round(t_fwd / n, 4), "of_which_graph_build_s": round(t_graph / n, 4),
+                 "pose_update_s_per_pose_step": round(t_pose / n, 5), "receptor_embedding_s_per_complex": round(t_rec, 3)}
+        return 1.0 / per_pose, t_fwd + t_pose + t_rec + t_graph, split
 
     all_threads = torch.get_num_threads()
-    v_all, t_all = timed()
-    # the reference's own --restrict_cpu setting (inference.py:225-234) is 16 threads: report that figure too
-    torch.set_num_threads(min(16, all_threads))
+    # the reference's own --restrict_cpu setting (inference.py:225-234) is 16 threads; all hardware threads is the other figure
+    n16 = min(16, all_threads)
+    torch.set_num_threads(n16)
     try:
-        v16, t16 = timed()
+        v16, t16, split16 = timed()
     finally:
         torch.set_num_threads(all_threads)
-    n16 = min(16, all_threads)
-    best, cores = (v16, n16) if v16 >= v_all else (v_all, all_threads)
+    if all_threads > n16:
+        v_all, t_all, split_all = timed()
+    else:
+        v_all, t_all, split_all = v16, 0.0, split16
+    (best, cores, split) = (v16, n16, split16) if v16 >= v_all else (v_all, all_threads, split_all)
     return {"value": round(best, 5), "unit": "poses/s", "cores": cores, "kind": "port",
-            "by_threads": {str(all_threads): round(v_all, 5), str(n16): round(v16, 5)},
-            "sample": f"{b} poses x {steps} of {DENOISE_STEPS} denoise steps (+ receptor embedding) of {WORKLOAD}, "
-                      f"oracle PyTorch-CPU fp32, {t_all:.1f}s measured with {all_threads} threads and {t16:.1f}s with 16, "
-                      f"extrapolated to 20 steps/pose"}
+            "by_threads": {str(all_threads): round(v_all, 5), str(n16): round(v16, 5)}, "split": split,
+            "sample": f"{b} poses x {steps} of {DENOISE_STEPS} denoise steps (+ receptor embedding) of {WORKLOAD} on the ideal path, "
+                      f"oracle PyTorch-CPU fp32, {t16:.1f}s measured with {n16} threads and {t_all:.1f}s with {all_threads}, "
+                      f"extrapolated to {DENOISE_STEPS} steps/pose"}
 
 
 def hbm_secondary(st, eng, poses, elapsed):
     edge_visits = st["conv_edge_visits"] + 3 * st["ll_edges"]
-    node_visits = poses * DENOISE_STEPS * (8 * eng.Nl + 4 * eng.engines[0].Nr)   # 3 + 5 ligand layers, 4 receptor layers
+    node_visits = poses * DENOISE_STEPS * (8 * eng.Nl + 4 * eng.Nr)   # 3 + 5 ligand layers, 4 receptor layers
     nbytes = 432.0 * edge_visits + 592.0 * node_visits
     gbps = nbytes / elapsed / 1e9
     return {"algorithmic_mb_per_pose_step": round(nbytes / (poses * DENOISE_STEPS) / 1e6, 2), "achieved_gbps": round(gbps, 1),
             "peak_gbps": 8000.0, "frac": round(gbps / 8000.0, 4)}
 
 
-def confidence_leg(cplx_seed, final_pos, dev):
+def confidence_leg(cplx_seed, final_pos, dev, geometry):
     """All-atom confidence scoring of the 40 final poses of the last complex, measured OUTSIDE the timed
     region of the headline metric: ms per 40-pose batch and the fused conv kernel's algorithmic TFLOP/s (HIP events)."""
     from confidence_bootstrapping_amd.synthetic import make_workload
@@ -112,7 +150,7 @@ def confidence_leg(cplx_seed, final_pos, dev):
     from tools.conf_bench import flops_per_edge as cflops
     cmodel, cargs = make_confidence_model(device=dev, seed=5)
     ceng = cmodel.engine(max_batch=SAMPLES)
-    ceng.set_complex(make_workload(WORKLOAD, seed=cplx_seed, all_atoms=True))
+    ceng.set_complex(make_workload(WORKLOAD, seed=cplx_seed, all_atoms=True, **geometry))
     for _ in range(2):
         ceng.score(final_pos, cargs.crop_beyond)
     counts = ceng.edge_counts()
@@ -169,6 +207,41 @@ def finetune_leg(dev, batch=8, warm=3, steps=6):
             "ms_per_step": round(dt * 1e3, 2), "complexes_per_s": round(batch / dt, 1), "loss": round(float(out[0]), 4), "dtype": "f32"}
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` run bare: start the N ranks as fresh child processes (torch.distributed.run, one per GPU) BEFORE
+    this process makes any GPU call (torch.cuda.device_count() does not initialise the GPU on this image) and exit with their status.
+    A process that has touched the GPU is never re-executed."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count()
+    if n_dev < n:
+        sys.stderr.write(f"bench.py: --gpus {n} requested but only {n_dev} GPU(s) are visible; refusing to report a smaller run\n")
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def ideal_path_noise(pos0, pocket, sched, margs):
+    """Pre-drawn translation noise that carries the centroid of pose b along pocket + sigma_tr(t_i) eps_b (module docstring):
+    z[i, b] = (sigma(t_{i+1}) - sigma(t_i)) eps_b / (g_i sqrt(dt_i)), eps_b fixed by the initial pose, sigma(t_S) = sigma_min."""
+    S = len(sched)
+    lo, hi = margs.tr_sigma_min, margs.tr_sigma_max
+    sig = np.array([lo ** (1 - t) * hi ** t for t in list(sched) + [0.0]])
+    eps = (pos0.mean(1) - pocket) / sig[0]                                   # [B, 3]
+    z = torch.zeros(S, pos0.shape[0], 3)
+    for i in range(S):
+        dt = sched[i] - sched[i + 1] if i < S - 1 else sched[i]
+        g = sig[i] * np.sqrt(2 * np.log(hi / lo))
+        z[i] = (sig[i + 1] - sig[i]) / (g * np.sqrt(dt)) * eps
+    return z
+
+
 def main():
     global WORKLOAD, SAMPLES, DENOISE_STEPS
     ap = argparse.ArgumentParser()
@@ -179,20 +252,34 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (confidence, other operand modes, fine-tuning, "
                     "CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
     ap.add_argument("--graph", type=int, default=0, help="1: replay the 20-step loop as one hipGraph (no per-kernel HIP events)")
-    ap.add_argument("--streams", type=int, default=1, help="concurrent HIP streams the 40-pose batch is split over")
     ap.add_argument("--workload", default=WORKLOAD, help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
+    ap.add_argument("--geometry", default="globular", choices=["globular", "loose"],
+                    help="receptor density: globular = folded-protein density, pocket at 0.7 R (SURVEY.md 8 edge counts); loose = the test complexes")
+    ap.add_argument("--poses", default="ideal", choices=["ideal", "free"],
+                    help="ideal: poses follow pocket + sigma_tr(t) eps (a trained model's path) through the pre-drawn translation noise; "
+                         "free: iid noise, un-scaled heads (random-init weights: the ligand random-walks off the protein)")
     ap.add_argument("--samples", type=int, default=SAMPLES)
     ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_split"],
                     help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3]); f32_split: fp32 operands as three bf16 planes on the bf16 MFMA")
     ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
-                    "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..4 = that many")
+                    "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..8 = that many")
     a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(a.gpus, sys.argv[1:])          # does not return
     WORKLOAD, SAMPLES, DENOISE_STEPS = a.workload, a.samples, a.denoise_steps
 
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run bare)\n")
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: no MI355X visible for this rank; there is no CPU path to fall back to\n")
+        sys.exit(2)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -202,31 +289,36 @@ def main():
 
     from confidence_bootstrapping_amd.synthetic import make_workload
     from confidence_bootstrapping_amd.utils import make_score_model
-    from confidence_bootstrapping_amd.engine import DockEngine, DockEnginePool, make_steps
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
     from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
     from confidence_bootstrapping_amd.sampling import randomize_position
     from confidence_bootstrapping_amd import Batch
     from confidence_bootstrapping_amd.distributed import gather_poses
 
+    geometry = dict(globular=True, pocket_depth=0.7) if a.geometry == "globular" else {}
     model, margs = make_score_model(seed=0)
-    cplx = make_workload(WORKLOAD, seed=1234)
-    eng = DockEnginePool.from_model(model, dev, n=a.streams, max_batch=SAMPLES)
-    eng.set_complex(cplx)
-    eng.set_option("graph", a.graph)
-    eng.set_option("bf16", int(a.dtype == "bf16"))
-    if a.dtype == "f32_split":
-        eng.set_option("f32_split", 1)
-    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 8))) if (a.pair and a.streams == 1 and not a.graph) else 1
-    pair = cosched > 1
-    extra = []   # further engines (own workspace, same device-resident weights) for the complexes that are co-scheduled
-    for _ in range(min(cosched, 7) if pair else 0):      # one spare partner: a group may carry cosched + 1 complexes (see run())
-        e2 = DockEnginePool.from_model(model, dev, n=1, max_batch=SAMPLES, share_from=eng)
-        e2.set_complex(cplx)
-        e2.set_option("bf16", int(a.dtype == "bf16"))
+    TR_HEAD_SCALE = 0.02
+    if a.poses == "ideal":
+        with torch.no_grad():
+            model.tr_final_layer[3].weight.mul_(TR_HEAD_SCALE)
+            model.tr_final_layer[3].bias.mul_(TR_HEAD_SCALE)
+    cplx = make_workload(WORKLOAD, seed=1234, **geometry)
+    pocket = cplx["ligand"].pos.mean(0)
+    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 8))) if a.pair else 1
+    n_eng = min(cosched + 1, 8) if cosched > 1 else 1        # one spare partner: a group may carry cosched + 1 complexes (see run())
+    engines = []
+    for k in range(n_eng):
+        e = DockEngine.from_model(model, dev, max_batch=SAMPLES) if k == 0 else DockEngine(
+            dev, max_batch=SAMPLES, lm_embedding_dim=engines[0].cfg.lm_embedding_dim, no_torsion=bool(engines[0].cfg.no_torsion))
+        if k > 0:
+            e.share_weights_from(engines[0])
+        e.set_complex(cplx)
+        e.set_option("graph", a.graph)
+        e.set_option("bf16", int(a.dtype == "bf16"))
         if a.dtype == "f32_split":
-            e2.set_option("f32_split", 1)
-        extra.append(e2)
-    eng2 = extra[0] if extra else None
+            e.set_option("f32_split", 1)
+        engines.append(e)
+    eng = engines[0]
     sched = get_t_schedule("expbeta", DENOISE_STEPS)
     steps = make_steps(sched, margs, model.timestep_emb_func)
     R = eng.R
@@ -237,42 +329,40 @@ def main():
         torch.manual_seed(42 + 1000 * rank + k)
         np.random.seed(42 + 1000 * rank + k)
         dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(SAMPLES)]
-        randomize_position(dl, False, False, margs.tr_sigma_max)
-        pos0.append(torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous())
-        noise.append((torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev), torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev),
-                      torch.randn(DENOISE_STEPS, SAMPLES * R).to(dev)))
-
-    def one_complex(k):
-        eng.recompute_receptor()
-        eng.sample(pos0[k], steps, *noise[k])
+        randomize_position(dl, False, False, margs.tr_sigma_max)             # prior centred on the receptor centroid (no pocket knowledge)
+        p0 = torch.stack([d["ligand"].pos for d in dl])
+        z_tr = torch.randn(DENOISE_STEPS, SAMPLES, 3)
+        if a.poses == "ideal":
+            p0 = p0 + (pocket - cplx["receptor"].pos.mean(0))                   # the same prior, centred on the pocket
+            z_tr = ideal_path_noise(p0, pocket, sched, margs)
+        pos0.append(p0.to(dev).contiguous())
+        noise.append((z_tr.to(dev), torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev), torch.randn(DENOISE_STEPS, SAMPLES * R).to(dev)))
 
     def run(lo, hi):
-        """complexes lo..hi-1, two at a time when pairing is on (each complex still gets its own receptor embedding pass)"""
+        """complexes lo..hi-1 in co-scheduled groups (each complex still gets its own receptor embedding pass)"""
         k = lo
         while k < hi:
-            if pair and k + 1 < hi:
-                left = hi - k
+            left = hi - k
+            if cosched > 1 and left > 1:
                 # no complex runs alone: one more than the nominal group rides along (5 -> 5), otherwise balanced groups (9 -> 3 x 3)
                 m = left if left <= min(cosched + 1, 8) else -(-left // -(-left // cosched))
-                pools = [eng] + extra[:m - 1]
-                for p_ in pools:
-                    p_.recompute_receptor()
-                DockEngine.sample_multi([p_.engines[0] for p_ in pools], [pos0[k + q] for q in range(m)], steps,
-                                        [noise[k + q] for q in range(m)])
-                k += m
             else:
-                one_complex(k)
-                k += 1
+                m = 1
+            for e in engines[:m]:
+                e.recompute_receptor()
+            if m == 1:
+                eng.sample(pos0[k], steps, *noise[k])
+            else:
+                DockEngine.sample_multi(engines[:m], [pos0[k + q] for q in range(m)], steps, [noise[k + q] for q in range(m)])
+            k += m
 
     run(0, a.warmup)
     torch.cuda.synchronize()
     alt_k = list(range(max(a.warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
     alt_init = {k: pos0[k].clone() for k in alt_k}
-    eng.kernel_timing(enable=not a.graph, reset=True)
-    eng.stats(reset=True)
-    for e2 in extra:
-        e2.kernel_timing(enable=True, reset=True)
-        e2.stats(reset=True)
+    for e in engines:
+        e.kernel_timing(enable=not a.graph, reset=True)
+        e.stats(reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -288,66 +378,88 @@ def main():
         tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    avg_ms, n_launch, total_ms = eng.kernel_timing(enable=False)
-    st = eng.stats()
-    for e2 in extra:   # merged launches are timed by whichever engine arrived last at the rendezvous
-        _, n2, t2 = e2.kernel_timing(enable=False)
+    n_launch, total_ms = 0, 0.0
+    st = {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0, "shared_rr_visits": 0}
+    for e in engines:   # merged launches are timed by the engine that launched them
+        _, n2, t2 = e.kernel_timing(enable=False)
         n_launch, total_ms = n_launch + n2, total_ms + t2
-        avg_ms = total_ms / max(n_launch, 1)
-        st = {k: st[k] + v for k, v in e2.stats().items()}
+        st = {k: st[k] + v for k, v in e.stats().items()}
+    avg_ms = total_ms / max(n_launch, 1)
     assert torch.isfinite(pos0[n_runs - 1]).all(), "non-finite poses"
+    drift = float((pos0[n_runs - 1].mean(1).cpu() - pocket).norm(dim=1).mean())     # mean final centroid distance from the pocket (A)
 
     if rank == 0:
         poses = SAMPLES * a.steps * world
+        pose_steps_rank = SAMPLES * a.steps * DENOISE_STEPS                  # the counters are this rank's
         f33 = flops_per_edge(3, 3)
         femb = flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3)
         total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
+        executed_flops = total_flops - st["shared_rr_visits"] * f33           # minus the credited-but-shared layer-0 rr messages
         flops_per_launch = total_flops / max(n_launch, 1)
-        traffic = None   # HBM bytes per tp_conv<3,3> launch from the PMC passes (FETCH_SIZE x2 + WRITE_SIZE), see profiles/
-        tp = next((q for q in (os.path.join(ROOT, "profiles", f"r01_{t}_traffic.json") for t in "mlhf") if os.path.exists(q)), "")   # same command (defaults), mean over ALL tp_conv launches like `achieved`
-        if os.path.exists(tp):
-            traffic = round(json.load(open(tp))["hbm_bytes_per_launch_all_tp_conv"])
+        Err = 24 * eng.Nr
+        elr_mean = (st["conv_edge_visits"] - 5 * st["ll_edges"] - 4 * pose_steps_rank * Err) / 9.0 / pose_steps_rank
+        gflop_ps = total_flops / pose_steps_rank / 1e9
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         algorithmic = achieved
         if a.dtype == "f32_split":
             achieved *= 6.0     # every fp32 product is issued as 6 bf16 plane products; price the ISSUED flops against the bf16 peak
-        headline = (WORKLOAD, SAMPLES, DENOISE_STEPS, a.dtype) == ("c2_dockgen_median", 40, 20, "f32")
+        headline = (WORKLOAD, SAMPLES, DENOISE_STEPS, a.dtype, a.geometry, a.poses) == ("c2_dockgen_median", 40, 20, "f32", "globular", "ideal")
         peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        if not headline:
-            traffic = None   # the PMC traffic figure under profiles/ belongs to the headline configuration
+        # HBM bytes per tp_conv launch from the PMC passes of THIS command line committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+        # separate --pmc runs): a recorded figure, not measured in this run -- the source file is named next to it
+        traffic, traffic_src = None, None
+        for tag in TRAFFIC_PROFILES.get((WORKLOAD, a.dtype, a.geometry, a.poses), []):
+            q = os.path.join(ROOT, "profiles", tag)
+            if os.path.exists(q):
+                traffic, traffic_src = round(json.load(open(q))["hbm_bytes_per_launch_all_tp_conv"]), "profiles/" + tag
+                break
+        value = poses / elapsed
         out = {
             "metric": "poses/sec (whole node), 40-sample x 20-step diffusion, DockGen median complex" if headline else
                       f"poses/sec (whole node), {SAMPLES}-sample x {DENOISE_STEPS}-step diffusion, {WORKLOAD}",
-            "value": round(poses / elapsed, 3), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "value": round(value, 3), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS, "streams": a.streams,
-                       "co_scheduled_complexes": cosched,
-                       "Nl": eng.Nl, "Nr": eng.engines[0].Nr, "R": eng.R, "weights": "random-init, reference state_dict layout",
+            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS,
+                       "co_scheduled_complexes": cosched, "hip_graph": int(a.graph),
+                       "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R,
+                       "geometry": "globular receptor (135 A^3/residue), pocket at 0.7 R" if a.geometry == "globular" else "loose coil (test complexes)",
+                       "poses": (f"ideal reverse path pocket + sigma_tr(t) eps via the pre-drawn translation noise; tr_final_layer.3 x {TR_HEAD_SCALE}"
+                                 if a.poses == "ideal" else "free-running reverse SDE, iid noise"),
+                       "weights": "random-init, reference state_dict layout",
                        "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
             "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": "tp_conv_kernel<OpsBf16>", "f32_split": "tp_conv_kernel<OpsBf16x3>"}[a.dtype],
                          "achieved": round(achieved, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
                          "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
                          "algorithmic_tflops": round(algorithmic, 3),
+                         # the work behind `value`, so that it can be checked against the blueprint (32.8 GFLOP, Elr ~ 6 200)
+                         "gflop_per_pose_step": round(gflop_ps, 3),
+                         "edge_visits_per_pose_step": round((st["conv_edge_visits"] + 3 * st["ll_edges"]) / pose_steps_rank, 1),
+                         "elr_step_mean": round(elr_mean, 1), "ell_mean": round(st["ll_edges"] / pose_steps_rank, 1), "err": Err,
+                         # `frac` credits the reference formulation's FLOPs; the layer-0 receptor->receptor messages are computed once
+                         # per complex, not once per sample: the fraction of the peak actually EXECUTED per second is
+                         "executed_frac": round(achieved / peak * executed_flops / max(total_flops, 1), 4),
+                         "poses_per_s_normalised_to_32p8_gflop": round(value * gflop_ps / 32.8, 2),
+                         "mean_final_centroid_distance_from_pocket_A": round(drift, 2),
                          "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
                          "pose_steps_per_s": round(poses * DENOISE_STEPS / elapsed, 1),
                          # secondary: fused-ideal algorithmic bytes = 432 B per edge-layer visit + 592 B per
                          # node-layer visit, against the 8 TB/s HBM3E peak -- the path is far from HBM-bound
-                         "hbm_secondary": hbm_secondary(st, eng, poses, elapsed)},
+                         "hbm_secondary": hbm_secondary(st, eng, SAMPLES * a.steps, elapsed)},
         }
         extras = world == 1 and headline and not a.headline_only
         if extras:
-            out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev)
-        if extras and pair:
+            out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev, geometry)
+        if extras and cosched > 1 and not a.graph:
             # The same complexes in the two other operand modes of the same kernel (NOT part of `value`): f32_split = fp32 operands as
             # three exact bf16 planes on the bf16 matrix cores (fp32-grade results, tests/test_gpu_bf16.py); bf16 = configs[3].
             out["other_operand_modes"] = {}
             for mode in ("f32_split", "bf16"):
-                for p_ in [eng] + extra:
-                    p_.set_option("bf16", int(mode == "bf16"))
-                    p_.set_option("f32_split", int(mode == "f32_split"))
+                for e in engines:
+                    e.set_option("bf16", int(mode == "bf16"))
+                    e.set_option("f32_split", int(mode == "f32_split"))
                 for timed in (False, True):
                     for k in alt_k:
                         pos0[k].copy_(alt_init[k])
@@ -357,9 +469,9 @@ def main():
                     torch.cuda.synchronize()
                     t1 = time.perf_counter() - t1
                 out["other_operand_modes"][mode] = {"value": round(SAMPLES * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k)}
-            for p_ in [eng] + extra:
-                p_.set_option("bf16", 0)
-                p_.set_option("f32_split", 0)
+            for e in engines:
+                e.set_option("bf16", 0)
+                e.set_option("f32_split", 0)
         if extras:
             try:
                 out["finetune"] = finetune_leg(dev)

@@ -191,7 +191,11 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphD
     if (stats) {   // edge-layer visits: 3 ligand embedding layers visit ll; 4 joint layers visit all groups, the last one ll + lr
       if (which == 0) { atomicAdd(&stats[0], total); atomicAdd(&stats[1], 5ull * total); atomicAdd(&stats[2], 1ull); }
       if (which == 1) atomicAdd(&stats[1], 5ull * total);
-      if (which == 2) atomicAdd(&stats[1], 4ull * total + 4ull * (unsigned long long)(B * gs.Err));
+      if (which == 2) {
+        atomicAdd(&stats[1], 4ull * total + 4ull * (unsigned long long)(B * gs.Err));
+        // credited but not executed: the layer-0 receptor->receptor messages are computed once per complex, not once per sample
+        atomicAdd(&stats[3], (unsigned long long)((B - 1) * gs.Err));
+      }
     }
   }
 }

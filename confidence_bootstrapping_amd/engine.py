@@ -309,7 +309,7 @@ class DockEngine:
     def stats(self, reset=False):
         out = (C.c_uint64 * 4)()
         _check(self.lib.cbd_stats(self.h, int(reset), out))
-        return {"ll_edges": out[0], "conv_edge_visits": out[1], "forwards": out[2]}
+        return {"ll_edges": out[0], "conv_edge_visits": out[1], "forwards": out[2], "shared_rr_visits": out[3]}
 
     # ---- introspection
     def debug(self, enable=True):
@@ -415,7 +415,7 @@ class DockEnginePool:
         return (tot_ms / n if n else 0.0), n, tot_ms
 
     def stats(self, reset=False):
-        out = {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0}
+        out = {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0, "shared_rr_visits": 0}
         for e in self.engines:
             for k, v in e.stats(reset).items():
                 out[k] += v

@@ -39,10 +39,13 @@ WORKLOADS = {
 }
 
 
-def _receptor_trace(rng, n):
-    """Compact self-avoiding C-alpha walk: 3.8 A steps inside a sphere sized for Rg ~ 2.2 n^0.38 A."""
+def _receptor_trace(rng, n, globular=False):
+    """Compact self-avoiding C-alpha walk: 3.8 A steps inside a sphere.  Default (the test complexes and their goldens): a loose
+    coil, sphere sized for Rg ~ 2.2 n^0.38 A (~ 320 A^3 per residue).  globular=True: the sphere of a folded protein, 135 A^3 per
+    residue (384 residues -> radius 23 A, ~ 27 C-alphas within 10 A), which gives the cross-edge counts of SURVEY.md 8:
+    ~ 125-150 residues within 20 A of a pocket atom."""
     rg = 2.2 * n ** 0.38
-    rs = 1.15 * rg / np.sqrt(0.6)
+    rs = (n * 135.0 * 3.0 / (4.0 * np.pi)) ** (1.0 / 3.0) if globular else 1.15 * rg / np.sqrt(0.6)
     pts = np.zeros((n, 3))
     i, stuck = 1, 0
     while i < n:
@@ -53,7 +56,7 @@ def _receptor_trace(rng, n):
             p = pts[i - 1] + 3.8 * d
             if np.linalg.norm(p) > rs:
                 continue
-            if i > 1 and np.min(np.linalg.norm(pts[:i - 1] - p, axis=1)) < 3.6:
+            if i > 1 and np.min(np.linalg.norm(pts[:i - 1] - p, axis=1)) < (3.7 if globular else 3.6):
                 continue
             pts[i], ok = p, True
             break
@@ -165,8 +168,10 @@ def _components_without(n, bonds, skip):
     return comp, c
 
 
-def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None) -> HeteroData:
-    """One synthetic complex.  Raises if the requested number of rotatable bonds cannot be realised."""
+def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None, globular=False, pocket_depth=0.85) -> HeteroData:
+    """One synthetic complex.  Raises if the requested number of rotatable bonds cannot be realised.
+    globular / pocket_depth: receptor at folded-protein density with the crystal pose at `pocket_depth` x the distance of the
+    outermost residue from the centroid (the benchmark geometry, see _receptor_trace); the defaults are the test geometry."""
     for attempt in range(200):
         rng = np.random.default_rng(seed + 7919 * attempt)
         try:
@@ -215,7 +220,7 @@ def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None) -> HeteroData
         edge_mask[e] = True
         mask_rotate[i] = side
 
-    rpos = _receptor_trace(rng, Nr)
+    rpos = _receptor_trace(rng, Nr, globular)
     tree = cKDTree(rpos)
     _, nbr = tree.query(rpos, k=min(knn, Nr - 1) + 1)
     nbr = nbr[:, 1:]
@@ -228,7 +233,7 @@ def make_complex(Nl=28, Nr=384, R=6, knn=24, seed=1234, name=None) -> HeteroData
     lig_x = np.stack([rng.integers(0, d, size=Nl) for d in LIG_FEATURE_DIMS], 1).astype(np.int64)
     # put the crystal pose on the protein surface
     surf = rpos[np.argmax(np.linalg.norm(rpos, axis=1))]
-    lpos = lpos - lpos.mean(0) + surf * 0.85
+    lpos = lpos - lpos.mean(0) + surf * pocket_depth
 
     d = HeteroData()
     d["ligand"].x = torch.from_numpy(lig_x)
@@ -293,6 +298,6 @@ def add_atoms(d: HeteroData, seed=1234, atom_knn=8, mean_side_atoms=4.0) -> Hete
     return d
 
 
-def make_workload(workload: str, seed=1234, all_atoms=False) -> HeteroData:
-    d = make_complex(seed=seed, name=workload, **WORKLOADS[workload])
+def make_workload(workload: str, seed=1234, all_atoms=False, **geometry) -> HeteroData:
+    d = make_complex(seed=seed, name=workload, **WORKLOADS[workload], **geometry)
     return add_atoms(d, seed=seed) if all_atoms else d

@@ -147,7 +147,9 @@ int cbd_recompute_receptor(cbd_engine* e, void* stream);
 
 /* Work accounting since the last reset (device-side counters, synchronises): out[0] = ligand-graph edges summed
  * over forward passes (each of the 3 ligand embedding layers visits them once), out[1] = edge visits of the 5
- * interaction layers, out[2] = forward passes, out[3] = reserved. */
+ * interaction layers (ALGORITHMIC: every sample's receptor->receptor edges of layer 0 are credited), out[2] = forward passes,
+ * out[3] = the part of out[1] that is credited but not executed (layer-0 receptor->receptor messages depend on the diffusion time
+ * only and are computed once per complex and shared by its B samples: (B - 1) * Err per forward pass). */
 int cbd_stats(cbd_engine* e, int32_t reset, uint64_t out[4]);
 
 /* Introspection used by the parity tests and the benchmark.  After a cbd_score call, copies a named

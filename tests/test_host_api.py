@@ -107,3 +107,20 @@ def test_make_steps_matches_oracle_scalars(score_model, tables):
     assert last.tr_noise_coef == 0.0 and last.tr_score_coef == steps[19].tr_score_coef
     ode = make_steps(sched, args, model.timestep_emb_func, ode=True)[3]
     assert ode.tr_score_coef == pytest.approx(0.5 * steps[3].tr_score_coef, rel=1e-6) and ode.rot_noise_coef == 0.0
+
+
+def test_bench_refuses_to_report_a_smaller_run():
+    """`python bench.py --gpus 2` on a box with fewer than 2 GPUs (here: none) exits non-zero and prints no JSON line -- it must never
+    report `n_gpus: 1` for a multi-GPU request; a rank whose WORLD_SIZE disagrees with --gpus fails the same way."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU" in r.stderr
+    assert not any(l.strip().startswith("{") for l in r.stdout.splitlines())
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()

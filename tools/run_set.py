@@ -43,10 +43,9 @@ def main():
     from confidence_bootstrapping_amd.sampling import randomize_position
     from confidence_bootstrapping_amd.distributed import shard_lpt
 
+    from confidence_bootstrapping_amd.distributed import run_complex_set
     rng = np.random.default_rng(a.seed)
     sizes = [(int(rng.integers(14, 56)), int(rng.integers(140, 720))) for _ in range(a.complexes)]
-    parts = shard_lpt([nl * nr for nl, nr in sizes], world)
-    mine = parts[rank]
     smodel, sargs = make_score_model(device=dev, seed=0)
     cmodel, cargs = make_confidence_model(device=dev, seed=5)
     from confidence_bootstrapping_amd.engine import DockEngine
@@ -59,32 +58,44 @@ def main():
     ceng = cmodel.engine(max_batch=a.samples)
     sched = get_t_schedule("expbeta", a.steps)
     steps = make_steps(sched, sargs, smodel.timestep_emb_func)
-    # host-side synthesis of this rank's complexes is data loading, outside the timed region
-    todo = []
-    for i in mine:
-        nl, nr = sizes[i]
-        R = max(1, min(nl // 5, 10))
-        c = add_atoms(make_complex(Nl=nl, Nr=nr, R=R, knn=24, seed=1000 + i, name=f"set{i}"), seed=1000 + i)
+    # host-side synthesis of ALL complexes is data loading, outside the timed region (every rank builds the same list; the LPT
+    # partition inside run_complex_set decides which ones this rank samples)
+
+    class _Lazy:
+        """complex i built on first use, sized like sizes[i] (run_complex_set only needs the sizes for its cost function)"""
+
+        def __init__(self, i):
+            self.i, self.c = i, None
+
+        def get(self):
+            if self.c is None:
+                nl, nr = sizes[self.i]
+                R = max(1, min(nl // 5, 10))
+                self.c = add_atoms(make_complex(Nl=nl, Nr=nr, R=R, knn=24, seed=1000 + self.i, name=f"set{self.i}"), seed=1000 + self.i)
+            return self.c
+    lazy = [_Lazy(i) for i in range(a.complexes)]
+    parts = shard_lpt([nl * nr for nl, nr in sizes], world)
+    prepared = {}
+    for i in parts[rank]:
+        c = lazy[i].get()
         torch.manual_seed(i); np.random.seed(i)
         dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(a.samples)]
         randomize_position(dl, False, False, sargs.tr_sigma_max)
         pos0 = torch.stack([d["ligand"].pos for d in dl]).contiguous()
         Rr = int(c["ligand"].edge_mask.sum())
-        noise = (torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples * Rr))
-        todo.append((i, c, pos0, noise))
+        prepared[i] = (c, pos0, (torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples * Rr)))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    t_setup = t_sample = t_conf = 0.0
-    results = []
-    t0 = time.perf_counter()
-    k = 0
-    while k < len(todo):
-        group = todo[k:k + 4]           # consecutive complexes are co-scheduled four at a time (cbd_sample_multi)
+    tm = {"setup": 0.0, "sample": 0.0, "conf": 0.0}
+
+    def sample_group(items):
+        """up to four complexes: per-complex set-up, ONE co-scheduled sampling call (cbd_sample_multi), confidence ranking"""
         ta = time.perf_counter()
-        engines = ([seng] + partners)[:len(group)]
+        engines = ([seng] + partners)[:len(items)]
         staged = []
-        for e, (i, c, pos0, noise) in zip(engines, group):
+        for e, (i, _) in zip(engines, items):
+            c, pos0, noise = prepared[i]
             e.set_complex(c)
             staged.append((pos0.to(dev), [z.to(dev) for z in noise]))
         torch.cuda.synchronize()
@@ -92,29 +103,32 @@ def main():
         DockEngine.sample_multi(engines, [st_[0] for st_ in staged], steps, [st_[1] for st_ in staged])
         torch.cuda.synchronize()
         tc = time.perf_counter()
-        for (i, c, _, _), (pos, _) in zip(group, staged):
-            ceng.set_complex(c)
+        out = []
+        for (i, _), (pos, _) in zip(items, staged):
+            ceng.set_complex(prepared[i][0])
             conf, _ = ceng.score(pos, cargs.crop_beyond)
             best = int(torch.argmax(conf))
-            results.append((i, float(conf[best]), pos[best].cpu()))
+            out.append({"complex": i, "confidence": float(conf[best]), "pos": pos[best].cpu().numpy()})
         td = time.perf_counter()
-        t_setup += tb - ta; t_sample += tc - tb; t_conf += td - tc
-        k += len(group)
+        tm["setup"] += tb - ta; tm["sample"] += tc - tb; tm["conf"] += td - tc
+        return out
+
+    t0 = time.perf_counter()
+    results = run_complex_set(lazy, sample_group, world, rank, group=4, cost=lambda z: float(sizes[z.i][0] * sizes[z.i][1]))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tm = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        elapsed = float(tm.item())
-        gathered = [None] * world if rank == 0 else None
-        dist.gather_object([(i, cf) for i, cf, _ in results], gathered, dst=0)
+        tmx = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+        elapsed = float(tmx.item())
     if rank == 0:
+        assert len(results) == a.complexes
         print(json.dumps({"what": "heterogeneous complex set, sampling + confidence ranking, set-up included", "complexes": a.complexes,
                           "samples": a.samples, "denoise_steps": a.steps, "n_gpus": world, "poses_per_s": round(a.complexes * a.samples / elapsed, 2),
-                          "s_total": round(elapsed, 3), "rank0": {"complexes": len(mine), "setup_s": round(t_setup, 3),
-                                                                  "sampling_s": round(t_sample, 3), "confidence_s": round(t_conf, 3)}}))
+                          "s_total": round(elapsed, 3), "rank0": {"complexes": len(parts[0]), "setup_s": round(tm["setup"], 3),
+                                                                  "sampling_s": round(tm["sample"], 3), "confidence_s": round(tm["conf"], 3)}}))
     if world > 1:
         dist.destroy_process_group()
 
