@@ -97,11 +97,11 @@ struct ConvGroupH : ConvGroup {
 // complexes co-scheduled by cbd_sample_multi so that one launch carries several times the waves -- the per-launch drain is
 // amortised).
 constexpr int CONV_MAX_GROUPS = 32;
-constexpr int CONV_MAX_COSCHED = 8;
 // node_proj_kernel jobs of one layer: P[row][0..95] = sum_k WT[k][.] * node[row][k] for rows [lo, lo + n)
-constexpr int PROJ_MAX_JOBS = 8;
-struct ProjJob { const float* WT; float* P; int lo, n; };
-struct ProjArgs { ProjJob job[PROJ_MAX_JOBS]; int n_jobs; const float* node_in; };
+constexpr int PROJ_MAX_JOBS = 64;   // 4 FCBlocks x {aggregating, read} role x up to 8 co-scheduled batches
+struct ProjJob { const float* WT; float* P; const float* node_in; int lo, n; };
+struct ProjArgs { ProjJob job[PROJ_MAX_JOBS]; int n_jobs; };
+static_assert(sizeof(ProjArgs) <= 4096, "ProjArgs is passed by value");
 
 struct ConvArgs {
   ConvGroup g[CONV_MAX_GROUPS];

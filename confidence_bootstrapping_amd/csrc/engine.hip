@@ -8,10 +8,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
-#include <condition_variable>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "host_util.h"
@@ -48,28 +45,8 @@ struct MlpDev {   // 2-layer edge MLP pieces
 
 }  // namespace
 
-// Rendezvous of two engines whose step loops run in lockstep (cbd_sample_pair): at every tensor-product launch both hand in
-// their edge groups and the later one launches ONE kernel covering both batches.
-struct PairCtx {
-  std::mutex m;
-  std::condition_variable cv;
-  int arrived = 0;
-  unsigned gen = 0;
-  bool abort = false;
-  int n = 2;                        // engines taking part
-  ConvArgs args[CONV_MAX_COSCHED];
-  int grid[CONV_MAX_COSCHED] = {};
-  int rc = 0;
-  // each engine enqueues on its own stream (their small kernels overlap); the merged launch is ordered after both streams
-  // through `ready[rank]` and both streams continue after `done`
-  hipEvent_t ready[CONV_MAX_COSCHED] = {};
-  hipEvent_t done = nullptr;
-};
-
 struct cbd_engine {
   cbd_config cfg{};
-  PairCtx* pair = nullptr;          // non-null while cbd_sample_pair drives this engine
-  int pair_rank = 0;
   std::map<std::string, HostTensor> host_w;
   bool weights_ready = false, complex_ready = false;
   DevPool wpool, cpool, bpool;   // weights / complex / batch workspace
@@ -96,12 +73,17 @@ struct cbd_engine {
   int *d_src0 = nullptr, *d_dst0 = nullptr, *d_ident = nullptr, *d_deg0 = nullptr;
   int use_bf16 = 0;                 // operand policy of the tensor-product kernel: 0 exact fp32 MFMA, 1 bf16 ("bf16" option),
                                     // 2 fp32 emulated by three bf16 planes ("f32_split" option)
-  // hipGraph of the step loop (optional)
+  // hipGraph of the step loop (optional).  The first engine of a co-scheduled group owns the instantiated graphs of the group
+  // (key: schedule, batch sizes, engines and their complex generations); every engine owns its staging buffers.
   bool use_graph = false;
-  hipGraphExec_t graph_exec = nullptr;
-  std::string graph_key;
+  struct GraphEntry { std::string key; hipGraphExec_t exec; };
+  std::vector<GraphEntry> graphs;
   float *g_pos = nullptr, *g_ztr = nullptr, *g_zrot = nullptr, *g_ztor = nullptr;
   int g_S_cap = 0;
+  unsigned complex_gen = 0;         // bumped by everything that invalidates captured launches of this engine
+  // device-resident description of the pose batch of the current call (kernels.h::PoseBatch) and its host image
+  PoseBatch desc_h{};
+  PoseBatch* desc_dev = nullptr;
   // per edge group (ll, lr, rr, rl, rr0 = single-copy receptor graph): pieces of the deterministic segmented reduction
   float *fsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *lsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* racc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -139,6 +121,14 @@ struct cbd_engine {
   double t_total_ms = 0;
   int64_t t_n = 0;
 };
+
+static void fill_static_desc(cbd_engine* e);
+static void drop_graphs(cbd_engine* e) {
+  for (auto& g : e->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  e->graphs.clear();
+  ++e->complex_gen;
+}
 
 // ======================================================================================================== weights
 static const HostTensor* find_w(cbd_engine* e, const std::string& k) {
@@ -245,30 +235,35 @@ static uint16_t f32_to_bf16_rne(float f) {
 }
 
 static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
+  // stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [7 k-steps][64 lanes][8 bf16] (7 KB); k-steps 0..5 carry the 96 input columns,
+  // k-step 6 is the bias step (K extended to 112: element k = 96 of every row holds the row's bias, the activation side supplies e_96)
   const TileRows tr = conv_tile_rows(IN, OUT);
-  constexpr int TILE_BF16 = 32 * KDIM;   // 3072 bf16 = 6 KB
-  std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + (size_t)tr.ntiles * 32 * 4) / 4, 0.f);
+  constexpr int NQ = KDIM / 16 + 1;
+  constexpr int TILE_BF16 = NQ * 64 * 8;   // 3584 bf16 = 7 KB
+  std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + 3) / 4, 0.f);
   uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
-  float* const bias_tab = reinterpret_cast<float*>(w + (size_t)(tr.ntiles + 1) * TILE_BF16);
   for (int T = 0; T < tr.ntiles; ++T) {
     uint16_t* tile = w + (size_t)T * TILE_BF16;
     const bool first = T < 3;
-    for (int q = 0; q < KDIM / 16; ++q)
+    for (int q = 0; q < NQ; ++q)
       for (int lane = 0; lane < 64; ++lane) {
         const int r = lane & 31, h = lane >> 5;
         const TileRow& R = tr.rows[(size_t)T * 32 + r];
         for (int j = 0; j < 8; ++j) {
-          // first Linear: k-step q = 2*part + sub covers input columns 16h + 8sub + j of the 32-wide part;
-          // second Linear: registers 8s..8s+7 of hidden tile m = q/2, s = q%2: unit 32m + 16s + 8(j>>2) + 4h + (j&3)
-          const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-          const float v = R.row < 0 ? 0.f : R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
+          float v = 0.f;
+          if (R.row >= 0) {
+            if (q < NQ - 1) {
+              // first Linear: k-step q = 2*part + sub covers input columns 16h + 8sub + j of the 32-wide part;
+              // second Linear: registers 8s..8s+7 of hidden tile m = q/2, s = q%2: unit 32m + 16s + 8(j>>2) + 4h + (j&3)
+              const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+              v = R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
+            } else if (h == 0 && j == 0) {
+              v = R.scale * (first ? b1 : b2)[R.row];
+            }
+          }
           tile[((size_t)q * 64 + lane) * 8 + j] = f32_to_bf16_rne(v);
         }
       }
-    for (int r = 0; r < 32; ++r) {
-      const TileRow& R = tr.rows[(size_t)T * 32 + r];
-      bias_tab[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
-    }
   }
   return out;
 }
@@ -417,6 +412,7 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   HIPCHK(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&e->desc_dev), sizeof(PoseBatch)));
   *out = e;
   return 0;
 }
@@ -425,7 +421,8 @@ int cbd_destroy(cbd_engine* e) {
   if (!e) return 0;
   (void)hipSetDevice(e->cfg.device);
   (void)hipDeviceSynchronize();
-  if (e->graph_exec) (void)hipGraphExecDestroy(e->graph_exec);
+  drop_graphs(e);
+  if (e->desc_dev) (void)hipFree(e->desc_dev);
   e->wpool.release(); e->cpool.release(); e->bpool.release();
   for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
@@ -582,6 +579,7 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
   return r;
 }
 
+
 static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
@@ -601,80 +599,62 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
   return 0;
 }
 
-static int run_conv(cbd_engine* e, const ConvLayerDev& L, const ConvGroupH* groups, int n_groups, const int* caps,
-                    const float* node_in, hipStream_t s, const int* widx = nullptr) {
+// The edge groups ONE pose batch contributes to a tensor-product launch.
+struct ConvJob {
+  cbd_engine* e = nullptr;
+  ConvGroupH g[4];
+  int caps[4] = {0, 0, 0, 0};
+  int widx[4] = {0, 1, 2, 3};      // which FCBlock of the layer each group uses
+  int n_groups = 0;
+  const float* node_in = nullptr;
+};
+
+// One tensor-product launch (+ the node-projection launch in front of it) over the groups of all jobs: the batches of up to eight
+// complexes share every launch of the step loop, so a launch carries several times the waves of a single 40-pose batch (the
+// per-launch drain of the long-lived waves is amortised).  Timed by jobs[0].e.
+static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipStream_t s, bool side) {
+  cbd_engine* e0 = jobs[0].e;
   ConvArgs a{};
-  a.n_groups = n_groups;
+  ProjArgs pa{};
   int grid = 0;
-  for (int g = 0; g < n_groups; ++g) {
-    a.g[g] = groups[g];
-    a.g[g].wstream = (e->use_bf16 == 1 ? L.wstream_bf16 : e->use_bf16 == 2 ? L.wstream_x3 : L.wstream)[widx ? widx[g] : g];   // which FCBlock of the layer this edge group uses
-    a.g[g].node_in = node_in;
-    if (a.g[g].i0e_hi == 0 && a.g[g].vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
-      a.g[g].i0e_lo = 0; a.g[g].i0e_hi = conv_shape(L.in_level, L.out_level).t0e; a.g[g].vec_on = 1;
-    }
-    grid += (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
-  }
-  if (e->use_bf16 != 1) {  // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual
-    ProjArgs pa{};         // slices share them.  (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)
-    pa.node_in = node_in;
-    const int base = s == e->side ? 8 : 0;
+  const ConvShape S = conv_shape(L.in_level, L.out_level);
+  for (int q = 0; q < n_jobs; ++q) {
+    const ConvJob& J = jobs[q];
+    cbd_engine* e = J.e;
+    if (a.n_groups + J.n_groups > CONV_MAX_GROUPS) return fail(CBD_ERR_STATE, "too many edge groups in one launch");
+    const int base = side ? 8 : 0;
     int slot_of[4] = {-1, -1, -1, -1}, n_slots = 0;
-    for (int g = 0; g < n_groups; ++g) {
-      const int w = widx ? widx[g] : g;
-      if (slot_of[w] < 0) {
-        slot_of[w] = n_slots++;
-        float* ps = e->proj[base + 2 * slot_of[w]];
-        float* pd = e->proj[base + 2 * slot_of[w] + 1];
-        if (base + 2 * slot_of[w] + 1 >= (int)(sizeof(e->proj) / sizeof(e->proj[0]))) return fail(CBD_ERR_STATE, "projection slots exhausted");
-        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w], ps, groups[g].src_lo, groups[g].src_n};
-        pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w] + (size_t)NS * KDIM, pd, groups[g].dst_lo, groups[g].dst_n};
+    for (int g = 0; g < J.n_groups; ++g) {
+      ConvGroup& G = a.g[a.n_groups + g];
+      G = J.g[g];
+      const int w = J.widx[g];
+      G.wstream = (e0->use_bf16 == 1 ? L.wstream_bf16 : e0->use_bf16 == 2 ? L.wstream_x3 : L.wstream)[w];
+      G.node_in = J.node_in;
+      if (G.i0e_hi == 0 && G.vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
+        G.i0e_lo = 0; G.i0e_hi = S.t0e; G.vec_on = 1;
       }
-      a.g[g].psrc = e->proj[base + 2 * slot_of[w]];
-      a.g[g].pdst = e->proj[base + 2 * slot_of[w] + 1];
-    }
-    HIPCHK(launch_node_proj(pa, s));
-  }
-  a.stamps = e->stamps_dev;
-  if (e->pair && s != e->side) {
-    // lockstep with the partner engine: the second to arrive launches one kernel over both batches' groups (same layer,
-    // hence the same weight streams) on its own stream, ordered after the partner's stream; both streams continue after it
-    PairCtx& P = *e->pair;
-    const int me = e->pair_rank;
-    HIPCHK(hipEventRecord(P.ready[me], s));
-    std::unique_lock<std::mutex> lk(P.m);
-    if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
-    P.args[me] = a;
-    P.grid[me] = grid;
-    if (++P.arrived == P.n) {
-      ConvArgs m = P.args[0];
-      int grid_all = P.grid[0], rc = 0;
-      for (int k = 1; k < P.n; ++k) {
-        for (int g = 0; g < P.args[k].n_groups; ++g) m.g[m.n_groups + g] = P.args[k].g[g];
-        m.n_groups += P.args[k].n_groups;
-        grid_all += P.grid[k];
+      grid += e0->use_bf16 == 1 ? (J.caps[g] + 63) / 64 : (J.caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;   // bf16: one wave per 64 edges
+      if (e0->use_bf16 != 1) {
+        // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual slices share them.
+        // (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)
+        if (slot_of[w] < 0) {
+          slot_of[w] = n_slots++;
+          if (base + 2 * slot_of[w] + 1 >= (int)(sizeof(e->proj) / sizeof(e->proj[0]))) return fail(CBD_ERR_STATE, "projection slots exhausted");
+          if (pa.n_jobs + 2 > PROJ_MAX_JOBS) return fail(CBD_ERR_STATE, "projection jobs exhausted");
+          float* ps = e->proj[base + 2 * slot_of[w]];
+          float* pd = e->proj[base + 2 * slot_of[w] + 1];
+          pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w], ps, J.node_in, J.g[g].src_lo, J.g[g].src_n};
+          pa.job[pa.n_jobs++] = ProjJob{L.w1sd[w] + (size_t)NS * KDIM, pd, J.node_in, J.g[g].dst_lo, J.g[g].dst_n};
+        }
+        G.psrc = e->proj[base + 2 * slot_of[w]];
+        G.pdst = e->proj[base + 2 * slot_of[w] + 1];
       }
-      for (int k = 0; k < P.n && rc == 0; ++k)
-        if (k != me && hipStreamWaitEvent(s, P.ready[k], 0) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipStreamWaitEvent failed");
-      if (rc == 0) rc = launch_conv_timed(e, L, m, grid_all, s);
-      if (rc == 0 && hipEventRecord(P.done, s) != hipSuccess) rc = fail(CBD_ERR_HIP, "hipEventRecord failed");
-      P.rc = rc;
-      if (rc != 0) P.abort = true;
-      P.arrived = 0;
-      ++P.gen;
-      lk.unlock();
-      P.cv.notify_all();
-      return rc;
     }
-    const unsigned my = P.gen;
-    P.cv.wait(lk, [&] { return P.gen != my || P.abort; });
-    if (P.abort) return fail(CBD_ERR_STATE, "paired sampling aborted by the partner engine");
-    const int rc = P.rc;
-    lk.unlock();
-    if (rc == 0) HIPCHK(hipStreamWaitEvent(s, P.done, 0));   // `done` is re-recorded only at the next rendezvous, which needs this thread
-    return rc;
+    a.n_groups += J.n_groups;
   }
-  return launch_conv_timed(e, L, a, grid, s);
+  if (pa.n_jobs) HIPCHK(launch_node_proj(pa, s));
+  a.stamps = e0->stamps_dev;
+  return launch_conv_timed(e0, L, a, grid, s);
 }
 
 static FinGroup fin_group(const ConvGroup& g, const int* start, const int* cnt, int node_mod = 0) {
@@ -695,17 +675,6 @@ static int run_finalize(cbd_engine* e, const ConvLayerDev& L, const float* node_
   return 0;
 }
 
-static int run_finalize2(cbd_engine* e, const ConvLayerDev& L, const float* node_in, float* node_out, const FinGroup* g0, int ng0,
-                         int n0, int off0, const FinGroup* g1, int ng1, int n1, int off1, hipStream_t s) {
-  FinArgs f0{}, f1{};
-  f0.n_groups = ng0; f1.n_groups = ng1;
-  for (int g = 0; g < ng0; ++g) f0.g[g] = g0[g];
-  for (int g = 0; g < ng1; ++g) f1.g[g] = g1[g];
-  HIPCHK(launch_conv_finalize2(f0, n0, off0, f1, n1, off1, node_in, node_out, L.bn_scale, L.bn_mean, L.bn_bias,
-                               in_level_dim(L.in_level), out_level_dim(L.out_level), s));
-  return 0;
-}
-
 // Time-independent receptor embedding for ONE copy of the receptor (score_model.py:297-320): node encoder,
 // edge embedding, three rec_emb_layers; result cached in rec_static (the reference caches it on the batch object).
 static int embed_receptor(cbd_engine* e, hipStream_t s) {
@@ -713,17 +682,23 @@ static int embed_receptor(cbd_engine* e, hipStream_t s) {
   const int Nr = gs.Nr, Err = gs.Err, lm = e->cfg.lm_embedding_dim;
   HIPCHK(launch_rec_node_embed(e->d_rec_x, Nr, lm, e->rec_emb_table, e->rec_node_w, e->rec_node_b, e->X0, s));
   HIPCHK(launch_edge_geom(gs.rec_pos, e->d_src0, e->d_dst0, Err, e->d_vec0, e->d_dist0, s));
-  HIPCHK(launch_edge_mlp(make_mlp(e->m_rec_edge, nullptr), e->d_dist0, nullptr, nullptr, Err, e->rr_attr0, s));
+  {
+    EdgeMlpArgs ma{};
+    ma.n = 1;
+    ma.seg[0] = EdgeSeg{make_mlp(e->m_rec_edge, nullptr), e->d_dist0, nullptr, nullptr, Err, e->rr_attr0};
+    HIPCHK(launch_edge_mlp(ma, s));
+  }
   HIPCHK(hipMemcpyAsync(e->rr_count_dev, &gs.Err, sizeof(int), hipMemcpyHostToDevice, s));
   float* in = e->X0;
   float* out = e->X1;
   for (int l = 0; l < 3; ++l) {
-    ConvGroupH g{};
+    ConvJob J;
+    J.e = e; J.n_groups = 1; J.node_in = in; J.caps[0] = Err; J.widx[0] = 0;
+    ConvGroupH& g = J.g[0];
     g.src = e->d_src0; g.dst = e->d_dst0; g.attr_idx = e->d_ident; g.vec = e->d_vec0; g.attr = e->rr_attr0; g.count = e->rr_count_dev;
     g.first_sum = e->fsum[4]; g.last_sum = e->lsum[4]; g.run_acc = e->racc[4];
     g.src_lo = 0; g.src_n = Nr; g.dst_lo = 0; g.dst_n = Nr;
-    int cap = Err;
-    CHK(run_conv(e, e->rec_emb[l], &g, 1, &cap, in, s));
+    CHK(run_conv(e->rec_emb[l], &J, 1, s, false));
     const FinGroup fg = fin_group(g, e->rr0_start, e->d_deg0);
     CHK(run_finalize(e, e->rec_emb[l], in, out, &fg, 1, Nr, 0, s));
     std::swap(in, out);
@@ -744,8 +719,8 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   if (Nl <= 0 || Nr <= 0 || nbd < 0 || R < 0 || Err < 0) return fail(CBD_ERR_ARG, "bad sizes");
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipDeviceSynchronize());
-  if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-  e->graph_key.clear(); e->g_pos = nullptr; e->g_S_cap = 0;
+  drop_graphs(e);
+  e->g_pos = nullptr; e->g_S_cap = 0;
   e->cpool.reset(); e->bpool.reset();
   e->complex_ready = false;
   const int Bm = e->cfg.max_batch, lm = e->cfg.lm_embedding_dim;
@@ -903,6 +878,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
     HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 8 * 8));
   } else e->stamps_dev = nullptr;
   HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
+  fill_static_desc(e);
   hipStream_t s = nullptr;
   CHK(embed_receptor(e, s));
   for (int b = 0; b < Bm; ++b)
@@ -922,137 +898,224 @@ static void snap(cbd_engine* e, const char* name, const float* dev, size_t n, hi
   e->dbg_snap.push_back({name, std::move(h)});
 }
 
-// One score-model forward on the engine's buffers.  sigma_emb_dev: device pointer to this step's 32-float embedding.
-static int forward(cbd_engine* e, int B, const float* pos_dev, const cbd_step& st, const float* sigma_emb_dev, float* tr_dev,
-                   float* rot_dev, float* tor_dev, hipStream_t s) {
+// The edge groups of one pose batch as the tensor-product kernel sees them: ligand-ligand, ligand->receptor, receptor->receptor,
+// receptor->ligand, and the single-copy receptor graph whose layer-0 messages are shared by all samples.
+struct BatchGroups { ConvGroupH ll, lr, rr, rl, rr_shared; };
+
+static BatchGroups batch_groups(cbd_engine* e, int B) {
   const GraphStatic& gs = e->gs;
-  GraphDyn gd = e->gd;
-  gd.pos = const_cast<float*>(pos_dev);
-  const int Nl = gs.Nl, Nr = gs.Nr, R = gs.R, nL = B * Nl, nR = B * Nr;
+  const GraphDyn& gd = e->gd;
+  const int nL = B * gs.Nl, nR = B * gs.Nr;
+  BatchGroups G{};
+  G.ll.src = gd.ll_src; G.ll.dst = gd.ll_dst; G.ll.attr_idx = gd.ll_aidx; G.ll.vec = gd.ll_vec; G.ll.attr = e->ll_attr; G.ll.count = gd.counts + 0;
+  G.lr.src = gd.lr_src; G.lr.dst = gd.lr_dst; G.lr.attr_idx = gd.lr_aidx; G.lr.vec = gd.lr_vec; G.lr.attr = e->lr_attr; G.lr.count = gd.counts + 1;
+  G.rr.src = e->rr_src; G.rr.dst = e->rr_dst; G.rr.attr_idx = e->rr_aidx; G.rr.vec = e->rr_vec; G.rr.attr = e->rr_attr_t; G.rr.count = gd.counts + 2;
+  G.rl.src = gd.rl_src; G.rl.dst = gd.rl_dst; G.rl.attr_idx = gd.rl_aidx; G.rl.vec = gd.rl_vec; G.rl.attr = e->lr_attr; G.rl.count = gd.counts + 3;
+  ConvGroupH* gg[4] = {&G.ll, &G.lr, &G.rr, &G.rl};
+  for (int g = 0; g < 4; ++g) { gg[g]->first_sum = e->fsum[g]; gg[g]->last_sum = e->lsum[g]; gg[g]->run_acc = e->racc[g]; }
+  // node-row ranges of the aggregating (src) and the read (dst) side: ligand rows [0, nL), receptor rows [rec_off, rec_off + nR)
+  G.ll.src_lo = 0; G.ll.src_n = nL; G.ll.dst_lo = 0; G.ll.dst_n = nL;
+  G.lr.src_lo = 0; G.lr.src_n = nL; G.lr.dst_lo = gs.rec_off; G.lr.dst_n = nR;
+  G.rr.src_lo = gs.rec_off; G.rr.src_n = nR; G.rr.dst_lo = gs.rec_off; G.rr.dst_n = nR;
+  G.rl.src_lo = gs.rec_off; G.rl.src_n = nR; G.rl.dst_lo = 0; G.rl.dst_n = nL;
+  // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
+  G.rr_shared.src = e->rr_src; G.rr_shared.dst = e->rr_dst; G.rr_shared.attr_idx = e->rr_aidx; G.rr_shared.vec = e->rr_vec;
+  G.rr_shared.attr = e->rr_attr_t; G.rr_shared.count = e->rr_count_dev;
+  G.rr_shared.first_sum = e->fsum[4]; G.rr_shared.last_sum = e->lsum[4]; G.rr_shared.run_acc = e->racc[2];
+  G.rr_shared.src_lo = gs.rec_off; G.rr_shared.src_n = gs.Nr; G.rr_shared.dst_lo = gs.rec_off; G.rr_shared.dst_n = gs.Nr;
+  return G;
+}
+
+// The ligand embedding layers hold only ~10 edge tiles per pose (a fraction of one round of waves) and are bound by the length of a
+// wave's weight-tile chain: the chain is split over two waves per edge tile (virtual slices of the ll group with their own pieces).
+constexpr int EMB_SLICES = 2;
+static void emb_slices(cbd_engine* e, const ConvGroupH& gll, int level, ConvGroupH (&sl)[EMB_SLICES]) {
+  const ConvShape ES = conv_shape(level, level + 1);
+  const int tvec = ES.t1o + ES.t1e + ES.t0o, nsl = EMB_SLICES;
+  const int per = (ES.t0e + tvec + nsl - 1) / nsl;
+  const int c_lo = ES.t0e - std::max(0, std::min(ES.t0e, per - tvec));   // 0e tiles the vector slice also takes
+  for (int k = 0; k < nsl; ++k) {
+    sl[k] = gll;
+    if (k > 0) { sl[k].first_sum = e->fsum_x[k - 1]; sl[k].last_sum = e->lsum_x[k - 1]; sl[k].run_acc = e->racc_x[k - 1]; }
+    if (k == nsl - 1) { sl[k].i0e_lo = c_lo; sl[k].i0e_hi = ES.t0e; sl[k].vec_on = 1; }
+    else { sl[k].i0e_lo = c_lo * k / (nsl - 1); sl[k].i0e_hi = c_lo * (k + 1) / (nsl - 1); sl[k].vec_on = 0; }
+  }
+}
+
+// Static part of the batch descriptor (everything that is fixed once the complex is set).
+static void fill_static_desc(cbd_engine* e) {
+  PoseBatch& D = e->desc_h;
+  D = PoseBatch{};
+  D.gs = e->gs;
+  D.gd = e->gd;
+  D.X[0] = e->X0; D.X[1] = e->X1;
+  D.lig_static32 = e->lig_static32; D.rec_static = e->rec_static; D.rr_attr0 = e->rr_attr0; D.rr_attr_t = e->rr_attr_t;
+  D.ll_attr = e->ll_attr; D.lr_attr = e->lr_attr;
+  D.center_msg = e->center_msg; D.dbg_global = e->dbg_global; D.dbg_torfeat = e->dbg_torfeat;
+  D.tor_nb = e->tor_nb; D.tor_nb_cnt = e->tor_nb_cnt;
+  D.stats = e->stats_dev;
+  const BatchGroups G = batch_groups(e, e->cfg.max_batch);   // pointers only: independent of B
+  const GraphDyn& gd = e->gd;
+  const FinGroup f_ll = fin_group(G.ll, gd.start_ll, gd.cnt_ll), f_lr = fin_group(G.lr, gd.start_lr, gd.cnt_lr);
+  const FinGroup f_rl = fin_group(G.rl, gd.start_rl, gd.cnt_rl), f_rr = fin_group(G.rr, e->rr_start, e->rr_cnt);
+  const FinGroup f_rr_shared = fin_group(G.rr_shared, e->rr_start, e->rr_cnt, e->gs.Nr);
+  D.fin_lig.n_groups = 2; D.fin_lig.g[0] = f_ll; D.fin_lig.g[1] = f_lr;
+  D.fin_rec.n_groups = 2; D.fin_rec.g[0] = f_rr; D.fin_rec.g[1] = f_rl;
+  D.fin_rec_shared.n_groups = 2; D.fin_rec_shared.g[0] = f_rr_shared; D.fin_rec_shared.g[1] = f_rl;
+  ConvGroupH sl[EMB_SLICES];
+  emb_slices(e, G.ll, 0, sl);   // the piece buffers of the slices do not depend on the layer
+  D.fin_emb.n_groups = EMB_SLICES;
+  for (int k = 0; k < EMB_SLICES; ++k) {
+    D.fin_emb.g[k] = fin_group(sl[k], gd.start_ll, gd.cnt_ll);
+    D.fin_emb.g[k].deg_weight = k == 0 ? 1 : 0;
+  }
+}
+
+// Per-call part of the descriptor -> device (stream ordered).
+static int push_desc(cbd_engine* e, int B, float* pos, float* tr, float* rot, float* tor, const float* ztr, const float* zrot,
+                     const float* ztor, hipStream_t s) {
+  PoseBatch& D = e->desc_h;
+  D.B = B;
+  D.cap_ll = B * e->cap_ll_per_sample;
+  D.cap_x = B * e->gs.Nl * e->gs.Nr;
+  D.gd.pos = pos;
+  D.tr_out = tr; D.rot_out = rot; D.tor_out = tor;
+  D.z_tr = ztr; D.z_rot = zrot; D.z_tor = ztor;
   e->last_B = B;
-  e->dbg_snap.clear();
-  HIPCHK(launch_step_prep(e->sw, e->sv, sigma_emb_dev, s));
+  HIPCHK(launch_set_desc(D, e->desc_dev, s));
+  return 0;
+}
+
+// One score-model forward for the pose batches of n engines (one complex each, same weights) in shared launches.  The scores
+// land in every batch's tr_out / rot_out / tor_out (descriptor).  sigma_emb_dev: device pointer to this step's 32-float embedding.
+static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const float* sigma_emb_dev, hipStream_t s) {
+  cbd_engine* e0 = E[0];
+  const PoseBatch* descs[MAX_COSCHED];
+  BatchGroups G[MAX_COSCHED];
+  int Bk[MAX_COSCHED];
+  for (int k = 0; k < n; ++k) {
+    descs[k] = E[k]->desc_dev;
+    Bk[k] = E[k]->desc_h.B;
+    G[k] = batch_groups(E[k], Bk[k]);
+    E[k]->dbg_snap.clear();
+  }
+  auto nl = [&](int k) { return Bk[k] * E[k]->gs.Nl; };
+  auto nr = [&](int k) { return Bk[k] * E[k]->gs.Nr; };
+  const bool dbg = n == 1 && e0->keep_debug;
+  const StepVectors& sv = e0->sv;   // functions of the diffusion time and the (shared) weights only: one set for all batches
+  HIPCHK(launch_step_prep(e0->sw, sv, sigma_emb_dev, s));
   // ---- fork: everything that depends only on the diffusion time runs on the side stream, concurrently with the
   //      pose-dependent graph construction and ligand embedding: receptor rows (static embedding + sigma embedding,
   //      score_model.py:323-326) and the receptor->receptor messages of interaction layer 0.  Those messages read only
   //      receptor features and shared edge attributes, so they are IDENTICAL for the B samples of a complex: they are
   //      computed once (Err edges instead of B*Err) and added to every sample's sum by the finalize kernel (node_mod = Nr).
-  ConvGroupH g_rr_shared{};   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
-  g_rr_shared.src = e->rr_src; g_rr_shared.dst = e->rr_dst; g_rr_shared.attr_idx = e->rr_aidx; g_rr_shared.vec = e->rr_vec;
-  g_rr_shared.attr = e->rr_attr_t; g_rr_shared.count = e->rr_count_dev;
-  g_rr_shared.first_sum = e->fsum[4]; g_rr_shared.last_sum = e->lsum[4]; g_rr_shared.run_acc = e->racc[2];
-  g_rr_shared.src_lo = gs.rec_off; g_rr_shared.src_n = Nr; g_rr_shared.dst_lo = gs.rec_off; g_rr_shared.dst_n = Nr;   // sample 0's rows
-  float* const Xa = e->X0;          // ligand embedding ping-pong: X0 -> X1 -> X0 -> X1 ; interaction layers read X1 first
-  float* const Xb = e->X1;
-  HIPCHK(hipEventRecord(e->ev_fork, s));
-  HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+  HIPCHK(hipEventRecord(e0->ev_fork, s));
+  HIPCHK(hipStreamWaitEvent(e0->side, e0->ev_fork, 0));
   {
     static const bool no_side = getenv("CBD_NO_SIDE") != nullptr;   // diagnostic: keep the time-only work on the main stream
-    hipStream_t ss = no_side ? s : e->side;
-    HIPCHK(launch_add_rows(e->rr_attr0, e->sv.rec_sigma_emb, e->rr_attr_t, gs.Err, ss));
-    HIPCHK(launch_rec_node_init(e->rec_static, e->sv.rec_sigma_emb, Xb, B, gs.rec_off, Nr, ss));
-    const int cap0 = gs.Err, w_rr = 2;
-    CHK(run_conv(e, e->conv[0], &g_rr_shared, 1, &cap0, Xb, ss, &w_rr));
-    HIPCHK(hipEventRecord(e->ev_join, ss));
-  }
-  HIPCHK(hipMemsetAsync(gd.counts, 0, 8 * sizeof(int), s));
-  HIPCHK(launch_graph_count(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
-  HIPCHK(launch_graph_scan(gs, gd, B, e->stats_dev, s));
-  HIPCHK(launch_graph_fill(gs, gd, B, e->cfg.lig_max_radius, e->cfg.lig_radius_cap, st.cross_cutoff, s));
-  const int cap_ll = B * e->cap_ll_per_sample, cap_x = B * Nl * Nr, cap_rr = B * gs.Err;
-  EdgeMlp mll = make_mlp(e->m_lig_edge, e->sv.ll_part), mlr = make_mlp(e->m_cross, e->sv.lr_part);
-  HIPCHK(launch_edge_mlp(mll, gd.ll_dist, gd.ll_bond4, gd.counts + 0, cap_ll, e->ll_attr, s));
-  HIPCHK(launch_edge_mlp(mlr, gd.lr_dist, nullptr, gd.counts + 1, cap_x, e->lr_attr, s));
-  HIPCHK(launch_lig_node_init(e->lig_static32, e->sv.lig_node_c, Xa, B, Nl, s));
-  snap(e, "lig_node_emb0", Xa, (size_t)nL * NODE_STRIDE, s);
-
-  ConvGroupH gll{}, glr{}, grr{}, grl{};
-  gll.src = gd.ll_src; gll.dst = gd.ll_dst; gll.attr_idx = gd.ll_aidx; gll.vec = gd.ll_vec; gll.attr = e->ll_attr; gll.count = gd.counts + 0;
-  glr.src = gd.lr_src; glr.dst = gd.lr_dst; glr.attr_idx = gd.lr_aidx; glr.vec = gd.lr_vec; glr.attr = e->lr_attr; glr.count = gd.counts + 1;
-  grr.src = e->rr_src; grr.dst = e->rr_dst; grr.attr_idx = e->rr_aidx; grr.vec = e->rr_vec; grr.attr = e->rr_attr_t; grr.count = gd.counts + 2;
-  grl.src = gd.rl_src; grl.dst = gd.rl_dst; grl.attr_idx = gd.rl_aidx; grl.vec = gd.rl_vec; grl.attr = e->lr_attr; grl.count = gd.counts + 3;
-  {
-    ConvGroupH* gg[4] = {&gll, &glr, &grr, &grl};
-    for (int g = 0; g < 4; ++g) { gg[g]->first_sum = e->fsum[g]; gg[g]->last_sum = e->lsum[g]; gg[g]->run_acc = e->racc[g]; }
-    // node-row ranges of the aggregating (src) and the read (dst) side: ligand rows [0, nL), receptor rows [rec_off, rec_off + nR)
-    gll.src_lo = 0; gll.src_n = nL; gll.dst_lo = 0; gll.dst_n = nL;
-    glr.src_lo = 0; glr.src_n = nL; glr.dst_lo = gs.rec_off; glr.dst_n = nR;
-    grr.src_lo = gs.rec_off; grr.src_n = nR; grr.dst_lo = gs.rec_off; grr.dst_n = nR;
-    grl.src_lo = gs.rec_off; grl.src_n = nR; grl.dst_lo = 0; grl.dst_n = nL;
-  }
-  const FinGroup f_ll = fin_group(gll, gd.start_ll, gd.cnt_ll), f_lr = fin_group(glr, gd.start_lr, gd.cnt_lr);
-  const FinGroup f_rl = fin_group(grl, gd.start_rl, gd.cnt_rl), f_rr = fin_group(grr, e->rr_start, e->rr_cnt);
-  const FinGroup f_rr_shared = fin_group(g_rr_shared, e->rr_start, e->rr_cnt, Nr);
-  const FinGroup lig2[2] = {f_ll, f_lr}, rec2[2] = {f_rr, f_rl}, rec2_shared[2] = {f_rr_shared, f_rl};
-
-  float* in = Xa;
-  float* out = Xb;
-  static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
-  for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
-    // These launches hold only ~10 edge tiles per pose (a fraction of one round of waves) and are bound by the length of a
-    // wave's weight-tile chain: split the chain over 2-3 waves per edge tile (virtual slices of the ll group, own pieces).
-    const ConvShape ES = conv_shape(e->lig_emb[l].in_level, e->lig_emb[l].out_level);
-    const int tvec = ES.t1o + ES.t1e + ES.t0o, nsl = 2;   // the same slicing with and without a partner engine: identical results
-    const int per = (ES.t0e + tvec + nsl - 1) / nsl;
-    const int c_lo = ES.t0e - std::max(0, std::min(ES.t0e, per - tvec));   // 0e tiles the vector slice also takes
-    ConvGroupH sl[3];
-    FinGroup fsl[3];
-    int caps_sl[3];
-    for (int k = 0; k < nsl; ++k) {
-      sl[k] = gll;
-      if (k > 0) { sl[k].first_sum = e->fsum_x[k - 1]; sl[k].last_sum = e->lsum_x[k - 1]; sl[k].run_acc = e->racc_x[k - 1]; }
-      if (k == nsl - 1) { sl[k].i0e_lo = c_lo; sl[k].i0e_hi = ES.t0e; sl[k].vec_on = 1; }
-      else { sl[k].i0e_lo = c_lo * k / (nsl - 1); sl[k].i0e_hi = c_lo * (k + 1) / (nsl - 1); sl[k].vec_on = 0; }
-      if (sl[k].i0e_hi == 0 && sl[k].vec_on == 0) sl[k].i0e_hi = sl[k].i0e_lo = 0, sl[k].vec_on = 0;
-      fsl[k] = fin_group(sl[k], gd.start_ll, gd.cnt_ll);
-      fsl[k].deg_weight = k == 0 ? 1 : 0;
-      caps_sl[k] = cap_ll;
+    hipStream_t ss = no_side ? s : e0->side;
+    const Multi mt = make_multi(n, descs, [&](int k) { return (nr(k) * NODE_STRIDE + 255) / 256 + (E[k]->gs.Err * 32 + 255) / 256; });
+    HIPCHK(launch_rec_time_init(mt, sv.rec_sigma_emb, 1, ss));
+    ConvJob jobs[MAX_COSCHED];
+    for (int k = 0; k < n; ++k) {
+      ConvJob& J = jobs[k];
+      J.e = E[k]; J.n_groups = 1; J.g[0] = G[k].rr_shared; J.caps[0] = E[k]->gs.Err; J.widx[0] = 2; J.node_in = E[k]->X1;
     }
-    const int widx_sl[3] = {0, 0, 0};
-    CHK(run_conv(e, e->lig_emb[l], sl, nsl, caps_sl, in, s, widx_sl));
-    CHK(run_finalize(e, e->lig_emb[l], in, out, fsl, nsl, nL, 0, s));
-    std::swap(in, out);
-    snap(e, emb_names[l], in, (size_t)nL * NODE_STRIDE, s);
+    CHK(run_conv(e0->conv[0], jobs, n, ss, true));
+    HIPCHK(hipEventRecord(e0->ev_join, ss));
   }
-  // ---- join: `in` == Xb now holds the embedded ligand rows (main stream) and the receptor rows (side stream)
-  HIPCHK(hipStreamWaitEvent(s, e->ev_join, 0));
+  const float lig_r = e0->cfg.lig_max_radius;
+  const int lig_cap = e0->cfg.lig_radius_cap;
+  HIPCHK(launch_graph_count(make_multi(n, descs, [&](int k) { return nl(k) + nr(k); }), lig_r, lig_cap, st.cross_cutoff, s));
+  HIPCHK(launch_graph_scan(make_multi(n, descs, [&](int) { return 3; }), s));
+  HIPCHK(launch_graph_fill(make_multi(n, descs, nl), make_multi(n, descs, nr), lig_r, lig_cap, st.cross_cutoff, s));
+  {
+    EdgeMlpArgs ma{};
+    const EdgeMlp mll = make_mlp(e0->m_lig_edge, sv.ll_part), mlr = make_mlp(e0->m_cross, sv.lr_part);
+    for (int k = 0; k < n; ++k) {
+      const GraphDyn& gd = E[k]->gd;
+      ma.seg[ma.n++] = EdgeSeg{mll, gd.ll_dist, gd.ll_bond4, gd.counts + 0, E[k]->desc_h.cap_ll, E[k]->ll_attr};
+      ma.seg[ma.n++] = EdgeSeg{mlr, gd.lr_dist, nullptr, gd.counts + 1, E[k]->desc_h.cap_x, E[k]->lr_attr};
+    }
+    HIPCHK(launch_edge_mlp(ma, s));
+  }
+  HIPCHK(launch_lig_node_init(make_multi(n, descs, [&](int k) { return (nl(k) * NODE_STRIDE + 255) / 256; }), sv.lig_node_c, 0, s));
+  if (dbg) snap(e0, "lig_node_emb0", e0->X0, (size_t)nl(0) * NODE_STRIDE, s);
+
+  const Multi m_lig_nodes = make_multi(n, descs, [&](int k) { return (nl(k) * NODE_STRIDE + 255) / 256; });
+  const Multi m_all_nodes = make_multi(n, descs, [&](int k) { return ((nl(k) + nr(k)) * NODE_STRIDE + 255) / 256; });
+  int xi = 0;   // ligand embedding ping-pong: X0 -> X1 -> X0 -> X1 ; the interaction layers read X1 first
+  static const char* emb_names[3] = {"lig_emb_0", "lig_emb_1", "lig_emb_2"};
+  ConvJob jobs[MAX_COSCHED];
+  for (int l = 0; l < 3; ++l) {   // ligand embedding layers on the ligand graph only (score_model.py:289-293)
+    const ConvLayerDev& L = e0->lig_emb[l];
+    for (int k = 0; k < n; ++k) {
+      ConvJob& J = jobs[k];
+      J = ConvJob{};
+      J.e = E[k]; J.n_groups = EMB_SLICES; J.node_in = E[k]->desc_h.X[xi];
+      ConvGroupH sl[EMB_SLICES];
+      emb_slices(E[k], G[k].ll, l, sl);
+      for (int q = 0; q < EMB_SLICES; ++q) { J.g[q] = sl[q]; J.caps[q] = E[k]->desc_h.cap_ll; J.widx[q] = 0; }
+    }
+    CHK(run_conv(L, jobs, n, s, false));
+    HIPCHK(launch_conv_finalize_multi(m_lig_nodes, FIN_EMB, xi, xi ^ 1, L.bn_scale, L.bn_mean, L.bn_bias, in_level_dim(L.in_level),
+                                      out_level_dim(L.out_level), s));
+    xi ^= 1;
+    if (dbg) snap(e0, emb_names[l], e0->desc_h.X[xi], (size_t)nl(0) * NODE_STRIDE, s);
+  }
+  // ---- join: X[xi] (== X1) now holds the embedded ligand rows (main stream) and the receptor rows (side stream)
+  HIPCHK(hipStreamWaitEvent(s, e0->ev_join, 0));
   static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
   for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
-    if (l == 0) {
-      const ConvGroupH g3[3] = {gll, glr, grl};
-      const int caps[3] = {cap_ll, cap_x, cap_x}, widx[3] = {0, 1, 3};
-      CHK(run_conv(e, e->conv[l], g3, 3, caps, in, s, widx));
-      CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2_shared, 2, nR, gs.rec_off, s));
-    } else if (l < 4) {
-      const ConvGroupH g4[4] = {gll, glr, grr, grl};
-      const int caps[4] = {cap_ll, cap_x, cap_rr, cap_x};
-      CHK(run_conv(e, e->conv[l], g4, 4, caps, in, s));
-      CHK(run_finalize2(e, e->conv[l], in, out, lig2, 2, nL, 0, rec2, 2, nR, gs.rec_off, s));
-    } else {
-      const ConvGroupH g2[2] = {gll, glr};
-      const int caps[2] = {cap_ll, cap_x};
-      CHK(run_conv(e, e->conv[l], g2, 2, caps, in, s));
-      CHK(run_finalize(e, e->conv[l], in, out, lig2, 2, nL, 0, s));   // receptor rows are never read again (quirk 3)
+    const ConvLayerDev& L = e0->conv[l];
+    for (int k = 0; k < n; ++k) {
+      ConvJob& J = jobs[k];
+      J = ConvJob{};
+      J.e = E[k]; J.node_in = E[k]->desc_h.X[xi];
+      const int cap_ll = E[k]->desc_h.cap_ll, cap_x = E[k]->desc_h.cap_x, cap_rr = Bk[k] * E[k]->gs.Err;
+      if (l == 0) {          // the receptor->receptor group of layer 0 is the shared one computed on the side stream
+        J.n_groups = 3;
+        J.g[0] = G[k].ll; J.g[1] = G[k].lr; J.g[2] = G[k].rl;
+        J.caps[0] = cap_ll; J.caps[1] = cap_x; J.caps[2] = cap_x;
+        J.widx[0] = 0; J.widx[1] = 1; J.widx[2] = 3;
+      } else if (l < 4) {
+        J.n_groups = 4;
+        J.g[0] = G[k].ll; J.g[1] = G[k].lr; J.g[2] = G[k].rr; J.g[3] = G[k].rl;
+        J.caps[0] = cap_ll; J.caps[1] = cap_x; J.caps[2] = cap_rr; J.caps[3] = cap_x;
+      } else {
+        J.n_groups = 2;
+        J.g[0] = G[k].ll; J.g[1] = G[k].lr;
+        J.caps[0] = cap_ll; J.caps[1] = cap_x;
+      }
     }
-    std::swap(in, out);
-    snap(e, conv_names[l], in, (size_t)nL * NODE_STRIDE, s);
-    if (l < 4) snap(e, (std::string(conv_names[l]) + "_rec").c_str(), in + (size_t)gs.rec_off * NODE_STRIDE, (size_t)nR * NODE_STRIDE, s);
+    CHK(run_conv(L, jobs, n, s, false));
+    const int kind = l == 0 ? FIN_FIRST : l < 4 ? FIN_MID : FIN_LAST;   // receptor rows of the last layer are never read again (quirk 3)
+    HIPCHK(launch_conv_finalize_multi(l < 4 ? m_all_nodes : m_lig_nodes, kind, xi, xi ^ 1, L.bn_scale, L.bn_mean, L.bn_bias,
+                                      in_level_dim(L.in_level), out_level_dim(L.out_level), s));
+    xi ^= 1;
+    if (dbg) {
+      snap(e0, conv_names[l], e0->desc_h.X[xi], (size_t)nl(0) * NODE_STRIDE, s);
+      if (l < 4) snap(e0, (std::string(conv_names[l]) + "_rec").c_str(), e0->desc_h.X[xi] + (size_t)e0->gs.rec_off * NODE_STRIDE, (size_t)nr(0) * NODE_STRIDE, s);
+    }
   }
-  const float* lig_node = in;
-  HIPCHK(launch_center_head(e->ch, e->sv, pos_dev, lig_node, B, Nl, st.tr_sigma, st.rot_score_norm, tr_dev, rot_dev, e->dbg_global, e->center_msg, s));
-  if (!e->cfg.no_torsion && R > 0) {
-    HIPCHK(launch_bond_nb(gs, pos_dev, B, e->cfg.lig_max_radius, 32, e->tor_nb, e->tor_nb_cnt, gd.counts + 4, s));
-    HIPCHK(launch_bond_conv(e->bh, gs, pos_dev, lig_node, B, e->tor_nb, e->tor_nb_cnt, e->bond_stream, st.tor_score_norm_sqrt, tor_dev,
-                            e->dbg_torfeat, s));
+  HIPCHK(launch_center_head(e0->ch, sv, make_multi(n, descs, nl), make_multi(n, descs, [&](int k) { return Bk[k]; }), xi, st.tr_sigma,
+                            st.rot_score_norm, s));
+  if (!e0->cfg.no_torsion) {
+    const Multi mb = make_multi(n, descs, [&](int k) { return Bk[k] * E[k]->gs.R; });
+    HIPCHK(launch_bond_nb(mb, lig_r, 32, s));
+    HIPCHK(launch_bond_conv(e0->bh, mb, xi, e0->bond_stream, st.tor_score_norm_sqrt, s));
   }
-  e->dbg.clear();
-  e->dbg["center_mean"] = {e->dbg_global, (size_t)B * 12};
-  e->dbg["tor_feat"] = {e->dbg_torfeat, (size_t)B * R * 64};
-  e->dbg["rec_node_static"] = {e->rec_static, (size_t)Nr * NODE_STRIDE};
-  e->dbg["rec_sigma_emb"] = {e->sv.rec_sigma_emb, 32};
-  e->dbg["lig_node_final"] = {lig_node, (size_t)nL * NODE_STRIDE};
-  e->dbg["ll_attr"] = {e->ll_attr, 0};   // count filled at fetch time
-  e->dbg["lr_attr"] = {e->lr_attr, 0};
+  for (int k = 0; k < n; ++k) {
+    cbd_engine* e = E[k];
+    e->dbg.clear();
+    e->dbg["center_mean"] = {e->dbg_global, (size_t)Bk[k] * 12};
+    e->dbg["tor_feat"] = {e->dbg_torfeat, (size_t)Bk[k] * e->gs.R * 64};
+    e->dbg["rec_node_static"] = {e->rec_static, (size_t)e->gs.Nr * NODE_STRIDE};
+    e->dbg["rec_sigma_emb"] = {sv.rec_sigma_emb, 32};
+    e->dbg["lig_node_final"] = {e->desc_h.X[xi], (size_t)nl(k) * NODE_STRIDE};
+    e->dbg["ll_attr"] = {e->ll_attr, 0};   // count filled at fetch time
+    e->dbg["lr_attr"] = {e->lr_attr, 0};
+  }
   return 0;
 }
 
@@ -1083,17 +1146,140 @@ int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* st
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 32 * sizeof(float), hipMemcpyHostToDevice, s));
-  CHK(forward(e, B, pos_dev, *step, e->sigma_emb_dev, tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, s));
+  CHK(push_desc(e, B, const_cast<float*>(pos_dev), tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, nullptr, nullptr, nullptr, s));
+  cbd_engine* E[1] = {e};
+  CHK(forward_multi(E, 1, *step, e->sigma_emb_dev, s));
   return 0;
 }
 
 int cbd_modify_conformer(cbd_engine* e, int32_t B, float* pos_dev, const float* tr_dev, const float* rot_dev, const float* tor_dev,
                          void* stream) {
   if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
-  if (B <= 0 || !pos_dev || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "bad argument");
+  if (B <= 0 || B > e->cfg.max_batch || !pos_dev || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(launch_pose_update(e->gs, pos_dev, B, tr_dev, rot_dev, tor_dev, nullptr, nullptr, nullptr, nullptr,
-                            reinterpret_cast<hipStream_t>(stream)));
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  // the given updates take the place of the scores (use_coefs = 0): descriptor outputs point at them
+  CHK(push_desc(e, B, pos_dev, const_cast<float*>(tr_dev), const_cast<float*>(rot_dev), const_cast<float*>(tor_dev), nullptr, nullptr,
+                nullptr, s));
+  const PoseBatch* d[1] = {e->desc_dev};
+  HIPCHK(launch_pose_update(make_multi(1, d, [&](int) { return B; }), 0, SdeCoefs{}, 0, tor_dev != nullptr && e->gs.R > 0, e->gs.Nl, s));
+  return 0;
+}
+
+// The step loop of n co-scheduled batches (n = 1: cbd_sample).
+static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S, const cbd_step* steps, float* const* pos_dev,
+                       const float* const* noise_tr, const float* const* noise_rot, const float* const* noise_tor, float* scores_out,
+                       hipStream_t s) {
+  cbd_engine* e0 = E[0];
+  auto nz = [](const float* const* a, int k) { return a ? a[k] : nullptr; };
+  if (S > e0->sigma_cap) {
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(e0->bpool.alloc(&e0->sigma_emb_dev, (size_t)S * 32));
+    e0->sigma_cap = S;
+  }
+  std::vector<float> se((size_t)S * 32);
+  for (int i = 0; i < S; ++i) std::memcpy(se.data() + (size_t)i * 32, steps[i].sigma_emb, 32 * sizeof(float));
+  HIPCHK(hipMemcpyAsync(e0->sigma_emb_dev, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(hipStreamSynchronize(s));   // `se` goes out of scope; also orders the upload before the loop
+  int max_nl = 0;
+  bool any_tors = false;
+  for (int k = 0; k < n; ++k) {
+    max_nl = std::max(max_nl, E[k]->gs.Nl);
+    any_tors = any_tors || (!E[k]->cfg.no_torsion && E[k]->gs.R > 0);
+  }
+  const PoseBatch* descs[MAX_COSCHED];
+  for (int k = 0; k < n; ++k) descs[k] = E[k]->desc_dev;
+  const Multi m_samples = make_multi(n, descs, [&](int k) { return (int)B[k]; });
+  auto run_steps = [&](float* scores) -> int {
+    for (int i = 0; i < S; ++i) {
+      const cbd_step& st = steps[i];
+      CHK(forward_multi(E, n, st, e0->sigma_emb_dev + (size_t)i * 32, s));
+      if (scores) {   // n == 1 only (tests)
+        const int R = e0->gs.R, B0 = B[0];
+        float* o = scores + (size_t)i * B0 * (6 + R);
+        HIPCHK(hipMemcpyAsync(o, e0->tr_out, (size_t)B0 * 3 * 4, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(o + B0 * 3, e0->rot_out, (size_t)B0 * 3 * 4, hipMemcpyDeviceToDevice, s));
+        if (any_tors) HIPCHK(hipMemcpyAsync(o + B0 * 6, e0->tor_out, (size_t)B0 * R * 4, hipMemcpyDeviceToDevice, s));
+      }
+      const SdeCoefs cf{st.tr_score_coef, st.tr_noise_coef, st.rot_score_coef, st.rot_noise_coef, st.tor_score_coef, st.tor_noise_coef};
+      HIPCHK(launch_pose_update(m_samples, i, cf, 1, any_tors ? 1 : 0, max_nl, s));
+    }
+    return 0;
+  };
+  bool graph_ok = e0->use_graph && !scores_out;
+  for (int k = 0; k < n; ++k) graph_ok = graph_ok && !E[k]->timing && !E[k]->keep_debug;
+  if (!graph_ok) {
+    for (int k = 0; k < n; ++k)
+      CHK(push_desc(E[k], B[k], pos_dev[k], E[k]->tr_out, E[k]->rot_out, E[k]->tor_out, nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), s));
+    CHK(run_steps(scores_out));
+    return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
+  }
+  // ---- the whole S-step loop of all batches as ONE hipGraph launch (static capacities + device-side edge counts make every launch
+  //      shape independent of the data).  Inputs are staged into engine-owned buffers so that the instantiated graph can be replayed
+  //      for every group of batches with the same engines, complexes, batch sizes and schedule.
+  hipStream_t user = s;
+  if (!user) {   // the legacy default stream cannot be captured: run on the engine's own stream, ordered after/before it
+    HIPCHK(hipEventRecord(e0->ev_a, user));
+    HIPCHK(hipStreamWaitEvent(e0->own, e0->ev_a, 0));
+    s = e0->own;
+  }
+  std::string key(reinterpret_cast<const char*>(steps), sizeof(cbd_step) * (size_t)S);
+  for (int k = 0; k < n; ++k) {
+    cbd_engine* e = E[k];
+    const int Bm = e->cfg.max_batch, Nl = e->gs.Nl, R = e->gs.R;
+    if (!e->g_pos || e->g_S_cap < S) {
+      HIPCHK(hipStreamSynchronize(s));
+      HIPCHK(e->bpool.alloc(&e->g_pos, (size_t)Bm * Nl * 3));
+      HIPCHK(e->bpool.alloc(&e->g_ztr, (size_t)S * Bm * 3)); HIPCHK(e->bpool.alloc(&e->g_zrot, (size_t)S * Bm * 3));
+      HIPCHK(e->bpool.alloc(&e->g_ztor, (size_t)S * Bm * std::max(R, 1)));
+      e->g_S_cap = S;
+      ++e->complex_gen;
+    }
+    char buf[96];
+    snprintf(buf, sizeof buf, "|%p:%u:%d:%d:%d", (void*)e, e->complex_gen, (int)B[k], e->use_bf16,
+             (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr));
+    key += buf;
+  }
+  // descriptors point at the staging buffers; refreshed before every launch (an eager call in between may have re-pointed them)
+  for (int k = 0; k < n; ++k) {
+    cbd_engine* e = E[k];
+    CHK(push_desc(e, B[k], e->g_pos, e->tr_out, e->rot_out, e->tor_out, nz(noise_tr, k) ? e->g_ztr : nullptr,
+                  nz(noise_rot, k) ? e->g_zrot : nullptr, nz(noise_tor, k) ? e->g_ztor : nullptr, s));
+  }
+  hipGraphExec_t exec = nullptr;
+  for (auto& g : e0->graphs)
+    if (g.key == key) exec = g.exec;
+  if (!exec) {
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    const int rc = run_steps(nullptr);
+    const hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    HIPCHK(ce);
+    HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    HIPCHK(hipGraphDestroy(graph));
+    if (e0->graphs.size() >= 4) {   // small cache: the oldest entry goes
+      HIPCHK(hipStreamSynchronize(s));
+      (void)hipGraphExecDestroy(e0->graphs.front().exec);
+      e0->graphs.erase(e0->graphs.begin());
+    }
+    e0->graphs.push_back({key, exec});
+  }
+  for (int k = 0; k < n; ++k) {
+    cbd_engine* e = E[k];
+    const int Nl = e->gs.Nl, R = e->gs.R, Bk = B[k];
+    HIPCHK(hipMemcpyAsync(e->g_pos, pos_dev[k], (size_t)Bk * Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (nz(noise_tr, k)) HIPCHK(hipMemcpyAsync(e->g_ztr, noise_tr[k], (size_t)S * Bk * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (nz(noise_rot, k)) HIPCHK(hipMemcpyAsync(e->g_zrot, noise_rot[k], (size_t)S * Bk * 3 * 4, hipMemcpyDeviceToDevice, s));
+    if (nz(noise_tor, k) && R > 0) HIPCHK(hipMemcpyAsync(e->g_ztor, noise_tor[k], (size_t)S * Bk * R * 4, hipMemcpyDeviceToDevice, s));
+  }
+  HIPCHK(hipGraphLaunch(exec, s));
+  for (int k = 0; k < n; ++k)
+    HIPCHK(hipMemcpyAsync(pos_dev[k], E[k]->g_pos, (size_t)B[k] * E[k]->gs.Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
+  if (!user) {
+    HIPCHK(hipEventRecord(e0->ev_b, s));
+    HIPCHK(hipStreamWaitEvent(user, e0->ev_b, 0));
+  }
   return 0;
 }
 
@@ -1102,144 +1288,37 @@ int cbd_sample(cbd_engine* e, int32_t B, int32_t S, const cbd_step* steps, float
   CHK(check_batch(e, B));
   if (S <= 0 || !steps || !pos_dev) return fail(CBD_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  const int R = e->gs.R;
-  if (S > e->sigma_cap) {
-    HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)S * 32));
-    e->sigma_cap = S;
-  }
-  std::vector<float> se((size_t)S * 32);
-  for (int i = 0; i < S; ++i) std::memcpy(se.data() + (size_t)i * 32, steps[i].sigma_emb, 32 * sizeof(float));
-  HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(hipStreamSynchronize(s));   // `se` goes out of scope; also orders the upload before the loop
-  const bool tors = !e->cfg.no_torsion && R > 0;
-  auto run_steps = [&](float* pos, const float* ntr, const float* nrot, const float* ntor, float* scores) -> int {
-    for (int i = 0; i < S; ++i) {
-      const cbd_step& st = steps[i];
-      CHK(forward(e, B, pos, st, e->sigma_emb_dev + (size_t)i * 32, e->tr_out, e->rot_out, e->tor_out, s));
-      if (scores) {
-        float* o = scores + (size_t)i * B * (6 + R);
-        HIPCHK(hipMemcpyAsync(o, e->tr_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemcpyAsync(o + B * 3, e->rot_out, (size_t)B * 3 * 4, hipMemcpyDeviceToDevice, s));
-        if (tors) HIPCHK(hipMemcpyAsync(o + B * 6, e->tor_out, (size_t)B * R * 4, hipMemcpyDeviceToDevice, s));
-      }
-      SdeCoefs cf{st.tr_score_coef, st.tr_noise_coef, st.rot_score_coef, st.rot_noise_coef, st.tor_score_coef, st.tor_noise_coef};
-      const float* ztr = (ntr && st.tr_noise_coef != 0.f) ? ntr + (size_t)i * B * 3 : nullptr;
-      const float* zrot = (nrot && st.rot_noise_coef != 0.f) ? nrot + (size_t)i * B * 3 : nullptr;
-      const float* ztor = (ntor && st.tor_noise_coef != 0.f) ? ntor + (size_t)i * B * R : nullptr;
-      HIPCHK(launch_pose_update(e->gs, pos, B, e->tr_out, e->rot_out, tors ? e->tor_out : nullptr, ztr, zrot, ztor, &cf, s));
-    }
-    return 0;
-  };
-  if (e->use_graph && !e->timing && !scores_out && !e->keep_debug && !e->pair) {
-    hipStream_t user = s;
-    if (!user) {   // the legacy default stream cannot be captured: run on the engine's own stream, ordered after/before it
-      HIPCHK(hipEventRecord(e->ev_a, user));
-      HIPCHK(hipStreamWaitEvent(e->own, e->ev_a, 0));
-      s = e->own;
-    }
-    // The whole S-step loop as ONE hipGraph launch (static capacities + device-side edge counts make every launch
-    // shape independent of the data).  Inputs are staged into engine-owned buffers so that the instantiated graph
-    // can be replayed for every batch with the same (B, S, schedule).
-    const int Bm = e->cfg.max_batch, Nl = e->gs.Nl;
-    if (!e->g_pos || e->g_S_cap < S) {
-      HIPCHK(hipStreamSynchronize(s));
-      HIPCHK(e->bpool.alloc(&e->g_pos, (size_t)Bm * Nl * 3));
-      HIPCHK(e->bpool.alloc(&e->g_ztr, (size_t)S * Bm * 3)); HIPCHK(e->bpool.alloc(&e->g_zrot, (size_t)S * Bm * 3));
-      HIPCHK(e->bpool.alloc(&e->g_ztor, (size_t)S * Bm * std::max(R, 1)));
-      e->g_S_cap = S;
-      e->graph_key.clear();
-    }
-    std::string key(reinterpret_cast<const char*>(steps), sizeof(cbd_step) * (size_t)S);
-    key += "|" + std::to_string(B) + "|" + std::to_string((noise_tr != nullptr) + 2 * (noise_rot != nullptr) + 4 * (noise_tor != nullptr));
-    if (!e->graph_exec || key != e->graph_key) {
-      if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; }
-      hipGraph_t graph = nullptr;
-      HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      const int rc = run_steps(e->g_pos, noise_tr ? e->g_ztr : nullptr, noise_rot ? e->g_zrot : nullptr,
-                               noise_tor ? e->g_ztor : nullptr, nullptr);
-      const hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (rc != 0) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIPCHK(ce);
-      HIPCHK(hipGraphInstantiate(&e->graph_exec, graph, nullptr, nullptr, 0));
-      HIPCHK(hipGraphDestroy(graph));
-      e->graph_key = key;
-    }
-    HIPCHK(hipMemcpyAsync(e->g_pos, pos_dev, (size_t)B * Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
-    if (noise_tr) HIPCHK(hipMemcpyAsync(e->g_ztr, noise_tr, (size_t)S * B * 3 * 4, hipMemcpyDeviceToDevice, s));
-    if (noise_rot) HIPCHK(hipMemcpyAsync(e->g_zrot, noise_rot, (size_t)S * B * 3 * 4, hipMemcpyDeviceToDevice, s));
-    if (noise_tor && R > 0) HIPCHK(hipMemcpyAsync(e->g_ztor, noise_tor, (size_t)S * B * R * 4, hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipGraphLaunch(e->graph_exec, s));
-    HIPCHK(hipMemcpyAsync(pos_dev, e->g_pos, (size_t)B * Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
-    if (!user) {
-      HIPCHK(hipEventRecord(e->ev_b, s));
-      HIPCHK(hipStreamWaitEvent(user, e->ev_b, 0));
-    }
-    return 0;
-  }
-  CHK(run_steps(pos_dev, noise_tr, noise_rot, noise_tor, scores_out));
-  return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
+  cbd_engine* E[1] = {e};
+  const int32_t Bs[1] = {B};
+  float* ps[1] = {pos_dev};
+  const float* tr[1] = {noise_tr};
+  const float* rot[1] = {noise_rot};
+  const float* tor[1] = {noise_tor};
+  return sample_impl(1, E, Bs, S, steps, ps, tr, rot, tor, scores_out, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, int32_t S, const cbd_step* steps, float* const* pos_dev,
                      const float* const* noise_tr, const float* const* noise_rot, const float* const* noise_tor, void* stream) {
-  if (n < 1 || n > CONV_MAX_COSCHED || !engines || !B || !pos_dev) return fail(CBD_ERR_ARG, "1..%d engines are required", CONV_MAX_COSCHED);
-  auto nz = [](const float* const* a, int k) { return a ? a[k] : nullptr; };
-  if (n == 1) return cbd_sample(engines[0], B[0], S, steps, pos_dev[0], nz(noise_tr, 0), nz(noise_rot, 0), nz(noise_tor, 0), nullptr, stream);
+  if (n < 1 || n > MAX_COSCHED || !engines || !B || !pos_dev) return fail(CBD_ERR_ARG, "1..%d engines are required", MAX_COSCHED);
+  if (S <= 0 || !steps) return fail(CBD_ERR_ARG, "bad argument");
   cbd_engine* e0 = engines[0];
   for (int k = 0; k < n; ++k) {
     cbd_engine* e = engines[k];
     if (!e) return fail(CBD_ERR_ARG, "null engine");
     for (int q = 0; q < k; ++q)
       if (engines[q] == e) return fail(CBD_ERR_ARG, "distinct engines are required");
+    if (!pos_dev[k]) return fail(CBD_ERR_ARG, "null pose buffer");
     if (e->cfg.device != e0->cfg.device) return fail(CBD_ERR_ARG, "co-scheduled engines must live on the same device");
     if (e->use_bf16 != e0->use_bf16) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
+    if (e->cfg.no_torsion != e0->cfg.no_torsion || e->cfg.lig_max_radius != e0->cfg.lig_max_radius ||
+        e->cfg.lig_radius_cap != e0->cfg.lig_radius_cap)
+      return fail(CBD_ERR_ARG, "co-scheduled engines must share one model configuration");
     if (!e->weights_ready || !e0->weights_ready || e->conv[0].wstream[0] != e0->conv[0].wstream[0])
       return fail(CBD_ERR_ARG, "co-scheduled engines must share one set of weights (cbd_share_weights)");
     CHK(check_batch(e, B[k]));
   }
   HIPCHK(hipSetDevice(e0->cfg.device));
-  hipStream_t s0 = reinterpret_cast<hipStream_t>(stream);
-  PairCtx ctx;
-  ctx.n = n;
-  for (int k = 0; k < n; ++k) HIPCHK(hipEventCreateWithFlags(&ctx.ready[k], hipEventDisableTiming));
-  HIPCHK(hipEventCreateWithFlags(&ctx.done, hipEventDisableTiming));
-  // engines 1.. work on their own streams, ordered after the caller's stream now and joined back at the end
-  for (int k = 1; k < n; ++k) {
-    HIPCHK(hipEventRecord(engines[k]->ev_a, s0));
-    HIPCHK(hipStreamWaitEvent(engines[k]->own, engines[k]->ev_a, 0));
-  }
-  for (int k = 0; k < n; ++k) { engines[k]->pair = &ctx; engines[k]->pair_rank = k; }
-  int rc[CONV_MAX_COSCHED] = {};
-  std::string err[CONV_MAX_COSCHED];
-  auto body = [&](int k) {
-    rc[k] = cbd_sample(engines[k], B[k], S, steps, pos_dev[k], nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), nullptr,
-                       k == 0 ? s0 : engines[k]->own);
-    if (rc[k] != 0) {
-      err[k] = cbd_last_error();
-      std::lock_guard<std::mutex> lk(ctx.m);
-      ctx.abort = true;
-      ctx.cv.notify_all();
-    }
-  };
-  std::vector<std::thread> partners;
-  for (int k = 1; k < n; ++k) partners.emplace_back(body, k);
-  body(0);
-  for (auto& t : partners) t.join();
-  hipError_t je = hipSuccess;
-  for (int k = 0; k < n; ++k) engines[k]->pair = nullptr;
-  for (int k = 1; k < n && je == hipSuccess; ++k) {
-    je = hipEventRecord(engines[k]->ev_b, engines[k]->own);
-    if (je == hipSuccess) je = hipStreamWaitEvent(s0, engines[k]->ev_b, 0);
-  }
-  // the events may still be referenced by enqueued work: destroying an event with pending work is deferred by the runtime
-  for (int k = 0; k < n; ++k) (void)hipEventDestroy(ctx.ready[k]);
-  (void)hipEventDestroy(ctx.done);
-  for (int k = 0; k < n; ++k)
-    if (rc[k] != 0) return fail(rc[k], "%s", err[k].c_str());
-  HIPCHK(je);
-  return 0;
+  return sample_impl(n, engines, B, S, steps, pos_dev, noise_tr, noise_rot, noise_tor, nullptr, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cbd_sample_pair(cbd_engine* e0, cbd_engine* e1, int32_t B0, int32_t B1, int32_t S, const cbd_step* steps, float* pos0_dev,
@@ -1260,17 +1339,17 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
   const std::string k(name);
   if (k == "graph") {
     e->use_graph = value != 0;
-    if (!e->use_graph && e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    if (!e->use_graph) drop_graphs(e);
     return 0;
   }
   if (k == "bf16") {   // captured graphs bake the kernel choice in: drop them
     if (value != 0) e->use_bf16 = 1; else if (e->use_bf16 == 1) e->use_bf16 = 0;
-    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    drop_graphs(e);
     return 0;
   }
   if (k == "f32_split") {   // fp32 operands as three bf16 planes on the bf16 matrix cores (OpsBf16x3)
     if (value != 0) e->use_bf16 = 2; else if (e->use_bf16 == 2) e->use_bf16 = 0;
-    if (e->graph_exec) { (void)hipGraphExecDestroy(e->graph_exec); e->graph_exec = nullptr; e->graph_key.clear(); }
+    drop_graphs(e);
     return 0;
   }
   return fail(CBD_ERR_ARG, "unknown option '%s'", name);

@@ -6,16 +6,42 @@
 
 namespace cbd {
 
+// Which pose batch does this workgroup belong to?  (Multi::off is a prefix sum over the batches of this launch; everything is
+// wave-uniform, so the descriptor fields are fetched with scalar loads.)
+CBD_DEV const PoseBatch& locate(const Multi& m, int& local) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_COSCHED; ++i) k = (i < m.n && (int)blockIdx.x >= m.off[i]) ? i : k;
+  local = blockIdx.x - m.off[k];
+  return *m.d[k];
+}
+
+// descriptor upload: by-value kernel argument -> device memory (stream ordered, capturable, no host buffer to keep alive)
+__global__ __launch_bounds__(64) void set_desc_kernel(PoseBatch v, PoseBatch* dst) {
+  const int* src = reinterpret_cast<const int*>(&v);
+  int* d = reinterpret_cast<int*>(dst);
+  for (int i = threadIdx.x; i < (int)(sizeof(PoseBatch) / sizeof(int)); i += 64) d[i] = src[i];
+}
+hipError_t launch_set_desc(const PoseBatch& v, PoseBatch* dst, hipStream_t s) {
+  static_assert(sizeof(PoseBatch) % sizeof(int) == 0 && sizeof(PoseBatch) <= 3584, "PoseBatch is passed by value");
+  hipLaunchKernelGGL(set_desc_kernel, dim3(1), dim3(64), 0, s, v, dst);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Graph construction.  One wave per node.  Blocks [0, B*Nl) handle ligand nodes (ligand radius graph,
 // score_model.py:502-507, and ligand->receptor cross edges, :564-573); blocks [B*Nl, B*Nl + B*Nr) handle
 // receptor nodes (the flipped cross edges, :356-357).  COUNT pass, single-block scan, FILL pass.
 template <bool FILL>
-__global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, int B, float lig_r2, int lig_cap, float cutoff) {
+__global__ __launch_bounds__(64) void graph_kernel(Multi mm, float lig_r2, int lig_cap, float cutoff) {
+  int node;
+  const PoseBatch& PB = locate(mm, node);
+  const GraphStatic gs = PB.gs;   // by value: kept in scalar registers, not re-read after every store
+  const GraphDyn gd = PB.gd;
+  const int B = PB.B;
   const int lane = lane_id();
   const int nL = B * gs.Nl;
   const int roff = gs.rec_off;
-  const int node = blockIdx.x;
   if (node < nL) {
     const int b = node / gs.Nl, a = node % gs.Nl;
     const float* P = gd.pos + (size_t)b * gs.Nl * 3;
@@ -114,14 +140,19 @@ __global__ __launch_bounds__(64) void graph_kernel(GraphStatic gs, GraphDyn gd, 
   }
 }
 
-hipError_t launch_graph_count(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
-  hipLaunchKernelGGL((graph_kernel<false>), dim3(B * (gs.Nl + gs.Nr)), dim3(64), 0, s, gs, gd, B, lig_r * lig_r, lig_cap, cutoff);
+// m: off = prefix sums of B * (Nl + Nr) workgroups
+hipError_t launch_graph_count(const Multi& m, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL((graph_kernel<false>), dim3(m.off[m.n]), dim3(64), 0, s, m, lig_r * lig_r, lig_cap, cutoff);
   return hipGetLastError();
 }
-__global__ __launch_bounds__(64) void graph_fill_rec(GraphStatic gs, GraphDyn gd, int B, float cutoff) {
+__global__ __launch_bounds__(64) void graph_fill_rec(Multi mm, float cutoff) {
+  int rn;
+  const PoseBatch& PB = locate(mm, rn);
+  const GraphStatic gs = PB.gs;   // by value: kept in scalar registers, not re-read after every store
+  const GraphDyn gd = PB.gd;
   const int lane = lane_id();
   const int roff = gs.rec_off;
-  const int rn = blockIdx.x;
   const int b = rn / gs.Nr, r = rn % gs.Nr;
   const float* P = gd.pos + (size_t)b * gs.Nl * 3;
   const float* rp = gs.rec_pos + 3 * r;
@@ -144,21 +175,28 @@ __global__ __launch_bounds__(64) void graph_fill_rec(GraphStatic gs, GraphDyn gd
 }
 
 // The fill pass runs as two launches: receptor-node blocks read pair_eid / lr_vec written by the ligand-node blocks.
-hipError_t launch_graph_fill(const GraphStatic& gs, const GraphDyn& gd, int B, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
-  hipLaunchKernelGGL((graph_kernel<true>), dim3(B * gs.Nl), dim3(64), 0, s, gs, gd, B, lig_r * lig_r, lig_cap, cutoff);
+// m_lig: off = prefix sums of B * Nl workgroups (ligand nodes only); m_rec: of B * Nr
+hipError_t launch_graph_fill(const Multi& m_lig, const Multi& m_rec, float lig_r, int lig_cap, float cutoff, hipStream_t s) {
+  if (m_lig.off[m_lig.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL((graph_kernel<true>), dim3(m_lig.off[m_lig.n]), dim3(64), 0, s, m_lig, lig_r * lig_r, lig_cap, cutoff);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(graph_fill_rec, dim3(B * gs.Nr), dim3(64), 0, s, gs, gd, B, cutoff);
+  hipLaunchKernelGGL(graph_fill_rec, dim3(m_rec.off[m_rec.n]), dim3(64), 0, s, m_rec, cutoff);
   return hipGetLastError();
 }
 
 // Exclusive scans of the three per-node count arrays, one 1024-thread workgroup per array (wave-shuffle scan over
 // coalesced 1024-entry chunks), edge totals -> counts[], algorithmic work accounting -> stats[] (bench.py).
-__global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphDyn gd, int B, unsigned long long* stats) {
+__global__ __launch_bounds__(1024) void graph_scan_kernel(Multi mm) {
   __shared__ int wsum[16];
   __shared__ int carry_s;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int which = blockIdx.x;
+  int which;
+  const PoseBatch& PB = locate(mm, which);
+  const GraphStatic gs = PB.gs;   // by value: kept in scalar registers, not re-read after every store
+  const GraphDyn gd = PB.gd;
+  const int B = PB.B;
+  unsigned long long* const stats = PB.stats;
   const int nL = B * gs.Nl, nR = B * gs.Nr;
   const int* cnt = which == 0 ? gd.cnt_ll : which == 1 ? gd.cnt_lr : gd.cnt_rl;
   int* start = which == 0 ? gd.start_ll : which == 1 ? gd.start_lr : gd.start_rl;
@@ -188,6 +226,7 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphD
     const unsigned long long total = (unsigned long long)carry_s;
     gd.counts[which == 0 ? 0 : which == 1 ? 1 : 3] = (int)total;
     if (which == 2) gd.counts[2] = B * gs.Err;
+    if (which == 0) gd.counts[4] = 0;   // torsion-edge counter of this forward pass (bond_nb_kernel adds to it later in the stream)
     if (stats) {   // edge-layer visits: 3 ligand embedding layers visit ll; 4 joint layers visit all groups, the last one ll + lr
       if (which == 0) { atomicAdd(&stats[0], total); atomicAdd(&stats[1], 5ull * total); atomicAdd(&stats[2], 1ull); }
       if (which == 1) atomicAdd(&stats[1], 5ull * total);
@@ -200,8 +239,9 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(GraphStatic gs, GraphD
   }
 }
 
-hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, unsigned long long* stats, hipStream_t s) {
-  hipLaunchKernelGGL(graph_scan_kernel, dim3(3), dim3(1024), 0, s, gs, gd, B, stats);
+// m: 3 workgroups per batch
+hipError_t launch_graph_scan(const Multi& m, hipStream_t s) {
+  hipLaunchKernelGGL(graph_scan_kernel, dim3(m.off[m.n]), dim3(1024), 0, s, m);
   return hipGetLastError();
 }
 
@@ -211,10 +251,20 @@ hipError_t launch_graph_scan(const GraphStatic& gs, const GraphDyn& gd, int B, u
 // score_model.py:111,114,123,259-264 applied at :286,311,352,660 on the features built at :504-518,534-535,578-580,658.
 // One lane per edge: all weight addresses are wave-uniform (scalar loads), the 2 x 32x32 products are straight-line
 // FMAs on register arrays, no cross-lane traffic; each lane writes its own 128-B row.
-__global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlp m, const float* __restrict__ dist, const float* __restrict__ bond4,
-                                                       const int* __restrict__ count, int cap, float* __restrict__ out) {
-  const int n = count ? min(*count, cap) : cap;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlpArgs a) {
+  // segment of this workgroup (every segment is padded to whole 256-edge workgroups)
+  int sg = 0, blk = blockIdx.x;
+  for (int i = 0; i < a.n; ++i) {
+    const int nb = (a.seg[i].cap + 255) / 256;
+    if (blk >= nb && i + 1 < a.n) { blk -= nb; sg = i + 1; } else break;
+  }
+  const EdgeSeg& S = a.seg[sg];
+  const EdgeMlp& m = S.m;
+  const float* __restrict__ dist = S.dist;
+  const float* __restrict__ bond4 = S.bond4;
+  float* __restrict__ out = S.out;
+  const int n = S.count ? min(*S.count, S.cap) : S.cap;
+  const int e = blk * 256 + threadIdx.x;
   if (e >= n) return;
   const float d = dist[e];
   float h[32];
@@ -247,9 +297,11 @@ __global__ __launch_bounds__(256) void edge_mlp_kernel(EdgeMlp m, const float* _
   for (int q = 0; q < 8; ++q) po[q] = f32x4{r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]};
 }
 
-hipError_t launch_edge_mlp(const EdgeMlp& m, const float* dist, const float* bond4, const int* count, int cap, float* out, hipStream_t s) {
-  if (cap <= 0) return hipSuccess;
-  hipLaunchKernelGGL(edge_mlp_kernel, dim3((cap + 255) / 256), dim3(256), 0, s, m, dist, bond4, count, cap, out);
+hipError_t launch_edge_mlp(const EdgeMlpArgs& a, hipStream_t s) {
+  int grid = 0;
+  for (int i = 0; i < a.n; ++i) grid += (a.seg[i].cap + 255) / 256;
+  if (grid <= 0) return hipSuccess;
+  hipLaunchKernelGGL(edge_mlp_kernel, dim3(grid), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
@@ -285,39 +337,45 @@ hipError_t launch_step_prep(const StepWeights& w, const StepVectors& v, const fl
   return hipGetLastError();
 }
 
-// node[b*Nl + a][c] = lig_static32[a][c] + lig_node_c[c] (c < 32), 0 elsewhere        (AtomEncoder, score_model.py:285)
-__global__ void lig_node_init_kernel(const float* __restrict__ st, const float* __restrict__ c32, float* __restrict__ node, int B, int Nl) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// X[xi][b*Nl + a][c] = lig_static32[a][c] + lig_node_c[c] (c < 32), 0 elsewhere        (AtomEncoder, score_model.py:285)
+__global__ void lig_node_init_kernel(Multi mm, const float* __restrict__ c32, int xi) {
+  int blk;
+  const PoseBatch& PB = locate(mm, blk);
+  const int Nl = PB.gs.Nl;
+  const int idx = blk * blockDim.x + threadIdx.x;
   const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
-  if (n >= B * Nl) return;
-  node[(size_t)n * NODE_STRIDE + c] = c < 32 ? st[(n % Nl) * 32 + c] + c32[c] : 0.f;
+  if (n >= PB.B * Nl) return;
+  PB.X[xi][(size_t)n * NODE_STRIDE + c] = c < 32 ? PB.lig_static32[(n % Nl) * 32 + c] + c32[c] : 0.f;
 }
-hipError_t launch_lig_node_init(const float* st, const float* c32, float* node, int B, int Nl, hipStream_t s) {
-  const int total = B * Nl * NODE_STRIDE;
-  hipLaunchKernelGGL(lig_node_init_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, c32, node, B, Nl);
+hipError_t launch_lig_node_init(const Multi& m, const float* c32, int xi, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL(lig_node_init_kernel, dim3(m.off[m.n]), dim3(256), 0, s, m, c32, xi);
   return hipGetLastError();
 }
 
-// node[nL + b*Nr + r] = rec_static[r] (+ rec_sigma_emb on the 32 scalars)              (score_model.py:324-325)
-__global__ void rec_node_init_kernel(const float* __restrict__ st, const float* __restrict__ se, float* __restrict__ node, int B, int rec_off, int Nr) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
-  if (n >= B * Nr) return;
-  const float v = st[(size_t)(n % Nr) * NODE_STRIDE + c];
-  node[(size_t)(rec_off + n) * NODE_STRIDE + c] = c < 32 ? v + se[c] : v;
+// Everything of a batch that depends on the diffusion time only, one launch: receptor rows
+//   X[xi][rec_off + b*Nr + r] = rec_static[r] (+ rec_sigma_emb on the 32 scalars)          (score_model.py:324-325)
+// followed by the receptor edge attributes rr_attr_t[e][c] = rr_attr0[e][c] + rec_sigma_emb[c]   (score_model.py:534-535).
+// Workgroups of a batch: ceil(B*Nr*NODE_STRIDE / 256) for the rows, then ceil(Err*32 / 256) for the attributes.
+__global__ void rec_time_init_kernel(Multi mm, const float* __restrict__ se, int xi) {
+  int blk;
+  const PoseBatch& PB = locate(mm, blk);
+  const int Nr = PB.gs.Nr;
+  const int row_blocks = (PB.B * Nr * NODE_STRIDE + 255) / 256;
+  if (blk < row_blocks) {
+    const int idx = blk * 256 + threadIdx.x;
+    const int n = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+    if (n >= PB.B * Nr) return;
+    const float v = PB.rec_static[(size_t)(n % Nr) * NODE_STRIDE + c];
+    PB.X[xi][(size_t)(PB.gs.rec_off + n) * NODE_STRIDE + c] = c < 32 ? v + se[c] : v;
+  } else {
+    const int idx = (blk - row_blocks) * 256 + threadIdx.x;
+    if (idx < PB.gs.Err * 32) PB.rr_attr_t[idx] = PB.rr_attr0[idx] + se[idx & 31];
+  }
 }
-hipError_t launch_rec_node_init(const float* st, const float* se, float* node, int B, int rec_off, int Nr, hipStream_t s) {
-  const int total = B * Nr * NODE_STRIDE;
-  hipLaunchKernelGGL(rec_node_init_kernel, dim3((total + 255) / 256), dim3(256), 0, s, st, se, node, B, rec_off, Nr);
-  return hipGetLastError();
-}
-
-__global__ void add_rows_kernel(const float* __restrict__ a, const float* __restrict__ v32, float* __restrict__ out, int rows) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx < rows * 32) out[idx] = a[idx] + v32[idx & 31];
-}
-hipError_t launch_add_rows(const float* a, const float* v32, float* out, int rows, hipStream_t s) {
-  hipLaunchKernelGGL(add_rows_kernel, dim3((rows * 32 + 255) / 256), dim3(256), 0, s, a, v32, out, rows);
+hipError_t launch_rec_time_init(const Multi& m, const float* se, int xi, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL(rec_time_init_kernel, dim3(m.off[m.n]), dim3(256), 0, s, m, se, xi);
   return hipGetLastError();
 }
 
@@ -327,10 +385,15 @@ hipError_t launch_add_rows(const float* a, const float* v32, float* out, int row
 // closed forms below (prototype + check against the Wigner-3j einsum: tests/test_kernel_math.py::final_conv_tp).
 // Stage 1: one workgroup per (sample, atom) edge -> 12-value message.  Stage 2: one wave per sample: mean over atoms in
 // index order (deterministic), BatchNorm, magnitude MLPs.
-__global__ __launch_bounds__(128) void center_msg_kernel(CenterHead h, StepVectors sv, const float* __restrict__ pos,
-                                                         const float* __restrict__ node, int Nl, float* __restrict__ msg) {
+__global__ __launch_bounds__(128) void center_msg_kernel(CenterHead h, StepVectors sv, Multi mm, int xi) {
   __shared__ float s_in[64], s_hid[64], s_w[124], s_c[3], s_g[32], s_eh[32];
-  const int b = blockIdx.x / Nl, a = blockIdx.x % Nl, tid = threadIdx.x;
+  int edge;   // (sample, atom) edge of this workgroup within its batch
+  const PoseBatch& PB = locate(mm, edge);
+  const int Nl = PB.gs.Nl;
+  const float* __restrict__ pos = PB.gd.pos;
+  const float* __restrict__ node = PB.X[xi];
+  float* __restrict__ msg = PB.center_msg;
+  const int b = edge / Nl, a = edge % Nl, tid = threadIdx.x;
   const float* P = pos + (size_t)b * Nl * 3;
   if (tid < 3) {
     float c = 0.f;
@@ -395,15 +458,20 @@ __global__ __launch_bounds__(128) void center_msg_kernel(CenterHead h, StepVecto
         r += pw_e * is3 * s_w[112 + u * 2 + wv] * x[COL_0O + u] * sh[k];
       }
     }
-    msg[(size_t)blockIdx.x * 12 + tid] = r;
+    msg[(size_t)edge * 12 + tid] = r;
   }
 }
 
-__global__ __launch_bounds__(64) void center_final_kernel(CenterHead h, StepVectors sv, const float* __restrict__ msg, int Nl,
-                                                          float tr_sigma, float rot_norm, float* __restrict__ tr_out,
-                                                          float* __restrict__ rot_out, float* __restrict__ dbg) {
+__global__ __launch_bounds__(64) void center_final_kernel(CenterHead h, StepVectors sv, Multi mm, float tr_sigma, float rot_norm) {
   __shared__ float s_acc[12];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  int b;
+  const PoseBatch& PB = locate(mm, b);
+  const int Nl = PB.gs.Nl;
+  const float* __restrict__ msg = PB.center_msg;
+  float* __restrict__ tr_out = PB.tr_out;
+  float* __restrict__ rot_out = PB.rot_out;
+  float* __restrict__ dbg = PB.dbg_global;
+  const int tid = threadIdx.x;
   if (tid < 12) {
     float a = 0.f;
     for (int k = 0; k < Nl; ++k) a += msg[((size_t)b * Nl + k) * 12 + tid];
@@ -431,13 +499,13 @@ __global__ __launch_bounds__(64) void center_final_kernel(CenterHead h, StepVect
   }
 }
 
-hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const float* pos, const float* node, int B, int Nl,
-                              float tr_sigma, float rot_norm, float* tr_out, float* rot_out, float* dbg_global, float* msg_ws,
-                              hipStream_t s) {
-  hipLaunchKernelGGL(center_msg_kernel, dim3(B * Nl), dim3(128), 0, s, h, v, pos, node, Nl, msg_ws);
+// m_atoms: B * Nl workgroups per batch; m_samples: B per batch
+hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const Multi& m_atoms, const Multi& m_samples, int xi,
+                              float tr_sigma, float rot_norm, hipStream_t s) {
+  hipLaunchKernelGGL(center_msg_kernel, dim3(m_atoms.off[m_atoms.n]), dim3(128), 0, s, h, v, m_atoms, xi);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(center_final_kernel, dim3(B), dim3(64), 0, s, h, v, msg_ws, Nl, tr_sigma, rot_norm, tr_out, rot_out, dbg_global);
+  hipLaunchKernelGGL(center_final_kernel, dim3(m_samples.off[m_samples.n]), dim3(64), 0, s, h, v, m_samples, tr_sigma, rot_norm);
   return hipGetLastError();
 }
 
@@ -450,10 +518,16 @@ hipError_t launch_center_head(const CenterHead& h, const StepVectors& v, const f
 // its <= 32 neighbour slots, mean over slots, BatchNorm, tor_final_layer.
 constexpr int TOR_SLOTS = 32;
 
-__global__ __launch_bounds__(64) void bond_nb_kernel(GraphStatic gs, const float* __restrict__ pos, float lig_r2, int cap,
-                                                     int* __restrict__ nb, int* __restrict__ nb_cnt, int* __restrict__ tor_edge_count) {
+__global__ __launch_bounds__(64) void bond_nb_kernel(Multi mm, float lig_r2, int cap) {
+  int bond;
+  const PoseBatch& PB = locate(mm, bond);
+  const GraphStatic gs = PB.gs;
+  const float* __restrict__ pos = PB.gd.pos;
+  int* __restrict__ nb = PB.tor_nb;
+  int* __restrict__ nb_cnt = PB.tor_nb_cnt;
+  int* __restrict__ tor_edge_count = PB.gd.counts + 4;
   const int tid = threadIdx.x;
-  const int b = blockIdx.x / gs.R, rho = blockIdx.x % gs.R, Nl = gs.Nl;
+  const int b = bond / gs.R, rho = bond % gs.R, Nl = gs.Nl;
   const float* P = pos + (size_t)b * Nl * 3;
   const int u = gs.rot_u[rho], v = gs.rot_v[rho];
   const float bx = (P[3 * u] + P[3 * v]) / 2, by = (P[3 * u + 1] + P[3 * v + 1]) / 2, bz = (P[3 * u + 2] + P[3 * v + 2]) / 2;
@@ -464,20 +538,20 @@ __global__ __launch_bounds__(64) void bond_nb_kernel(GraphStatic gs, const float
     if (a < Nl) in = dist2_nofma(P[3 * a], P[3 * a + 1], P[3 * a + 2], bx, by, bz) < lig_r2;
     const unsigned long long m = __ballot(in);
     const int slot = n + popc_below(m, tid);
-    if (in && slot < cap && slot < TOR_SLOTS) nb[(size_t)blockIdx.x * TOR_SLOTS + slot] = a;
+    if (in && slot < cap && slot < TOR_SLOTS) nb[(size_t)bond * TOR_SLOTS + slot] = a;
     n += __popcll(m);
   }
   if (tid == 0) {
     const int ne = min(n, min(cap, TOR_SLOTS));
-    nb_cnt[blockIdx.x] = ne;
-    if (tor_edge_count) atomicAdd(tor_edge_count, ne);
+    nb_cnt[bond] = ne;
+    atomicAdd(tor_edge_count, ne);
   }
 }
 
-hipError_t launch_bond_nb(const GraphStatic& gs, const float* pos, int B, float lig_r, int cap, int* nb_ws, int* nb_cnt_ws, int* tor_edge_count,
-                          hipStream_t s) {
-  if (gs.R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bond_nb_kernel, dim3(B * gs.R), dim3(64), 0, s, gs, pos, lig_r * lig_r, cap, nb_ws, nb_cnt_ws, tor_edge_count);
+// m: B * R workgroups per batch
+hipError_t launch_bond_nb(const Multi& m, float lig_r, int cap, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bond_nb_kernel, dim3(m.off[m.n]), dim3(64), 0, s, m, lig_r * lig_r, cap);
   return hipGetLastError();
 }
 
@@ -507,13 +581,21 @@ CBD_DEV double wave_sum_d(double v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void pose_update_kernel(GraphStatic gs, float* __restrict__ pos, const float* __restrict__ tr,
-                                                         const float* __restrict__ rot, const float* __restrict__ tor,
-                                                         const float* __restrict__ z_tr, const float* __restrict__ z_rot,
-                                                         const float* __restrict__ z_tor, SdeCoefs cf, int use_coefs) {
+__global__ __launch_bounds__(64) void pose_update_kernel(Multi mm, int step, SdeCoefs cf, int use_coefs, int with_torsion) {
   extern __shared__ float sp[];   // [Nl][3] flexible pose, [Nl][3] rigid pose
-  const int b = blockIdx.x, lane = lane_id();
-  const int Nl = gs.Nl, R = gs.R;
+  int b;
+  const PoseBatch& PB = locate(mm, b);
+  const GraphStatic gs = PB.gs;
+  const int lane = lane_id();
+  const int Nl = gs.Nl, R = gs.R, B = PB.B;
+  float* __restrict__ pos = PB.gd.pos;
+  const float* __restrict__ tr = PB.tr_out;
+  const float* __restrict__ rot = PB.rot_out;
+  const float* __restrict__ tor = with_torsion ? PB.tor_out : nullptr;
+  // noise rows of this step; a term whose coefficient is 0 is skipped (no_final_step_noise / ODE, utils/sampling.py:119-141)
+  const float* __restrict__ z_tr = (use_coefs && PB.z_tr && cf.tr_n != 0.f) ? PB.z_tr + (size_t)step * B * 3 : nullptr;
+  const float* __restrict__ z_rot = (use_coefs && PB.z_rot && cf.rot_n != 0.f) ? PB.z_rot + (size_t)step * B * 3 : nullptr;
+  const float* __restrict__ z_tor = (use_coefs && PB.z_tor && cf.tor_n != 0.f) ? PB.z_tor + (size_t)step * B * R : nullptr;
   float* flex = sp;
   float* rigid = sp + 3 * Nl;
   float* P = pos + (size_t)b * Nl * 3;
@@ -627,12 +709,9 @@ __global__ __launch_bounds__(64) void pose_update_kernel(GraphStatic gs, float* 
   }
 }
 
-hipError_t launch_pose_update(const GraphStatic& gs, float* pos, int B, const float* tr, const float* rot, const float* tor,
-                              const float* z_tr, const float* z_rot, const float* z_tor, const SdeCoefs* coefs, hipStream_t s) {
-  SdeCoefs c{};
-  if (coefs) c = *coefs;
-  hipLaunchKernelGGL(pose_update_kernel, dim3(B), dim3(64), gs.Nl * 6 * sizeof(float), s, gs, pos, tr, rot, tor, z_tr, z_rot, z_tor,
-                     c, coefs ? 1 : 0);
+// m: B workgroups per batch; max_nl: the largest Nl among the batches (dynamic LDS)
+hipError_t launch_pose_update(const Multi& m, int step, const SdeCoefs& coefs, int use_coefs, int with_torsion, int max_nl, hipStream_t s) {
+  hipLaunchKernelGGL(pose_update_kernel, dim3(m.off[m.n]), dim3(64), max_nl * 6 * sizeof(float), s, m, step, coefs, use_coefs, with_torsion);
   return hipGetLastError();
 }
 
@@ -750,7 +829,7 @@ __global__ __launch_bounds__(256) void node_proj_kernel(ProjArgs a) {
   for (int r = 0; r < 4; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.f;
   const float* xr[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) xr[r] = a.node_in + (size_t)(J.lo + (r0 + r < J.n ? r0 + r : J.n - 1)) * NODE_STRIDE;   // clamped: no divergent loads
+  for (int r = 0; r < 4; ++r) xr[r] = J.node_in + (size_t)(J.lo + (r0 + r < J.n ? r0 + r : J.n - 1)) * NODE_STRIDE;   // clamped: no divergent loads
 #pragma unroll
   for (int k4 = 0; k4 < NS / 4; ++k4) {
     f32x4 x[4];

@@ -314,15 +314,30 @@ __global__ void conv_finalize_kernel(FinArgs fa, const float* __restrict__ node_
   finalize_one(fa, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, node_off);
 }
 
-// both node types of a joint layer in one launch: nodes [0, n0) use the ligand-side groups, [n0, n0 + n1) the receptor-side
-__global__ void conv_finalize2_kernel(FinArgs fa0, int n0, int off0, FinArgs fa1, int n1, int off1, const float* __restrict__ node_in,
-                                      float* __restrict__ node_out, const float* __restrict__ bn_scale,
-                                      const float* __restrict__ bn_mean, const float* __restrict__ bn_bias, int in_dim, int out_dim) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+// One layer of every co-scheduled batch in one launch.  kind (FinKind): FIN_EMB ligand rows with the embedding layer's slices;
+// FIN_FIRST ligand rows + receptor rows with the shared layer-0 receptor group; FIN_MID ligand + receptor rows; FIN_LAST ligand
+// rows only (the receptor rows of the last interaction layer are never read, reference quirk 3).
+__device__ __forceinline__ const PoseBatch& fin_locate(const Multi& m, int& local) {
+  int k = 0;
+#pragma unroll
+  for (int i = 1; i < MAX_COSCHED; ++i) k = (i < m.n && (int)blockIdx.x >= m.off[i]) ? i : k;
+  local = blockIdx.x - m.off[k];
+  return *m.d[k];
+}
+
+__global__ void conv_finalize_multi_kernel(Multi mm, int kind, int xi_in, int xi_out, const float* __restrict__ bn_scale,
+                                           const float* __restrict__ bn_mean, const float* __restrict__ bn_bias, int in_dim, int out_dim) {
+  int blk;
+  const PoseBatch& PB = fin_locate(mm, blk);
+  const int idx = blk * blockDim.x + threadIdx.x;
   const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
+  const int n0 = PB.B * PB.gs.Nl, n1 = (kind == FIN_FIRST || kind == FIN_MID) ? PB.B * PB.gs.Nr : 0;
   if (i >= n0 + n1) return;
-  if (i < n0) finalize_one(fa0, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, off0);
-  else finalize_one(fa1, node_in, node_out, bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim, off1);
+  const float* node_in = PB.X[xi_in];
+  float* node_out = PB.X[xi_out];
+  if (i < n0) finalize_one(kind == FIN_EMB ? PB.fin_emb : PB.fin_lig, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, 0);
+  else finalize_one(kind == FIN_FIRST ? PB.fin_rec_shared : PB.fin_rec, node_in, node_out, bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim,
+                    PB.gs.rec_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -335,15 +350,20 @@ __global__ void conv_finalize2_kernel(FinArgs fa0, int n0, int off0, FinArgs fa1
 //   per bond: mean over its edges -> BatchNorm -> tor_final_layer -> * sqrt(torus score norm)
 // Weight stream: 3 tiles of W1, then one tile per mid index (6 of path A, 6 of path B), 32 outputs each.
 constexpr int BOND_TILES = 15;
-__global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, GraphStatic gs, const float* __restrict__ pos,
-                                                       const float* __restrict__ node, const int* __restrict__ nb,
-                                                       const int* __restrict__ nb_cnt, const float* __restrict__ wstream,
-                                                       float tor_norm_sqrt, float* __restrict__ tor_out, float* __restrict__ dbg_feat) {
+__global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, Multi mm, int xi, const float* __restrict__ wstream, float tor_norm_sqrt) {
   __shared__ __attribute__((aligned(16))) float bias_l[BOND_TILES * 32];
   __shared__ float msg_l[64 * 33];
   __shared__ float s_feat[64];
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
-  const int bond = blockIdx.x;
+  int bond;
+  const PoseBatch& PB = fin_locate(mm, bond);
+  const GraphStatic gs = PB.gs;
+  const float* __restrict__ pos = PB.gd.pos;
+  const float* __restrict__ node = PB.X[xi];
+  const int* __restrict__ nb = PB.tor_nb;
+  const int* __restrict__ nb_cnt = PB.tor_nb_cnt;
+  float* __restrict__ tor_out = PB.tor_out;
+  float* __restrict__ dbg_feat = PB.dbg_torfeat;
   const int ne = nb_cnt[bond];
   const int b = bond / gs.R, rho = bond % gs.R, Nl = gs.Nl;
   const float* P = pos + (size_t)b * Nl * 3;
@@ -472,10 +492,10 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, GraphStatic g
   }
 }
 
-hipError_t launch_bond_conv(const BondHead& h, const GraphStatic& gs, const float* pos, const float* node, int B, const int* nb,
-                            const int* nb_cnt, const float* wstream, float tor_norm_sqrt, float* tor_out, float* dbg_feat, hipStream_t s) {
-  if (gs.R <= 0) return hipSuccess;
-  hipLaunchKernelGGL(bond_conv_kernel, dim3(B * gs.R), dim3(64), 0, s, h, gs, pos, node, nb, nb_cnt, wstream, tor_norm_sqrt, tor_out, dbg_feat);
+// m: B * R workgroups per batch
+hipError_t launch_bond_conv(const BondHead& h, const Multi& m, int xi, const float* wstream, float tor_norm_sqrt, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL(bond_conv_kernel, dim3(m.off[m.n]), dim3(64), 0, s, h, m, xi, wstream, tor_norm_sqrt);
   return hipGetLastError();
 }
 
@@ -493,25 +513,7 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   return hipGetLastError();
 }
 
-// bf16-operand variant (cbd_set_option("bf16", 1), BASELINE.json configs[3]): the same kernel with OpsBf16 -- weights packed as
-// bf16 (pack_conv_stream_bf16), gathered inputs / hidden activations converted in registers (v_cvt_pk_bf16_f32); node features,
-// CG contraction, messages and the segmented reduction stay fp32.  Tolerance vs the fp32 path: tests/test_gpu_bf16.py.
-template <int IN, int OUT>
-static hipError_t launch_one_bf16(const ConvArgs& a, int grid, hipStream_t s) {
-  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
-  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsBf16>), dim3(grid), dim3(64), lds_bytes, s, a);
-  return hipGetLastError();
-}
-
-hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s) {
-  if (grid <= 0) return hipSuccess;
-  if (in_level == 0 && out_level == 1) return launch_one_bf16<0, 1>(a, grid, s);
-  if (in_level == 1 && out_level == 2) return launch_one_bf16<1, 2>(a, grid, s);
-  if (in_level == 2 && out_level == 3) return launch_one_bf16<2, 3>(a, grid, s);
-  if (in_level == 3 && out_level == 3) return launch_one_bf16<3, 3>(a, grid, s);
-  return hipErrorInvalidValue;
-}
-
+// The bf16-operand variant (cbd_set_option("bf16", 1), BASELINE.json configs[3]) lives in tp_conv_bf16.hip (64 edges per wave).
 template <int IN, int OUT>
 static hipError_t launch_one_x3(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
@@ -547,13 +549,12 @@ hipError_t launch_conv_finalize(const FinArgs& fa, const float* node_in, float* 
   return hipGetLastError();
 }
 
-hipError_t launch_conv_finalize2(const FinArgs& fa0, int n0, int off0, const FinArgs& fa1, int n1, int off1, const float* node_in,
-                                 float* node_out, const float* bn_scale, const float* bn_mean, const float* bn_bias, int in_dim,
-                                 int out_dim, hipStream_t s) {
-  const int total = (n0 + n1) * NODE_STRIDE;
-  if (total <= 0) return hipSuccess;
-  hipLaunchKernelGGL(conv_finalize2_kernel, dim3((total + 255) / 256), dim3(256), 0, s, fa0, n0, off0, fa1, n1, off1, node_in, node_out,
-                     bn_scale, bn_mean, bn_bias, in_dim, out_dim);
+// m: ceil((n0 + n1) * NODE_STRIDE / 256) workgroups per batch with n0 = B * Nl and n1 = B * Nr for the kinds that include receptor rows
+hipError_t launch_conv_finalize_multi(const Multi& m, int kind, int xi_in, int xi_out, const float* bn_scale, const float* bn_mean,
+                                      const float* bn_bias, int in_dim, int out_dim, hipStream_t s) {
+  if (m.off[m.n] <= 0) return hipSuccess;
+  hipLaunchKernelGGL(conv_finalize_multi_kernel, dim3(m.off[m.n]), dim3(256), 0, s, m, kind, xi_in, xi_out, bn_scale, bn_mean, bn_bias,
+                     in_dim, out_dim);
   return hipGetLastError();
 }
 

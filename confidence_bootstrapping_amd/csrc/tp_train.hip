@@ -435,6 +435,36 @@ __global__ __launch_bounds__(64, 2) void outer_accum_kernel(const float* __restr
 
 }  // namespace cbd
 
+namespace cbd {
+
+// Deterministic segmented sum: out[n][c] = sum_{k in [rowptr[n], rowptr[n+1])} vals[perm[k]][c], added in index order (no atomics).
+// Stands in for torch_scatter.scatter(..., reduce='sum') in TensorProductConvLayer.forward (reference models/tensor_layers.py:206;
+// the mean divides afterwards) and for the backward of the node gathers `node_attr[edge_dst]` (an index_add in autograd) in the
+// fine-tuning step: with every scatter in a fixed order the training step is bitwise repeatable.
+// One wave per output row, lanes over columns (rows of <= 128 floats are read as coalesced segments), 4 gathered rows in flight.
+__global__ __launch_bounds__(256) void segment_sum_kernel(int64_t n_rows, int width, const float* __restrict__ vals,
+                                                          const int64_t* __restrict__ perm, const int64_t* __restrict__ rowptr,
+                                                          float* __restrict__ out) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= n_rows) return;
+  const int64_t lo = rowptr[row], hi = rowptr[row + 1];
+  for (int c = lane; c < width; c += 64) {
+    float acc = 0.f;
+    int64_t k = lo;
+    for (; k + 4 <= hi; k += 4) {
+      const int64_t p0 = perm[k], p1 = perm[k + 1], p2 = perm[k + 2], p3 = perm[k + 3];
+      const float v0 = vals[p0 * width + c], v1 = vals[p1 * width + c], v2 = vals[p2 * width + c], v3 = vals[p3 * width + c];
+      acc = ((acc + v0) + v1) + v2;
+      acc += v3;
+    }
+    for (; k < hi; ++k) acc += vals[perm[k] * width + c];
+    out[row * width + c] = acc;
+  }
+}
+
+}  // namespace cbd
+
 extern "C" {
 
 int64_t cbd_tp_packed_width(int32_t in_level, int32_t out_level) {
@@ -495,6 +525,17 @@ int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n
                      chunk, partial_dev);
   const hipError_t r = hipGetLastError();
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_outer_accum: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
+                    float* out_dev, void* stream) {
+  if (n_rows < 0 || width <= 0 || !rowptr_dev || !out_dev) return fail(CBD_ERR_ARG, "bad argument");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(cbd::segment_sum_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_segment_sum: %s", hipGetErrorString(r));
   return 0;
 }
 

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import LEVEL_DIMS, NODE_STRIDE, first_linear, stream_map, tensor_product
+from .train_ops import LEVEL_DIMS, NODE_STRIDE, csr_of, first_linear, gather_rows, scatter_sum, stream_map, tensor_product
 
 SQ3 = math.sqrt(3.0)
 
@@ -105,16 +105,18 @@ def radius_graph(x, r, batch, max_num_neighbors=32):
 
 
 def scatter_mean(src, index, dim_size):
-    out = torch.zeros((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    out = out.index_add(0, index, src)
-    cnt = torch.zeros(dim_size, dtype=src.dtype, device=src.device).index_add(0, index, torch.ones_like(index, dtype=src.dtype))
+    """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce='mean') with the sum in a fixed order (train_ops.scatter_sum:
+    `cbd_segment_sum`, no atomics)."""
+    out = scatter_sum(src, index, dim_size)
+    cnt = csr_of(index, dim_size).counts.to(src.dtype) if index.shape[0] else torch.zeros(dim_size, dtype=src.dtype, device=src.device)
     return out / cnt.clamp(min=1).reshape((dim_size,) + (1,) * (src.dim() - 1))
 
 
 def take(x, idx):
-    """x[idx] along dim 0 through index_select: its backward is one atomic index_add (torch's fancy-index backward sorts the
-    indices first -- 30 % of the step's GPU time in the first profile, profiles/r01_h_train_*)."""
-    return x.index_select(0, idx)
+    """x[idx] along dim 0 whose backward is a fixed-order segmented sum (train_ops.gather_rows) -- autograd's own backward for an
+    index is an atomic index_add (non-deterministic), torch's fancy-index backward additionally sorts (30 % of the step's GPU time in
+    the first profile, profiles/r01_h_train_*)."""
+    return gather_rows(x, idx)
 
 
 def gaussian_smearing(mod, dist):
@@ -255,6 +257,8 @@ def forward(model, data):
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
+    from .train_ops import clear_csr_cache
+    clear_csr_cache()          # edge groupings are per step (the graphs change with the poses)
     data = collate(data, dev)
     ns = model.ns
     lig, rec = data["ligand"], data["receptor"]
@@ -339,7 +343,7 @@ def forward(model, data):
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
     counts = torch.bincount(lig_batch, minlength=B).unsqueeze(1)
-    center = torch.zeros(B, 3, device=dev).index_add(0, lig_batch, lig_pos) / counts
+    center = scatter_sum(lig_pos, lig_batch, B) / counts
     c_vec2 = lig_pos - center[lig_batch]
     c_attr = torch.cat([gaussian_smearing(model.center_distance_expansion, c_vec2.norm(dim=-1)), node_sigma_emb], 1)
     c_attr = torch.cat([model.center_edge_embedding(c_attr), lig_node[:, :ns]], -1)

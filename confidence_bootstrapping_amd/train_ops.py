@@ -241,3 +241,91 @@ def first_linear(x, linear):
     if x.shape[0] == 0:
         return x.new_zeros(0, linear.weight.shape[0]) + 0 * linear.bias
     return FirstLinearFn.apply(x, linear.weight, linear.bias)
+
+
+# ----------------------------------------------------------------------------- deterministic scatter / gather
+# The reference's training graph scatters with atomics twice per layer: torch_scatter.scatter in TensorProductConvLayer.forward
+# (models/tensor_layers.py:206) and autograd's index_add for every `node_attr[edge_index]` gather.  Atomic float adds make the step
+# differ from run to run in the last bits.  Here every scatter is a segmented sum over edges grouped by target row (`cbd_segment_sum`,
+# fixed order), so a training step is bitwise repeatable; the grouping (stable argsort + row pointers) is cached per index tensor.
+class Csr:
+    """Edges grouped by target row: perm = stable argsort of `index`, rowptr = exclusive scan of the per-row counts."""
+
+    def __init__(self, index: torch.Tensor, n_rows: int):
+        index = index.long()
+        self.n_rows = int(n_rows)
+        self.index = index
+        self.perm = torch.argsort(index, stable=True)
+        counts = torch.bincount(index, minlength=self.n_rows)
+        self.counts = counts
+        self.rowptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+
+
+_CSR_CACHE = {}
+
+
+def csr_of(index: torch.Tensor, n_rows: int) -> Csr:
+    key = (index.data_ptr(), int(index.shape[0]), int(index.stride(0)), str(index.dtype), int(n_rows), str(index.device), index._version)
+    c = _CSR_CACHE.get(key)
+    if c is None:
+        if len(_CSR_CACHE) > 256:
+            _CSR_CACHE.clear()
+        c = Csr(index, n_rows)
+        c.keep = index             # keeps the storage alive: the data_ptr in the key cannot be recycled while the entry exists
+        _CSR_CACHE[key] = c
+    return c
+
+
+def clear_csr_cache():
+    _CSR_CACHE.clear()
+
+
+def _segment_sum(vals: torch.Tensor, csr: Csr) -> torch.Tensor:
+    if not vals.is_cuda:
+        raise RuntimeError("segment_sum runs on the MI355X only (HIP kernel, no CPU fallback)")
+    lib = _bind(load_library())
+    v = vals.contiguous().float()
+    v2 = v.reshape(v.shape[0], -1)
+    out = torch.empty(csr.n_rows, v2.shape[1], device=v.device, dtype=torch.float32)
+    if v2.shape[1] == 0 or csr.n_rows == 0:
+        return out.reshape((csr.n_rows,) + tuple(v.shape[1:]))
+    _check(lib.cbd_segment_sum(csr.n_rows, v2.shape[1], _ptr(v2), _ptr(csr.perm), _ptr(csr.rowptr), _ptr(out), _stream_handle()))
+    return out.reshape((csr.n_rows,) + tuple(v.shape[1:]))
+
+
+class ScatterSumFn(torch.autograd.Function):
+    """out[n] = sum_{e: index[e] = n} src[e]  (fixed order); backward = gather."""
+
+    @staticmethod
+    def forward(ctx, src, csr):
+        ctx.csr = csr
+        return _segment_sum(src, csr)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.index_select(0, ctx.csr.index), None
+
+
+class GatherFn(torch.autograd.Function):
+    """x[index]; backward = segmented sum of the incoming gradient rows per source row (fixed order) instead of an atomic index_add."""
+
+    @staticmethod
+    def forward(ctx, x, csr):
+        ctx.csr = csr
+        return x.index_select(0, csr.index)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _segment_sum(g, ctx.csr), None
+
+
+def scatter_sum(src, index, dim_size):
+    if src.shape[0] == 0:
+        return src.new_zeros((dim_size,) + tuple(src.shape[1:]))
+    return ScatterSumFn.apply(src, csr_of(index, dim_size))
+
+
+def gather_rows(x, index):
+    if index.shape[0] == 0:
+        return x.index_select(0, index)
+    return GatherFn.apply(x, csr_of(index, x.shape[0]))

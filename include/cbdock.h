@@ -260,6 +260,14 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
 int64_t cbd_outer_accum_part_floats(void);
 int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n_parts, float* partial_dev, void* stream);
 
+/* Deterministic segmented sum for the fine-tuning step: out[n][c] = sum over k in [rowptr[n], rowptr[n+1]) of vals[perm[k]][c], added in
+ * index order.  Replaces the atomic scatters of the reference's training graph -- torch_scatter.scatter in
+ * TensorProductConvLayer.forward (models/tensor_layers.py:206) and autograd's index_add for node_attr[edge_dst] -- so that a training
+ * step is bitwise repeatable.  vals [E][width], perm [E] (edges grouped by target row: a stable argsort of the scatter index),
+ * rowptr [n_rows + 1]; out [n_rows][width].  Device pointers, int64 indices (torch's index dtype). */
+int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
+                    float* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

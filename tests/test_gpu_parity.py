@@ -375,3 +375,75 @@ def test_sample_pair_equals_two_samples():
     q = inputs[0][0].clone()
     e0.sample(q, steps, *inputs[0][1])
     assert torch.equal(q, ref[0])
+
+
+def test_multi_complex_graph_replay_equals_eager():
+    """One engine group, many complexes, one hipGraph: the S-step loop of three DIFFERENT complexes (different Nl / Nr / R / B) captured
+    once and replayed is bitwise the eager multi-complex run, which is bitwise the three separate cbd_sample calls; a change of a
+    batch size or of a complex re-captures instead of replaying a stale graph."""
+    import copy
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, make_complex
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    dev = torch.device("cuda:0")
+    model, args = make_score_model(device=dev, seed=0)
+    cps = [make_workload("tiny"), make_complex(Nl=17, Nr=60, R=3, knn=10, seed=77), make_complex(Nl=9, Nr=33, R=0, knn=8, seed=78)]
+    Bs = [5, 3, 6]
+    S = 5
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    engs = [DockEngine.from_model(model, dev, max_batch=8)]
+    for _ in range(2):
+        e = DockEngine(dev, max_batch=8)
+        e.share_weights_from(engs[0])
+        engs.append(e)
+    g = torch.Generator().manual_seed(4)
+    inputs = []
+    for e, c, B in zip(engs, cps, Bs):
+        e.set_complex(c)
+        torch.manual_seed(B); np.random.seed(B)
+        dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        R = int(c["ligand"].edge_mask.sum())
+        inputs.append((torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous(),
+                       [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * R, generator=g).to(dev)]))
+    ref = []
+    for e, (p, nz) in zip(engs, inputs):
+        q = p.clone()
+        e.sample(q, steps, *nz)
+        ref.append(q)
+
+    def run_multi(which=(0, 1, 2), cut=None):
+        ps = [inputs[k][0].clone() if cut is None or k != 0 else inputs[k][0][:cut].clone() for k in which]
+        nzs = [inputs[k][1] if cut is None or k != 0 else [inputs[0][1][0][:, :cut].contiguous(), inputs[0][1][1][:, :cut].contiguous(),
+                                                         inputs[0][1][2][:, :cut * 2].contiguous()] for k in which]
+        DockEngine.sample_multi([engs[k] for k in which], ps, steps, nzs)
+        torch.cuda.synchronize()
+        return ps
+    eager = run_multi()
+    assert all(torch.equal(a, b) for a, b in zip(eager, ref))
+    for e in engs:
+        e.set_option("graph", 1)
+    try:
+        for _ in range(3):                                   # capture, then two replays
+            got = run_multi()
+            assert all(torch.equal(a, b) for a, b in zip(got, ref))
+        # a smaller batch of complex 0 (tiny has R = 2): new key -> new capture, results = the first rows of the reference
+        got = run_multi(cut=2)
+        assert torch.equal(got[0], ref[0][:2]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
+        # another complex on engine 2: the stale graph must not be replayed
+        engs[2].set_complex(cps[1])
+        engs[2].set_option("graph", 1)
+        p2 = inputs[1][0].clone()
+        DockEngine.sample_multi([engs[0], engs[2]], [inputs[0][0].clone(), p2], steps, [inputs[0][1], inputs[1][1]])
+        torch.cuda.synchronize()
+        assert torch.equal(p2, ref[1])
+        # single engine under graph replay (cbd_sample) as before
+        q = inputs[0][0].clone()
+        engs[0].sample(q, steps, *inputs[0][1])
+        assert torch.equal(q, ref[0])
+    finally:
+        for e in engs:
+            e.set_option("graph", 0)
