@@ -350,12 +350,14 @@ def main():
                 m = 1
             for e in engines[:m]:
                 e.recompute_receptor()
+            GROUPS_RUN.append(m)
             if m == 1:
                 eng.sample(pos0[k], steps, *noise[k])
             else:
                 DockEngine.sample_multi(engines[:m], [pos0[k + q] for q in range(m)], steps, [noise[k + q] for q in range(m)])
             k += m
 
+    GROUPS_RUN = []
     run(0, a.warmup)
     torch.cuda.synchronize()
     alt_k = list(range(max(a.warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
@@ -366,6 +368,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    GROUPS_RUN.clear()
     t0 = time.perf_counter()
     run(a.warmup, n_runs)
     final = gather_poses(pos0[n_runs - 1], world, rank)

@@ -76,7 +76,7 @@ struct cbd_engine {
   // hipGraph of the step loop (optional).  The first engine of a co-scheduled group owns the instantiated graphs of the group
   // (key: schedule, batch sizes, engines and their complex generations); every engine owns its staging buffers.
   bool use_graph = false;
-  struct GraphEntry { std::string key; hipGraphExec_t exec; };
+  struct GraphEntry { std::string key; hipGraphExec_t exec; size_t ev_lo, ev_hi; bool replayed; };   // [ev_lo, ev_hi): timing events recorded by its nodes
   std::vector<GraphEntry> graphs;
   float *g_pos = nullptr, *g_ztr = nullptr, *g_zrot = nullptr, *g_ztor = nullptr;
   int g_S_cap = 0;
@@ -126,6 +126,7 @@ static void fill_static_desc(cbd_engine* e);
 static void drop_graphs(cbd_engine* e) {
   for (auto& g : e->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (!e->graphs.empty()) e->ev_used = 0;   // the event pairs their nodes recorded into are free again
   e->graphs.clear();
   ++e->complex_gen;
 }
@@ -1127,8 +1128,8 @@ static int check_batch(cbd_engine* e, int B) {
   return 0;
 }
 
-static void collect_timing(cbd_engine* e) {
-  for (size_t i = 0; i < e->ev_used; ++i) {
+static void collect_range(cbd_engine* e, size_t lo, size_t hi) {
+  for (size_t i = lo; i < hi; ++i) {
     float ms = 0.f;
     if (hipEventSynchronize(e->ev_pool[i].second) == hipSuccess &&
         hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) {
@@ -1136,7 +1137,18 @@ static void collect_timing(cbd_engine* e) {
       e->t_n += 1;
     }
   }
-  e->ev_used = 0;
+}
+
+// Eager launches: every launch since the last collection has its own event pair.  Captured graphs: the pairs are nodes of the graph
+// and hold the durations of its most recent replay; only graphs replayed since the last reset are read.
+static void collect_timing(cbd_engine* e) {
+  if (e->graphs.empty()) {
+    collect_range(e, 0, e->ev_used);
+    e->ev_used = 0;
+    return;
+  }
+  for (auto& g : e->graphs)
+    if (g.replayed) { collect_range(e, g.ev_lo, g.ev_hi); g.replayed = false; }
 }
 
 int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* step, float* tr_dev, float* rot_dev, float* tor_dev,
@@ -1206,6 +1218,8 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
     }
     return 0;
   };
+  // Kernel timing needs eager launches: event-record nodes captured into a graph cannot be queried afterwards on this runtime
+  // (hipEventSynchronize / hipEventElapsedTime on them return "invalid resource handle", measured in round 2).
   bool graph_ok = e0->use_graph && !scores_out;
   for (int k = 0; k < n; ++k) graph_ok = graph_ok && !E[k]->timing && !E[k]->keep_debug;
   if (!graph_ok) {
@@ -1236,8 +1250,8 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       ++e->complex_gen;
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "|%p:%u:%d:%d:%d", (void*)e, e->complex_gen, (int)B[k], e->use_bf16,
-             (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr));
+    snprintf(buf, sizeof buf, "|%p:%u:%d:%d:%d:%d", (void*)e, e->complex_gen, (int)B[k], e->use_bf16,
+             (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr), (int)e->timing);
     key += buf;
   }
   // descriptors point at the staging buffers; refreshed before every launch (an eager call in between may have re-pointed them)
@@ -1248,9 +1262,10 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
   }
   hipGraphExec_t exec = nullptr;
   for (auto& g : e0->graphs)
-    if (g.key == key) exec = g.exec;
+    if (g.key == key) { exec = g.exec; g.replayed = true; }
   if (!exec) {
     hipGraph_t graph = nullptr;
+    const size_t ev_lo = e0->ev_used;
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = run_steps(nullptr);
     const hipError_t ce = hipStreamEndCapture(s, &graph);
@@ -1263,7 +1278,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       (void)hipGraphExecDestroy(e0->graphs.front().exec);
       e0->graphs.erase(e0->graphs.begin());
     }
-    e0->graphs.push_back({key, exec});
+    e0->graphs.push_back({key, exec, ev_lo, e0->ev_used, true});
   }
   for (int k = 0; k < n; ++k) {
     cbd_engine* e = E[k];
@@ -1452,7 +1467,11 @@ int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_
   if (!e) return fail(CBD_ERR_ARG, "null engine");
   (void)hipSetDevice(e->cfg.device);
   if (e->ev_used) { HIPCHK(hipDeviceSynchronize()); collect_timing(e); }
-  if (reset) { e->t_total_ms = 0; e->t_n = 0; e->ev_used = 0; }
+  if (reset) {
+    e->t_total_ms = 0; e->t_n = 0;
+    if (e->graphs.empty()) e->ev_used = 0;   // pairs recorded by captured graphs stay reserved
+    for (auto& g : e->graphs) g.replayed = false;
+  }
   e->timing = enable != 0;
   if (avg_ms) *avg_ms = e->t_n ? e->t_total_ms / (double)e->t_n : 0.0;
   if (n) *n = e->t_n;

@@ -166,8 +166,10 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
 #pragma unroll 1
   for (int i = i_lo; i < i_hi; ++i) {
-    CBD_TILE(h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
+    // the mid is read from LDS BEFORE the MFMA chain (the scheduling fences of the chain keep the read above it; its wait lands at the
+    // first use below): the LDS latency is covered by the tile's MFMAs instead of being exposed after them
     const float m = mid0e<IN>(xc, i, v);
+    CBD_TILE(h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
   }
@@ -182,17 +184,18 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
+      float m[VEC_TILE_I][3];   // the five mids of the tile, evaluated (LDS reads + cross products) before the MFMA chain
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) mid_fn(xc, VEC_TILE_I * t + q, v, m[q]);
       CBD_TILE(h1, T + 1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
-        float m[3];
-        mid_fn(xc, VEC_TILE_I * t + q, v, m);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float w = acc[3 * q + o];
-          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
-          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
-          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
+          keep[3 * o + 0] = fmaf(m[q][0], w, keep[3 * o + 0]);
+          keep[3 * o + 1] = fmaf(m[q][1], w, keep[3 * o + 1]);
+          keep[3 * o + 2] = fmaf(m[q][2], w, keep[3 * o + 2]);
         }
       }
     }
@@ -205,12 +208,14 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   if constexpr (OUT >= 3) {
 #pragma unroll 1
     for (int t = 0; t < S.t0o; ++t) {
+      float m[VEC_TILE_I];
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) m[q] = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
       CBD_TILE(h1, T + 1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
-        const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
 #pragma unroll
-        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
+        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m[q], acc[3 * q + o], k0o[o]);
       }
     }
   }

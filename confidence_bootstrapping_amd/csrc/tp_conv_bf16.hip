@@ -158,8 +158,10 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   for (int r = 0; r < 16; ++r) { o0e0[r] = 0.f; o0e1[r] = 0.f; }
 #pragma unroll 1
   for (int i = i_lo; i < i_hi; ++i) {
-    V2_TILE(h0, h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
+    // the mids are read from LDS BEFORE the MFMA chain (the fences inside v2_gemm keep the reads above it, their wait lands at the
+    // first use below it): the LDS latency is covered by the 14 MFMAs instead of being exposed after them
     const float m0 = mid0e<IN>(xc0, i, v0), m1 = mid0e<IN>(xc1, i, v1);
+    V2_TILE(h0, h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0e0[r] = fmaf(m0, acc0[r], o0e0[r]); o0e1[r] = fmaf(m1, acc1[r], o0e1[r]); }
   }

@@ -1,0 +1,75 @@
+"""BASELINE.json configs[2] in miniature on one GPU: a SET of heterogeneous complexes (different Nl / Nr / R) through the multi-GPU entry
+point `distributed.run_complex_set` (LPT partition, co-scheduled groups of four, gather), each group advanced by ONE
+`cbd_sample_multi` call and ranked by the confidence model -- against the same complexes sampled one at a time.  (The world_size-2
+path of the same entry point runs under gloo in tests/test_distributed_cpu.py.)"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_complex_set_co_scheduled_equals_one_by_one():
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    from confidence_bootstrapping_amd.distributed import run_complex_set, shard_lpt
+    dev = torch.device("cuda:0")
+    smodel, sargs = make_score_model(device=dev, seed=0)
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    sizes = [(9, 30, 1), (21, 75, 4), (12, 44, 2), (30, 120, 6), (7, 25, 0), (16, 60, 3), (25, 90, 5)]
+    cps = [add_atoms(make_complex(Nl=nl, Nr=nr, R=r, knn=8, seed=300 + i, name=f"set{i}"), seed=300 + i) for i, (nl, nr, r) in enumerate(sizes)]
+    B, S = 6, 4
+    steps = make_steps(get_t_schedule("expbeta", S), sargs, smodel.timestep_emb_func)
+    engs = [DockEngine.from_model(smodel, dev, max_batch=B)]
+    for _ in range(3):
+        e = DockEngine(dev, max_batch=B)
+        e.share_weights_from(engs[0])
+        engs.append(e)
+    ceng = cmodel.engine(max_batch=B)
+    g = torch.Generator().manual_seed(8)
+    inputs = {}
+    for i, c in enumerate(cps):
+        torch.manual_seed(i); np.random.seed(i)
+        dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        R = int(c["ligand"].edge_mask.sum())
+        inputs[i] = (torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous(),
+                     [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * R, generator=g).to(dev)])
+
+    def score(i, pos):
+        ceng.set_complex(cps[i])
+        conf, _ = ceng.score(pos, cargs.crop_beyond)
+        k = int(torch.argmax(conf))
+        return {"complex": i, "best": k, "confidence": float(conf[k]), "pos": pos[k].cpu()}
+
+    groups_seen = []
+
+    def sample_group(items):
+        groups_seen.append([i for i, _ in items])
+        es = engs[:len(items)]
+        ps = []
+        for e, (i, c) in zip(es, items):
+            e.set_complex(c)
+            ps.append(inputs[i][0].clone())
+        DockEngine.sample_multi(es, ps, steps, [inputs[i][1] for i, _ in items])
+        return [score(i, p) for (i, _), p in zip(items, ps)]
+
+    got = run_complex_set(cps, sample_group, world=1, rank=0, group=4)
+    assert [r["complex"] for r in got] == list(range(len(cps)))
+    assert sorted(i for grp in groups_seen for i in grp) == list(range(len(cps))) and max(map(len, groups_seen)) == 4
+    for i, c in enumerate(cps):                      # one complex at a time on a fresh engine state
+        engs[0].set_complex(c)
+        p = inputs[i][0].clone()
+        engs[0].sample(p, steps, *inputs[i][1])
+        ref = score(i, p)
+        assert ref["best"] == got[i]["best"] and ref["confidence"] == got[i]["confidence"]
+        assert torch.equal(ref["pos"], got[i]["pos"])
+    # the LPT partition over 8 ranks: every complex exactly once, loads within one complex of each other
+    parts = shard_lpt([nl * nr for nl, nr, _ in sizes], 8)
+    assert sorted(sum(parts, [])) == list(range(len(sizes)))
