@@ -634,8 +634,7 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
       if (G.i0e_hi == 0 && G.vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
         G.i0e_lo = 0; G.i0e_hi = S.t0e; G.vec_on = 1;
       }
-      const int wg_edges = e0->use_bf16 == 1 ? 32 * bf16_wg_waves() : CONV_WG_EDGES;   // bf16: a workgroup of 4 or 8 waves shares every weight tile
-      grid += (J.caps[g] + wg_edges - 1) / wg_edges;
+      grid += e0->use_bf16 == 1 ? (J.caps[g] + 63) / 64 : (J.caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;   // bf16: one wave per 64 edges
       if (e0->use_bf16 != 1) {
         // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual slices share them.
         // (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)
