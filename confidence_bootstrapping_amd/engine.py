@@ -117,35 +117,44 @@ def _hptr(a: np.ndarray):
 
 
 def make_steps(t_schedule, model_args, timestep_emb_func, ode=False, no_random=False, no_final_step_noise=False,
-               temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5):
+               temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None):
     """Per-step host scalars, computed with the reference's own scalar arithmetic and dtypes
-    (utils/sampling.py:94-167; models/score_model.py:338,347,419-420,447).  Returns a ctypes array of cbd_step."""
+    (utils/sampling.py:94-167; models/score_model.py:338,347,419-420,447).  Returns a ctypes array of cbd_step.
+    `t_schedule` is the translation schedule; `rot_schedule` / `tor_schedule` default to it (inference.py:393-396) and differ
+    under --different_schedules (inference.py:375-383): the model embeds the TRANSLATION time only (score_model.py:323,499),
+    sigma_rot(t_rot) / sigma_tor(t_tor) enter through the score normalisers and the SDE coefficients of their component."""
     S = len(t_schedule)
+    scheds = [np.asarray(t_schedule, dtype=np.float64),
+              np.asarray(t_schedule if rot_schedule is None else rot_schedule, dtype=np.float64),
+              np.asarray(t_schedule if tor_schedule is None else tor_schedule, dtype=np.float64)]
+    if any(len(x) != S for x in scheds):
+        raise ValueError("tr / rot / tor schedules must have the same length")
     steps = (cbd_step * S)()
     a = model_args
     temp_sampling = list(temp_sampling) if np.iterable(temp_sampling) else [temp_sampling] * 3
     temp_psi = list(temp_psi) if np.iterable(temp_psi) else [temp_psi] * 3
     lims = [(a.tr_sigma_min, a.tr_sigma_max), (a.rot_sigma_min, a.rot_sigma_max), (a.tor_sigma_min, a.tor_sigma_max)]
     for i in range(S):
-        t = t_schedule[i]
-        dt = t_schedule[i] - t_schedule[i + 1] if i < S - 1 else t_schedule[i]
+        t = scheds[0][i]
         st = steps[i]
         st.t = float(t)
-        # model side: complex_t is an fp32 tensor, t_to_sigma evaluated on it
-        ct = float(t) * torch.ones(1)
-        sig_t = [lo ** (1 - ct) * hi ** ct for lo, hi in lims]
+        # model side: complex_t[k] is an fp32 tensor, t_to_sigma evaluated on it
+        cts = [float(sc[i]) * torch.ones(1) for sc in scheds]
+        sig_t = [lo ** (1 - ct) * hi ** ct for (lo, hi), ct in zip(lims, cts)]
         st.tr_sigma = float(sig_t[0][0])
         st.cross_cutoff = float((sig_t[0] * 3 + 20)[0])
         st.rot_score_norm = float(so3.score_norm(sig_t[1])[0])
         st.tor_score_norm_sqrt = float(torch.sqrt(torch.tensor(torus.score_norm(sig_t[2].numpy())).float())[0])
-        emb = timestep_emb_func(ct)[0]
+        emb = timestep_emb_func(cts[0])[0]
         for k in range(32):
             st.sigma_emb[k] = float(emb[k])
-        # sampler side: float64 sigma, fp32 g (0-dim tensor), python/numpy scalars for dt
+        # sampler side: float64 sigma, fp32 g (0-dim tensor), python/numpy scalars for dt -- per component on its own schedule
         noise_on = not (no_random or ode or (no_final_step_noise and i == S - 1))
         coefs = []
         for k, (lo, hi) in enumerate(lims):
-            sigma = lo ** (1 - t) * hi ** t
+            tk = scheds[k][i]
+            dt = scheds[k][i] - scheds[k][i + 1] if i < S - 1 else scheds[k][i]
+            sigma = lo ** (1 - tk) * hi ** tk
             g = sigma * torch.sqrt(torch.tensor(2 * np.log(hi / lo)))
             if ode:
                 sc, nc = 0.5 * g ** 2 * dt, 0.0
@@ -630,15 +639,15 @@ def score_batch(model, data):
     """TensorProductScoreModel.forward(batch): returns (tr_pred, rot_pred, tor_pred, None)."""
     eng = model.engine()
     ct = data.complex_t
-    t_tr = ct["tr"].detach().cpu()
-    if not (torch.all(t_tr == t_tr[0]) and torch.equal(ct["rot"].cpu(), t_tr) and torch.equal(ct["tor"].cpu(), t_tr)):
-        raise NotImplementedError("per-sample / separate diffusion times are outside the MI355X hot path")
+    t_tr, t_rot, t_tor = (ct[k].detach().cpu() for k in ("tr", "rot", "tor"))
+    if not all(bool(torch.all(x == x[0])) for x in (t_tr, t_rot, t_tor)):
+        raise NotImplementedError("per-sample diffusion times within one batch are outside the MI355X hot path")
     g, B, Nl = _single_complex(data)
     key = complex_fingerprint(data)
     if eng.complex_key != key:
         eng.set_complex(g, key)
-    t = float(t_tr[0])
-    steps = make_steps(np.array([t]), _ArgsFromModel(model), model.timestep_emb_func)
+    steps = make_steps(np.array([float(t_tr[0])]), _ArgsFromModel(model), model.timestep_emb_func,
+                       rot_schedule=np.array([float(t_rot[0])]), tor_schedule=np.array([float(t_tor[0])]))
     pos = data["ligand"].pos.reshape(B, Nl, 3)
     tr, rot, tor = eng.score(pos, steps[0])
     if model.no_torsion or eng.R == 0:

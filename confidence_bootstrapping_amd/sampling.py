@@ -15,7 +15,7 @@ Differences from the reference that are deliberate and documented (SURVEY.md 8a 
     rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
   * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
     rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
-  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model), asynchronous schedules raise
+  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model: not in the shipped yml), asynchronous schedules raise
     NotImplementedError (the first three also raise in the reference).
 Confidence scoring (reference utils/sampling.py:240-261): with `confidence_model` set, the final poses of every batch
 are scored by the all-atom confidence engine (cbd_conf_score) -- crop_beyond per pose, t = 0 -- on the all-atom graphs
@@ -133,16 +133,16 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         raise ValueError("filtering_data_list must have one graph per pose")
     confidence = []
     tr_schedule, rot_schedule, tor_schedule = (np.asarray(s, dtype=np.float64) for s in (tr_schedule, rot_schedule, tor_schedule))
-    if not (np.array_equal(tr_schedule, rot_schedule) and np.array_equal(tr_schedule, tor_schedule)):
-        raise NotImplementedError("--different_schedules: the engine takes one diffusion time per step")
-    if len(tr_schedule) != inference_steps:
+    if not (len(tr_schedule) == len(rot_schedule) == len(tor_schedule) == inference_steps):
         raise ValueError("schedule length != inference_steps")
     device = torch.device(device)
     model = getattr(model, "module", model)
     eng = model.engine_pool(n_streams=n_streams, max_batch=max(int(batch_size), 1)) if n_streams > 1 else model.engine()
+    # --different_schedules (inference.py:375-383): rot / tor run on their own time grids; everything schedule-dependent is a host
+    # scalar of the step (engine.make_steps), the engine itself is agnostic
     steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
                        no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
-                       temp_sigma_data=temp_sigma_data)
+                       temp_sigma_data=temp_sigma_data, rot_schedule=rot_schedule, tor_schedule=tor_schedule)
     S = inference_steps
     use_noise = not (no_random or ode)
     if co_schedule is None:

@@ -98,23 +98,25 @@ def get_t_schedule(inference_steps, alpha=1, beta_=1, t_max=1):
     return beta.ppf(c, a=alpha, b=beta_)
 
 
-def sde_coefficients(t_idx, schedule, cfg: ScoreConfig):
-    """(dt, sigma, g) for tr/rot/tor at step t_idx, scalars typed like the reference (sampling.py:94-135):
-    t, dt, sigma are numpy float64; g is a 0-dim fp32 tensor."""
+def sde_coefficients(t_idx, schedule, cfg: ScoreConfig, rot_schedule=None, tor_schedule=None):
+    """(t, dt, sigma, g) for tr/rot/tor at step t_idx, scalars typed like the reference (sampling.py:94-135):
+    t, dt, sigma are numpy float64; g is a 0-dim fp32 tensor.  With --different_schedules (inference.py:375-383) every component
+    runs on its own time grid; t / dt are then 3-lists."""
     S = len(schedule)
-    t = schedule[t_idx]
-    dt = schedule[t_idx] - schedule[t_idx + 1] if t_idx < S - 1 else schedule[t_idx]
-    sig = t_to_sigma(t, t, t, cfg)
+    scheds = [schedule, schedule if rot_schedule is None else rot_schedule, schedule if tor_schedule is None else tor_schedule]
+    ts = [sc[t_idx] for sc in scheds]
+    dts = [sc[t_idx] - sc[t_idx + 1] if t_idx < S - 1 else sc[t_idx] for sc in scheds]
+    sig = t_to_sigma(ts[0], ts[1], ts[2], cfg)
     lims = [(cfg.tr_sigma_min, cfg.tr_sigma_max), (cfg.rot_sigma_min, cfg.rot_sigma_max),
             (cfg.tor_sigma_min, cfg.tor_sigma_max)]
     g = [s * torch.sqrt(torch.tensor(2 * np.log(hi / lo))) for s, (lo, hi) in zip(sig, lims)]
-    return t, dt, sig, g
+    return ts, dts, sig, g
 
 
 @torch.no_grad()
 def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreConfig, so3_table, torus_table,
                  noise=None, no_final_step_noise=False, ode=False, record=False, temp_sampling=1.0, temp_psi=0.0,
-                 temp_sigma_data=0.5):
+                 temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None):
     """Reverse diffusion for b poses of ONE complex: pos0 [b,N,3] -> final pos [b,N,3].
     noise: dict of 'tr' [S,b,3], 'rot' [S,b,3], 'tor' [S,b*R] (explicit, lifted out of the reference's
     unseeded torch.normal calls, drawn in the reference's order) or None => zeros (no_random)."""
@@ -124,36 +126,36 @@ def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreCon
     rec_cache = receptor_embedding(w, cx, cfg)
     trace = []
     for s in range(S):
-        t, dt, sig, g = sde_coefficients(s, schedule, cfg)
-        out = score_forward(w, cx, pos, t, t, t, cfg, so3_table, torus_table, rec_cache=rec_cache)
+        ts, dts, sig, g = sde_coefficients(s, schedule, cfg, rot_schedule, tor_schedule)
+        out = score_forward(w, cx, pos, ts[0], ts[1], ts[2], cfg, so3_table, torus_table, rec_cache=rec_cache)
         tr_s, rot_s, tor_s = out["tr_pred"], out["rot_pred"], out["tor_pred"]
         last = (s == S - 1)
         zero = noise is None or (no_final_step_noise and last)
         z_tr = torch.zeros(b, 3) if zero else noise["tr"][s]
         z_rot = torch.zeros(b, 3) if zero else noise["rot"][s]
         if ode:
-            tr_p = 0.5 * g[0] ** 2 * dt * tr_s
-            rot_p = 0.5 * rot_s * dt * g[1] ** 2
+            tr_p = 0.5 * g[0] ** 2 * dts[0] * tr_s
+            rot_p = 0.5 * rot_s * dts[1] * g[1] ** 2
         else:
-            tr_p = g[0] ** 2 * dt * tr_s + g[0] * np.sqrt(dt) * z_tr
-            rot_p = rot_s * dt * g[1] ** 2 + g[1] * np.sqrt(dt) * z_rot
+            tr_p = g[0] ** 2 * dts[0] * tr_s + g[0] * np.sqrt(dts[0]) * z_tr
+            rot_p = rot_s * dts[1] * g[1] ** 2 + g[1] * np.sqrt(dts[1]) * z_rot
         tor_p = None
         if not cfg.no_torsion and R > 0:
             z_tor = torch.zeros(b * R) if zero else noise["tor"][s]
-            tor_p = 0.5 * g[2] ** 2 * dt * tor_s if ode else g[2] ** 2 * dt * tor_s + g[2] * np.sqrt(dt) * z_tor
+            tor_p = 0.5 * g[2] ** 2 * dts[2] * tor_s if ode else g[2] ** 2 * dts[2] * tor_s + g[2] * np.sqrt(dts[2]) * z_tor
         # low-temperature sampling (utils/sampling.py:146-167): overrides the perturbation of every component whose
         # temperature differs from 1
-        ts = list(temp_sampling) if np.iterable(temp_sampling) else [temp_sampling] * 3
+        tsamp = list(temp_sampling) if np.iterable(temp_sampling) else [temp_sampling] * 3
         tp = list(temp_psi) if np.iterable(temp_psi) else [temp_psi] * 3
         lims = [(cfg.tr_sigma_min, cfg.tr_sigma_max), (cfg.rot_sigma_min, cfg.rot_sigma_max), (cfg.tor_sigma_min, cfg.tor_sigma_max)]
         scores, zs = [tr_s, rot_s, tor_s], [z_tr, z_rot, None if tor_p is None else z_tor]
         new = [tr_p, rot_p, tor_p]
         for k in range(3):
-            if ts[k] != 1.0 and new[k] is not None and not ode:
+            if tsamp[k] != 1.0 and new[k] is not None and not ode:
                 lo, hi = lims[k]
                 sigma_data = np.exp(temp_sigma_data * np.log(hi) + (1 - temp_sigma_data) * np.log(lo))
-                lam = (sigma_data + sig[k]) / (sigma_data + sig[k] / ts[k])
-                new[k] = g[k] ** 2 * dt * (lam + ts[k] * tp[k] / 2) * scores[k] + g[k] * np.sqrt(dt * (1 + tp[k])) * zs[k]
+                lam = (sigma_data + sig[k]) / (sigma_data + sig[k] / tsamp[k])
+                new[k] = g[k] ** 2 * dts[k] * (lam + tsamp[k] * tp[k] / 2) * scores[k] + g[k] * np.sqrt(dts[k] * (1 + tp[k])) * zs[k]
         tr_p, rot_p, tor_p = new
         pos = modify_conformer_batch(pos, cx, tr_p.float(), rot_p.float(), None if tor_p is None else tor_p.float())
         if record:

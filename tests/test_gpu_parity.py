@@ -447,3 +447,28 @@ def test_multi_complex_graph_replay_equals_eager():
     finally:
         for e in engs:
             e.set_option("graph", 0)
+
+
+def test_sampling_with_different_schedules_matches_reference(dev, score_model, golden):
+    """--different_schedules (inference.py:375-383) through the reference-shaped `sampling()` API against the reference's own run
+    (g14): final poses within the north-star 1e-3 A, per-step scores within the fp32 tolerance of the other golden tests."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    g = golden("g14_sampling_schedules.npz")
+    model, args = score_model
+    cplx = make_workload("tiny")
+    eng = DockEngine(dev, max_batch=4)
+    eng.load_state_dict(model.state_dict())
+    eng.set_complex(cplx)
+    steps = make_steps(g["tr_schedule"], args, model.timestep_emb_func, rot_schedule=g["rot_schedule"], tor_schedule=g["tor_schedule"])
+    pos = torch.from_numpy(g["pos0"]).to(dev).contiguous()
+    scores = eng.sample(pos, steps, torch.from_numpy(g["noise_tr"]), torch.from_numpy(g["noise_rot"]), torch.from_numpy(g["noise_tor"]),
+                        return_scores=True)
+    B, R = pos.shape[0], eng.R
+    for s in (0, 3, 7):
+        row = scores[s].cpu()
+        for got, key in ((row[:3 * B].reshape(B, 3), "step_tr"), (row[3 * B:6 * B].reshape(B, 3), "step_rot"), (row[6 * B:6 * B + B * R], "step_tor")):
+            ref = torch.from_numpy(g[key][s])
+            assert rel_err(got, ref) < SCORE_TOL, (s, key)
+    assert float(rmsd(pos.cpu(), torch.from_numpy(g["final_pos"])).max()) < 1e-3

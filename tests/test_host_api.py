@@ -94,7 +94,8 @@ def test_make_steps_matches_oracle_scalars(score_model, tables):
     cfg = sr.ScoreConfig()
     so3, torus = tables
     for i in (0, 7, 19):
-        t, dt, sig, g = pr.sde_coefficients(i, sched, cfg)
+        ts, dts, sig, g = pr.sde_coefficients(i, sched, cfg)
+        t, dt = ts[0], dts[0]
         assert steps[i].tr_score_coef == pytest.approx(float(g[0] ** 2 * dt), rel=1e-6)
         assert steps[i].tor_noise_coef == pytest.approx(float(g[2] * np.sqrt(dt)), rel=1e-6)
         ct = float(t) * torch.ones(1)
@@ -107,6 +108,17 @@ def test_make_steps_matches_oracle_scalars(score_model, tables):
     assert last.tr_noise_coef == 0.0 and last.tr_score_coef == steps[19].tr_score_coef
     ode = make_steps(sched, args, model.timestep_emb_func, ode=True)[3]
     assert ode.tr_score_coef == pytest.approx(0.5 * steps[3].tr_score_coef, rel=1e-6) and ode.rot_noise_coef == 0.0
+    # --different_schedules: every component on its own grid (the translation grid drives the embedding and the cross cutoff)
+    rot_s, tor_s = sched ** 2, np.sqrt(sched)
+    diff = make_steps(sched, args, model.timestep_emb_func, rot_schedule=rot_s, tor_schedule=tor_s)
+    for i in (0, 5, 19):
+        ts, dts, sig, g = pr.sde_coefficients(i, sched, cfg, rot_s, tor_s)
+        assert diff[i].tr_score_coef == steps[i].tr_score_coef and diff[i].cross_cutoff == steps[i].cross_cutoff
+        assert [diff[i].sigma_emb[k] for k in range(32)] == [steps[i].sigma_emb[k] for k in range(32)]
+        assert diff[i].rot_score_coef == pytest.approx(float(g[1] ** 2 * dts[1]), rel=1e-6)
+        assert diff[i].tor_noise_coef == pytest.approx(float(g[2] * np.sqrt(dts[2])), rel=1e-6)
+        s_t = sr.t_to_sigma(float(ts[0]) * torch.ones(1), float(ts[1]) * torch.ones(1), float(ts[2]) * torch.ones(1), cfg)
+        assert diff[i].rot_score_norm == float(sr.so3_score_norm(so3, s_t[1].numpy())[0])
 
 
 def test_bench_refuses_to_report_a_smaller_run():

@@ -22,8 +22,10 @@ def main():
     root, tag = sys.argv[1], sys.argv[2]
     cmd = sys.argv[3] if len(sys.argv) > 3 else "bench.py"
     out_rows, per = [], {}
+    import glob
     for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"):
-        rows = load(os.path.join(root, c, "p_counter_collection.csv"))
+        found = glob.glob(os.path.join(root, c, "**", "*counter_collection.csv"), recursive=True)
+        rows = load(found[0])
         for (k, cn), v in rows.items():
             if "cbd::tp_conv_kernel" not in k or "OpsF32" not in k or cn != c:
                 continue
