@@ -581,12 +581,6 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
 }
 
 
-// bf16 kernel variant: CBD_BF16_WIDE=1 selects the 128-edge-per-wave kernel (tp_conv_bf16_wide.hip)
-static bool bf16_wide() {
-  static const bool w = getenv("CBD_BF16_WIDE") && atoi(getenv("CBD_BF16_WIDE")) != 0;
-  return w;
-}
-
 static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (e->timing) {
@@ -599,7 +593,7 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++e->ev_used;
     HIPCHK(hipEventRecord(e0, s));
   }
-  if (e->use_bf16 == 1) HIPCHK(bf16_wide() ? launch_tp_conv_bf16_wide(L.in_level, L.out_level, a, grid, s) : launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) HIPCHK(hipEventRecord(e1, s));
@@ -640,8 +634,7 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
       if (G.i0e_hi == 0 && G.vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
         G.i0e_lo = 0; G.i0e_hi = S.t0e; G.vec_on = 1;
       }
-      const int wave_edges = e0->use_bf16 == 1 ? (bf16_wide() ? 128 : 64) : CONV_WG_EDGES;   // bf16: one wave per 64 (or 128) edges
-      grid += (J.caps[g] + wave_edges - 1) / wave_edges;
+      grid += e0->use_bf16 == 1 ? (J.caps[g] + 63) / 64 : (J.caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;   // bf16: one wave per 64 edges
       if (e0->use_bf16 != 1) {
         // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual slices share them.
         // (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)

@@ -1,0 +1,45 @@
+"""Repeatability soak of the bf16 tensor-product kernel: the C4 workload (64 poses x 40 steps) sampled N times from identical inputs must
+give bitwise identical poses (no atomics anywhere; a difference means a data race / operand hazard in the kernel).  GPU box only."""
+import copy
+import sys
+import os
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from confidence_bootstrapping_amd import Batch
+from confidence_bootstrapping_amd.synthetic import make_workload
+from confidence_bootstrapping_amd.utils import make_score_model
+from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+from confidence_bootstrapping_amd.sampling import randomize_position
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"
+dev = torch.device("cuda:0")
+model, args = make_score_model(device=dev, seed=0)
+cplx = make_workload("c4_large_pocket")
+B, S = 64, 40
+eng = DockEngine.from_model(model, dev, max_batch=B)
+eng.set_complex(cplx)
+torch.manual_seed(12); np.random.seed(12)
+dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(B)]
+randomize_position(dl, False, False, args.tr_sigma_max)
+pos0 = torch.stack([d["ligand"].pos for d in dl]).to(dev)
+steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+g = torch.Generator().manual_seed(5)
+noise = [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * eng.R, generator=g).to(dev)]
+eng.set_option(mode, 1) if mode != "f32" else None
+ref, bad = None, 0
+for k in range(n):
+    p = pos0.clone()
+    eng.sample(p, steps, *noise)
+    torch.cuda.synchronize()
+    if ref is None:
+        ref = p
+    elif not torch.equal(p, ref):
+        bad += 1
+        print(f"run {k}: DIFFERS from run 0, max |d| = {float((p - ref).abs().max()):.3e}", flush=True)
+print(f"{mode}: {n} runs, {bad} differing", flush=True)
+sys.exit(1 if bad else 0)
