@@ -73,3 +73,39 @@ def test_complex_set_co_scheduled_equals_one_by_one():
     # the LPT partition over 8 ranks: every complex exactly once, loads within one complex of each other
     parts = shard_lpt([nl * nr for nl, nr, _ in sizes], 8)
     assert sorted(sum(parts, [])) == list(range(len(sizes)))
+
+
+def test_sampling_distributed_on_the_engine_world1():
+    """The north-star entry point with the REAL sampler on one GPU (world 1): `sampling_distributed` = `sampling()` under the same seed
+    (its pre-drawn, sliced noise reproduces the reference's draw order) + the confidence-ranked ordering of inference.py:537-547."""
+    from functools import partial
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule, t_to_sigma
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position
+    from confidence_bootstrapping_amd.distributed import sampling_distributed
+    dev = torch.device("cuda:0")
+    smodel, sargs = make_score_model(device=dev, seed=0)
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    cplx = make_workload("tiny", all_atoms=True)
+    N, S = 7, 4
+    sched = get_t_schedule("expbeta", S)
+
+    def fresh():
+        torch.manual_seed(31); np.random.seed(31)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(N)]
+        randomize_position(dl, False, False, sargs.tr_sigma_max)
+        return dl
+    t2s = partial(t_to_sigma, args=sargs)
+    torch.manual_seed(99)
+    ref_list, ref_conf = sampling(fresh(), smodel, S, sched, sched, sched, dev, t2s, sargs, confidence_model=cmodel,
+                                  filtering_model_args=cargs, batch_size=3)
+    ref_pos = torch.stack([g["ligand"].pos.reshape(-1, 3).cpu() for g in ref_list])
+    torch.manual_seed(99)
+    out = sampling_distributed(fresh(), smodel, S, sched, sched, sched, dev, t2s, sargs, confidence_model=cmodel,
+                               filtering_model_args=cargs, batch_size=3, world=1, rank=0)
+    order = torch.argsort(ref_conf.cpu().reshape(-1), descending=True, stable=True)
+    assert torch.equal(out["index"], order)
+    assert torch.equal(out["pos"].cpu(), ref_pos[order])
+    assert torch.equal(out["confidence"].cpu(), ref_conf.cpu().reshape(-1)[order])

@@ -33,6 +33,12 @@ noise = [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generat
 eng.set_option(mode, 1) if mode != "f32" else None
 ref, bad = None, 0
 for k in range(n):
+    if k % 3 == 0:      # disturb the engine's buffers with a call of another shape: results must not depend on what ran before
+        q = pos0[:1].clone()
+        eng.sample(q, (type(steps[0]) * 3)(*[steps[i] for i in range(3)]), noise[0][:3, :1].contiguous(), noise[1][:3, :1].contiguous(),
+                   noise[2][:3, :eng.R].contiguous())
+        step = make_steps(np.array([0.3]), args, model.timestep_emb_func)[0]
+        eng.score(pos0[:7].contiguous(), step)
     p = pos0.clone()
     eng.sample(p, steps, *noise)
     torch.cuda.synchronize()
