@@ -49,7 +49,7 @@ SAMPLES, DENOISE_STEPS = 40, 20
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (~2.5 PF)
 # PMC traffic summaries (tools/pmc_summary.py) of the default command line per (workload, dtype, geometry, poses), newest first
-TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r02_e_traffic.json"],
+TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r02_t_traffic.json", "r02_e_traffic.json"],
                     ("c2_dockgen_median", "f32", "loose", "free"): ["r01_m_traffic.json"],
                     ("c4_large_pocket", "bf16", "globular", "ideal"): ["r02_c4_bf16_traffic.json"]}
 
@@ -251,7 +251,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (confidence, other operand modes, fine-tuning, "
                     "CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
-    ap.add_argument("--graph", type=int, default=0, help="1: replay the 20-step loop as one hipGraph (no per-kernel HIP events)")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): the whole step loop of a group of complexes is one hipGraph launch, the "
+                    "tensor-product kernels timed by event-record nodes of the graph; 0: eager launches")
     ap.add_argument("--workload", default=WORKLOAD, help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
     ap.add_argument("--geometry", default="globular", choices=["globular", "loose"],
                     help="receptor density: globular = folded-protein density, pocket at 0.7 R (SURVEY.md 8 edge counts); loose = the test complexes")
@@ -338,9 +339,9 @@ def main():
         pos0.append(p0.to(dev).contiguous())
         noise.append((z_tr.to(dev), torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev), torch.randn(DENOISE_STEPS, SAMPLES * R).to(dev)))
 
-    def run(lo, hi):
-        """complexes lo..hi-1 in co-scheduled groups (each complex still gets its own receptor embedding pass)"""
-        k = lo
+    def plan(lo, hi):
+        """group sizes for complexes lo..hi-1"""
+        out, k = [], lo
         while k < hi:
             left = hi - k
             if cosched > 1 and left > 1:
@@ -348,22 +349,43 @@ def main():
                 m = left if left <= min(cosched + 1, 8) else -(-left // -(-left // cosched))
             else:
                 m = 1
-            for e in engines[:m]:
-                e.recompute_receptor()
+            out.append(m)
+            k += m
+        return out
+
+    def run_group(k, m, poses):
+        for e in engines[:m]:
+            e.recompute_receptor()
+        if m == 1:
+            eng.sample(poses[0], steps, *noise[k])
+        else:
+            DockEngine.sample_multi(engines[:m], poses, steps, [noise[k + q] for q in range(m)])
+
+    def run(lo, hi):
+        """complexes lo..hi-1 in co-scheduled groups (each complex still gets its own receptor embedding pass)"""
+        k = lo
+        for m in plan(lo, hi):
             GROUPS_RUN.append(m)
-            if m == 1:
-                eng.sample(pos0[k], steps, *noise[k])
-            else:
-                DockEngine.sample_multi(engines[:m], [pos0[k + q] for q in range(m)], steps, [noise[k + q] for q in range(m)])
+            run_group(k, m, [pos0[k + q] for q in range(m)])
             k += m
 
     GROUPS_RUN = []
+    for e in engines:
+        e.kernel_timing(enable=True, reset=True)      # before the warm-up: a captured graph carries its timing events as nodes
     run(0, a.warmup)
+    if a.graph:
+        # the step loop of a group is one hipGraph per group shape: instantiate the shapes the timed region uses (on scratch poses)
+        done, k = set(plan(0, a.warmup)), a.warmup
+        for m in plan(a.warmup, n_runs):
+            if m not in done:
+                done.add(m)
+                run_group(k, m, [pos0[k + q].clone() for q in range(m)])
+            k += m
     torch.cuda.synchronize()
     alt_k = list(range(max(a.warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
     alt_init = {k: pos0[k].clone() for k in alt_k}
     for e in engines:
-        e.kernel_timing(enable=not a.graph, reset=True)
+        e.kernel_timing(enable=True, reset=True)
         e.stats(reset=True)
     if world > 1:
         dist.barrier()
@@ -455,7 +477,7 @@ def main():
         extras = world == 1 and headline and not a.headline_only
         if extras:
             out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev, geometry)
-        if extras and cosched > 1 and not a.graph:
+        if extras and cosched > 1:
             # The same complexes in the two other operand modes of the same kernel (NOT part of `value`): f32_split = fp32 operands as
             # three exact bf16 planes on the bf16 matrix cores (fp32-grade results, tests/test_gpu_bf16.py); bf16 = configs[3].
             out["other_operand_modes"] = {}

@@ -116,8 +116,11 @@ struct cbd_engine {
 
   // ---- timing of the dominant kernel
   bool timing = false;
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+  typedef std::vector<std::pair<hipEvent_t, hipEvent_t>> EvPool;
+  EvPool ev_pool;       // pairs of the eager launches since the last collection
   size_t ev_used = 0;
+  EvPool gev_pool;      // pairs recorded by the nodes of the cached graphs (GraphEntry::ev_lo/ev_hi index this pool)
+  size_t gev_used = 0;
   double t_total_ms = 0;
   int64_t t_n = 0;
 };
@@ -126,7 +129,7 @@ static void fill_static_desc(cbd_engine* e);
 static void drop_graphs(cbd_engine* e) {
   for (auto& g : e->graphs)
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
-  if (!e->graphs.empty()) e->ev_used = 0;   // the event pairs their nodes recorded into are free again
+  e->gev_used = 0;   // the event pairs their nodes recorded into are free again
   e->graphs.clear();
   ++e->complex_gen;
 }
@@ -426,6 +429,7 @@ int cbd_destroy(cbd_engine* e) {
   if (e->desc_dev) (void)hipFree(e->desc_dev);
   e->wpool.release(); e->cpool.release(); e->bpool.release();
   for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+  for (auto& p : e->gev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
@@ -581,22 +585,46 @@ static EdgeMlp make_mlp(const MlpDev& m, const float* part) {
 }
 
 
+// Records `ev` on `s`.  Under stream capture the record becomes an explicit event-record node appended to the captured graph (the node
+// is re-executed by every replay and the event can be queried from the host afterwards; an event recorded through hipEventRecord on a
+// capturing stream belongs to the capture and cannot -- "invalid resource handle", measured in round 2; hipEventRecordWithFlags with
+// hipEventRecordExternal is refused with "invalid argument" by this runtime).
+static int record_event(hipEvent_t ev, hipStream_t s, bool capturing) {
+  if (!capturing) { HIPCHK(hipEventRecord(ev, s)); return 0; }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long id = 0;
+  hipGraph_t graph = nullptr;
+  const hipGraphNode_t* deps = nullptr;
+  size_t n_deps = 0;
+  HIPCHK(hipStreamGetCaptureInfo_v2(s, &cs, &id, &graph, &deps, &n_deps));
+  hipGraphNode_t node = nullptr;
+  HIPCHK(hipGraphAddEventRecordNode(&node, graph, deps, n_deps, ev));
+  HIPCHK(hipStreamUpdateCaptureDependencies(s, &node, 1, hipStreamSetCaptureDependencies));
+  return 0;
+}
+
 static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  bool cap = false;
   if (e->timing) {
-    if (e->ev_used == e->ev_pool.size()) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    HIPCHK(hipStreamIsCapturing(s, &cs));
+    cap = cs == hipStreamCaptureStatusActive;
+    cbd_engine::EvPool& pool = cap ? e->gev_pool : e->ev_pool;
+    size_t& used = cap ? e->gev_used : e->ev_used;
+    if (used == pool.size()) {
       hipEvent_t a0, a1;
       HIPCHK(hipEventCreate(&a0)); HIPCHK(hipEventCreate(&a1));
-      e->ev_pool.push_back({a0, a1});
+      pool.push_back({a0, a1});
     }
-    e0 = e->ev_pool[e->ev_used].first; e1 = e->ev_pool[e->ev_used].second;
-    ++e->ev_used;
-    HIPCHK(hipEventRecord(e0, s));
+    e0 = pool[used].first; e1 = pool[used].second;
+    ++used;
+    CHK(record_event(e0, s, cap));
   }
   if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
-  if (e->timing) HIPCHK(hipEventRecord(e1, s));
+  if (e->timing) CHK(record_event(e1, s, cap));
   return 0;
 }
 
@@ -1128,11 +1156,10 @@ static int check_batch(cbd_engine* e, int B) {
   return 0;
 }
 
-static void collect_range(cbd_engine* e, size_t lo, size_t hi) {
+static void collect_range(cbd_engine* e, const cbd_engine::EvPool& pool, size_t lo, size_t hi) {
   for (size_t i = lo; i < hi; ++i) {
     float ms = 0.f;
-    if (hipEventSynchronize(e->ev_pool[i].second) == hipSuccess &&
-        hipEventElapsedTime(&ms, e->ev_pool[i].first, e->ev_pool[i].second) == hipSuccess) {
+    if (hipEventSynchronize(pool[i].second) == hipSuccess && hipEventElapsedTime(&ms, pool[i].first, pool[i].second) == hipSuccess) {
       e->t_total_ms += ms;
       e->t_n += 1;
     }
@@ -1140,15 +1167,12 @@ static void collect_range(cbd_engine* e, size_t lo, size_t hi) {
 }
 
 // Eager launches: every launch since the last collection has its own event pair.  Captured graphs: the pairs are nodes of the graph
-// and hold the durations of its most recent replay; only graphs replayed since the last reset are read.
+// and hold the durations of its most recent replay; a graph is read before it is replayed again (sample_impl) and here.
 static void collect_timing(cbd_engine* e) {
-  if (e->graphs.empty()) {
-    collect_range(e, 0, e->ev_used);
-    e->ev_used = 0;
-    return;
-  }
+  collect_range(e, e->ev_pool, 0, e->ev_used);
+  e->ev_used = 0;
   for (auto& g : e->graphs)
-    if (g.replayed) { collect_range(e, g.ev_lo, g.ev_hi); g.replayed = false; }
+    if (g.replayed) { collect_range(e, e->gev_pool, g.ev_lo, g.ev_hi); g.replayed = false; }
 }
 
 int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* step, float* tr_dev, float* rot_dev, float* tor_dev,
@@ -1218,10 +1242,9 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
     }
     return 0;
   };
-  // Kernel timing needs eager launches: event-record nodes captured into a graph cannot be queried afterwards on this runtime
-  // (hipEventSynchronize / hipEventElapsedTime on them return "invalid resource handle", measured in round 2).
+  // Kernel timing under a graph: the event pairs are explicit event-record nodes of the graph (record_event).
   bool graph_ok = e0->use_graph && !scores_out;
-  for (int k = 0; k < n; ++k) graph_ok = graph_ok && !E[k]->timing && !E[k]->keep_debug;
+  for (int k = 0; k < n; ++k) graph_ok = graph_ok && !E[k]->keep_debug;
   if (!graph_ok) {
     for (int k = 0; k < n; ++k)
       CHK(push_desc(E[k], B[k], pos_dev[k], E[k]->tr_out, E[k]->rot_out, E[k]->tor_out, nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), s));
@@ -1262,10 +1285,13 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
   }
   hipGraphExec_t exec = nullptr;
   for (auto& g : e0->graphs)
-    if (g.key == key) { exec = g.exec; g.replayed = true; }
+    if (g.key == key) {
+      if (g.replayed && g.ev_hi > g.ev_lo) { collect_range(e0, e0->gev_pool, g.ev_lo, g.ev_hi); }   // waits for the previous replay
+      exec = g.exec; g.replayed = true;
+    }
   if (!exec) {
     hipGraph_t graph = nullptr;
-    const size_t ev_lo = e0->ev_used;
+    const size_t ev_lo = e0->gev_used;
     HIPCHK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     const int rc = run_steps(nullptr);
     const hipError_t ce = hipStreamEndCapture(s, &graph);
@@ -1273,12 +1299,12 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
     HIPCHK(ce);
     HIPCHK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     HIPCHK(hipGraphDestroy(graph));
-    if (e0->graphs.size() >= 4) {   // small cache: the oldest entry goes
+    if (e0->graphs.size() >= 8) {   // small cache: the oldest entry goes
       HIPCHK(hipStreamSynchronize(s));
       (void)hipGraphExecDestroy(e0->graphs.front().exec);
       e0->graphs.erase(e0->graphs.begin());
     }
-    e0->graphs.push_back({key, exec, ev_lo, e0->ev_used, true});
+    e0->graphs.push_back({key, exec, ev_lo, e0->gev_used, true});
   }
   for (int k = 0; k < n; ++k) {
     cbd_engine* e = E[k];
@@ -1466,12 +1492,8 @@ int cbd_last_edge_counts(cbd_engine* e, int64_t counts[5]) {
 int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_ms, int64_t* n, double* total_ms) {
   if (!e) return fail(CBD_ERR_ARG, "null engine");
   (void)hipSetDevice(e->cfg.device);
-  if (e->ev_used) { HIPCHK(hipDeviceSynchronize()); collect_timing(e); }
-  if (reset) {
-    e->t_total_ms = 0; e->t_n = 0;
-    if (e->graphs.empty()) e->ev_used = 0;   // pairs recorded by captured graphs stay reserved
-    for (auto& g : e->graphs) g.replayed = false;
-  }
+  if (e->ev_used || e->gev_used) { HIPCHK(hipDeviceSynchronize()); collect_timing(e); }
+  if (reset) { e->t_total_ms = 0; e->t_n = 0; }
   e->timing = enable != 0;
   if (avg_ms) *avg_ms = e->t_n ? e->t_total_ms / (double)e->t_n : 0.0;
   if (n) *n = e->t_n;

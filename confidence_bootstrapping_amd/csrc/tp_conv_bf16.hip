@@ -41,20 +41,28 @@ __device__ __forceinline__ void v2_set_hidden(Act7& h, int m, const f32x16& acc)
   for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
 }
 
-// acc_s = A_tile * B_s (s = 0, 1), A fragments refilled in place with the NEXT tile right after their two uses.  The refill
-// address is pinned before the MFMAs and nothing but the load sits behind them (tp_conv_dev.h: in-flight MFMA operand hazard).
+// acc_s = A_tile * B_s (s = 0, 1); the A fragments are refilled in place with the NEXT tile's data.  Two rules keep the in-flight MFMA
+// operand hazard of tp_conv_dev.h out (a VALU write, or a returning load, into a register that an issued MFMA has not read yet):
+//   * the whole chain contains NO VALU instruction: the two base addresses are computed and pinned before the first MFMA and every load
+//     uses an immediate offset (fragments 0..3: base + q KB, fragments 4..6: base + 4 KB + (q - 4) KB; the field holds < 4 KB), so a
+//     fragment register that is momentarily dead cannot be handed to address arithmetic (measured, round 2: the same delayed schedule
+//     with per-fragment address computation between the pairs gave run-to-run differences in 8 of 9 repeats of tools/bf16_repeat.py);
+//   * fragment q-1 is re-loaded after the MFMA pair of fragment q has been issued -- one pair late, so that even a load that hits in
+//     L1 (~120 cycles) lands after the pair that read the register has started; the last fragment follows its own pair directly.
 __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], const bf16x8* __restrict__ next, const Act7& B0, const Act7& B1,
                                         f32x16& acc0, f32x16& acc1) {
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const bf16x8* pa = next;
+  const bf16x8* pb = next + 4 * 64;
+  pin(pa); pin(pb);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < V2_NFRAG; ++q) {
-    const bf16x8* p = next + q * 64;
-    pin(p);
-    __builtin_amdgcn_sched_barrier(0);
     acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B0.v[q], q == 0 ? zero : acc0, 0, 0, 0);
     acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B1.v[q], q == 0 ? zero : acc1, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    a[q] = *p;
+    if (q > 0) a[q - 1] = q - 1 < 4 ? pa[(q - 1) * 64] : pb[(q - 5) * 64];
+    if (q == V2_NFRAG - 1) a[q] = pb[(q - 4) * 64];
     __builtin_amdgcn_sched_barrier(0);
   }
 }

@@ -158,7 +158,9 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out_host, int64_
 /* Device-side edge counts of the last forward pass: [ll, lr, rr, rl, tor]. */
 int cbd_last_edge_counts(cbd_engine* e, int64_t counts_host[5]);
 /* Average duration (ms) of the dominant kernel (tp_conv) over the launches since the last reset, measured
- * with HIP events on the launch stream when timing is enabled; n_launches out.  enable: 0/1. */
+ * with HIP events on the launch stream when timing is enabled; n_launches out.  enable: 0/1.  With "graph" = 1
+ * the event pairs are event-record nodes of the captured graph (enable timing BEFORE the call that captures);
+ * a graph's pairs are read before it is replayed again, so every replay is counted. */
 int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_ms_out, int64_t* n_launches_out,
                       double* total_ms_out);
 

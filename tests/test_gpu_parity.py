@@ -444,7 +444,28 @@ def test_multi_complex_graph_replay_equals_eager():
         q = inputs[0][0].clone()
         engs[0].sample(q, steps, *inputs[0][1])
         assert torch.equal(q, ref[0])
+        # kernel timing under a graph: the event pairs are nodes of the graph; every replay is counted (a replayed graph is read
+        # before it is launched again), the launch count equals the eager one and the results stay bitwise
+        engs[2].set_complex(cps[2])
+        engs[2].set_option("graph", 1)
+        counts = {}
+        for mode in (0, 1):
+            for e in engs:
+                e.set_option("graph", mode)
+                e.kernel_timing(enable=True, reset=True)
+            for _ in range(3):
+                got = run_multi()
+                assert all(torch.equal(a, b) for a, b in zip(got, ref))
+            n_tot, t_tot = 0, 0.0
+            for e in engs:
+                _, n1, t1 = e.kernel_timing(enable=False)
+                n_tot, t_tot = n_tot + n1, t_tot + t1
+            counts[mode] = n_tot
+            assert n_tot > 0 and 0.0 < t_tot / n_tot < 50.0, (mode, n_tot, t_tot)
+        assert counts[0] == counts[1], counts
     finally:
+        for e in engs:
+            e.kernel_timing(enable=False, reset=True)
         for e in engs:
             e.set_option("graph", 0)
 

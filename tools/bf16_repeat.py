@@ -20,7 +20,8 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 dev = torch.device("cuda:0")
 model, args = make_score_model(device=dev, seed=0)
 cplx = make_workload("c4_large_pocket")
-B, S = 64, 40
+B, S = 64, int(os.environ.get("REPEAT_STEPS", 40))
+DISTURB = os.environ.get("REPEAT_DISTURB", "1") == "1"
 eng = DockEngine.from_model(model, dev, max_batch=B)
 eng.set_complex(cplx)
 torch.manual_seed(12); np.random.seed(12)
@@ -31,9 +32,9 @@ steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
 g = torch.Generator().manual_seed(5)
 noise = [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * eng.R, generator=g).to(dev)]
 eng.set_option(mode, 1) if mode != "f32" else None
-ref, bad = None, 0
+ref, bad, prev = None, 0, None
 for k in range(n):
-    if k % 3 == 0:      # disturb the engine's buffers with a call of another shape: results must not depend on what ran before
+    if DISTURB and k % 3 == 0:      # disturb the engine's buffers with a call of another shape: results must not depend on what ran before
         q = pos0[:1].clone()
         eng.sample(q, (type(steps[0]) * 3)(*[steps[i] for i in range(3)]), noise[0][:3, :1].contiguous(), noise[1][:3, :1].contiguous(),
                    noise[2][:3, :eng.R].contiguous())
@@ -46,6 +47,8 @@ for k in range(n):
         ref = p
     elif not torch.equal(p, ref):
         bad += 1
-        print(f"run {k}: DIFFERS from run 0, max |d| = {float((p - ref).abs().max()):.3e}", flush=True)
-print(f"{mode}: {n} runs, {bad} differing", flush=True)
+        print(f"run {k}: DIFFERS from run 0, max |d| = {float((p - ref).abs().max()):.3e}, poses differing {int((p != ref).any(2).any(1).sum())}/{B}"
+              f"; equal to the previous run: {bool(torch.equal(p, prev))}", flush=True)
+    prev = p
+print(f"{mode}: S={S} disturb={int(DISTURB)} no_side={int(bool(os.environ.get('CBD_NO_SIDE')))}: {n} runs, {bad} differing", flush=True)
 sys.exit(1 if bad else 0)

@@ -6,10 +6,10 @@ cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do
-  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc/$c -o p -- python bench.py --steps 20 --warmup 5 --headline-only > $OUT/pmc_$c.log 2>&1 || echo FAILED $c
+  timeout 900 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc/$c -o p -- python bench.py --steps 20 --warmup 5 --headline-only > $OUT/pmc_$c.log 2>&1 || echo FAILED $c
 done
 python tools/pmc_summary.py $OUT/pmc $TAG "bench.py --steps 20 --warmup 5 --headline-only" > $OUT/pmc_summary.log 2>&1
 cat $OUT/pmc_summary.log
