@@ -38,6 +38,8 @@ namespace cbd {
 template <int IN, int OUT, int VAR, class Ops>
 __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
+  constexpr bool STAMPS = VAR == 8 || VAR == 13;     // diagnostics: 13 = the stamps of 8 on the gather pattern of 12
+  constexpr int GV = VAR == 13 ? 12 : VAR;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* bias_l = lds;                                 // [ntiles][32]
   float* xT = lds + S.ntiles * 32;                     // [80][32] gathered destination rows, transposed
@@ -47,28 +49,22 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 
   // ---- which group / edge range does this wave own?  (edge counts live on the device)
   int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
-  {
-    int t = blockIdx.x;
-    for (int g = 0; g < args.n_groups; ++g) {
-      const int c = *args.g[g].count;
-      const int nt = (c + CONV_WG_EDGES - 1) / CONV_WG_EDGES;
-      if (grp < 0) {
-        if (t < nt) { grp = g; e0 = t * CONV_WG_EDGES; cnt = c; tile_local = t; }
-        else t -= nt;
-      }
-    }
-  }
-  if (grp < 0) return;
+  if (!find_group(args, blockIdx.x, lane, CONV_WG_EDGES, grp, tile_local, cnt)) return;
+  e0 = tile_local * CONV_WG_EDGES;
   const ConvGroup G = args.g[grp];
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_g0 = 0;
-  if constexpr (VAR == 8) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (STAMPS) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
   using Frag = typename Ops::Frag;
   const Frag* gp = reinterpret_cast<const Frag*>(G.wstream) + lane;   // tile T fragment sg: gp[T * TILE_FRAGS + sg * 64]
   Frag a[Ops::NFRAG];
+  if constexpr (Ops::NODE_PROJ) {
+    Ops::load_first(a, gp);   // the live fragments of all three first-Linear tiles
+  } else {
 #pragma unroll
-  for (int sg = 0; sg < Ops::NFRAG; ++sg) a[sg] = gp[sg * 64];
+    for (int sg = 0; sg < Ops::NFRAG; ++sg) a[sg] = gp[sg * 64];
+  }
   {  // bias table -> LDS: fixed number of unconditional, clamped loads (a counted loop compiles to a load/wait waterfall)
     const f32x4* gb = reinterpret_cast<const f32x4*>(reinterpret_cast<const Frag*>(G.wstream) + (size_t)(S.ntiles + 1) * Ops::TILE_FRAGS);
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
@@ -91,6 +87,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const float v[3] = {vv.x, vv.y, vv.z};
   if (hf == 0) srcl[j] = src;
 
+  f32x16 acc1[Ops::NODE_PROJ ? 3 : 1];
   typename Ops::Act Bx;  // first-Linear input on the matrix cores: edge_attr(32), lane half hf holds cols 16hf..16hf+15.  The
                          // x_src[:32] / x_dst[:32] parts arrive as per-node projections through the accumulator (G.psrc / G.pdst)
   {
@@ -106,8 +103,28 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
         Ops::set_in(Bx, 2, q, pd[q]);
       }
     }
+    if constexpr (Ops::NODE_PROJ) {
+      // accumulator start values of the three first-Linear tiles, gathered HERE with everything else the edge needs (the first Linear
+      // then waits on nothing): b1 + W1s x_src + W1d x_dst for rows 32m + (r&3) + 8(r>>2) + 4hf; the bias rows straight from the
+      // stream's table in global memory (its LDS copy is still being written)
+      const f32x4* const gb = reinterpret_cast<const f32x4*>(reinterpret_cast<const Frag*>(G.wstream) + (size_t)(S.ntiles + 1) * Ops::TILE_FRAGS);
+      const f32x4* const p_s = reinterpret_cast<const f32x4*>(G.psrc + (size_t)src_r * KDIM + 4 * hf);
+      // diagnostics with WRONG results (timing only): VAR 10 reads the destination projection at the aggregating node's row (run-
+      // coherent instead of random), VAR 11 skips both projection gathers, VAR 12 also gathers the node row at the aggregating node
+      const f32x4* const p_d = reinterpret_cast<const f32x4*>(G.pdst + (size_t)(GV >= 10 ? src_r : dst) * KDIM + 4 * hf);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = gb[8 * m + 2 * q + hf];
+          f32x4 u = b, w = b;
+          if constexpr (GV < 11) { u = p_s[8 * m + 2 * q]; w = p_d[8 * m + 2 * q]; }
+          acc1[m][4 * q + 0] = b.x + u.x + w.x; acc1[m][4 * q + 1] = b.y + u.y + w.y;
+          acc1[m][4 * q + 2] = b.z + u.z + w.z; acc1[m][4 * q + 3] = b.w + u.w + w.w;
+        }
+    }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
-    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
+    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)(GV == 12 ? src_r : dst) * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
       const f32x4 r = pr[q];
@@ -116,7 +133,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     }
   }
   __syncthreads();   // single-wave workgroup: orders the LDS writes above before the reads below
-  if constexpr (VAR == 8) st_t1 = stamp();
+  if constexpr (STAMPS) st_t1 = stamp();
 
   int T = 0;
   f32x16 acc;
@@ -135,30 +152,30 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
   const bool vec_on = G.vec_on != 0;
   const int T_vec = 3 + S.t0e;
-  const f32x4* const p_s = reinterpret_cast<const f32x4*>(G.psrc + (size_t)src_r * KDIM + 4 * hf);
-  const f32x4* const p_d = reinterpret_cast<const f32x4*>(G.pdst + (size_t)dst * KDIM + 4 * hf);
+  if constexpr (!Ops::NODE_PROJ) {
 #pragma unroll
-  for (int m = 0; m < 3; ++m) {
-    if constexpr (!Ops::NODE_PROJ) {
+    for (int m = 0; m < 3; ++m) {
       CBD_TILE(Bx, m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec));
-    } else {  // acc = b1 + W1s x_src + W1d x_dst (rows 32m + (r&3) + 8(r>>2) + 4hf), then the K = 32 edge-attribute product
-      const int tn_ = m < 2 ? T + 1 : (i_lo < i_hi ? 3 + i_lo : T_vec);
-      const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l + T * 32);
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 b = bp[2 * q + hf], u = p_s[8 * m + 2 * q], w = p_d[8 * m + 2 * q];
-        acc[4 * q + 0] = b.x + u.x + w.x; acc[4 * q + 1] = b.y + u.y + w.y;
-        acc[4 * q + 2] = b.z + u.z + w.z; acc[4 * q + 3] = b.w + u.w + w.w;
-      }
-      Ops::gemm_first(a, gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), Bx, acc);
-      T = tn_;
+      if constexpr (!Ops::EXACT_F32) { if (m == 2) mfma_operand_guard(); }   // the first-Linear operands die here without a refill
+      Ops::set_hidden(h1, m, acc);
+      if constexpr (STAMPS) { if (m == 0) st_g0 = stamp(); }
     }
-    if constexpr (!Ops::EXACT_F32) { if (m == 2) mfma_operand_guard(); }   // the first-Linear operands die here without a refill
-    Ops::set_hidden(h1, m, acc);
-    if constexpr (VAR == 8) { if (m == 0) st_g0 = stamp(); }
+  } else {
+    // K = 32 edge-attribute product on top of acc1[m]; tile m's registers are refilled with the first second-Linear tile's fragments
+    const int tn_ = i_lo < i_hi ? 3 + i_lo : T_vec;
+    const Frag* const next = gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS);
+    Ops::template gemm_first<0>(a, next, Bx, acc1[0]);
+    Ops::set_hidden(h1, 0, acc1[0]);
+    if constexpr (STAMPS) st_g0 = stamp();
+    Ops::template gemm_first<1>(a, next, Bx, acc1[1]);
+    Ops::set_hidden(h1, 1, acc1[1]);
+    Ops::template gemm_first<2>(a, next, Bx, acc1[2]);
+    if constexpr (!Ops::EXACT_F32) mfma_operand_guard();   // Bx dies here without a refill
+    Ops::set_hidden(h1, 2, acc1[2]);
+    T = tn_;
   }
 
-  if constexpr (VAR == 8) st_t2 = stamp();
+  if constexpr (STAMPS) st_t2 = stamp();
   const float* xc = xT + j;
   // ---- block 0e: one tile per mid index, 32 output scalars
   float o0e[16];
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
 
 #undef CBD_TILE
-  if constexpr (VAR == 8) st_t3 = stamp();
+  if constexpr (STAMPS) st_t3 = stamp();
   // ---- messages -> LDS (re-using the gathered-row tile, stride 33 so that the column reads below are conflict free),
   //      then run-length sum per aggregating node
   __syncthreads();   // every read of xT (mids) is complete before it is overwritten
@@ -263,7 +280,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     }
     if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;   // run that reaches edge 31 of a full tile
   }
-  if constexpr (VAR == 8) {
+  if constexpr (STAMPS) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
       unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
       o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
@@ -514,6 +531,10 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   // CBD_CONV_VARIANT=9 (diagnostic, WRONG results): every tile re-reads weight tile 0, i.e. the L2 -> register weight stream
   // is replaced by L1-resident loads; the speed-up, if any, is what a perfect weight-reuse scheme could gain
   else if (IN == 3 && var == 9) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 9 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && var == 10) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 10 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && var == 11) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 11 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && var == 13) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 13 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && var == 12) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 12 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }

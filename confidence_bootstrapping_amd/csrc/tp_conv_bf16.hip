@@ -80,17 +80,11 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   // ---- which group / edge range does this wave own?  (edge counts live on the device; a wave owns 64 edges = two reduction tiles)
   int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
   {
-    int t = blockIdx.x;
-    for (int g = 0; g < args.n_groups; ++g) {
-      const int c = *args.g[g].count;
-      const int nt = (c + 63) / 64;
-      if (grp < 0) {
-        if (t < nt) { grp = g; e0 = t * 64; cnt = c; tile_local = 2 * t; }
-        else t -= nt;
-      }
-    }
+    int wave_in_group = 0;
+    if (!find_group(args, blockIdx.x, lane, 64, grp, wave_in_group, cnt)) return;
+    e0 = wave_in_group * 64;
+    tile_local = 2 * wave_in_group;
   }
-  if (grp < 0) return;
   const ConvGroup G = args.g[grp];
 
   // ---- start the weight stream

@@ -1,6 +1,8 @@
 // Device-side building blocks shared by the inference kernels (tp_conv.hip) and the training kernels (tp_train.hip):
 // MFMA operand policies, one-tile GEMM with register prefetch, and the CG "mid" evaluators of FasterTensorProduct.
 #pragma once
+#include <cstddef>
+
 #include "kernels.h"
 
 namespace cbd {
@@ -12,6 +14,35 @@ __device__ __forceinline__ unsigned long long stamp() {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
   __builtin_amdgcn_sched_barrier(0);
   return t;
+}
+
+// Which edge group does workgroup `t` of a tensor-product launch own, and which of its tiles?  The edge counts live on the device
+// (ConvGroup::count), so every wave has to read them: lane g reads group g's count (two dependent vector loads for all groups at
+// once -- a scalar loop over the groups costs two dependent scalar loads PER GROUP, ~6 k cycles for a wave of the 16th group), a wave
+// prefix sum turns the tile counts into tile ranges, and a ballot finds the owner.  Returns false when t is past the last tile.
+// `edges_per_wg` = 32 (tp_conv_kernel) or 64 (tp_conv64_kernel).
+__device__ __forceinline__ bool find_group(const ConvArgs& args, int t, int lane, int edges_per_wg, int& grp, int& tile_in_group, int& cnt) {
+  const int ng = args.n_groups;
+  int c = 0;
+  if (lane < ng) {
+    // per-lane read of the kernel-argument segment (indexing `args` by lane would make hipcc copy the 4 KB argument to scratch)
+    const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();   // constant address space -> generic
+    const int* cp = *reinterpret_cast<const int* const*>(ka + offsetof(ConvArgs, g) + (size_t)lane * sizeof(ConvGroup) + offsetof(ConvGroup, count));
+    c = *cp;
+  }
+  const int nt = (c + edges_per_wg - 1) / edges_per_wg;
+  int incl = nt;
+#pragma unroll
+  for (int d = 1; d < CONV_MAX_GROUPS; d <<= 1) {
+    const int v = __shfl_up(incl, d);
+    if (lane >= d) incl += v;
+  }
+  const unsigned long long owner = __ballot(t >= incl - nt && t < incl);
+  if (owner == 0) return false;
+  grp = __builtin_ctzll(owner);
+  cnt = __builtin_amdgcn_readlane(c, grp);
+  tile_in_group = t - (__builtin_amdgcn_readlane(incl, grp) - __builtin_amdgcn_readlane(nt, grp));
+  return true;
 }
 
 // ---- operand policies: how the two Linears of the radial MLP run on the matrix cores ------------------------------------
@@ -50,19 +81,28 @@ struct OpsF32 {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-  // first Linear, edge part only (K = 32: the edge_attr columns = fragments 0..3); the node parts enter through `acc`
-  // (ConvGroup::psrc / pdst).  All twelve fragments are still refilled: the next tile needs them.
+  // first Linear, edge part only (K = 32: the edge_attr columns = fragments 0..3 of a tile); the node parts enter through `acc`
+  // (ConvGroup::psrc / pdst).  The three first-Linear tiles need 3 x 4 fragments = the whole register tile: the kernel loads them all
+  // in its prologue (load_first), so the first Linear runs without a single wait on memory, and tile m's four registers are
+  // refilled in place with fragments 4m..4m+3 of the first second-Linear tile (`next`) right after their use.
+  static constexpr int FIRST_FRAGS = NFRAG / 3;            // 4
+  static __device__ __forceinline__ void load_first(Frag (&a)[NFRAG], const Frag* __restrict__ gp) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int s = 0; s < FIRST_FRAGS; ++s) a[FIRST_FRAGS * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64];
+  }
+  template <int M>
   static __device__ __forceinline__ void gemm_first(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
 #pragma unroll
-    for (int sg = 0; sg < NFRAG; ++sg) {
-      if (sg < NFRAG / 3) {
-        const f32x4 w = a[sg];
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * sg + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * sg + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * sg + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * sg + 3], acc, 0, 0, 0);
-      }
-      a[sg] = next[sg * 64];
+    for (int s = 0; s < FIRST_FRAGS; ++s) {
+      constexpr int base = FIRST_FRAGS * M;
+      const f32x4 w = a[base + s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * s + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * s + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * s + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * s + 3], acc, 0, 0, 0);
+      a[base + s] = next[(base + s) * 64];
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -192,25 +232,33 @@ struct OpsBf16x3 {
       __builtin_amdgcn_sched_barrier(0);
     }
   }
+  // first Linear: K = 32 = 2 k-steps x 3 planes = 6 fragments per tile, 3 tiles = the whole register tile (see OpsF32::gemm_first)
+  static constexpr int FIRST_FRAGS = NFRAG / 3;            // 6
+  static __device__ __forceinline__ void load_first(Frag (&a)[NFRAG], const Frag* __restrict__ gp) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int s = 0; s < FIRST_FRAGS; ++s) a[FIRST_FRAGS * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64];
+  }
+  template <int M>
   static __device__ __forceinline__ void gemm_first(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
 #pragma unroll
-    for (int q = 0; q < NFRAG / 3; ++q) {
-      const int k = 3 * q;
-      const Frag* p = next + k * 64;
+    for (int q = 0; q < FIRST_FRAGS / 3; ++q) {
+      constexpr int base = FIRST_FRAGS * M;
+      const int k = 3 * q, ka = base + 3 * q;
+      const Frag* p = next + ka * 64;
       pin(p);
       __builtin_amdgcn_sched_barrier(0);
-      if (q < NFRAG / 9) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 2], B.v[k + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 2], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
-      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 2], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 1], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 1], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 0], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      a[k + 0] = p[0];
-      a[k + 1] = p[64];
-      a[k + 2] = p[128];
+      a[ka + 0] = p[0];
+      a[ka + 1] = p[64];
+      a[ka + 2] = p[128];
       __builtin_amdgcn_sched_barrier(0);
     }
   }

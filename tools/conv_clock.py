@@ -7,7 +7,7 @@ from confidence_bootstrapping_amd.synthetic import make_workload
 from confidence_bootstrapping_amd.utils import make_score_model
 from confidence_bootstrapping_amd.engine import DockEngine, make_steps
 from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
-assert os.environ.get("CBD_CONV_VARIANT") == "8"
+assert os.environ.get("CBD_CONV_VARIANT") in ("8", "13")
 dev = torch.device("cuda:0")
 model, args = make_score_model(seed=0)
 cplx = make_workload("c2_dockgen_median")
