@@ -13,6 +13,7 @@
 // runs on the VALU with canonical intermediates x, x.n, x n, x cross n and (n n^T - I/3) x; the e3nn path weights,
 // sqrt(2l+1) spherical-harmonic scales and Wigner-3j constants are folded into the packed weights.
 #include "conf_common.h"
+#include "reduce_runs.h"
 
 namespace cbd {
 
@@ -288,25 +289,8 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       if constexpr (OUT >= 2) xT[(CC_1E + 3 * (3 * hf + o) + c) * C_OUT_STRIDE + j] = k1e[3 * o + c];
     }
   __syncthreads();
-  float* const fs = G.first_sum + (size_t)tile_local * CN_STRIDE;
-  float* const ls = G.last_sum + (size_t)tile_local * CN_STRIDE;
-  for (int col = lane; col < S.out_dim; col += 64) {
-    const float* oc = xT + col * C_OUT_STRIDE;
-    float sum = 0.f;
-    int cur = srcl[0], a0 = 0;
-    for (int jj = 0; jj < 32; ++jj) {
-      const int sj = srcl[jj];
-      if (sj != cur) {
-        float* d = a0 == 0 ? fs : G.run_acc + (size_t)cur * CN_STRIDE;
-        d[col] = sum;
-        sum = 0.f;
-        a0 = jj;
-        cur = sj;
-      }
-      sum += oc[jj];
-    }
-    if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;
-  }
+  reduce_runs<CN_STRIDE, C_OUT_STRIDE>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * CN_STRIDE,
+                                       G.last_sum + (size_t)tile_local * CN_STRIDE, G.run_acc);
 }
 
 // mean over all incoming edge types -> e3nn BatchNorm (eval) -> residual (reference tensor_layers.py:206-216)

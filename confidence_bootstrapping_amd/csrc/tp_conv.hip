@@ -257,29 +257,9 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
   }
   __syncthreads();
-  // Run-length sums without atomics (bitwise reproducible): a run that starts at the tile's first edge goes to
-  // first_sum[tile], one that ends at edge 31 to last_sum[tile], any other run (strictly inside the tile) is the
-  // node's only contribution from this group and is stored directly; conv_finalize_kernel adds the pieces in tile order.
-  float* const fs = G.first_sum + (size_t)tile_local * NODE_STRIDE;
-  float* const ls = G.last_sum + (size_t)tile_local * NODE_STRIDE;
-  for (int col = lane; col < S.out_dim; col += 64) {
-    const float* oc = xT + col * OUT_STRIDE;
-    float sum = 0.f;
-    int cur = srcl[0], a0 = 0;
-    for (int jj = 0; jj < 32; ++jj) {
-      const int sj = srcl[jj];
-      if (sj != cur) {   // run [a0, jj-1] of node cur is complete (invalid lanes, src = -1, only follow valid ones)
-        // (a run that ends at the last edge of the group's partial tile has no other tile either: stored as interior)
-        float* dst = a0 == 0 ? fs : G.run_acc + (size_t)cur * NODE_STRIDE;
-        dst[col] = sum;
-        sum = 0.f;
-        a0 = jj;
-        cur = sj;
-      }
-      sum += oc[jj];
-    }
-    if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;   // run that reaches edge 31 of a full tile
-  }
+  // Run-length sums per aggregating node (reduce_runs, tp_conv_dev.h)
+  reduce_runs<NODE_STRIDE, OUT_STRIDE>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * NODE_STRIDE, G.last_sum + (size_t)tile_local * NODE_STRIDE,
+              G.run_acc);
   if constexpr (STAMPS) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
       unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;

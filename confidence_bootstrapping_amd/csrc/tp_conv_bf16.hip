@@ -67,7 +67,9 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], const bf16x8* __r
   }
 }
 
-template <int IN, int OUT>
+// DIAG (timing only, WRONG results; CBD_BF16_DIAG=n): 1 = every tile re-reads weight tile 0 (the weight stream becomes L1-resident),
+// 2 = no CG epilogue (the accumulators are only summed up), 3 = both; 4 = correct results + phase stamps (tools/conv_clock.py bf16)
+template <int IN, int OUT, int DIAG = 0>
 __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -86,6 +88,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     tile_local = 2 * wave_in_group;
   }
   const ConvGroup G = args.g[grp];
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+  if constexpr (DIAG == 4) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream
   const bf16x8* gp = reinterpret_cast<const bf16x8*>(G.wstream) + lane;   // tile T fragment q: gp[T * V2_TILE_FRAGS + q * 64]
@@ -134,6 +138,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     }
   }
   __syncthreads();   // single-wave workgroup: orders the LDS writes above before the reads below
+  if constexpr (DIAG == 4) st_t1 = stamp();
 
   int T = 0;
   f32x16 acc0, acc1;
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #define V2_TILE(BA, BB, NEXT)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    v2_gemm(a, gp + (size_t)tn_ * V2_TILE_FRAGS, BA, BB, acc0, acc1);       \
+    v2_gemm(a, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), BA, BB, acc0, acc1);       \
     T = tn_;                                                                \
   }
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
@@ -157,6 +162,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     v2_set_hidden(h1, m, acc1);
   }
 
+  if constexpr (DIAG == 4) st_t2 = stamp();
   const float* xc0 = xT0 + j;
   const float* xc1 = xT1 + j;
   // ---- block 0e: one tile per mid index, 32 output scalars
@@ -169,6 +175,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     // first use below it): the LDS latency is covered by the 14 MFMAs instead of being exposed after them
     const float m0 = mid0e<IN>(xc0, i, v0), m1 = mid0e<IN>(xc1, i, v1);
     V2_TILE(h0, h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
+    if constexpr (DIAG & 2) { o0e0[0] += acc0[0] + m0; o0e1[0] += acc1[0] + m1; } else
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0e0[r] = fmaf(m0, acc0[r], o0e0[r]); o0e1[r] = fmaf(m1, acc1[r], o0e1[r]); }
   }
@@ -184,6 +191,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #pragma unroll 1
     for (int t = 0; t < ntile; ++t) {
       V2_TILE(h0, h1, T + 1);
+      if constexpr (DIAG & 2) { keep0[0] += acc0[0]; keep1[0] += acc1[0]; continue; }
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
         float ma[3], mb[3];
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #pragma unroll 1
       for (int t = 0; t < S.t0o; ++t) {
         V2_TILE(h0, h1, T + 1);
+        if constexpr (DIAG & 2) { k0o0[0] += acc0[0]; k0o1[0] += acc1[0]; continue; }
 #pragma unroll
         for (int q = 0; q < VEC_TILE_I; ++q) {
           const float ma = mid0o<IN>(xc0, VEC_TILE_I * t + q, v0), mb = mid0o<IN>(xc1, VEC_TILE_I * t + q, v1);
@@ -221,6 +230,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #undef V2_TILE
 
   // ---- messages -> LDS (re-using the gathered-row tiles, stride 33), then run-length sums per aggregating node and sub-tile
+  if constexpr (DIAG == 4) st_t3 = stamp();
   __syncthreads();   // every read of xT (mids) is complete before it is overwritten
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
@@ -244,31 +254,16 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     }
   }
   __syncthreads();
-  // Run-length sums without atomics (bitwise reproducible), exactly the pieces of tp_conv_kernel: per 32-edge reduction tile the sum of
-  // its first run -> first_sum[tile], of the run that reaches edge 31 -> last_sum[tile], any other run is the node's only contribution
-  // from this group and is stored directly; conv_finalize adds the pieces in tile order.
+  // Run-length sums per aggregating node and 32-edge reduction tile, exactly the pieces of tp_conv_kernel (reduce_runs, tp_conv_dev.h)
 #pragma unroll 1
-  for (int sub = 0; sub < 2; ++sub) {
-    const float* xT = sub ? xT1 : xT0;
-    const int* sl = srcl + 32 * sub;
-    float* const fs = G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE;
-    float* const ls = G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE;
-    for (int col = lane; col < S.out_dim; col += 64) {
-      const float* oc = xT + col * OUT_STRIDE;
-      float sum = 0.f;
-      int cur = sl[0], a0 = 0;
-      for (int jj = 0; jj < 32; ++jj) {
-        const int sj = sl[jj];
-        if (sj != cur) {
-          float* dst = a0 == 0 ? fs : G.run_acc + (size_t)cur * NODE_STRIDE;
-          dst[col] = sum;
-          sum = 0.f;
-          a0 = jj;
-          cur = sj;
-        }
-        sum += oc[jj];
-      }
-      if (cur >= 0) (a0 == 0 ? fs : ls)[col] = sum;
+  for (int sub = 0; sub < 2; ++sub)
+    reduce_runs<NODE_STRIDE, OUT_STRIDE>(sub ? xT1 : xT0, srcl + 32 * sub, lane, S.out_dim, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
+                G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc);
+  if constexpr (DIAG == 4) {   // same record layout as tp_conv_kernel's CBD_CONV_VARIANT=8 stamps (tools/conv_clock.py)
+    if (lane == 0 && args.stamps && blockIdx.x < 8192) {
+      unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
+      o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
+      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = st_t2;
     }
   }
 }
@@ -276,6 +271,12 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 template <int IN, int OUT>
 static hipError_t launch_one64(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = (2 * V2_SUB_FLOATS + 64) * 4;
+  static const int diag = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
+  if (IN == 3 && diag == 1) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 1 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 2) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 2 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 4) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 4 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 3) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 3 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else
   hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }

@@ -4,6 +4,7 @@
 #include <cstddef>
 
 #include "kernels.h"
+#include "reduce_runs.h"
 
 namespace cbd {
 
@@ -44,6 +45,8 @@ __device__ __forceinline__ bool find_group(const ConvArgs& args, int t, int lane
   tile_in_group = t - (__builtin_amdgcn_readlane(incl, grp) - __builtin_amdgcn_readlane(nt, grp));
   return true;
 }
+
+constexpr int OUT_STRIDE = 33;   // message tile stride (conflict-free column reads)
 
 // ---- operand policies: how the two Linears of the radial MLP run on the matrix cores ------------------------------------
 // One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers, loaded one tile ahead
@@ -339,7 +342,6 @@ __device__ __forceinline__ float mid0o(const float* xc, int i, const float (&v)[
 }
 
 constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed copy of the gathered rows
-constexpr int OUT_STRIDE = 33;                           // message tile stride (conflict-free column reads)
 __host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
 }  // namespace cbd
