@@ -239,13 +239,15 @@ static uint16_t f32_to_bf16_rne(float f) {
 }
 
 static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
-  // stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [7 k-steps][64 lanes][8 bf16] (7 KB); k-steps 0..5 carry the 96 input columns,
-  // k-step 6 is the bias step (K extended to 112: element k = 96 of every row holds the row's bias, the activation side supplies e_96)
+  // stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] (6 KB) carrying the 96 input columns, then the fp32
+  // bias rows [ntiles + 1][32] (the kernel feeds a tile's bias as the C operand of its first MFMA pair; row ntiles is the zero tile's)
   const TileRows tr = conv_tile_rows(IN, OUT);
-  constexpr int NQ = KDIM / 16 + 1;
-  constexpr int TILE_BF16 = NQ * 64 * 8;   // 3584 bf16 = 7 KB
-  std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + 3) / 4, 0.f);
+  constexpr int NQ = KDIM / 16;
+  constexpr int TILE_BF16 = NQ * 64 * 8;   // 3072 bf16 = 6 KB
+  const size_t tile_floats = (size_t)(tr.ntiles + 1) * TILE_BF16 / 2;
+  std::vector<float> out(tile_floats + (size_t)(tr.ntiles + 1) * 32, 0.f);
   uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
+  float* const bias = out.data() + tile_floats;
   for (int T = 0; T < tr.ntiles; ++T) {
     uint16_t* tile = w + (size_t)T * TILE_BF16;
     const bool first = T < 3;
@@ -256,18 +258,18 @@ static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1
         for (int j = 0; j < 8; ++j) {
           float v = 0.f;
           if (R.row >= 0) {
-            if (q < NQ - 1) {
-              // first Linear: k-step q = 2*part + sub covers input columns 16h + 8sub + j of the 32-wide part;
-              // second Linear: registers 8s..8s+7 of hidden tile m = q/2, s = q%2: unit 32m + 16s + 8(j>>2) + 4h + (j&3)
-              const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
-              v = R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
-            } else if (h == 0 && j == 0) {
-              v = R.scale * (first ? b1 : b2)[R.row];
-            }
+            // first Linear: k-step q = 2*part + sub covers input columns 16h + 8sub + j of the 32-wide part;
+            // second Linear: registers 8s..8s+7 of hidden tile m = q/2, s = q%2: unit 32m + 16s + 8(j>>2) + 4h + (j&3)
+            const int k = first ? 32 * (q >> 1) + 16 * h + 8 * (q & 1) + j : 32 * (q >> 1) + 16 * (q & 1) + 8 * (j >> 2) + 4 * h + (j & 3);
+            v = R.scale * (first ? W1 : W2)[(size_t)R.row * KDIM + k];
           }
           tile[((size_t)q * 64 + lane) * 8 + j] = f32_to_bf16_rne(v);
         }
       }
+    for (int r = 0; r < 32; ++r) {
+      const TileRow& R = tr.rows[(size_t)T * 32 + r];
+      bias[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
+    }
   }
   return out;
 }

@@ -19,49 +19,68 @@
 // fp32 everywhere outside the two Linears (gathered rows, CG contraction, messages, reduction), like the first generation.
 // Weight stream (pack_conv_stream_bf16v2, engine.hip): (ntiles + 1) tiles of [7 k-steps][64 lanes][8 bf16] = 7 KB.
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.h"
 #include "tp_conv_dev.h"
 
 namespace cbd {
 
-constexpr int V2_NFRAG = 7;                      // 6 k-steps of the 96 inputs + 1 bias step
+constexpr int V2_NFRAG = 6;                      // 6 k-steps of 16 = the 96 inputs; the bias enters as the C operand of the first pair
 constexpr int V2_TILE_FRAGS = V2_NFRAG * 64;     // 16-byte fragments per tile
 constexpr int V2_SUB_FLOATS = NODE_DIM * OUT_STRIDE;   // 74 x 33 floats per 32-edge sub-tile (>= 76 x 32 of the gather image)
 static_assert(V2_SUB_FLOATS >= 76 * 32, "gather image must fit the message tile");
 
-struct Act7 { bf16x8 v[V2_NFRAG]; };
+struct Act6 { bf16x8 v[V2_NFRAG]; };
 
-__device__ __forceinline__ void v2_set_in(Act7& B, int seg, int q, f32x4 x) {
+__device__ __forceinline__ void v2_set_in(Act6& B, int seg, int q, f32x4 x) {
   const int k = 2 * seg + (q >> 1), o = 4 * (q & 1);
   B.v[k][o + 0] = (__bf16)x.x; B.v[k][o + 1] = (__bf16)x.y; B.v[k][o + 2] = (__bf16)x.z; B.v[k][o + 3] = (__bf16)x.w;
 }
-__device__ __forceinline__ void v2_set_hidden(Act7& h, int m, const f32x16& acc) {
+__device__ __forceinline__ void v2_set_hidden(Act6& h, int m, const f32x16& acc) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
 }
 
-// acc_s = A_tile * B_s (s = 0, 1); the A fragments are refilled in place with the NEXT tile's data.  Two rules keep the in-flight MFMA
-// operand hazard of tp_conv_dev.h out (a VALU write, or a returning load, into a register that an issued MFMA has not read yet):
-//   * the whole chain contains NO VALU instruction: the two base addresses are computed and pinned before the first MFMA and every load
-//     uses an immediate offset (fragments 0..3: base + q KB, fragments 4..6: base + 4 KB + (q - 4) KB; the field holds < 4 KB), so a
-//     fragment register that is momentarily dead cannot be handed to address arithmetic (measured, round 2: the same delayed schedule
-//     with per-fragment address computation between the pairs gave run-to-run differences in 8 of 9 repeats of tools/bf16_repeat.py);
+// acc_s = bias + A_tile * B_s (s = 0, 1).  The bias (fp32, one value per weight row) sits in 16 registers in the accumulator layout
+// and is the C operand of the first MFMA pair (D != C): no bias k-step, no accumulator initialisation.
+// The A fragments and the bias registers are refilled in place with the NEXT tile's data.  Two rules keep the in-flight MFMA operand
+// hazard of tp_conv_dev.h out (a VALU write, or a returning load, into a register that an issued MFMA has not read yet):
+//   * the whole chain contains NO VALU instruction: the base addresses are computed and pinned before the first MFMA and every load
+//     uses an immediate offset (fragments 0..3: base + q KB, fragments 4..5: base + 4 KB + (q - 4) KB; the field holds < 4 KB), so a
+//     register that is momentarily dead cannot be handed to address arithmetic (measured, round 2: the same delayed schedule with
+//     per-fragment address computation between the pairs gave run-to-run differences in 8 of 9 repeats of tools/bf16_repeat.py);
 //   * fragment q-1 is re-loaded after the MFMA pair of fragment q has been issued -- one pair late, so that even a load that hits in
-//     L1 (~120 cycles) lands after the pair that read the register has started; the last fragment follows its own pair directly.
-__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], const bf16x8* __restrict__ next, const Act7& B0, const Act7& B1,
-                                        f32x16& acc0, f32x16& acc1) {
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+//     L1 (~120 cycles) lands after the pair that read the register has started; the bias follows the second pair, the last fragment
+//     its own pair directly.
+__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const bf16x8* __restrict__ next, const f32x4* __restrict__ next_bias,
+                                        const Act6& B0, const Act6& B1, f32x16& acc0, f32x16& acc1) {
   const bf16x8* pa = next;
   const bf16x8* pb = next + 4 * 64;
-  pin(pa); pin(pb);
+  const f32x4* pc = next_bias;
+  pin(pa); pin(pb); pin(pc);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < V2_NFRAG; ++q) {
-    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B0.v[q], q == 0 ? zero : acc0, 0, 0, 0);
-    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B1.v[q], q == 0 ? zero : acc1, 0, 0, 0);
+    if (q == 0) {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B0.v[q], cb, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B1.v[q], cb, 0, 0, 0);
+    } else {
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B0.v[q], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[q], B1.v[q], acc1, 0, 0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
+    // keep the bias registers a live 16-register tuple of their own: otherwise hipcc lets an accumulator take them over after the first
+    // pair, loads the next bias somewhere else and copies it back with 16 v_mov behind a vmcnt(0) at the end of every tile
+    if (q == 0) asm volatile("" : "+v"(cb));
     if (q > 0) a[q - 1] = q - 1 < 4 ? pa[(q - 1) * 64] : pb[(q - 5) * 64];
+    if (q == 1) {   // rows (r & 3) + 8 (r >> 2) + 4 hf of the next tile's bias: float4 2q' + hf of its 32 floats (hf is in `next_bias`)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 b = pc[2 * qq];
+        cb[4 * qq + 0] = b.x; cb[4 * qq + 1] = b.y; cb[4 * qq + 2] = b.z; cb[4 * qq + 3] = b.w;
+      }
+    }
     if (q == V2_NFRAG - 1) a[q] = pb[(q - 4) * 64];
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -96,42 +115,68 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   bf16x8 a[V2_NFRAG];
 #pragma unroll
   for (int q = 0; q < V2_NFRAG; ++q) a[q] = gp[q * 64];
+  // fp32 bias rows behind the (ntiles + 1) tiles: [ntiles + 1][32]; this lane half's float4s are 2q' + hf
+  const f32x4* const gbias = reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)(S.ntiles + 1) * V2_TILE_FRAGS) + hf;
+  f32x16 cb;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const f32x4 b = gbias[2 * qq];
+    cb[4 * qq + 0] = b.x; cb[4 * qq + 1] = b.y; cb[4 * qq + 2] = b.z; cb[4 * qq + 3] = b.w;
+  }
 
   // ---- gather both sub-tiles.  Lanes past the end of the group read the group's last edge (unconditional loads) and are dropped
   //      at the end through src = -1.
-  Act7 Bx0, Bx1;
+  Act6 Bx0, Bx1;
   float v0[3], v1[3];
-  {
-    bf16x8 one = {0, 0, 0, 0, 0, 0, 0, 0};
-    one[0] = hf == 0 ? (__bf16)1.0f : (__bf16)0.0f;      // activation fragment of the bias step: unit vector e_96
-    Bx0.v[6] = one; Bx1.v[6] = one;
-  }
+  // Two rounds of memory latency instead of four: the edge indices of BOTH sub-tiles first, then every gather that depends on them in
+  // one batch (attributes, the two 32-column node segments, sub-tile 0's full destination row: 136 registers in flight), sub-tile 1's
+  // row while the first is transposed into LDS.  (In source order per sub-tile the compiler waited for each sub-tile's indices and
+  // gathers in turn: 21.5 k cycles of a 113 k lifetime, in-kernel stamps.)
+  int src_r[2], dstn[2], aidx[2];
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
-    Act7& Bx = sub ? Bx1 : Bx0;
-    float* xT = sub ? xT1 : xT0;
     const int e = e0 + 32 * sub + j;
     const bool valid = e < cnt;
     const int ec = valid ? e : cnt - 1;
-    const int src_r = G.src[ec], dst = G.dst[ec], aidx = G.attr_idx[ec];
+    src_r[sub] = G.src[ec]; dstn[sub] = G.dst[ec]; aidx[sub] = G.attr_idx[ec];
     const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[ec];
     if (sub) { v1[0] = vv.x; v1[1] = vv.y; v1[2] = vv.z; } else { v0[0] = vv.x; v0[1] = vv.y; v0[2] = vv.z; }
-    if (hf == 0) srcl[32 * sub + j] = valid ? src_r : -1;
-    const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
-    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
+    if (hf == 0) srcl[32 * sub + j] = valid ? src_r[sub] : -1;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  f32x4 ta[2][4], ts[2][4], td[2][4], tr[10];
+  const f32x4* pr[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx[sub] * 32 + 16 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r[sub] * NODE_STRIDE + 16 * hf);
+    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dstn[sub] * NODE_STRIDE + 16 * hf);
+    // full destination row; lane half hf takes cols 40hf .. 40hf+39 (cols 76..79 are the row's padding: loaded, not stored)
+    pr[sub] = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dstn[sub] * NODE_STRIDE + 40 * hf);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ta[sub][q] = pa[q]; ts[sub][q] = ps[q]; td[sub][q] = pd[q]; }
+  }
+#pragma unroll
+  for (int q = 0; q < 10; ++q) tr[q] = pr[0][q];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int sub = 0; sub < 2; ++sub) {
+    Act6& Bx = sub ? Bx1 : Bx0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      v2_set_in(Bx, 0, q, pa[q]);
-      v2_set_in(Bx, 1, q, ps[q]);
-      v2_set_in(Bx, 2, q, pd[q]);
+      v2_set_in(Bx, 0, q, ta[sub][q]);
+      v2_set_in(Bx, 1, q, ts[sub][q]);
+      v2_set_in(Bx, 2, q, td[sub][q]);
     }
-    // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39 (cols >= 76 are padding)
-    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 40 * hf);
+  }
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {
+  for (int sub = 0; sub < 2; ++sub) {
+    float* xT = sub ? xT1 : xT0;
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {   // transposed LDS copy xT[col][j]
+      const f32x4 r = tr[q];
+      if (sub == 0) tr[q] = pr[1][q];
       if (40 * hf + 4 * q < 76) {
-        const f32x4 r = pr[q];
         float* o = xT + (40 * hf + 4 * q) * 32 + j;
         o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
       }
@@ -142,15 +187,14 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 
   int T = 0;
   f32x16 acc0, acc1;
-  Act7 h0, h1;
-  h0.v[6] = Bx0.v[6]; h1.v[6] = Bx0.v[6];
+  Act6 h0, h1;
   const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
   const bool vec_on = G.vec_on != 0;
   const int T_vec = 3 + S.t0e;
 #define V2_TILE(BA, BB, NEXT)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    v2_gemm(a, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), BA, BB, acc0, acc1);       \
+    v2_gemm(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)tn_ * 8, BA, BB, acc0, acc1); \
     T = tn_;                                                                \
   }
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
@@ -169,15 +213,26 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   float o0e0[16], o0e1[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { o0e0[r] = 0.f; o0e1[r] = 0.f; }
-#pragma unroll 1
-  for (int i = i_lo; i < i_hi; ++i) {
-    // the mids are read from LDS BEFORE the MFMA chain (the fences inside v2_gemm keep the reads above it, their wait lands at the
-    // first use below it): the LDS latency is covered by the 14 MFMAs instead of being exposed after them
-    const float m0 = mid0e<IN>(xc0, i, v0), m1 = mid0e<IN>(xc1, i, v1);
+  // the mids are read from LDS BEFORE the MFMA chain (the fences inside v2_gemm keep the reads above it, their wait lands at the first
+  // use below it): the LDS latency is covered by the MFMAs instead of being exposed after them.  Two loops, one per kind of mid (the
+  // scalar features themselves, then the 1o . direction dot products), so that neither body branches on the mid index.
+  auto tile0e = [&](int i, float m0, float m1) __attribute__((always_inline)) {
     V2_TILE(h0, h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
-    if constexpr (DIAG & 2) { o0e0[0] += acc0[0] + m0; o0e1[0] += acc1[0] + m1; } else
+    if constexpr (DIAG & 2) { o0e0[0] += acc0[0] + m0; o0e1[0] += acc1[0] + m1; } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0e0[r] = fmaf(m0, acc0[r], o0e0[r]); o0e1[r] = fmaf(m1, acc1[r], o0e1[r]); }
+      for (int r = 0; r < 16; ++r) { o0e0[r] = fmaf(m0, acc0[r], o0e0[r]); o0e1[r] = fmaf(m1, acc1[r], o0e1[r]); }
+    }
+  };
+  const int i_mid = i_hi < NS ? i_hi : NS;
+#pragma unroll 1
+  for (int i = i_lo; i < i_mid; ++i) tile0e(i, xc0[i * 32], xc1[i * 32]);
+  if constexpr (IN >= 1) {
+#pragma unroll 1
+    for (int i = i_lo > NS ? i_lo : NS; i < i_hi; ++i) {
+      const float* p0 = xc0 + (COL_1O + 3 * (i - NS)) * 32;
+      const float* p1 = xc1 + (COL_1O + 3 * (i - NS)) * 32;
+      tile0e(i, p0[0] * v0[0] + p0[32] * v0[1] + p0[64] * v0[2], p1[0] * v1[0] + p1[32] * v1[1] + p1[64] * v1[2]);
+    }
   }
 
   // ---- vector / pseudoscalar blocks: tile = 5 mid indices x 6 outputs; lane half hf owns outputs 3hf..3hf+2
@@ -187,42 +242,90 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   k0o0[0] = k0o0[1] = k0o0[2] = 0.f;
   k0o1[0] = k0o1[1] = k0o1[2] = 0.f;
 
-  auto vec_block = [&](auto mid_fn, int ntile, float (&keep0)[9], float (&keep1)[9]) __attribute__((always_inline)) {
-#pragma unroll 1
+  // The tile loops of the vector blocks are FULLY unrolled: the mid index is then a compile-time constant, the kind of every mid
+  // (scalar x direction, copy, cross product, padding) is resolved by the compiler, and the LDS reads of a tile's ten mids are issued
+  // together before the chain.  Rolled, every mid was a chain of scalar branches around LDS reads that were each waited for in turn:
+  // 44 s_waitcnt and ~3.6 k cycles per vector tile against ~0.7 k for a scalar tile (in-kernel stamps, round 2).
+  // Mids of the form (scalar feature) x (edge direction) -- the first NS mids of block 1o, the last n0o of block 1e -- are not
+  // multiplied out: sum_i (x_i v_c) w_io = v_c sum_i x_i w_io, so they cost one FMA per output instead of three and the direction is
+  // applied once per block (`is_scalar(i)` / `scalar_of(x, i)` describe them; padded slots i >= fan are skipped altogether).
+  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep0)[9], float (&keep1)[9])
+                       __attribute__((always_inline)) {
+    constexpr int ntile = decltype(ntile_c)::value, fan = decltype(fan_c)::value;
+    float s0[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f};
+#pragma unroll
     for (int t = 0; t < ntile; ++t) {
+      // vector-valued mids are evaluated before the chain (LDS latency and the cross products under the MFMAs); the scalar ones are
+      // read behind it -- ten more live registers across the chain would spill
+      float ma[VEC_TILE_I][3], mb[VEC_TILE_I][3];
+      if constexpr (!(DIAG & 2)) {
+#pragma unroll
+        for (int q = 0; q < VEC_TILE_I; ++q) {
+          const int i = VEC_TILE_I * t + q;
+          if (i >= fan || is_scalar(i)) continue;
+          mid_fn(xc0, i, v0, ma[q]); mid_fn(xc1, i, v1, mb[q]);
+        }
+      }
       V2_TILE(h0, h1, T + 1);
       if constexpr (DIAG & 2) { keep0[0] += acc0[0]; keep1[0] += acc1[0]; continue; }
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
-        float ma[3], mb[3];
-        mid_fn(xc0, VEC_TILE_I * t + q, v0, ma);
-        mid_fn(xc1, VEC_TILE_I * t + q, v1, mb);
+        const int i = VEC_TILE_I * t + q;
+        if (i >= fan) continue;
+        float xa = 0.f, xb = 0.f;
+        if (is_scalar(i)) { xa = scalar_of(xc0, i); xb = scalar_of(xc1, i); }
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float wa = acc0[3 * q + o], wb = acc1[3 * q + o];
+          if (is_scalar(i)) {
+            s0[o] = fmaf(xa, wa, s0[o]);
+            s1[o] = fmaf(xb, wb, s1[o]);
+          } else {
 #pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            keep0[3 * o + c] = fmaf(ma[c], wa, keep0[3 * o + c]);
-            keep1[3 * o + c] = fmaf(mb[c], wb, keep1[3 * o + c]);
+            for (int c = 0; c < 3; ++c) {
+              keep0[3 * o + c] = fmaf(ma[q][c], wa, keep0[3 * o + c]);
+              keep1[3 * o + c] = fmaf(mb[q][c], wb, keep1[3 * o + c]);
+            }
           }
         }
       }
+      // the tile's FMAs have no side effect, so nothing ties them to this place in the fully unrolled code: without the pins hipcc
+      // parks the accumulators of the scalar tiles in scratch and does their FMAs several tiles later (1 KB of spills per lane)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) { pin(s0[o]); pin(s1[o]); }
     }
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        keep0[3 * o + c] = fmaf(v0[c], s0[o], keep0[3 * o + c]);
+        keep1[3 * o + c] = fmaf(v1[c], s1[o], keep1[3 * o + c]);
+      }
   };
   if (vec_on) {
-    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); }, S.t1o, k1o0, k1o1);
+    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
+              [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
+              std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o0, k1o1);
     if constexpr (OUT >= 2)
-      vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); }, S.t1e, k1e0, k1e1);
+      vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
+                [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
+                std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e0, k1e1);
     if constexpr (OUT >= 3) {
-#pragma unroll 1
+#pragma unroll
       for (int t = 0; t < S.t0o; ++t) {
+        float ma[VEC_TILE_I], mb[VEC_TILE_I];
+#pragma unroll
+        for (int q = 0; q < VEC_TILE_I; ++q) {
+          if (VEC_TILE_I * t + q >= S.fan0o) continue;
+          ma[q] = mid0o<IN>(xc0, VEC_TILE_I * t + q, v0); mb[q] = mid0o<IN>(xc1, VEC_TILE_I * t + q, v1);
+        }
         V2_TILE(h0, h1, T + 1);
         if constexpr (DIAG & 2) { k0o0[0] += acc0[0]; k0o1[0] += acc1[0]; continue; }
 #pragma unroll
         for (int q = 0; q < VEC_TILE_I; ++q) {
-          const float ma = mid0o<IN>(xc0, VEC_TILE_I * t + q, v0), mb = mid0o<IN>(xc1, VEC_TILE_I * t + q, v1);
+          if (VEC_TILE_I * t + q >= S.fan0o) continue;
 #pragma unroll
-          for (int o = 0; o < 3; ++o) { k0o0[o] = fmaf(ma, acc0[3 * q + o], k0o0[o]); k0o1[o] = fmaf(mb, acc1[3 * q + o], k0o1[o]); }
+          for (int o = 0; o < 3; ++o) { k0o0[o] = fmaf(ma[q], acc0[3 * q + o], k0o0[o]); k0o1[o] = fmaf(mb[q], acc1[3 * q + o], k0o1[o]); }
         }
       }
     }
