@@ -29,6 +29,8 @@
 //     in a fixed order -> bitwise reproducible results.
 #include <cstdlib>
 
+#include <type_traits>
+
 #include "kernels.h"
 #include "tp_conv_dev.h"
 
@@ -181,14 +183,23 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   float o0e[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
-#pragma unroll 1
-  for (int i = i_lo; i < i_hi; ++i) {
-    // the mid is read from LDS BEFORE the MFMA chain (the scheduling fences of the chain keep the read above it; its wait lands at the
-    // first use below): the LDS latency is covered by the tile's MFMAs instead of being exposed after them
-    const float m = mid0e<IN>(xc, i, v);
+  // the mid is read from LDS BEFORE the MFMA chain (the scheduling fences of the chain keep the read above it; its wait lands at the
+  // first use below): the LDS latency is covered by the tile's MFMAs instead of being exposed after them.  Two loops, one per kind of
+  // mid (the scalar features themselves, then the 1o . direction dot products), so that neither body branches on the mid index.
+  auto tile0e = [&](int i, float m) __attribute__((always_inline)) {
     CBD_TILE(h1, i + 1 < i_hi ? T + 1 : (vec_on ? T_vec : S.ntiles));
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
+  };
+  const int i_mid = i_hi < NS ? i_hi : NS;
+#pragma unroll 1
+  for (int i = i_lo; i < i_mid; ++i) tile0e(i, xc[i * 32]);
+  if constexpr (IN >= 1) {
+#pragma unroll 1
+    for (int i = i_lo > NS ? i_lo : NS; i < i_hi; ++i) {
+      const float* p = xc + (COL_1O + 3 * (i - NS)) * 32;
+      tile0e(i, p[0] * v[0] + p[32] * v[1] + p[64] * v[2]);
+    }
   }
 
   // ---- vector / pseudoscalar blocks: tile = 5 mid indices x 6 outputs; lane half hf owns outputs 3hf..3hf+2, register
@@ -198,44 +209,82 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
   k0o[0] = k0o[1] = k0o[2] = 0.f;
 
-  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
-#pragma unroll 1
-    for (int t = 0; t < ntile; ++t) {
-      float m[VEC_TILE_I][3];   // the five mids of the tile, evaluated (LDS reads + cross products) before the MFMA chain
+  // The tile loops of the vector blocks are FULLY unrolled: the mid index is then a compile-time constant, the kind of every mid
+  // (scalar x direction, copy, cross product, padding) is resolved by the compiler and the LDS reads of a tile's mids are issued
+  // together.  Rolled, every mid was a chain of scalar branches around LDS reads that were each waited for in turn (44 s_waitcnt and
+  // ~3.6 k cycles per vector tile, in-kernel stamps of the bf16 kernel, round 2).
+  // Mids of the form (scalar feature) x (edge direction) -- the first NS mids of block 1o, the last n0o of block 1e -- are not
+  // multiplied out: sum_i (x_i v_c) w_io = v_c sum_i x_i w_io, one FMA per output instead of three, the direction applied once per
+  // block (`is_scalar(i)` / `scalar_of(x, i)`); padded slots i >= fan are skipped.
+  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep)[9]) __attribute__((always_inline)) {
+    constexpr int ntile = decltype(ntile_c)::value, fan = decltype(fan_c)::value;
+    float sc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-      for (int q = 0; q < VEC_TILE_I; ++q) mid_fn(xc, VEC_TILE_I * t + q, v, m[q]);
+    for (int t = 0; t < ntile; ++t) {
+      float m[VEC_TILE_I][3], xs[VEC_TILE_I];   // the tile's mids, evaluated (LDS reads + cross products) before the MFMA chain
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const int i = VEC_TILE_I * t + q;
+        if (i >= fan) continue;
+        if (is_scalar(i)) xs[q] = scalar_of(xc, i);
+        else mid_fn(xc, i, v, m[q]);
+      }
       CBD_TILE(h1, T + 1);
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
+        const int i = VEC_TILE_I * t + q;
+        if (i >= fan) continue;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float w = acc[3 * q + o];
-          keep[3 * o + 0] = fmaf(m[q][0], w, keep[3 * o + 0]);
-          keep[3 * o + 1] = fmaf(m[q][1], w, keep[3 * o + 1]);
-          keep[3 * o + 2] = fmaf(m[q][2], w, keep[3 * o + 2]);
+          if (is_scalar(i)) {
+            sc[o] = fmaf(xs[q], w, sc[o]);
+          } else {
+            keep[3 * o + 0] = fmaf(m[q][0], w, keep[3 * o + 0]);
+            keep[3 * o + 1] = fmaf(m[q][1], w, keep[3 * o + 1]);
+            keep[3 * o + 2] = fmaf(m[q][2], w, keep[3 * o + 2]);
+          }
         }
       }
+      // pure FMAs are not tied to their place in the unrolled code: pin the running sums to the tile (otherwise hipcc parks the
+      // accumulator in scratch and does the FMAs tiles later)
+#pragma unroll
+      for (int o = 0; o < 3; ++o) pin(sc[o]);
     }
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) keep[3 * o + c] = fmaf(v[c], sc[o], keep[3 * o + c]);
   };
 
   if (vec_on) {
-  vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); }, S.t1o, k1o);
-  if constexpr (OUT >= 2)
-    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); }, S.t1e, k1e);
-  if constexpr (OUT >= 3) {
-#pragma unroll 1
-    for (int t = 0; t < S.t0o; ++t) {
-      float m[VEC_TILE_I];
+    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
+              [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
+              std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o);
+    if constexpr (OUT >= 2)
+      vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
+                [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
+                std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e);
+    if constexpr (OUT >= 3) {
 #pragma unroll
-      for (int q = 0; q < VEC_TILE_I; ++q) m[q] = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
-      CBD_TILE(h1, T + 1);
+      for (int t = 0; t < S.t0o; ++t) {
+        float m[VEC_TILE_I];
 #pragma unroll
-      for (int q = 0; q < VEC_TILE_I; ++q) {
+        for (int q = 0; q < VEC_TILE_I; ++q) {
+          if (VEC_TILE_I * t + q >= S.fan0o) continue;
+          m[q] = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+        }
+        CBD_TILE(h1, T + 1);
 #pragma unroll
-        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m[q], acc[3 * q + o], k0o[o]);
+        for (int q = 0; q < VEC_TILE_I; ++q) {
+          if (VEC_TILE_I * t + q >= S.fan0o) continue;
+#pragma unroll
+          for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m[q], acc[3 * q + o], k0o[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) pin(k0o[o]);
       }
     }
-  }
   }
 
 #undef CBD_TILE
