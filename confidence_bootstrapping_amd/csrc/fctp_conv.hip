@@ -12,6 +12,8 @@
 // group of 4 mids; vector blocks (6 outputs) use tiles of 5 mid indices x 6 outputs.  The Clebsch-Gordan contraction
 // runs on the VALU with canonical intermediates x, x.n, x n, x cross n and (n n^T - I/3) x; the e3nn path weights,
 // sqrt(2l+1) spherical-harmonic scales and Wigner-3j constants are folded into the packed weights.
+#include <type_traits>
+
 #include "conf_common.h"
 #include "reduce_runs.h"
 
@@ -214,60 +216,114 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   float o0e[12], o0o[12];
 #pragma unroll
   for (int r = 0; r < 12; ++r) { o0e[r] = 0.f; o0o[r] = 0.f; }
-#pragma unroll 1
-  for (int g = 0; g < S.g0e; ++g) {
-    float m[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) m[i] = cmid0e<IN>(xc, 4 * g + i, n);
+  // One group = 4 mids x 3 tiles.  Groups whose four mids are plain scalar features run in a rolled, branch-free loop; the few
+  // groups with dot-product mids or padding are unrolled so that the kind of each mid is a compile-time fact (rolled, every mid was a
+  // chain of scalar branches around LDS reads that were waited for one by one -- see tp_conv.hip).
+  auto scalar_group = [&](const float (&m)[4], float (&out)[12]) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       CBD_CTILE(h1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) o0e[4 * q + c] = fmaf(m[i], acc[4 * i + c], o0e[4 * q + c]);
+        for (int c = 0; c < 4; ++c) out[4 * q + c] = fmaf(m[i], acc[4 * i + c], out[4 * q + c]);
     }
+  };
+  constexpr int G0E_PLAIN = CNS / 4;   // groups 0 .. G0E_PLAIN-1 of block 0e read x0e[4g .. 4g+3]
+#pragma unroll 1
+  for (int g = 0; g < G0E_PLAIN; ++g) {
+    const float m[4] = {xc[(4 * g + 0) * 32], xc[(4 * g + 1) * 32], xc[(4 * g + 2) * 32], xc[(4 * g + 3) * 32]};
+    scalar_group(m, o0e);
+  }
+#pragma unroll
+  for (int g = G0E_PLAIN; g < S.g0e; ++g) {
+    float m[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[i] = cmid0e<IN>(xc, 4 * g + i, n);
+    scalar_group(m, o0e);
+#pragma unroll
+    for (int r = 0; r < 12; ++r) pin(o0e[r]);   // ties the FMAs of an unrolled group to its place (tp_conv.hip)
   }
 
-  // ---- vector blocks: tile = 5 mids x 6 outputs; register reg < 15 of lane half hf = (mid 5t + reg/3, output 3hf + reg%3)
+  // ---- vector blocks: tile = 5 mids x 6 outputs; register reg < 15 of lane half hf = (mid 5t + reg/3, output 3hf + reg%3).
+  //      Fully unrolled (compile-time mids, a tile's LDS reads issued together before the chain); mids of the form scalar x direction
+  //      cost one FMA per output, the direction is applied once per block; padded slots are skipped (as in tp_conv.hip).
   float k1o[9], k1e[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
-  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
-#pragma unroll 1
+  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep)[9]) __attribute__((always_inline)) {
+    constexpr int ntile = decltype(ntile_c)::value, fan = decltype(fan_c)::value;
+    float sc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
     for (int t = 0; t < ntile; ++t) {
+      float m[C_VEC_TILE_I][3], xs[C_VEC_TILE_I];
+#pragma unroll
+      for (int q = 0; q < C_VEC_TILE_I; ++q) {
+        const int i = C_VEC_TILE_I * t + q;
+        if (i >= fan) continue;
+        if (is_scalar(i)) xs[q] = scalar_of(xc, i);
+        else mid_fn(xc, i, n, m[q]);
+      }
       CBD_CTILE(h1);
 #pragma unroll
       for (int q = 0; q < C_VEC_TILE_I; ++q) {
-        float m[3];
-        mid_fn(xc, C_VEC_TILE_I * t + q, n, m);
+        const int i = C_VEC_TILE_I * t + q;
+        if (i >= fan) continue;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float w = acc[3 * q + o];
-          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
-          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
-          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
+          if (is_scalar(i)) {
+            sc[o] = fmaf(xs[q], w, sc[o]);
+          } else {
+            keep[3 * o + 0] = fmaf(m[q][0], w, keep[3 * o + 0]);
+            keep[3 * o + 1] = fmaf(m[q][1], w, keep[3 * o + 1]);
+            keep[3 * o + 2] = fmaf(m[q][2], w, keep[3 * o + 2]);
+          }
         }
       }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) pin(sc[o]);
+#pragma unroll
+      for (int r = 0; r < 9; ++r) pin(keep[r]);
     }
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) keep[3 * o + c] = fmaf(n[c], sc[o], keep[3 * o + c]);
   };
-  vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1o<IN>(x, i, nn, m); }, S.t1o, k1o);
+  vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1o<IN>(x, i, nn, m); },
+            [](int i) { return i < CNS; }, [](const float* x, int i) { return x[i * 32]; },
+            std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o);
   if constexpr (OUT >= 2)
-    vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1e<IN>(x, i, nn, m); }, S.t1e, k1e);
+    vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1e<IN>(x, i, nn, m); },
+              [](int i) { return i >= S.n1o + 2 * S.n1e; }, [](const float* x, int i) { return x[(CC_0O + (i - S.n1o - 2 * S.n1e)) * 32]; },
+              std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e);
   if constexpr (OUT >= 3) {
-#pragma unroll 1
-    for (int g = 0; g < S.g0o; ++g) {
+    // block 0o: mids 0 .. n1e-1 are 1e . direction dot products, the rest plain 0o features: unrolled head (and padded tail), rolled middle
+    constexpr int G_HEAD = (S.n1e + 3) / 4, G_FULL = S.fan0o / 4;
+#pragma unroll
+    for (int g = 0; g < (G_HEAD < S.g0o ? G_HEAD : S.g0o); ++g) {
       float m[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
+      scalar_group(m, o0o);
 #pragma unroll
-      for (int q = 0; q < 3; ++q) {
-        CBD_CTILE(h1);
+      for (int r = 0; r < 12; ++r) pin(o0o[r]);
+    }
+#pragma unroll 1
+    for (int g = G_HEAD; g < G_FULL; ++g) {
+      const float* p = xc + (CC_0O + 4 * g - S.n1e) * 32;
+      const float m[4] = {p[0], p[32], p[64], p[96]};
+      scalar_group(m, o0o);
+    }
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int g = (G_FULL > G_HEAD ? G_FULL : G_HEAD); g < S.g0o; ++g) {
+      float m[4];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) o0o[4 * q + c] = fmaf(m[i], acc[4 * i + c], o0o[4 * q + c]);
-      }
+      for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
+      scalar_group(m, o0o);
+#pragma unroll
+      for (int r = 0; r < 12; ++r) pin(o0o[r]);
     }
   }
 #undef CBD_CTILE

@@ -1,9 +1,15 @@
-// Deterministic segmented reduction shared by the score-model kernels (tp_conv.hip, tp_conv_bf16.hip) and the confidence-model kernel
+// Device helpers shared by the score-model kernels (tp_conv.hip, tp_conv_bf16.hip) and the confidence-model kernel
 // (fctp_conv.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 
 namespace cbd {
+
+// Makes a register value opaque to the optimiser at this point of the program (an empty volatile asm that reads and writes it): used to
+// keep addresses computed BEFORE an MFMA chain from being recomputed inside it, and to tie side-effect-free FMAs of fully unrolled tile
+// loops to their tile.
+template <class P>
+__device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
 
 // Run-length sums of one 32-edge message tile without atomics (bitwise reproducible).  `msg` = LDS tile [col][OUT_STR] of the
 // 32 edges' messages, `sl` = LDS [32] aggregating node of every edge (sorted; -1 for the lanes past the end of the group, which only

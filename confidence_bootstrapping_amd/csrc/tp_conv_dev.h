@@ -125,8 +125,6 @@ __device__ __forceinline__ void mfma_operand_guard() {
   asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
   __builtin_amdgcn_sched_barrier(0);
 }
-template <class P>
-__device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
 
 // OpsBf16: bf16 operands, fp32 accumulate, v_mfma_f32_32x32x16_bf16, 6 k-steps of 16, 6 fragments of 8 bf16 (6 KB tile).
 // Lane (r = lane&31, h = lane>>5) holds A[row r][k = 8h + j] and B[k = 8h + j][col r], j = 0..7 (cdna_hip_programming.md
