@@ -205,11 +205,11 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   for (int m = 0; m < 2; ++m) {
     CBD_CTILE(Bx);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h1[16 * m + r] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; ++r) h1[16 * m + r] = relu1(acc[r]);
   }
   CBD_CTILE(Bx);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) h1[32 + r] = fmaxf(acc[r], 0.f);
+  for (int r = 0; r < 4; ++r) h1[32 + r] = relu1(acc[r]);
 
   const float* xc = xT + j;
   // ---- scalar blocks: group of 4 mids, three tiles (8 outputs each); register 4i+c of lane half hf = (mid 4g+i, output 8q+c+4hf)

@@ -11,6 +11,11 @@ namespace cbd {
 template <class P>
 __device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
 
+// ReLU in ONE VALU instruction (v_med3_f32 with a finite upper bound).  fmaxf(x, 0) costs two -- hipcc first canonicalises the operand
+// with v_max_f32 x, x -- and med3(x, 0, +inf) is folded back into that pair.  (An inline-asm v_max_f32 is one instruction too, but
+// the hazard recogniser does not see its operands and drops the wait states between an MFMA and the read of its result.)
+__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, 3.0e38f); }
+
 // Run-length sums of one 32-edge message tile without atomics (bitwise reproducible).  `msg` = LDS tile [col][OUT_STR] of the
 // 32 edges' messages, `sl` = LDS [32] aggregating node of every edge (sorted; -1 for the lanes past the end of the group, which only
 // follow valid ones).  Lane = column.  A run that starts at the tile's first edge goes to first_sum[tile] (`fs`), one that reaches

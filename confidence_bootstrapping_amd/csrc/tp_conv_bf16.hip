@@ -39,7 +39,7 @@ __device__ __forceinline__ void v2_set_in(Act6& B, int seg, int q, f32x4 x) {
 }
 __device__ __forceinline__ void v2_set_hidden(Act6& h, int m, const f32x16& acc) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
+  for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)relu1(acc[r]);
 }
 
 // acc_s = bias + A_tile * B_s (s = 0, 1).  The bias (fp32, one value per weight row) sits in 16 registers in the accumulator layout

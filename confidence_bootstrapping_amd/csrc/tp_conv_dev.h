@@ -68,7 +68,7 @@ struct OpsF32 {
   // ReLU'd accumulator of hidden tile m IS the B operand of the second Linear (W2's k order follows the C/D layout)
   static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h.v[16 * m + r] = fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; ++r) h.v[16 * m + r] = relu1(acc[r]);
   }
   static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
 #pragma unroll
@@ -146,7 +146,7 @@ struct OpsBf16 {
   }
   static __device__ __forceinline__ void set_hidden(Act& h, int m, const f32x16& acc) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)fmaxf(acc[r], 0.f);
+    for (int r = 0; r < 16; ++r) h.v[2 * m + (r >> 3)][r & 7] = (__bf16)relu1(acc[r]);
   }
   static __device__ __forceinline__ void gemm(Frag (&a)[NFRAG], const Frag* __restrict__ next, const Act& B, f32x16& acc) {
 #pragma unroll
@@ -209,7 +209,7 @@ struct OpsBf16x3 {
     for (int r = 0; r < 16; ++r) {
       const int k = 3 * (2 * m + (r >> 3));
       __bf16 hh, mm, ll;
-      split(fmaxf(acc[r], 0.f), hh, mm, ll);
+      split(relu1(acc[r]), hh, mm, ll);
       h.v[k][r & 7] = hh; h.v[k + 1][r & 7] = mm; h.v[k + 2][r & 7] = ll;
     }
   }
