@@ -93,9 +93,11 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   typename Ops::Act Bx;  // first-Linear input on the matrix cores: edge_attr(32), lane half hf holds cols 16hf..16hf+15.  The
                          // x_src[:32] / x_dst[:32] parts arrive as per-node projections through the accumulator (G.psrc / G.pdst)
   {
+    // VAR 14 (diagnostic, correct results): the per-edge gathers as non-temporal loads, so that they do not push the weight tiles out of L2
+    auto gl = [](const f32x4* p) __attribute__((always_inline)) { return VAR == 14 ? __builtin_nontemporal_load(p) : *p; };
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * 32 + 16 * hf);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Ops::set_in(Bx, 0, q, pa[q]);
+    for (int q = 0; q < 4; ++q) Ops::set_in(Bx, 0, q, gl(pa + q));
     if constexpr (!Ops::NODE_PROJ) {
       const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * NODE_STRIDE + 16 * hf);
       const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * NODE_STRIDE + 16 * hf);
@@ -113,14 +115,14 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
       const f32x4* const p_s = reinterpret_cast<const f32x4*>(G.psrc + (size_t)src_r * KDIM + 4 * hf);
       // diagnostics with WRONG results (timing only): VAR 10 reads the destination projection at the aggregating node's row (run-
       // coherent instead of random), VAR 11 skips both projection gathers, VAR 12 also gathers the node row at the aggregating node
-      const f32x4* const p_d = reinterpret_cast<const f32x4*>(G.pdst + (size_t)(GV >= 10 ? src_r : dst) * KDIM + 4 * hf);
+      const f32x4* const p_d = reinterpret_cast<const f32x4*>(G.pdst + (size_t)(GV >= 10 && GV < 14 ? src_r : dst) * KDIM + 4 * hf);
 #pragma unroll
       for (int m = 0; m < 3; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const f32x4 b = gb[8 * m + 2 * q + hf];
           f32x4 u = b, w = b;
-          if constexpr (GV < 11) { u = p_s[8 * m + 2 * q]; w = p_d[8 * m + 2 * q]; }
+          if constexpr (GV < 11 || GV == 14) { u = gl(p_s + 8 * m + 2 * q); w = gl(p_d + 8 * m + 2 * q); }
           acc1[m][4 * q + 0] = b.x + u.x + w.x; acc1[m][4 * q + 1] = b.y + u.y + w.y;
           acc1[m][4 * q + 2] = b.z + u.z + w.z; acc1[m][4 * q + 3] = b.w + u.w + w.w;
         }
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)(GV == 12 ? src_r : dst) * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
-      const f32x4 r = pr[q];
+      const f32x4 r = gl(pr + q);
       float* o = xT + (40 * hf + 4 * q) * 32 + j;
       o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
     }
@@ -562,6 +564,7 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   else if (IN == 3 && var == 9) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 9 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 10) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 10 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 11) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 11 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && var == 14) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 14 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 13) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 13 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 12) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 12 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
