@@ -1,23 +1,24 @@
 // bf16-operand tensor-product message passing for gfx950, second generation (BASELINE.json configs[3]; cbd_set_option("bf16", 1)).
 //
 // Same math as tp_conv.hip (FCBlock -> FasterTensorProduct -> segmented sum, reference models/tensor_layers.py:195-206,66-117),
-// re-tiled for the bf16 matrix pipe, where the fp32-era layout is no longer bound by the MFMAs:
-//   * one 32x32x16 bf16 MFMA is 8 passes (32 cycles) against 64 for the fp32 k=2 form, so a 32-edge tile of weights is consumed
-//     in 192 cycles while it is 6 KB of L2 -> register traffic: at the full matrix rate that is 128 B/clk/CU, more than twice what
-//     the L2 delivers (~56 B/clk/CU, MI355X_MICROARCH.md "L2");  ONE WAVE THEREFORE OWNS 64 EDGES: every weight fragment is used for
-//     two MFMAs (two 32-edge sub-tiles, two independent accumulator chains), which halves the stream per FLOP and doubles the time a
-//     prefetched tile has to land (the first-generation kernel waited vmcnt(0) at the head of every tile).
-//     Measured round 2 on C4 (64 x 40): 137.6 -> 161-164 poses/s, 0.27 -> 0.32 of the bf16 peak; matrix pipe busy 0.37, ~36 TB/s of
-//     L2 -> CU traffic (profiles/r02_c_pmc_bf16_c4_tp_conv64_summary.txt).  Tried on top and NOT kept: sharing every tile between
-//     the 4 or 8 waves of a workgroup through a 4-stage LDS ring with one barrier per tile and the wave halves half a tile out of
-//     phase (122 / 108 poses/s: the per-tile barrier costs more than the L2 traffic it saves); 4 independent waves per workgroup so
-//     that co-dispatched waves hit each other's tiles in L1 (164 vs 161: noise); global_load instead of FLAT loads (no change).
-//   * the bias enters through the matrix core: K is extended from 96 to 112 (a 7th k-step whose activation fragment is the constant
-//     unit vector e_96 and whose weight fragment carries the bias row), so the accumulator starts from the inline constant 0 -- no
-//     bias table in LDS, no 16 register moves per tile;
+// re-tiled for the bf16 matrix pipe, where the fp32-era layout is no longer bound by the MFMAs (one 32x32x16 bf16 MFMA is 8 passes =
+// 32 cycles against 64 for the fp32 k=2 form):
+//   * ONE WAVE OWNS 64 EDGES: every weight fragment is used for two MFMAs (two 32-edge sub-tiles, two independent accumulator
+//     chains), which halves the weight stream per FLOP and the per-tile fixed costs;
+//   * the bias (fp32) is the C operand of a tile's first MFMA pair, kept in 16 registers that are re-loaded in place: 6 k-steps and
+//     6 KB per tile, no accumulator initialisation (an earlier version spent a 7th k-step on it);
+//   * what bounds this kernel is not the matrix core but everything next to it (in-kernel stamps and timing-only diagnostics,
+//     CBD_BF16_DIAG=1..4): every VALU instruction costs matrix-pipe time, so the CG epilogue was trimmed --
+//     -fno-slp-vectorize (packed fp32 FMAs are the most expensive kind), scalar x direction mids factored out of the sums, one-
+//     instruction ReLU, padded slots skipped -- and the per-wave latency phases shortened: gathers in two rounds, vector-block tile
+//     loops fully unrolled so that mids are compile-time constants and their LDS reads batch, run-length reduction with scalar run
+//     masks.  Round 1 137.6 -> round 2 195 poses/s on C4 (64 x 40), 0.27 -> 0.39 of the bf16 peak.  Tried and NOT kept: sharing every
+//     tile between the 4 or 8 waves of a workgroup through an LDS ring with one barrier per tile (122 / 108 poses/s), 4 independent
+//     waves per workgroup (no change), 128 edges per wave at one wave per SIMD (114), global instead of FLAT loads (no change);
 //   * LDS per wave = two transposed row tiles of 9.8 KB (the gathered destination rows, later the message tiles): 8 waves per CU.
 // fp32 everywhere outside the two Linears (gathered rows, CG contraction, messages, reduction), like the first generation.
-// Weight stream (pack_conv_stream_bf16v2, engine.hip): (ntiles + 1) tiles of [7 k-steps][64 lanes][8 bf16] = 7 KB.
+// Weight stream (pack_conv_stream_bf16, engine.hip): (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] = 6 KB, then the fp32 bias
+// rows [ntiles + 1][32].
 #include <cstdlib>
 #include <type_traits>
 
