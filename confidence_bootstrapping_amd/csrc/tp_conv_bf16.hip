@@ -34,6 +34,13 @@ static_assert(V2_SUB_FLOATS >= 76 * 32, "gather image must fit the message tile"
 
 struct Act6 { bf16x8 v[V2_NFRAG]; };
 
+// Weight tiles and bias rows are read with global loads whose base address is wave-uniform (an SGPR pair, advanced per tile on the
+// scalar unit) plus the constant per-lane offset in one VGPR plus an immediate: no vector address arithmetic per tile at all.
+typedef const bf16x8 __attribute__((address_space(1)))* GFrag;
+typedef const f32x4 __attribute__((address_space(1)))* GBias;
+template <class P>
+__device__ __forceinline__ void pin_s(P& p) { asm volatile("" : "+s"(p)); }
+
 __device__ __forceinline__ void v2_set_in(Act6& B, int seg, int q, f32x4 x) {
   const int k = 2 * seg + (q >> 1), o = 4 * (q & 1);
   B.v[k][o + 0] = (__bf16)x.x; B.v[k][o + 1] = (__bf16)x.y; B.v[k][o + 2] = (__bf16)x.z; B.v[k][o + 3] = (__bf16)x.w;
@@ -54,12 +61,12 @@ __device__ __forceinline__ void v2_set_hidden(Act6& h, int m, const f32x16& acc)
 //   * fragment q-1 is re-loaded after the MFMA pair of fragment q has been issued -- one pair late, so that even a load that hits in
 //     L1 (~120 cycles) lands after the pair that read the register has started; the bias follows the second pair, the last fragment
 //     its own pair directly.
-__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const bf16x8* __restrict__ next, const f32x4* __restrict__ next_bias,
+__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag next, GBias next_bias, int lane, int hf,
                                         const Act6& B0, const Act6& B1, f32x16& acc0, f32x16& acc1) {
-  const bf16x8* pa = next;
-  const bf16x8* pb = next + 4 * 64;
-  const f32x4* pc = next_bias;
-  pin(pa); pin(pb); pin(pc);
+  GFrag pa = next;            // uniform: tile base (fragments 0..3: immediate offsets 0..3 KB)
+  GFrag pb = next + 4 * 64;   // fragments 4..5 (the immediate field holds < 4 KB)
+  GBias pc = next_bias;       // uniform: the tile's 32 bias floats
+  pin_s(pa); pin_s(pb); pin_s(pc);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int q = 0; q < V2_NFRAG; ++q) {
@@ -74,15 +81,15 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const
     // keep the bias registers a live 16-register tuple of their own: otherwise hipcc lets an accumulator take them over after the first
     // pair, loads the next bias somewhere else and copies it back with 16 v_mov behind a vmcnt(0) at the end of every tile
     if (q == 0) asm volatile("" : "+v"(cb));
-    if (q > 0) a[q - 1] = q - 1 < 4 ? pa[(q - 1) * 64] : pb[(q - 5) * 64];
-    if (q == 1) {   // rows (r & 3) + 8 (r >> 2) + 4 hf of the next tile's bias: float4 2q' + hf of its 32 floats (hf is in `next_bias`)
+    if (q > 0) a[q - 1] = q - 1 < 4 ? pa[lane + (q - 1) * 64] : pb[lane + (q - 5) * 64];
+    if (q == 1) {   // rows (r & 3) + 8 (r >> 2) + 4 hf of the next tile's bias: float4 2q' + hf of its 32 floats
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
-        const f32x4 b = pc[2 * qq];
+        const f32x4 b = pc[hf + 2 * qq];
         cb[4 * qq + 0] = b.x; cb[4 * qq + 1] = b.y; cb[4 * qq + 2] = b.z; cb[4 * qq + 3] = b.w;
       }
     }
-    if (q == V2_NFRAG - 1) a[q] = pb[(q - 4) * 64];
+    if (q == V2_NFRAG - 1) a[q] = pb[lane + (q - 4) * 64];
     __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -112,16 +119,16 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   if constexpr (DIAG == 4) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream
-  const bf16x8* gp = reinterpret_cast<const bf16x8*>(G.wstream) + lane;   // tile T fragment q: gp[T * V2_TILE_FRAGS + q * 64]
+  const GFrag gp = (GFrag)reinterpret_cast<const bf16x8*>(G.wstream);   // uniform; tile T fragment q of this lane: gp[T * V2_TILE_FRAGS + q * 64 + lane]
   bf16x8 a[V2_NFRAG];
 #pragma unroll
-  for (int q = 0; q < V2_NFRAG; ++q) a[q] = gp[q * 64];
+  for (int q = 0; q < V2_NFRAG; ++q) a[q] = gp[q * 64 + lane];
   // fp32 bias rows behind the (ntiles + 1) tiles: [ntiles + 1][32]; this lane half's float4s are 2q' + hf
-  const f32x4* const gbias = reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)(S.ntiles + 1) * V2_TILE_FRAGS) + hf;
+  const GBias gbias = (GBias)reinterpret_cast<const f32x4*>(reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)(S.ntiles + 1) * V2_TILE_FRAGS);   // uniform
   f32x16 cb;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
-    const f32x4 b = gbias[2 * qq];
+    const f32x4 b = gbias[hf + 2 * qq];
     cb[4 * qq + 0] = b.x; cb[4 * qq + 1] = b.y; cb[4 * qq + 2] = b.z; cb[4 * qq + 3] = b.w;
   }
 
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #define V2_TILE(BA, BB, NEXT)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    v2_gemm(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)tn_ * 8, BA, BB, acc0, acc1); \
+    v2_gemm(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)tn_ * 8, lane, hf, BA, BB, acc0, acc1); \
     T = tn_;                                                                \
   }
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
