@@ -59,10 +59,12 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 
   // ---- start the weight stream: tile 0 fragments + the bias table of the group
   using Frag = typename Ops::Frag;
-  const Frag* gp = reinterpret_cast<const Frag*>(G.wstream) + lane;   // tile T fragment sg: gp[T * TILE_FRAGS + sg * 64]
+  // NODE_PROJ policies: wave-uniform stream base, tile T fragment sg of this lane = gu[T * TILE_FRAGS + sg * 64 + lane]
+  const GPtr<Frag> gu = (GPtr<Frag>)reinterpret_cast<const Frag*>(G.wstream);
+  const Frag* gp = reinterpret_cast<const Frag*>(G.wstream) + lane;   // per-lane form (policies without NODE_PROJ)
   Frag a[Ops::NFRAG];
   if constexpr (Ops::NODE_PROJ) {
-    Ops::load_first(a, gp);   // the live fragments of all three first-Linear tiles
+    Ops::load_first_u(a, gu, lane);   // the live fragments of all three first-Linear tiles
   } else {
 #pragma unroll
     for (int sg = 0; sg < Ops::NFRAG; ++sg) a[sg] = gp[sg * 64];
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 #define CBD_TILE(BOP, NEXT)                                                                         \
   {                                                                                                 \
     const int tn_ = (NEXT);                                                                         \
-    gemm_tile<Ops>(a, gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), bias_l + T * 32, BOP, acc, hf); \
+    if constexpr (Ops::NODE_PROJ) gemm_tile_u<Ops>(a, gu + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), lane, bias_l + T * 32, BOP, acc, hf); \
+    else gemm_tile<Ops>(a, gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS), bias_l + T * 32, BOP, acc, hf); \
     T = tn_;                                                                                        \
   }
 
@@ -167,13 +170,13 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   } else {
     // K = 32 edge-attribute product on top of acc1[m]; tile m's registers are refilled with the first second-Linear tile's fragments
     const int tn_ = i_lo < i_hi ? 3 + i_lo : T_vec;
-    const Frag* const next = gp + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS);
-    Ops::template gemm_first<0>(a, next, Bx, acc1[0]);
+    const GPtr<Frag> next = gu + (VAR == 9 ? (size_t)0 : (size_t)tn_ * Ops::TILE_FRAGS);
+    Ops::template gemm_first_u<0>(a, next, lane, Bx, acc1[0]);
     Ops::set_hidden(h1, 0, acc1[0]);
     if constexpr (STAMPS) st_g0 = stamp();
-    Ops::template gemm_first<1>(a, next, Bx, acc1[1]);
+    Ops::template gemm_first_u<1>(a, next, lane, Bx, acc1[1]);
     Ops::set_hidden(h1, 1, acc1[1]);
-    Ops::template gemm_first<2>(a, next, Bx, acc1[2]);
+    Ops::template gemm_first_u<2>(a, next, lane, Bx, acc1[2]);
     if constexpr (!Ops::EXACT_F32) mfma_operand_guard();   // Bx dies here without a refill
     Ops::set_hidden(h1, 2, acc1[2]);
     T = tn_;

@@ -36,10 +36,8 @@ struct Act6 { bf16x8 v[V2_NFRAG]; };
 
 // Weight tiles and bias rows are read with global loads whose base address is wave-uniform (an SGPR pair, advanced per tile on the
 // scalar unit) plus the constant per-lane offset in one VGPR plus an immediate: no vector address arithmetic per tile at all.
-typedef const bf16x8 __attribute__((address_space(1)))* GFrag;
-typedef const f32x4 __attribute__((address_space(1)))* GBias;
-template <class P>
-__device__ __forceinline__ void pin_s(P& p) { asm volatile("" : "+s"(p)); }
+typedef GPtr<bf16x8> GFrag;
+typedef GPtr<f32x4> GBias;
 
 __device__ __forceinline__ void v2_set_in(Act6& B, int seg, int q, f32x4 x) {
   const int k = 2 * seg + (q >> 1), o = 4 * (q & 1);

@@ -8,6 +8,14 @@
 
 namespace cbd {
 
+// Weight tiles are read with global loads whose base address is wave-uniform (an SGPR pair, advanced per tile on the scalar unit) plus
+// the constant per-lane offset in one VGPR plus an immediate (< 4 KB, hence one base per four 1-KB fragments): no vector address
+// arithmetic per tile, exact vmcnt waits.  `pin_s` keeps such a base opaque and scalar across the MFMA chain.
+template <class P>
+__device__ __forceinline__ void pin_s(P& p) { asm volatile("" : "+s"(p)); }
+template <class T>
+using GPtr = const T __attribute__((address_space(1)))*;
+
 // diagnostic stamp (CBD_CONV_VARIANT=8 build only): s_memtime pinned in place (cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;
@@ -88,6 +96,43 @@ struct OpsF32 {
   // (ConvGroup::psrc / pdst).  The three first-Linear tiles need 3 x 4 fragments = the whole register tile: the kernel loads them all
   // in its prologue (load_first), so the first Linear runs without a single wait on memory, and tile m's four registers are
   // refilled in place with fragments 4m..4m+3 of the first second-Linear tile (`next`) right after their use.
+  // ---- the same three routines on a wave-uniform tile base (tp_conv_kernel; bond_conv / tp_train keep the per-lane pointer forms)
+  static __device__ __forceinline__ void gemm_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
+    GPtr<Frag> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64;
+    pin_s(p0); pin_s(p1); pin_s(p2);
+#pragma unroll
+    for (int sg = 0; sg < NFRAG; ++sg) {
+      const f32x4 w = a[sg];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * sg + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * sg + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * sg + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * sg + 3], acc, 0, 0, 0);
+      a[sg] = (sg < 4 ? p0 : sg < 8 ? p1 : p2)[lane + (sg & 3) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  static __device__ __forceinline__ void load_first_u(Frag (&a)[NFRAG], GPtr<Frag> gp, int lane) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int s = 0; s < NFRAG / 3; ++s) a[(NFRAG / 3) * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64 + lane];
+  }
+  template <int M>
+  static __device__ __forceinline__ void gemm_first_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
+    GPtr<Frag> pm = next + (NFRAG / 3) * M * 64;   // fragments 4M .. 4M+3 of the first second-Linear tile
+    pin_s(pm);
+#pragma unroll
+    for (int s = 0; s < NFRAG / 3; ++s) {
+      constexpr int base = (NFRAG / 3) * M;
+      const f32x4 w = a[base + s];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, B.v[4 * s + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, B.v[4 * s + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, B.v[4 * s + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, B.v[4 * s + 3], acc, 0, 0, 0);
+      a[base + s] = pm[lane + s * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   static constexpr int FIRST_FRAGS = NFRAG / 3;            // 4
   static __device__ __forceinline__ void load_first(Frag (&a)[NFRAG], const Frag* __restrict__ gp) {
 #pragma unroll
@@ -234,6 +279,56 @@ struct OpsBf16x3 {
     }
   }
   // first Linear: K = 32 = 2 k-steps x 3 planes = 6 fragments per tile, 3 tiles = the whole register tile (see OpsF32::gemm_first)
+  // ---- on a wave-uniform tile base (see OpsF32::gemm_u): fragment f is base[f / 4][lane + (f % 4) * 64]
+  static __device__ __forceinline__ void gemm_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
+    GPtr<Frag> pb[5] = {next, next + 4 * 64, next + 8 * 64, next + 12 * 64, next + 16 * 64};
+#pragma unroll
+    for (int i = 0; i < 5; ++i) pin_s(pb[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NFRAG / 3; ++q) {
+      const int k = 3 * q;   // smallest terms first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 2], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 1], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[k + 0], B.v[k + 0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) a[k + i] = pb[(k + i) / 4][lane + ((k + i) % 4) * 64];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  static __device__ __forceinline__ void load_first_u(Frag (&a)[NFRAG], GPtr<Frag> gp, int lane) {
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int s = 0; s < NFRAG / 3; ++s) a[(NFRAG / 3) * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64 + lane];
+  }
+  template <int M>
+  static __device__ __forceinline__ void gemm_first_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
+    constexpr int base = (NFRAG / 3) * M;          // fragments 6M .. 6M+5 of the first second-Linear tile
+    GPtr<Frag> pm0 = next + base * 64, pm1 = next + (base + 3) * 64;
+    pin_s(pm0); pin_s(pm1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < (NFRAG / 3) / 3; ++q) {
+      const int k = 3 * q, ka = base + 3 * q;
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 2], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 2], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 1], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 1], B.v[k + 0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 1], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ka + 0], B.v[k + 0], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      GPtr<Frag> p = q == 0 ? pm0 : pm1;
+      a[ka + 0] = p[lane];
+      a[ka + 1] = p[lane + 64];
+      a[ka + 2] = p[lane + 128];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   static constexpr int FIRST_FRAGS = NFRAG / 3;            // 6
   static __device__ __forceinline__ void load_first(Frag (&a)[NFRAG], const Frag* __restrict__ gp) {
 #pragma unroll
@@ -275,6 +370,18 @@ __device__ __forceinline__ void gemm_tile(typename Ops::Frag (&a)[Ops::NFRAG], c
     acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
   }
   Ops::gemm(a, next, B, acc);
+}
+
+template <class Ops>
+__device__ __forceinline__ void gemm_tile_u(typename Ops::Frag (&a)[Ops::NFRAG], GPtr<typename Ops::Frag> next, int lane,
+                                            const float* __restrict__ bias_l, const typename Ops::Act& B, f32x16& acc, int hf) {
+  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 b = bp[2 * q + hf];
+    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+  }
+  Ops::gemm_u(a, next, lane, B, acc);
 }
 
 // "mid" evaluators: value of the CG intermediate with index i for edge j (xc = &xT[0][j], column stride 32).
