@@ -23,8 +23,12 @@ __device__ __forceinline__ f32x16 cmfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], const f32x4* __restrict__ next, const float* __restrict__ bias_l,
+// `next` is the wave-uniform base of the next tile (an SGPR pair; one pinned base per four 1-KB fragments because the immediate field
+// holds < 4 KB), the lane adds its constant offset: no vector address arithmetic per tile (see tp_conv_dev.h)
+__device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], GPtr<f32x4> next, int lane, const float* __restrict__ bias_l,
                                            const float (&B)[CKSTEPS], f32x16& acc, int hf) {
+  GPtr<f32x4> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64;
+  pin_s(p0); pin_s(p1); pin_s(p2);
   const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -38,7 +42,7 @@ __device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], const f32x4*
     acc = cmfma32(w.y, B[4 * sg + 1], acc);
     acc = cmfma32(w.z, B[4 * sg + 2], acc);
     acc = cmfma32(w.w, B[4 * sg + 3], acc);
-    a[sg] = next[sg * 64];
+    a[sg] = (sg < 4 ? p0 : sg < 8 ? p1 : p2)[lane + (sg & 3) * 64];
     __builtin_amdgcn_sched_barrier(0);   // keep each refill right behind its last use (see tp_conv.hip)
   }
 }
@@ -147,10 +151,10 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   if (grp < 0) return;
   const CGroup G = args.g[grp];
 
-  const f32x4* gp = reinterpret_cast<const f32x4*>(G.wstream) + lane;   // tile T fragment sg: gp[T*576 + sg*64]
+  const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(G.wstream);   // uniform; tile T fragment sg of this lane: gp[T*576 + sg*64 + lane]
   f32x4 a[CKSTEPS / 4];
 #pragma unroll
-  for (int sg = 0; sg < CKSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  for (int sg = 0; sg < CKSTEPS / 4; ++sg) a[sg] = gp[sg * 64 + lane];
   {
     const f32x4* gb = reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * CTILE_W_FLOATS);
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   f32x16 acc;
   float h1[CKSTEPS];
 #define CBD_CTILE(BOP)                                                                             \
-  cgemm_tile(a, gp + (size_t)(T + 1) * (CTILE_W_FLOATS / 4), bias_l + T * 32, BOP, acc, hf);      \
+  cgemm_tile(a, gp + (size_t)(T + 1) * (CTILE_W_FLOATS / 4), lane, bias_l + T * 32, BOP, acc, hf); \
   ++T
 
   // ---- first Linear: 72 hidden units = two full tiles + 8 live rows (registers 0..3 of both halves) of a third

@@ -11,6 +11,13 @@ namespace cbd {
 template <class P>
 __device__ __forceinline__ void pin(P& p) { asm volatile("" : "+v"(p)); }
 
+// A wave-uniform pointer kept opaque and in SGPRs, and the global-address-space pointer type for loads of the form
+// `global_load v, v_lane_offset, s[base:base+1] offset:imm` (tp_conv_dev.h explains why the weight streams are read that way).
+template <class P>
+__device__ __forceinline__ void pin_s(P& p) { asm volatile("" : "+s"(p)); }
+template <class T>
+using GPtr = const T __attribute__((address_space(1)))*;
+
 // ReLU in ONE VALU instruction (v_med3_f32 with a finite upper bound).  fmaxf(x, 0) costs two -- hipcc first canonicalises the operand
 // with v_max_f32 x, x -- and med3(x, 0, +inf) is folded back into that pair.  (An inline-asm v_max_f32 is one instruction too, but
 // the hazard recogniser does not see its operands and drops the wait states between an MFMA and the read of its result.)

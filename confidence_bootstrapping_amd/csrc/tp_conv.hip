@@ -425,10 +425,10 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, Multi mm, int
   const float* P = pos + (size_t)b * Nl * 3;
   const int u = gs.rot_u[rho], v = gs.rot_v[rho];
 
-  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
+  const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(wstream);   // wave-uniform stream base (tp_conv_dev.h: gemm_u)
   f32x4 a[KSTEPS / 4];
 #pragma unroll
-  for (int sg = 0; sg < KSTEPS / 4; ++sg) a[sg] = gp[sg * 64];
+  for (int sg = 0; sg < KSTEPS / 4; ++sg) a[sg] = gp[sg * 64 + lane];
   {
     const f32x4* gb = reinterpret_cast<const f32x4*>(wstream + (size_t)(BOND_TILES + 1) * TILE_W_FLOATS);
     constexpr int NB4 = BOND_TILES * 8, NBI = (NB4 + 63) / 64;
@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, Multi mm, int
   OpsF32::Act h1;
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, BxA, acc, hf);
+    gemm_tile_u<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), lane, bias_l + T * 32, BxA, acc, hf);
     ++T;
     OpsF32::set_hidden(h1, m, acc);
   }
@@ -512,7 +512,7 @@ __global__ __launch_bounds__(64) void bond_conv_kernel(BondHead h, Multi mm, int
   for (int r = 0; r < 16; ++r) { oA[r] = 0.f; oB[r] = 0.f; }
 #pragma unroll
   for (int q = 0; q < 12; ++q) {
-    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), bias_l + T * 32, h1, acc, hf);
+    gemm_tile_u<OpsF32>(a, gp + (size_t)(T + 1) * (TILE_W_FLOATS / 4), lane, bias_l + T * 32, h1, acc, hf);
     ++T;
     if (q < 6) {
 #pragma unroll

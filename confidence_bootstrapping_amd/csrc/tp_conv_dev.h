@@ -11,11 +11,7 @@ namespace cbd {
 // Weight tiles are read with global loads whose base address is wave-uniform (an SGPR pair, advanced per tile on the scalar unit) plus
 // the constant per-lane offset in one VGPR plus an immediate (< 4 KB, hence one base per four 1-KB fragments): no vector address
 // arithmetic per tile, exact vmcnt waits.  `pin_s` keeps such a base opaque and scalar across the MFMA chain.
-template <class P>
-__device__ __forceinline__ void pin_s(P& p) { asm volatile("" : "+s"(p)); }
-template <class T>
-using GPtr = const T __attribute__((address_space(1)))*;
-
+// (`pin_s`, `GPtr`: reduce_runs.h)
 // diagnostic stamp (CBD_CONV_VARIANT=8 build only): s_memtime pinned in place (cdna_hip_programming.md section 7)
 __device__ __forceinline__ unsigned long long stamp() {
   unsigned long long t;

@@ -67,12 +67,12 @@ __device__ __forceinline__ void train_locate(const TrainTpArgs& A, int block, in
 
 // common prologue: weight stream start (tile 3), bias table, gathered row tile, hidden activations as the MFMA B operand
 template <int IN, int OUT>
-__device__ __forceinline__ void train_prologue(const TrainTpArgs& A, const float* wstream, float* bias_l, float* xT, int lane, int ec, const f32x4* gp,
+__device__ __forceinline__ void train_prologue(const TrainTpArgs& A, const float* wstream, float* bias_l, float* xT, int lane, int ec, GPtr<f32x4> gp,
                                                f32x4 (&a)[OpsF32::NFRAG], OpsF32::Act& h1) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
-  for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[(size_t)3 * OpsF32::TILE_FRAGS + sg * 64];
+  for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[(size_t)3 * OpsF32::TILE_FRAGS + sg * 64 + lane];
   {
     const f32x4* gb = reinterpret_cast<const f32x4*>(wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS;
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
   const int e = e0 + j;
   const int ec = e < e_end ? e : e_end - 1;
   const float* const wstream = A.wstream[grp];
-  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
+  const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(wstream);   // wave-uniform stream base (tp_conv_dev.h: gemm_u)
   f32x4 a[OpsF32::NFRAG];
   OpsF32::Act h1;
   train_prologue<IN, OUT>(A, wstream, bias_l, xT, lane, ec, gp, a, h1);
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
   f32x16 acc;
 #define CBD_TT()                                                                                              \
   {                                                                                                           \
-    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, bias_l + T * 32, h1, acc, hf);            \
+    gemm_tile_u<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, lane, bias_l + T * 32, h1, acc, hf);            \
     ++T;                                                                                                      \
   }
   const float* xc = xT + j;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   const bool valid = e < e_end;
   const int ec = valid ? e : e_end - 1;
   const float* const wstream = A.wstream[grp];
-  const f32x4* gp = reinterpret_cast<const f32x4*>(wstream) + lane;
+  const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(wstream);   // wave-uniform stream base (tp_conv_dev.h: gemm_u)
   f32x4 a[OpsF32::NFRAG];
   OpsF32::Act h1;
   train_prologue<IN, OUT>(A, wstream, bias_l, xT, lane, ec, gp, a, h1);
@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   f32x16 acc;
 #define CBD_TT()                                                                                              \
   {                                                                                                           \
-    gemm_tile<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, bias_l + T * 32, h1, acc, hf);            \
+    gemm_tile_u<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, lane, bias_l + T * 32, h1, acc, hf);            \
     ++T;                                                                                                      \
   }
   const float* xc = xT + j;
