@@ -1,6 +1,6 @@
 """Benchmark of the hot path: reverse-diffusion docking sampler on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--split complexes|samples]
   N > 1: run bare, this process starts the N ranks itself (`python -m torch.distributed.run --nproc-per-node N ...`, before any
   GPU call is made here) and exits with their status; launched under torch.distributed.run (RANK / WORLD_SIZE set, as the
   driver does) it is one of the ranks.  Fails loudly -- non-zero exit, no JSON line -- when fewer than N GPUs are visible or
@@ -10,8 +10,11 @@ One "step" = one complex of the named workload: 40 poses x 20 denoise steps (BAS
 synthetic DockGen-median complex: Nl=28, Nr=384, R=6), i.e. the time-independent receptor embedding +
 20 x (score-model forward + reverse-SDE perturbation + pose update) for a batch of 40 poses.
 Inputs (weights, complex, initial poses, pre-drawn noise) are resident in HBM before the timed region.
-Multi-GPU: complexes are independent -> every rank runs K complexes of its own (weak scaling), no collective in
-the data path; the only exchange is the final gather of poses to rank 0 (kept inside the timed region).
+Multi-GPU, `--split complexes` (default): complexes are independent -> every rank runs K complexes of its own (weak scaling), no
+collective in the data path; the only exchange is the final gather of poses to rank 0 (kept inside the timed region).
+`--split samples`: the north-star split of ONE complex -- the 40 samples of each of the K complexes are divided
+round-robin over the ranks (5 per GPU at 8), every rank runs its share of every complex, one ranked gather per complex to rank 0
+(strong scaling: K x 40 poses in total whatever N; the noise is drawn for all 40 samples and sliced, so the poses do not depend on N).
 
 Workload geometry (SURVEY.md 8 table / BASELINE.md section 4: 32.8 GFLOP per pose-step at a step-mean of ~6 200 cross edges per
 pose).  With random-init weights the score carries no information about the pocket, so a free-running reverse SDE is a random
@@ -22,11 +25,16 @@ data distribution), realised through the PRE-DRAWN translation noise z_tr (an in
 head's last layer scaled by 0.02 so that its random drift stays below 1 A; the receptor is a globular 384-residue trace at
 folded-protein density (135 A^3 per residue) with the pocket at 0.7 of the surface radius.  Every kernel runs exactly as
 in production; only the DATA differ.  The measured edge counts and FLOPs per pose-step are printed in `roofline`.
-`--poses free --geometry loose` reproduces the round-1 workload.
+`--poses free --geometry loose` reproduces the round-1 workload.  tests/test_gpu_configs.py checks THIS workload against the oracle.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = tp_conv,
-fp32 MFMA bound, duration from HIP events on the launch stream) and `cpu_baseline` (the oracle's PyTorch-CPU
-restatement of the same path, timed on a bounded sample on rank 0 at N=1 only).
+fp32 MFMA bound, duration from HIP events on the launch stream; `achieved` / `frac` count the FLOPs the kernel EXECUTES -- the
+layer-0 receptor->receptor messages are computed once per complex and shared by its samples -- the reference formulation's
+un-shared count is printed beside it as `algorithmic_tflops` / `algorithmic_frac`) and `cpu_baseline` (the oracle's PyTorch-CPU
+restatement of the same path, timed on a bounded sample on rank 0 at N=1 only).  Secondary legs of the default N=1 run (never part
+of `value`): `python_api` (the same workload through `sampling()` incl. noise drawing, co-scheduling, confidence ranking and
+write-back), `c4_bf16` (BASELINE.json configs[3]: 64 x 40 on the large-pocket complex, bf16 operands), `complex_set`
+(configs[2]: a heterogeneous set through distributed.run_complex_set), `confidence`, `other_operand_modes`, `finetune` (configs[4]).
 """
 from __future__ import annotations
 
@@ -44,14 +52,13 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WORKLOAD = "c2_dockgen_median"
-SAMPLES, DENOISE_STEPS = 40, 20
+HEADLINE = ("c2_dockgen_median", 40, 20, "f32", "globular", "ideal")
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (~2.5 PF)
 # PMC traffic summaries (tools/pmc_summary.py) of the default command line per (workload, dtype, geometry, poses), newest first
-TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r02_z_traffic.json", "r02_t_traffic.json", "r02_e_traffic.json"],
+TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r03_z_traffic.json", "r02_z_traffic.json", "r02_t_traffic.json", "r02_e_traffic.json"],
                     ("c2_dockgen_median", "f32", "loose", "free"): ["r01_m_traffic.json"],
-                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r02_c4_bf16_traffic.json"]}
+                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r03_z_c4_bf16_traffic.json", "r02_c4_bf16_traffic.json"]}
 
 
 def flops_per_edge(in_level: int, out_level: int) -> float:
@@ -66,7 +73,7 @@ def flops_per_edge(in_level: int, out_level: int) -> float:
     return 2.0 * (96 * 96 + 96 * W) + 2.0 * tp
 
 
-def cpu_baseline(model, cplx, args, sched):
+def cpu_baseline(model, cplx, args, sched, workload, samples, denoise_steps):
     """Oracle (PyTorch-CPU port of the reference arithmetic) on a bounded sample of the same workload, with the split BASELINE.md
     section 3 asks for: score-model forward / graph construction (radius_graph + the two radius searches, re-run on the same poses
     and timed on their own; contained in the forward figure) / pose update."""
@@ -75,7 +82,7 @@ def cpu_baseline(model, cplx, args, sched):
     d = os.path.join(ROOT, "confidence_bootstrapping_amd", "data")
     so3, torus = np.load(os.path.join(d, "so3_exp_score_norms.npy")), np.load(os.path.join(d, "torus_score_norm.npy"))
     cx = to_cx(cplx)
-    b, steps = 4, 4
+    b, steps = 4, 6
     g = torch.Generator().manual_seed(0)
     pocket = cplx["ligand"].pos.mean(0)
     eps = torch.randn(b, 1, 3, generator=g)
@@ -108,7 +115,7 @@ def cpu_baseline(model, cplx, args, sched):
             t3 = time.perf_counter()
             t_fwd, t_pose, t_graph = t_fwd + (t1 - t0), t_pose + (t2 - t1), t_graph + (t3 - t2)
         n = steps * b
-        per_pose = ((t_fwd + t_pose) / n) * DENOISE_STEPS + t_rec / SAMPLES   # receptor embedding amortised over the 40 poses
+        per_pose = ((t_fwd + t_pose) / n) * denoise_steps + t_rec / samples   # receptor embedding amortised over the poses of a complex
         split = {"forward_s_per_pose_step": round(t_fwd / n, 4), "of_which_graph_build_s": round(t_graph / n, 4),
                  "pose_update_s_per_pose_step": round(t_pose / n, 5), "receptor_embedding_s_per_complex": round(t_rec, 3)}
         return 1.0 / per_pose, t_fwd + t_pose + t_rec + t_graph, split
@@ -128,29 +135,29 @@ def cpu_baseline(model, cplx, args, sched):
     (best, cores, split) = (v16, n16, split16) if v16 >= v_all else (v_all, all_threads, split_all)
     return {"value": round(best, 5), "unit": "poses/s", "cores": cores, "kind": "port",
             "by_threads": {str(all_threads): round(v_all, 5), str(n16): round(v16, 5)}, "split": split,
-            "sample": f"{b} poses x {steps} of {DENOISE_STEPS} denoise steps (+ receptor embedding) of {WORKLOAD} on the ideal path, "
+            "sample": f"{b} poses x {steps} of {denoise_steps} denoise steps (+ receptor embedding) of {workload} on the ideal path, "
                       f"oracle PyTorch-CPU fp32, {t16:.1f}s measured with {n16} threads and {t_all:.1f}s with {all_threads}, "
-                      f"extrapolated to {DENOISE_STEPS} steps/pose"}
+                      f"extrapolated to {denoise_steps} steps/pose"}
 
 
-def hbm_secondary(st, eng, poses, elapsed):
+def hbm_secondary(st, eng, poses, denoise_steps, elapsed):
     edge_visits = st["conv_edge_visits"] + 3 * st["ll_edges"]
-    node_visits = poses * DENOISE_STEPS * (8 * eng.Nl + 4 * eng.Nr)   # 3 + 5 ligand layers, 4 receptor layers
+    node_visits = poses * denoise_steps * (8 * eng.Nl + 4 * eng.Nr)   # 3 + 5 ligand layers, 4 receptor layers
     nbytes = 432.0 * edge_visits + 592.0 * node_visits
     gbps = nbytes / elapsed / 1e9
-    return {"algorithmic_mb_per_pose_step": round(nbytes / (poses * DENOISE_STEPS) / 1e6, 2), "achieved_gbps": round(gbps, 1),
+    return {"algorithmic_mb_per_pose_step": round(nbytes / (poses * denoise_steps) / 1e6, 2), "achieved_gbps": round(gbps, 1),
             "peak_gbps": 8000.0, "frac": round(gbps / 8000.0, 4)}
 
 
-def confidence_leg(cplx_seed, final_pos, dev, geometry):
-    """All-atom confidence scoring of the 40 final poses of the last complex, measured OUTSIDE the timed
-    region of the headline metric: ms per 40-pose batch and the fused conv kernel's algorithmic TFLOP/s (HIP events)."""
+def confidence_leg(workload, samples, cplx_seed, final_pos, dev, geometry):
+    """All-atom confidence scoring of the final poses of the last complex, measured OUTSIDE the timed
+    region of the headline metric: ms per batch and the fused conv kernel's algorithmic TFLOP/s (HIP events)."""
     from confidence_bootstrapping_amd.synthetic import make_workload
     from confidence_bootstrapping_amd.utils import make_confidence_model
     from tools.conf_bench import flops_per_edge as cflops
     cmodel, cargs = make_confidence_model(device=dev, seed=5)
-    ceng = cmodel.engine(max_batch=SAMPLES)
-    ceng.set_complex(make_workload(WORKLOAD, seed=cplx_seed, all_atoms=True, **geometry))
+    ceng = cmodel.engine(max_batch=samples)
+    ceng.set_complex(make_workload(workload, seed=cplx_seed, all_atoms=True, **geometry))
     for _ in range(2):
         ceng.score(final_pos, cargs.crop_beyond)
     counts = ceng.edge_counts()
@@ -166,7 +173,7 @@ def confidence_leg(cplx_seed, final_pos, dev, geometry):
     e_all, e_last = sum(counts.values()), counts["ll"] + counts["lr"] + counts["la"]
     fl = e_all * (cflops(0, 1) + cflops(1, 2) + cflops(2, 3) + cflops(3, 3)) + e_last * cflops(3, 3)
     tf = fl * reps / (tot_ms * 1e-3) / 1e12
-    return {"what": "all-atom confidence model on the 40 final poses (crop 20 A, t=0), not part of `value`", "ms_per_40_poses": round(dt * 1e3, 3),
+    return {"what": f"all-atom confidence model on the {samples} final poses (crop 20 A, t=0), not part of `value`", "ms_per_40_poses": round(dt * 1e3, 3),
             "edges_per_layer": e_all, "kernel": "fctp_conv_kernel", "achieved": round(tf, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
@@ -207,6 +214,108 @@ def finetune_leg(dev, batch=8, warm=3, steps=6):
             "ms_per_step": round(dt * 1e3, 2), "complexes_per_s": round(batch / dt, 1), "loss": round(float(out[0]), 4), "dtype": "f32"}
 
 
+def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry, n_complexes, engine_value):
+    """The headline workload through the API north_star names: `sampling(data_list, model, ..., confidence_model=...)` over the poses of
+    `n_complexes` complexes.  Inside the timed region, as in the reference (inference.py:450-495 takes its run time around the
+    filtering-list copies and the `sampling()` call): the per-pose copies of the all-atom graphs, drawing the N(0,1) noise in the
+    reference's order on the CPU generator, collation / co-scheduling of the complexes, H2D copies, per-complex set-up of both engines
+    (graph upload, receptor embedding, all-atom tables), the step loops, confidence scoring of every final pose and the write-back
+    into `data_list`.  Outside (the caller's job in the reference too): building `data_list` and `randomize_position`.
+    The poses follow the ideal path like the headline: the drawn translation noise is replaced by the pre-computed ideal-path noise
+    AFTER it has been drawn (the drawing cost stays in the timed region)."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, ideal_path_noise
+    from confidence_bootstrapping_amd.utils import make_confidence_model
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule, t_to_sigma
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position, draw_noise_like_reference
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    model = model.to(dev)
+    sched = get_t_schedule("expbeta", denoise_steps)
+    t2s = partial(t_to_sigma, args=margs)
+    base = make_workload(workload, seed=1234, all_atoms=True, **geometry)
+    pocket = base["ligand"].pos.mean(0)
+    R = int(base["ligand"].edge_mask.sum())
+
+    def build(n, tag):
+        """n complexes x `samples` randomised poses (the caller's side of the API) + the ideal-path translation noise of every pose"""
+        dl, ztr = [], []
+        for k in range(n):
+            c = base.shallow_copy()
+            c.name = f"{workload}_{tag}{k}"
+            torch.manual_seed(900 + k)
+            np.random.seed(900 + k)
+            b1 = Batch.from_data_list([c])                          # what the reference's loader yields (batch_size 1) ...
+            mine = [b1.shallow_copy() for _ in range(samples)]      # ... copied once per pose (inference.py:424; shallow here)
+            randomize_position(mine, False, False, margs.tr_sigma_max)
+            for g in mine:
+                g["ligand"].pos = g["ligand"].pos + (pocket - base["receptor"].pos.mean(0))
+            p0 = torch.stack([g["ligand"].pos for g in mine])
+            ztr.append(ideal_path_noise(p0, pocket, sched, margs))
+            dl.extend(mine)
+        return dl, torch.cat(ztr, dim=1)
+
+    def run(dl, ztr):
+        filt = [g.shallow_copy() for g in dl]                       # inference.py:452-455 (deep copies there)
+        noise = draw_noise_like_reference(len(dl), R, denoise_steps, samples)
+        noise["tr"] = ztr
+        out, conf = sampling(data_list=dl, model=model, inference_steps=denoise_steps, tr_schedule=sched, rot_schedule=sched,
+                             tor_schedule=sched, device=dev, t_to_sigma=t2s, model_args=margs, confidence_model=cmodel,
+                             filtering_data_list=filt, filtering_model_args=cargs, batch_size=samples, noise=noise)
+        torch.cuda.synchronize()
+        return out, conf
+
+    warm = build(4, "w")
+    run(*warm)
+    run(*build(4, "v"))          # second warm-up on new names: engines, partner engines and graphs of the group shape exist now
+    dl, ztr = build(n_complexes, "t")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out, conf = run(dl, ztr)
+    dt = time.perf_counter() - t0
+    final = torch.stack([g["ligand"].pos for g in out[-samples:]])
+    drift = float((final.mean(1).cpu() - pocket).norm(dim=1).mean())
+    v = n_complexes * samples / dt
+    return {"what": "the same workload through sampling(data_list, model, ..., confidence_model=...): noise drawing, co-scheduling, per-complex "
+                    "set-up of both engines, step loops, confidence scoring of every pose, write-back; not part of `value`",
+            "value": round(v, 2), "unit": "poses/s", "complexes": n_complexes, "s_total": round(dt, 3),
+            "vs_engine_level_value": round(v / engine_value, 4) if engine_value else None,
+            "confidences_finite": bool(torch.isfinite(conf).all()), "mean_final_centroid_distance_from_pocket_A": round(drift, 2)}
+
+
+def complex_set_leg(dev, n_complexes=24, samples=40, denoise_steps=20, seed=7):
+    """BASELINE.json configs[2] in small: a heterogeneous set (sizes log-normal around the median complex)
+    through distributed.run_complex_set on this rank -- per-complex set-up, co-scheduled groups of four, confidence ranking --
+    whole-job poses/s, set-up included.  (tools/run_set.py is the same code for the full 189-complex set and for N ranks.)"""
+    from confidence_bootstrapping_amd.synthetic import complex_set_sizes, make_set_complex
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
+    from confidence_bootstrapping_amd.distributed import run_complex_set
+    from confidence_bootstrapping_amd.complex_set import ComplexSetRunner
+    sizes = complex_set_sizes(n_complexes, seed)
+    smodel, sargs = make_score_model(device=dev, seed=0)
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    runner = ComplexSetRunner(smodel, sargs, cmodel, cargs, dev, samples=samples, denoise_steps=denoise_steps, group=4)
+    cps = [make_set_complex(i, sizes[i], seed) for i in range(n_complexes)]
+    for i, c in enumerate(cps):
+        runner.prepare(i, c)
+    # warm-up: library / allocator / engines on four complexes of the set (their results are discarded)
+    runner.sample_group([(i, cps[i]) for i in range(min(4, n_complexes))])
+    runner.times.update(setup=0.0, sample=0.0, conf=0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run_complex_set(cps, runner.sample_group, world=1, rank=0, group=4)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert len(res) == n_complexes and all(np.isfinite(r["pos"]).all() for r in res)
+    a = np.array(sizes)
+    return {"what": "heterogeneous complex set (configs[2] in small) through run_complex_set: set-up + sampling + confidence ranking, "
+                    "not part of `value`", "complexes": n_complexes, "samples": samples, "denoise_steps": denoise_steps,
+            "value": round(n_complexes * samples / dt, 2), "unit": "poses/s", "s_total": round(dt, 3),
+            "Nl_min_median_max": [int(a[:, 0].min()), int(np.median(a[:, 0])), int(a[:, 0].max())],
+            "Nr_min_median_max": [int(a[:, 1].min()), int(np.median(a[:, 1])), int(a[:, 1].max())],
+            "setup_s": round(runner.times["setup"], 3), "sampling_s": round(runner.times["sample"], 3),
+            "confidence_s": round(runner.times["conf"], 3)}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` run bare: start the N ranks as fresh child processes (torch.distributed.run, one per GPU) BEFORE
     this process makes any GPU call (torch.cuda.device_count() does not initialise the GPU on this image) and exit with their status.
@@ -221,123 +330,74 @@ def launch_ranks(n, argv):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: the host driver of this pool only supports dmabuf IPC; without it RCCL's intra-node buffer
+    # registration fails with `hipIpcGetMemHandle: invalid argument` (task statement, Environment).  The image exports it already;
+    # it is set here as well so that a bare run from a scrubbed environment still works.  An explicit setting of the caller wins.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     sys.exit(subprocess.call(cmd, env=env))
 
 
-def ideal_path_noise(pos0, pocket, sched, margs):
-    """Pre-drawn translation noise that carries the centroid of pose b along pocket + sigma_tr(t_i) eps_b (module docstring):
-    z[i, b] = (sigma(t_{i+1}) - sigma(t_i)) eps_b / (g_i sqrt(dt_i)), eps_b fixed by the initial pose, sigma(t_S) = sigma_min."""
-    S = len(sched)
-    lo, hi = margs.tr_sigma_min, margs.tr_sigma_max
-    sig = np.array([lo ** (1 - t) * hi ** t for t in list(sched) + [0.0]])
-    eps = (pos0.mean(1) - pocket) / sig[0]                                   # [B, 3]
-    z = torch.zeros(S, pos0.shape[0], 3)
-    for i in range(S):
-        dt = sched[i] - sched[i + 1] if i < S - 1 else sched[i]
-        g = sig[i] * np.sqrt(2 * np.log(hi / lo))
-        z[i] = (sig[i + 1] - sig[i]) / (g * np.sqrt(dt)) * eps
-    return z
-
-
-def main():
-    global WORKLOAD, SAMPLES, DENOISE_STEPS
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (confidence, other operand modes, fine-tuning, "
-                    "CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
-    ap.add_argument("--graph", type=int, default=1, help="1 (default): the whole step loop of a group of complexes is one hipGraph launch, the "
-                    "tensor-product kernels timed by event-record nodes of the graph; 0: eager launches")
-    ap.add_argument("--workload", default=WORKLOAD, help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
-    ap.add_argument("--geometry", default="globular", choices=["globular", "loose"],
-                    help="receptor density: globular = folded-protein density, pocket at 0.7 R (SURVEY.md 8 edge counts); loose = the test complexes")
-    ap.add_argument("--poses", default="ideal", choices=["ideal", "free"],
-                    help="ideal: poses follow pocket + sigma_tr(t) eps (a trained model's path) through the pre-drawn translation noise; "
-                         "free: iid noise, un-scaled heads (random-init weights: the ligand random-walks off the protein)")
-    ap.add_argument("--samples", type=int, default=SAMPLES)
-    ap.add_argument("--denoise-steps", type=int, default=DENOISE_STEPS)
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_split"],
-                    help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3]); f32_split: fp32 operands as three bf16 planes on the bf16 MFMA")
-    ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
-                    "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..8 = that many")
-    a = ap.parse_args()
-    if a.gpus < 1:
-        ap.error("--gpus must be >= 1")
-    if a.gpus > 1 and "RANK" not in os.environ:
-        launch_ranks(a.gpus, sys.argv[1:])          # does not return
-    WORKLOAD, SAMPLES, DENOISE_STEPS = a.workload, a.samples, a.denoise_steps
-
-    rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    if world != a.gpus:
-        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run bare)\n")
-        sys.exit(2)
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
-        sys.stderr.write("bench.py: no MI355X visible for this rank; there is no CPU path to fall back to\n")
-        sys.exit(2)
+def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geometry_name, poses_mode, graph, pair, warmup, steps_timed,
+            rank=0, world=1, split="complexes", keep=False):
+    """`steps_timed` complexes of `workload` (after `warmup` untimed ones) through the engine, inputs resident in HBM.
+    Returns the JSON fields of this measurement (value, ms_per_step, config, roofline) and, with keep=True, the context the secondary
+    legs re-use (engines, poses, noise)."""
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    from confidence_bootstrapping_amd.synthetic import make_workload
-    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.synthetic import make_workload, ideal_path_noise, BENCH_GEOMETRY, TR_HEAD_SCALE
     from confidence_bootstrapping_amd.engine import DockEngine, make_steps
     from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
     from confidence_bootstrapping_amd.sampling import randomize_position
     from confidence_bootstrapping_amd import Batch
-    from confidence_bootstrapping_amd.distributed import gather_poses
+    from confidence_bootstrapping_amd.distributed import gather_poses, gather_ranked, shard_round_robin
 
-    geometry = dict(globular=True, pocket_depth=0.7) if a.geometry == "globular" else {}
-    model, margs = make_score_model(seed=0)
-    TR_HEAD_SCALE = 0.02
-    if a.poses == "ideal":
-        with torch.no_grad():
-            model.tr_final_layer[3].weight.mul_(TR_HEAD_SCALE)
-            model.tr_final_layer[3].bias.mul_(TR_HEAD_SCALE)
-    cplx = make_workload(WORKLOAD, seed=1234, **geometry)
+    geometry = dict(BENCH_GEOMETRY) if geometry_name == "globular" else {}
+    cplx = make_workload(workload, seed=1234, **geometry)
     pocket = cplx["ligand"].pos.mean(0)
-    cosched = (2 if a.pair == 1 else max(1, min(a.pair, 8))) if a.pair else 1
+    by_samples = split == "samples" and world > 1
+    mine = shard_round_robin(samples, world, rank) if by_samples else list(range(samples))    # the sample indices this rank runs
+    b_loc = len(mine)
+    cosched = (2 if pair == 1 else max(1, min(pair, 8))) if pair else 1
     n_eng = min(cosched + 1, 8) if cosched > 1 else 1        # one spare partner: a group may carry cosched + 1 complexes (see run())
     engines = []
     for k in range(n_eng):
-        e = DockEngine.from_model(model, dev, max_batch=SAMPLES) if k == 0 else DockEngine(
-            dev, max_batch=SAMPLES, lm_embedding_dim=engines[0].cfg.lm_embedding_dim, no_torsion=bool(engines[0].cfg.no_torsion))
+        e = DockEngine.from_model(model, dev, max_batch=max(b_loc, 1)) if k == 0 else DockEngine(
+            dev, max_batch=max(b_loc, 1), lm_embedding_dim=engines[0].cfg.lm_embedding_dim, no_torsion=bool(engines[0].cfg.no_torsion))
         if k > 0:
             e.share_weights_from(engines[0])
         e.set_complex(cplx)
-        e.set_option("graph", a.graph)
-        e.set_option("bf16", int(a.dtype == "bf16"))
-        if a.dtype == "f32_split":
+        e.set_option("graph", graph)
+        e.set_option("bf16", int(dtype == "bf16"))
+        if dtype == "f32_split":
             e.set_option("f32_split", 1)
         engines.append(e)
     eng = engines[0]
-    sched = get_t_schedule("expbeta", DENOISE_STEPS)
+    sched = get_t_schedule("expbeta", denoise_steps)
     steps = make_steps(sched, margs, model.timestep_emb_func)
     R = eng.R
-    n_runs = a.warmup + a.steps
-    # initial poses via the reference's randomisation, noise pre-drawn (seeded per (rank, complex)), all resident in HBM
+    n_runs = warmup + steps_timed
+    # initial poses via the reference's randomisation, noise pre-drawn (seeded per (rank, complex); per complex only under
+    # --split samples, where every rank draws the noise of ALL samples of a complex and keeps its own), all resident in HBM
     pos0, noise = [], []
+    idx = torch.as_tensor(mine, dtype=torch.long)
+    cols = (idx[:, None] * R + torch.arange(R)[None, :]).reshape(-1)
     for k in range(n_runs):
-        torch.manual_seed(42 + 1000 * rank + k)
-        np.random.seed(42 + 1000 * rank + k)
-        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(SAMPLES)]
+        seed = 42 + (0 if by_samples else 1000 * rank) + k
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(samples)]
         randomize_position(dl, False, False, margs.tr_sigma_max)             # prior centred on the receptor centroid (no pocket knowledge)
         p0 = torch.stack([d["ligand"].pos for d in dl])
-        z_tr = torch.randn(DENOISE_STEPS, SAMPLES, 3)
-        if a.poses == "ideal":
+        z_tr = torch.randn(denoise_steps, samples, 3)
+        if poses_mode == "ideal":
             p0 = p0 + (pocket - cplx["receptor"].pos.mean(0))                   # the same prior, centred on the pocket
             z_tr = ideal_path_noise(p0, pocket, sched, margs)
+        z_rot, z_tor = torch.randn(denoise_steps, samples, 3), torch.randn(denoise_steps, samples * R)
+        if by_samples:
+            p0, z_tr, z_rot, z_tor = p0[idx], z_tr[:, idx], z_rot[:, idx], z_tor[:, cols]
         pos0.append(p0.to(dev).contiguous())
-        noise.append((z_tr.to(dev), torch.randn(DENOISE_STEPS, SAMPLES, 3).to(dev), torch.randn(DENOISE_STEPS, SAMPLES * R).to(dev)))
+        noise.append((z_tr.to(dev).contiguous(), z_rot.to(dev).contiguous(), z_tor.to(dev).contiguous()))
 
     def plan(lo, hi):
         """group sizes for complexes lo..hi-1"""
@@ -354,6 +414,8 @@ def main():
         return out
 
     def run_group(k, m, poses):
+        if b_loc == 0:
+            return
         for e in engines[:m]:
             e.recompute_receptor()
         if m == 1:
@@ -365,24 +427,22 @@ def main():
         """complexes lo..hi-1 in co-scheduled groups (each complex still gets its own receptor embedding pass)"""
         k = lo
         for m in plan(lo, hi):
-            GROUPS_RUN.append(m)
             run_group(k, m, [pos0[k + q] for q in range(m)])
             k += m
 
-    GROUPS_RUN = []
     for e in engines:
         e.kernel_timing(enable=True, reset=True)      # before the warm-up: a captured graph carries its timing events as nodes
-    run(0, a.warmup)
-    if a.graph:
+    run(0, warmup)
+    if graph:
         # the step loop of a group is one hipGraph per group shape: instantiate the shapes the timed region uses (on scratch poses)
-        done, k = set(plan(0, a.warmup)), a.warmup
-        for m in plan(a.warmup, n_runs):
+        done, k = set(plan(0, warmup)), warmup
+        for m in plan(warmup, n_runs):
             if m not in done:
                 done.add(m)
                 run_group(k, m, [pos0[k + q].clone() for q in range(m)])
             k += m
     torch.cuda.synchronize()
-    alt_k = list(range(max(a.warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
+    alt_k = list(range(max(warmup, n_runs - 2 * cosched), n_runs))     # complexes re-run in the other operand modes afterwards
     alt_init = {k: pos0[k].clone() for k in alt_k}
     for e in engines:
         e.kernel_timing(enable=True, reset=True)
@@ -390,10 +450,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    GROUPS_RUN.clear()
     t0 = time.perf_counter()
-    run(a.warmup, n_runs)
-    final = gather_poses(pos0[n_runs - 1], world, rank)
+    run(warmup, n_runs)
+    if by_samples:
+        # one ranked gather per complex (inference.py:537-547 ranks the samples of a complex; without a confidence model here: by index)
+        for k in range(warmup, n_runs):
+            gather_ranked(pos0[k], -idx.float().to(dev), world, rank, 0, ids=idx, rows=-(-samples // world))
+    else:
+        gather_poses(pos0[n_runs - 1], world, rank)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -411,73 +475,150 @@ def main():
         st = {k: st[k] + v for k, v in e.stats().items()}
     avg_ms = total_ms / max(n_launch, 1)
     assert torch.isfinite(pos0[n_runs - 1]).all(), "non-finite poses"
-    drift = float((pos0[n_runs - 1].mean(1).cpu() - pocket).norm(dim=1).mean())     # mean final centroid distance from the pocket (A)
+    drift = float((pos0[n_runs - 1].mean(1).cpu() - pocket).norm(dim=1).mean()) if b_loc else 0.0   # mean final centroid distance from the pocket (A)
 
+    poses = samples * steps_timed * (1 if by_samples else world)
+    pose_steps_rank = max(b_loc, 1) * steps_timed * denoise_steps               # the counters are this rank's
+    f33 = flops_per_edge(3, 3)
+    femb = flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3)
+    total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # reference formulation: un-shared edge counts
+    executed_flops = total_flops - st["shared_rr_visits"] * f33           # minus the credited-but-shared layer-0 rr messages
+    Err = 24 * eng.Nr
+    elr_mean = (st["conv_edge_visits"] - 5 * st["ll_edges"] - 4 * pose_steps_rank * Err) / 9.0 / pose_steps_rank
+    gflop_ps = total_flops / pose_steps_rank / 1e9
+    # `achieved` / `frac` = what the kernel EXECUTES per second; the reference formulation's (un-shared) count, which
+    # SURVEY.md 8d pre-authorises as credit, is reported beside it under its own name
+    per_s = 1.0 / (avg_ms * 1e-3) / 1e12 / max(n_launch, 1) if avg_ms > 0 else 0.0
+    achieved, algorithmic = executed_flops * per_s, total_flops * per_s
+    issue = 6.0 if dtype == "f32_split" else 1.0     # every fp32 product is issued as 6 bf16 plane products, priced against the bf16 peak
+    peak = PEAK_FP32_MFMA_TFLOPS if dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+    headline = (workload, samples, denoise_steps, dtype, geometry_name, poses_mode) == HEADLINE
+    # HBM bytes per tp_conv launch from the PMC passes of THIS command line committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
+    # separate --pmc runs): a recorded figure, not measured in this run -- the source file is named next to it
+    traffic, traffic_src = None, None
+    for tag in TRAFFIC_PROFILES.get((workload, dtype, geometry_name, poses_mode), []):
+        q = os.path.join(ROOT, "profiles", tag)
+        if os.path.exists(q):
+            traffic, traffic_src = round(json.load(open(q))["hbm_bytes_per_launch_all_tp_conv"]), "profiles/" + tag
+            break
+    value = poses / elapsed
+    out = {
+        "metric": "poses/sec (whole node), 40-sample x 20-step diffusion, DockGen median complex" if headline else
+                  f"poses/sec (whole node), {samples}-sample x {denoise_steps}-step diffusion, {workload}",
+        "value": round(value, 3), "unit": "poses/s", "n_gpus": world, "steps": steps_timed, "warmup": warmup,
+        "ms_per_step": round(elapsed / steps_timed * 1e3, 3), "higher_is_better": True, "scaling": "strong" if by_samples else "weak",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "config": {"workload": workload, "samples_per_complex": samples, "denoise_steps": denoise_steps,
+                   "co_scheduled_complexes": cosched, "hip_graph": int(graph),
+                   "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R,
+                   "geometry": "globular receptor (135 A^3/residue), pocket at 0.7 R" if geometry_name == "globular" else "loose coil (test complexes)",
+                   "poses": (f"ideal reverse path pocket + sigma_tr(t) eps via the pre-drawn translation noise; tr_final_layer.3 x {TR_HEAD_SCALE}"
+                             if poses_mode == "ideal" else "free-running reverse SDE, iid noise"),
+                   "weights": "random-init, reference state_dict layout",
+                   "sharding": (f"{world} rank(s), the {samples} samples of each of the {steps_timed} complexes split round-robin "
+                                f"({b_loc} on rank 0), one ranked gather per complex" if by_samples else
+                                f"{world} rank(s) x {steps_timed} complexes each, no data-path collective")},
+        "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": "tp_conv64_kernel (bf16 operands)", "f32_split": "tp_conv_kernel<OpsBf16x3>"}[dtype],
+                     "achieved": round(achieved * issue, 3), "peak": peak,
+                     "unit": "TFLOP/s", "frac": round(achieved * issue / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "flops_counted": "executed (layer-0 receptor->receptor messages once per complex)",
+                     "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                     "executed_gflop_per_launch": round(executed_flops / max(n_launch, 1) / 1e9, 3),
+                     # the reference formulation's count (every sample credited with its own layer-0 rr messages)
+                     "algorithmic_gflop_per_launch": round(total_flops / max(n_launch, 1) / 1e9, 3),
+                     "algorithmic_tflops": round(algorithmic, 3), "algorithmic_frac": round(algorithmic * issue / peak, 4),
+                     # the work behind `value`, so that it can be checked against the blueprint (32.8 GFLOP, Elr ~ 6 200)
+                     "gflop_per_pose_step": round(gflop_ps, 3),
+                     "edge_visits_per_pose_step": round((st["conv_edge_visits"] + 3 * st["ll_edges"]) / pose_steps_rank, 1),
+                     "elr_step_mean": round(elr_mean, 1), "ell_mean": round(st["ll_edges"] / pose_steps_rank, 1), "err": Err,
+                     "poses_per_s_normalised_to_32p8_gflop": round(value * gflop_ps / 32.8, 2),
+                     "mean_final_centroid_distance_from_pocket_A": round(drift, 2),
+                     "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
+                     "pose_steps_per_s": round(poses * denoise_steps / elapsed, 1),
+                     # secondary: fused-ideal algorithmic bytes = 432 B per edge-layer visit + 592 B per
+                     # node-layer visit, against the 8 TB/s HBM3E peak -- the path is far from HBM-bound
+                     "hbm_secondary": hbm_secondary(st, eng, max(b_loc, 1) * steps_timed, denoise_steps, elapsed)},
+    }
+    ctx = None
+    if keep:
+        ctx = dict(engines=engines, pos0=pos0, noise=noise, run=run, alt_k=alt_k, alt_init=alt_init, n_runs=n_runs, cosched=cosched,
+                   cplx=cplx, sched=sched, geometry=geometry)
+    return out, ctx
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (python_api, c4_bf16, complex_set, confidence, "
+                    "other operand modes, fine-tuning, CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
+    ap.add_argument("--graph", type=int, default=1, help="1 (default): the whole step loop of a group of complexes is one hipGraph launch, the "
+                    "tensor-product kernels timed by event-record nodes of the graph; 0: eager launches")
+    ap.add_argument("--workload", default=HEADLINE[0], help="synthetic complex: c2_dockgen_median (headline) or c4_large_pocket")
+    ap.add_argument("--geometry", default="globular", choices=["globular", "loose"],
+                    help="receptor density: globular = folded-protein density, pocket at 0.7 R (SURVEY.md 8 edge counts); loose = the test complexes")
+    ap.add_argument("--poses", default="ideal", choices=["ideal", "free"],
+                    help="ideal: poses follow pocket + sigma_tr(t) eps (a trained model's path) through the pre-drawn translation noise; "
+                         "free: iid noise, un-scaled heads (random-init weights: the ligand random-walks off the protein)")
+    ap.add_argument("--samples", type=int, default=HEADLINE[1])
+    ap.add_argument("--denoise-steps", type=int, default=HEADLINE[2])
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_split"],
+                    help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3]); f32_split: fp32 operands as three bf16 planes on the bf16 MFMA")
+    ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
+                    "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..8 = that many")
+    ap.add_argument("--split", default="complexes", choices=["complexes", "samples"],
+                    help="N > 1: complexes = every rank runs K complexes of its own (weak scaling, default); samples = the samples of each "
+                         "of the K complexes are split round-robin over the ranks with one ranked gather per complex (north-star split, strong scaling)")
+    a = ap.parse_args()
+    if a.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if a.gpus > 1 and "RANK" not in os.environ:
+        launch_ranks(a.gpus, sys.argv[1:])          # does not return
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run bare)\n")
+        sys.exit(2)
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        sys.stderr.write("bench.py: no MI355X visible for this rank; there is no CPU path to fall back to\n")
+        sys.exit(2)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from confidence_bootstrapping_amd.synthetic import scale_tr_head, BENCH_GEOMETRY
+    from confidence_bootstrapping_amd.utils import make_score_model
+
+    model, margs = make_score_model(seed=0)
+    if a.poses == "ideal":
+        scale_tr_head(model)
+    out, ctx = measure(model, margs, dev, workload=a.workload, samples=a.samples, denoise_steps=a.denoise_steps, dtype=a.dtype,
+                       geometry_name=a.geometry, poses_mode=a.poses, graph=a.graph, pair=a.pair, warmup=a.warmup, steps_timed=a.steps,
+                       rank=rank, world=world, split=a.split, keep=True)
     if rank == 0:
-        poses = SAMPLES * a.steps * world
-        pose_steps_rank = SAMPLES * a.steps * DENOISE_STEPS                  # the counters are this rank's
-        f33 = flops_per_edge(3, 3)
-        femb = flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3)
-        total_flops = st["conv_edge_visits"] * f33 + st["ll_edges"] * femb      # algorithmic work of the timed tp_conv launches
-        executed_flops = total_flops - st["shared_rr_visits"] * f33           # minus the credited-but-shared layer-0 rr messages
-        flops_per_launch = total_flops / max(n_launch, 1)
-        Err = 24 * eng.Nr
-        elr_mean = (st["conv_edge_visits"] - 5 * st["ll_edges"] - 4 * pose_steps_rank * Err) / 9.0 / pose_steps_rank
-        gflop_ps = total_flops / pose_steps_rank / 1e9
-        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
-        algorithmic = achieved
-        if a.dtype == "f32_split":
-            achieved *= 6.0     # every fp32 product is issued as 6 bf16 plane products; price the ISSUED flops against the bf16 peak
-        headline = (WORKLOAD, SAMPLES, DENOISE_STEPS, a.dtype, a.geometry, a.poses) == ("c2_dockgen_median", 40, 20, "f32", "globular", "ideal")
-        peak = PEAK_FP32_MFMA_TFLOPS if a.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
-        # HBM bytes per tp_conv launch from the PMC passes of THIS command line committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
-        # separate --pmc runs): a recorded figure, not measured in this run -- the source file is named next to it
-        traffic, traffic_src = None, None
-        for tag in TRAFFIC_PROFILES.get((WORKLOAD, a.dtype, a.geometry, a.poses), []):
-            q = os.path.join(ROOT, "profiles", tag)
-            if os.path.exists(q):
-                traffic, traffic_src = round(json.load(open(q))["hbm_bytes_per_launch_all_tp_conv"]), "profiles/" + tag
-                break
-        value = poses / elapsed
-        out = {
-            "metric": "poses/sec (whole node), 40-sample x 20-step diffusion, DockGen median complex" if headline else
-                      f"poses/sec (whole node), {SAMPLES}-sample x {DENOISE_STEPS}-step diffusion, {WORKLOAD}",
-            "value": round(value, 3), "unit": "poses/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": WORKLOAD, "samples_per_complex": SAMPLES, "denoise_steps": DENOISE_STEPS,
-                       "co_scheduled_complexes": cosched, "hip_graph": int(a.graph),
-                       "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R,
-                       "geometry": "globular receptor (135 A^3/residue), pocket at 0.7 R" if a.geometry == "globular" else "loose coil (test complexes)",
-                       "poses": (f"ideal reverse path pocket + sigma_tr(t) eps via the pre-drawn translation noise; tr_final_layer.3 x {TR_HEAD_SCALE}"
-                                 if a.poses == "ideal" else "free-running reverse SDE, iid noise"),
-                       "weights": "random-init, reference state_dict layout",
-                       "sharding": f"{world} rank(s) x {a.steps} complexes each, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": "tp_conv_kernel<OpsBf16>", "f32_split": "tp_conv_kernel<OpsBf16x3>"}[a.dtype],
-                         "achieved": round(achieved, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
-                         "algorithmic_gflop_per_launch": round(flops_per_launch / 1e9, 3),
-                         "algorithmic_tflops": round(algorithmic, 3),
-                         # the work behind `value`, so that it can be checked against the blueprint (32.8 GFLOP, Elr ~ 6 200)
-                         "gflop_per_pose_step": round(gflop_ps, 3),
-                         "edge_visits_per_pose_step": round((st["conv_edge_visits"] + 3 * st["ll_edges"]) / pose_steps_rank, 1),
-                         "elr_step_mean": round(elr_mean, 1), "ell_mean": round(st["ll_edges"] / pose_steps_rank, 1), "err": Err,
-                         # `frac` credits the reference formulation's FLOPs; the layer-0 receptor->receptor messages are computed once
-                         # per complex, not once per sample: the fraction of the peak actually EXECUTED per second is
-                         "executed_frac": round(achieved / peak * executed_flops / max(total_flops, 1), 4),
-                         "poses_per_s_normalised_to_32p8_gflop": round(value * gflop_ps / 32.8, 2),
-                         "mean_final_centroid_distance_from_pocket_A": round(drift, 2),
-                         "tp_conv_share_of_wall": round(total_ms * 1e-3 / elapsed, 4),
-                         "pose_steps_per_s": round(poses * DENOISE_STEPS / elapsed, 1),
-                         # secondary: fused-ideal algorithmic bytes = 432 B per edge-layer visit + 592 B per
-                         # node-layer visit, against the 8 TB/s HBM3E peak -- the path is far from HBM-bound
-                         "hbm_secondary": hbm_secondary(st, eng, SAMPLES * a.steps, elapsed)},
-        }
+        headline = (a.workload, a.samples, a.denoise_steps, a.dtype, a.geometry, a.poses) == HEADLINE
         extras = world == 1 and headline and not a.headline_only
+        engines, pos0, run, alt_k, alt_init, n_runs = (ctx[k] for k in ("engines", "pos0", "run", "alt_k", "alt_init", "n_runs"))
+
+        def leg(name, fn):
+            """a secondary leg must never cost the headline line"""
+            t = time.perf_counter()
+            try:
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": repr(e)[:300]}
+            if isinstance(out[name], dict):
+                out[name]["leg_wall_s"] = round(time.perf_counter() - t, 1)
         if extras:
-            out["confidence"] = confidence_leg(1234, pos0[n_runs - 1], dev, geometry)
-        if extras and cosched > 1:
+            leg("confidence", lambda: confidence_leg(a.workload, a.samples, 1234, pos0[n_runs - 1], dev, ctx["geometry"]))
+        if extras and ctx["cosched"] > 1:
             # The same complexes in the two other operand modes of the same kernel (NOT part of `value`): f32_split = fp32 operands as
             # three exact bf16 planes on the bf16 matrix cores (fp32-grade results, tests/test_gpu_bf16.py); bf16 = configs[3].
             out["other_operand_modes"] = {}
@@ -493,17 +634,26 @@ def main():
                     run(alt_k[0], n_runs)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter() - t1
-                out["other_operand_modes"][mode] = {"value": round(SAMPLES * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k)}
+                out["other_operand_modes"][mode] = {"value": round(a.samples * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k)}
             for e in engines:
                 e.set_option("bf16", 0)
                 e.set_option("f32_split", 0)
         if extras:
-            try:
-                out["finetune"] = finetune_leg(dev)
-            except Exception as e:      # a secondary leg must never cost the headline line
-                out["finetune"] = {"error": repr(e)[:200]}
-        if extras and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(model, cplx, margs, sched)
+            cplx, sched, geometry = ctx["cplx"], ctx["sched"], ctx["geometry"]
+            ctx = engines = pos0 = run = None          # release the headline's engines before the other legs allocate theirs
+            leg("python_api", lambda: python_api_leg(model, margs, dev, a.workload, a.samples, a.denoise_steps, geometry, 20, out["value"]))
+
+            def c4():
+                r, _ = measure(model.cpu(), margs, dev, workload="c4_large_pocket", samples=64, denoise_steps=40, dtype="bf16",
+                               geometry_name="globular", poses_mode="ideal", graph=a.graph, pair=4, warmup=1, steps_timed=4)
+                return {"what": "BASELINE.json configs[3]: large-pocket complex, 64 samples x 40 steps, bf16 operands / fp32 accumulate, "
+                                "not part of `value`", "value": r["value"], "unit": "poses/s", "ms_per_step": r["ms_per_step"],
+                        "config": r["config"], "roofline": r["roofline"]}
+            leg("c4_bf16", c4)
+            leg("complex_set", lambda: complex_set_leg(dev))
+            leg("finetune", lambda: finetune_leg(dev))
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(model.cpu(), cplx, margs, sched, a.workload, a.samples, a.denoise_steps)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

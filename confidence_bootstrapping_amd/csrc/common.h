@@ -5,11 +5,12 @@
 
 namespace cbd {
 
-// Measured and NOT used (round 2): the weight stream reaches the tensor-product kernels through a pointer inside a by-value struct, i.e.
-// a GENERIC pointer, so its loads are FLAT instructions (vmcnt and lgkmcnt, conservative `s_waitcnt vmcnt(0) lgkmcnt(0)` in front of a
-// tile's first MFMA).  Casting to address space 1 turns them into global_load with exact vmcnt(N) waits -- and changed nothing in
-// throughput (fp32 209.1 -> 208.4 poses/s, bf16 C4 164 -> 160), while the earlier data return exposed the in-flight-MFMA-operand
-// hazard of the in-place fragment refill (tp_conv_dev.h): the 64 x 40 bf16 run stopped being bitwise repeatable.  The loads stay FLAT.
+// Weight streams are read through address-space-1 pointers (`GPtr`, reduce_runs.h) with a WAVE-UNIFORM base: global_load with an SGPR
+// base pair advanced on the scalar unit + one constant per-lane VGPR offset + an immediate, i.e. exact vmcnt(N) waits and no vector
+// address arithmetic inside or between the MFMA chains (tp_conv, tp_conv_bf16, fctp_conv, tp_train).  History: a first attempt that
+// only cast the per-lane FLAT pointers to address space 1 changed nothing in throughput and exposed the in-flight-MFMA-operand
+// hazard of the in-place fragment refill in the bf16 kernel (tp_conv_dev.h); with the bases pinned in SGPRs BEFORE a chain the chain
+// holds only MFMAs and loads and the hazard is out (repeatability soak: tools/bf16_repeat.py, all three operand modes).
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <numeric>
 #include <string>
@@ -80,7 +81,12 @@ struct cbd_engine {
   std::vector<GraphEntry> graphs;
   float *g_pos = nullptr, *g_ztr = nullptr, *g_zrot = nullptr, *g_ztor = nullptr;
   int g_S_cap = 0;
-  unsigned complex_gen = 0;         // bumped by everything that invalidates captured launches of this engine
+  // Generation stamp of everything a captured launch of this engine depends on (complex, staging buffers, weights).  Drawn from ONE
+  // process-wide monotonic counter (next_gen), never from a per-engine 0: the graphs of a co-scheduled group live on its first engine
+  // and are keyed by (engine address, generation) of every member, so a partner that is destroyed and re-created at the same heap
+  // address must not reach a generation an old key already holds (its kernel arguments point at freed device buffers).
+  uint64_t complex_gen = next_gen();
+  static uint64_t next_gen() { static std::atomic<uint64_t> g{1}; return g.fetch_add(1, std::memory_order_relaxed); }
   // device-resident description of the pose batch of the current call (kernels.h::PoseBatch) and its host image
   PoseBatch desc_h{};
   PoseBatch* desc_dev = nullptr;
@@ -131,7 +137,7 @@ static void drop_graphs(cbd_engine* e) {
     if (g.exec) (void)hipGraphExecDestroy(g.exec);
   e->gev_used = 0;   // the event pairs their nodes recorded into are free again
   e->graphs.clear();
-  ++e->complex_gen;
+  e->complex_gen = cbd_engine::next_gen();
 }
 
 // ======================================================================================================== weights
@@ -1273,10 +1279,10 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       HIPCHK(e->bpool.alloc(&e->g_ztr, (size_t)S * Bm * 3)); HIPCHK(e->bpool.alloc(&e->g_zrot, (size_t)S * Bm * 3));
       HIPCHK(e->bpool.alloc(&e->g_ztor, (size_t)S * Bm * std::max(R, 1)));
       e->g_S_cap = S;
-      ++e->complex_gen;
+      e->complex_gen = cbd_engine::next_gen();
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "|%p:%u:%d:%d:%d:%d", (void*)e, e->complex_gen, (int)B[k], e->use_bf16,
+    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16,
              (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr), (int)e->timing);
     key += buf;
   }

@@ -14,7 +14,9 @@
 //     loops fully unrolled so that mids are compile-time constants and their LDS reads batch, run-length reduction with scalar run
 //     masks.  Round 1 137.6 -> round 2 195 poses/s on C4 (64 x 40), 0.27 -> 0.39 of the bf16 peak.  Tried and NOT kept: sharing every
 //     tile between the 4 or 8 waves of a workgroup through an LDS ring with one barrier per tile (122 / 108 poses/s), 4 independent
-//     waves per workgroup (no change), 128 edges per wave at one wave per SIMD (114), global instead of FLAT loads (no change);
+//     waves per workgroup (no change), 128 edges per wave at one wave per SIMD (114), global instead of FLAT loads (no change), wave
+//     priorities (round 3: static s_setprio by workgroup number, raised inside or outside the MFMA chains: 196.3-199.1 vs 197.7-198.2
+//     poses/s, profiles/r03_b_prio_sweep.txt -- the two residents of a SIMD are not phase-locked);
 //   * LDS per wave = two transposed row tiles of 9.8 KB (the gathered destination rows, later the message tiles): 8 waves per CU.
 // fp32 everywhere outside the two Linears (gathered rows, CG contraction, messages, reduction), like the first generation.
 // Weight stream (pack_conv_stream_bf16, engine.hip): (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] = 6 KB, then the fp32 bias
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     tile_local = 2 * wave_in_group;
   }
   const ConvGroup G = args.g[grp];
-  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0;
+  unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_0e = 0;
   if constexpr (DIAG == 4) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
   // ---- start the weight stream
@@ -241,6 +243,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     }
   }
 
+  if constexpr (DIAG == 4) st_0e = stamp();
   // ---- vector / pseudoscalar blocks: tile = 5 mid indices x 6 outputs; lane half hf owns outputs 3hf..3hf+2
   float k1o0[9], k1e0[9], k0o0[3], k1o1[9], k1e1[9], k0o1[3];
 #pragma unroll
@@ -372,7 +375,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
       unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
       o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
-      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = st_t2;
+      o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = st_0e;   // slot 7: end of the 0e block (fp32 kernel: end of the first first-Linear tile)
     }
   }
 }

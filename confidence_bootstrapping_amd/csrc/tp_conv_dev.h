@@ -93,6 +93,11 @@ struct OpsF32 {
   // in its prologue (load_first), so the first Linear runs without a single wait on memory, and tile m's four registers are
   // refilled in place with fragments 4m..4m+3 of the first second-Linear tile (`next`) right after their use.
   // ---- the same three routines on a wave-uniform tile base (tp_conv_kernel; bond_conv / tp_train keep the per-lane pointer forms)
+  // The refill of fragment sg directly follows its four MFMAs (no one-pair delay as in tp_conv_bf16.hip::v2_gemm).  That is safe here
+  // because (i) the bases p0..p2 are pinned in SGPRs before the chain and every load uses an immediate, so NO VALU instruction can be
+  // scheduled into the just-died registers, and (ii) a returning global load is ordered behind the operand reads of the MFMAs issued
+  // before it: the fp32 MFMA reads its scalar-per-lane operands over its 16 passes, but the load's data needs an L2 round trip (> 500
+  // cycles) where the four MFMAs take 256.  Covered by the bitwise-repeat tests of all three operand modes and tools/bf16_repeat.py.
   static __device__ __forceinline__ void gemm_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
     GPtr<Frag> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64;
     pin_s(p0); pin_s(p1); pin_s(p2);
@@ -275,7 +280,8 @@ struct OpsBf16x3 {
     }
   }
   // first Linear: K = 32 = 2 k-steps x 3 planes = 6 fragments per tile, 3 tiles = the whole register tile (see OpsF32::gemm_first)
-  // ---- on a wave-uniform tile base (see OpsF32::gemm_u): fragment f is base[f / 4][lane + (f % 4) * 64]
+  // ---- on a wave-uniform tile base (see OpsF32::gemm_u): fragment f is base[f / 4][lane + (f % 4) * 64].  The three planes of a k-step
+  //      are refilled right behind its six MFMAs (192 cycles of matrix-pipe time ahead of an L2 round trip; no VALU in the chain).
   static __device__ __forceinline__ void gemm_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
     GPtr<Frag> pb[5] = {next, next + 4 * 64, next + 8 * 64, next + 12 * 64, next + 16 * 64};
 #pragma unroll

@@ -62,7 +62,13 @@ def gather_ranked(pos: torch.Tensor, confidence: torch.Tensor, world: int, rank:
     `ids` [b] (optional): global sample indices, returned in ranked order as a third value.  `rows`: rows every rank sends (ranks
     holding fewer -- an uneven round-robin split -- are padded and the padding is dropped on `dst`); default: b on every rank."""
     b = pos.shape[0]
-    idv = torch.arange(b, dtype=torch.float64) if ids is None else torch.as_tensor(ids, dtype=torch.float64)
+    if ids is None:
+        # no global sample indices given: number the rows rank-major (rank * rows + local row), so that the tie-break "by sample
+        # index" is still a total order over ALL gathered rows and does not number every rank's rows 0..b-1
+        off = rank * (b if rows is None else rows) if (world > 1 and dist.is_initialized()) else 0
+        idv = torch.arange(b, dtype=torch.float64) + off
+    else:
+        idv = torch.as_tensor(ids, dtype=torch.float64)
     if world == 1 or not dist.is_initialized():
         order = torch.argsort(confidence, descending=True, stable=True)
         out = (pos[order], confidence[order])
@@ -106,6 +112,9 @@ def sampling_distributed(data_list, model, inference_steps, tr_schedule, rot_sch
     if sampler is None:
         from .sampling import sampling as sampler
     world, rank = world_rank(world, rank)
+    if world > 1 and not (dist.is_available() and dist.is_initialized()):
+        raise RuntimeError(f"sampling_distributed(world={world}) needs an initialised torch.distributed process group "
+                           "(init_process_group('nccl' | 'gloo') before the call)")
     N = len(data_list)
     if N == 0:
         raise ValueError("empty data_list")

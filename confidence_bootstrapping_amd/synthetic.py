@@ -301,3 +301,82 @@ def add_atoms(d: HeteroData, seed=1234, atom_knn=8, mean_side_atoms=4.0) -> Hete
 def make_workload(workload: str, seed=1234, all_atoms=False, **geometry) -> HeteroData:
     d = make_complex(seed=seed, name=workload, **WORKLOADS[workload], **geometry)
     return add_atoms(d, seed=seed) if all_atoms else d
+
+
+# ---- the benchmark workload of BASELINE.json configs[1] (bench.py, tests/test_gpu_configs.py) ----------------------------------
+BENCH_GEOMETRY = dict(globular=True, pocket_depth=0.7)   # folded-protein density, pocket at 0.7 of the surface radius
+TR_HEAD_SCALE = 0.02
+
+
+def scale_tr_head(model, scale=TR_HEAD_SCALE):
+    """Random-init weights know nothing about the pocket; scaling the last layer of the translation head keeps its random drift
+    below 1 A over a trajectory, so that the poses stay on the path the pre-drawn noise prescribes (ideal_path_noise)."""
+    with torch.no_grad():
+        model.tr_final_layer[3].weight.mul_(scale)
+        model.tr_final_layer[3].bias.mul_(scale)
+    return model
+
+
+def ideal_path_noise(pos0, pocket, sched, margs):
+    """Pre-drawn translation noise that carries the centroid of pose b along pocket + sigma_tr(t_i) eps_b -- the probability-flow path
+    of the reverse process for a point-mass data distribution, i.e. what a trained score model produces:
+    z[i, b] = (sigma(t_{i+1}) - sigma(t_i)) eps_b / (g_i sqrt(dt_i)), eps_b fixed by the initial pose, sigma(t_S) = sigma_min."""
+    S = len(sched)
+    lo, hi = margs.tr_sigma_min, margs.tr_sigma_max
+    sig = np.array([lo ** (1 - t) * hi ** t for t in list(sched) + [0.0]])
+    eps = (pos0.mean(1) - pocket) / sig[0]                                   # [B, 3]
+    z = torch.zeros(S, pos0.shape[0], 3)
+    for i in range(S):
+        dt = sched[i] - sched[i + 1] if i < S - 1 else sched[i]
+        g = sig[i] * np.sqrt(2 * np.log(hi / lo))
+        z[i] = (sig[i + 1] - sig[i]) / (g * np.sqrt(dt)) * eps
+    return z
+
+
+def ideal_path_inputs(cplx, margs, sched, samples, seed):
+    """Initial poses (the reference's randomize_position, re-centred on the pocket) and the noise of one complex of the benchmark
+    workload: (pos0 [B,Nl,3], z_tr [S,B,3], z_rot [S,B,3], z_tor [S,B*R]) CPU tensors, deterministic in `seed`."""
+    import copy
+    from .hetero import Batch
+    from .sampling import randomize_position
+    state = (np.random.get_state(), torch.random.get_rng_state())
+    try:
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(samples)]
+        randomize_position(dl, False, False, margs.tr_sigma_max)             # prior centred on the receptor centroid (no pocket knowledge)
+        p0 = torch.stack([d["ligand"].pos for d in dl])
+        pocket = cplx["ligand"].pos.mean(0)
+        p0 = p0 + (pocket - cplx["receptor"].pos.mean(0))                    # the same prior, centred on the pocket
+        S, R = len(sched), int(cplx["ligand"].edge_mask.sum())
+        torch.randn(S, samples, 3)                                           # (the draw bench.py makes for the free-running variant)
+        z_tr = ideal_path_noise(p0, pocket, sched, margs)
+        return p0.contiguous(), z_tr, torch.randn(S, samples, 3), torch.randn(S, samples * R)
+    finally:
+        np.random.set_state(state[0])
+        torch.random.set_rng_state(state[1])
+
+
+# ---- BASELINE.json configs[2]: a heterogeneous set of complexes (SURVEY.md section 8 table, row C3) ---------------------------------
+def complex_set_sizes(n, seed=7):
+    """(Nl, Nr, R) of n complexes: log-normal around the DockGen-median complex (Nl 28, Nr 384), clipped to Nl in [6, 80] and
+    Nr in [64, 1500]; R ~ Nl / 5 rotatable bonds, at most 14."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        nl = int(np.clip(round(28 * np.exp(0.42 * rng.normal())), 6, 80))
+        nr = int(np.clip(round(384 * np.exp(0.50 * rng.normal())), 64, 1500))
+        out.append((nl, nr, int(np.clip(nl // 5, 0 if nl < 8 else 1, 14))))
+    return out
+
+
+def make_set_complex(i, size, seed=7, all_atoms=True):
+    """complex i of the set (deterministic in (seed, i)); falls back to fewer rotatable bonds when a small ligand cannot realise R"""
+    nl, nr, R = size
+    for r in range(R, -1, -1):
+        try:
+            c = make_complex(Nl=nl, Nr=nr, R=r, knn=24, seed=1000 * seed + i, name=f"set{i}")
+            return add_atoms(c, seed=1000 * seed + i) if all_atoms else c
+        except RuntimeError:
+            continue
+    raise RuntimeError(f"could not build complex {i} of size {size}")

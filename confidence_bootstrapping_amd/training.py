@@ -180,7 +180,11 @@ def uniform_step_count(loader):
     """Number of batches every rank runs this epoch: the minimum of the ranks' loader lengths (each rank's buffer / loader has its
     own length; the surplus batches of longer loaders are dropped, like drop_last over ranks)."""
     import torch.distributed as dist
-    n = len(loader)
+    try:
+        n = len(loader)
+    except TypeError:                       # an iterable without __len__: materialise it once to count its batches
+        raise TypeError("train_epoch under torch.distributed needs a loader with __len__ (the ranks agree on a step count before "
+                        "the epoch starts); wrap the iterable in a list") from None
     if _dist_world() == 1:
         return n
     t = torch.tensor([n], dtype=torch.int64)

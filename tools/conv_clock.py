@@ -27,3 +27,6 @@ ghz, dur_ns, n, pro, g1, tiles, fin, g1a = eng.fetch("conv_clock_ghz", 16)
 print(f"in-kernel clock of tp_conv<3,3>: median {ghz:.3f} GHz over {int(n)} workgroups, median workgroup lifetime {dur_ns/1e3:.1f} us")
 print(f"median cycles: prologue(gather+bias) {pro:.0f}, first Linear (3 tiles) {g1:.0f}, 54 weight tiles {tiles:.0f} ({tiles/54:.0f}/tile), "
       f"message reduce {fin:.0f}; total {pro+g1+tiles+fin:.0f}; first tile of the first Linear alone {g1a:.0f}")
+if BF16:
+    e0 = g1a - g1
+    print(f"bf16: 0e block (38 scalar tiles) {e0:.0f} ({e0/38:.0f}/tile), vector blocks (16 tiles) {tiles-e0:.0f} ({(tiles-e0)/16:.0f}/tile)")

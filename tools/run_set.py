@@ -7,7 +7,6 @@ including the per-complex set-up (graph upload, receptor embedding, all-atom sta
   python -m torch.distributed.run --nproc-per-node N tools/run_set.py --complexes 189
 """
 import argparse
-import copy
 import json
 import os
 import sys
@@ -35,83 +34,30 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    from confidence_bootstrapping_amd import Batch
-    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
+    from confidence_bootstrapping_amd.synthetic import complex_set_sizes, make_set_complex
     from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model
-    from confidence_bootstrapping_amd.engine import make_steps
-    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
-    from confidence_bootstrapping_amd.sampling import randomize_position
-    from confidence_bootstrapping_amd.distributed import shard_lpt
+    from confidence_bootstrapping_amd.distributed import shard_lpt, run_complex_set
+    from confidence_bootstrapping_amd.complex_set import ComplexSetRunner
 
-    from confidence_bootstrapping_amd.distributed import run_complex_set
-    rng = np.random.default_rng(a.seed)
-    sizes = [(int(rng.integers(14, 56)), int(rng.integers(140, 720))) for _ in range(a.complexes)]
+    sizes = complex_set_sizes(a.complexes, a.seed)          # log-normal around the median complex
     smodel, sargs = make_score_model(device=dev, seed=0)
     cmodel, cargs = make_confidence_model(device=dev, seed=5)
-    from confidence_bootstrapping_amd.engine import DockEngine
-    seng = DockEngine.from_model(smodel, dev, max_batch=a.samples)
-    partners = []                                         # engines for the co-scheduled complexes (same weights)
-    for _ in range(3):
-        p_ = DockEngine(dev, max_batch=a.samples)
-        p_.share_weights_from(seng)
-        partners.append(p_)
-    ceng = cmodel.engine(max_batch=a.samples)
-    sched = get_t_schedule("expbeta", a.steps)
-    steps = make_steps(sched, sargs, smodel.timestep_emb_func)
-    # host-side synthesis of ALL complexes is data loading, outside the timed region (every rank builds the same list; the LPT
-    # partition inside run_complex_set decides which ones this rank samples)
+    runner = ComplexSetRunner(smodel, sargs, cmodel, cargs, dev, samples=a.samples, denoise_steps=a.steps, group=4)
+    # host-side synthesis of the complexes is data loading, outside the timed region (the LPT partition inside run_complex_set decides
+    # which ones this rank samples; it only needs the sizes)
 
     class _Lazy:
-        """complex i built on first use, sized like sizes[i] (run_complex_set only needs the sizes for its cost function)"""
-
         def __init__(self, i):
-            self.i, self.c = i, None
-
-        def get(self):
-            if self.c is None:
-                nl, nr = sizes[self.i]
-                R = max(1, min(nl // 5, 10))
-                self.c = add_atoms(make_complex(Nl=nl, Nr=nr, R=R, knn=24, seed=1000 + self.i, name=f"set{self.i}"), seed=1000 + self.i)
-            return self.c
+            self.i = i
     lazy = [_Lazy(i) for i in range(a.complexes)]
-    parts = shard_lpt([nl * nr for nl, nr in sizes], world)
-    prepared = {}
+    parts = shard_lpt([nl * nr for nl, nr, _ in sizes], world)
     for i in parts[rank]:
-        c = lazy[i].get()
-        torch.manual_seed(i); np.random.seed(i)
-        dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(a.samples)]
-        randomize_position(dl, False, False, sargs.tr_sigma_max)
-        pos0 = torch.stack([d["ligand"].pos for d in dl]).contiguous()
-        Rr = int(c["ligand"].edge_mask.sum())
-        prepared[i] = (c, pos0, (torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples, 3), torch.randn(a.steps, a.samples * Rr)))
+        runner.prepare(i, make_set_complex(i, sizes[i], a.seed))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    tm = {"setup": 0.0, "sample": 0.0, "conf": 0.0}
-
-    def sample_group(items):
-        """up to four complexes: per-complex set-up, ONE co-scheduled sampling call (cbd_sample_multi), confidence ranking"""
-        ta = time.perf_counter()
-        engines = ([seng] + partners)[:len(items)]
-        staged = []
-        for e, (i, _) in zip(engines, items):
-            c, pos0, noise = prepared[i]
-            e.set_complex(c)
-            staged.append((pos0.to(dev), [z.to(dev) for z in noise]))
-        torch.cuda.synchronize()
-        tb = time.perf_counter()
-        DockEngine.sample_multi(engines, [st_[0] for st_ in staged], steps, [st_[1] for st_ in staged])
-        torch.cuda.synchronize()
-        tc = time.perf_counter()
-        out = []
-        for (i, _), (pos, _) in zip(items, staged):
-            ceng.set_complex(prepared[i][0])
-            conf, _ = ceng.score(pos, cargs.crop_beyond)
-            best = int(torch.argmax(conf))
-            out.append({"complex": i, "confidence": float(conf[best]), "pos": pos[best].cpu().numpy()})
-        td = time.perf_counter()
-        tm["setup"] += tb - ta; tm["sample"] += tc - tb; tm["conf"] += td - tc
-        return out
+    tm = runner.times
+    sample_group = runner.sample_group
 
     t0 = time.perf_counter()
     results = run_complex_set(lazy, sample_group, world, rank, group=4, cost=lambda z: float(sizes[z.i][0] * sizes[z.i][1]))
