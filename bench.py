@@ -254,18 +254,17 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
             dl.extend(mine)
         return dl, torch.cat(ztr, dim=1)
 
-    def run(dl, ztr):
-        filt = [g.shallow_copy() for g in dl]                       # inference.py:452-455 (deep copies there)
+    def run(dl, ztr, with_conf=True):
+        filt = [g.shallow_copy() for g in dl] if with_conf else None       # inference.py:452-455 (deep copies there)
         noise = draw_noise_like_reference(len(dl), R, denoise_steps, samples)
         noise["tr"] = ztr
         out, conf = sampling(data_list=dl, model=model, inference_steps=denoise_steps, tr_schedule=sched, rot_schedule=sched,
-                             tor_schedule=sched, device=dev, t_to_sigma=t2s, model_args=margs, confidence_model=cmodel,
+                             tor_schedule=sched, device=dev, t_to_sigma=t2s, model_args=margs, confidence_model=cmodel if with_conf else None,
                              filtering_data_list=filt, filtering_model_args=cargs, batch_size=samples, noise=noise)
         torch.cuda.synchronize()
         return out, conf
 
-    warm = build(4, "w")
-    run(*warm)
+    run(*build(4, "w"))
     run(*build(4, "v"))          # second warm-up on new names: engines, partner engines and graphs of the group shape exist now
     dl, ztr = build(n_complexes, "t")
     torch.cuda.synchronize()
@@ -274,11 +273,20 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
     dt = time.perf_counter() - t0
     final = torch.stack([g["ligand"].pos for g in out[-samples:]])
     drift = float((final.mean(1).cpu() - pocket).norm(dim=1).mean())
-    v = n_complexes * samples / dt
+    # the same call without the confidence model: what the API costs on top of the engine-level figure without the extra WORK of
+    # scoring every pose (the engine-level `value` has no confidence model either)
+    dl2, ztr2 = build(n_complexes, "u")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(dl2, ztr2, with_conf=False)
+    dt2 = time.perf_counter() - t0
+    v, v2 = n_complexes * samples / dt, n_complexes * samples / dt2
     return {"what": "the same workload through sampling(data_list, model, ..., confidence_model=...): noise drawing, co-scheduling, per-complex "
                     "set-up of both engines, step loops, confidence scoring of every pose, write-back; not part of `value`",
             "value": round(v, 2), "unit": "poses/s", "complexes": n_complexes, "s_total": round(dt, 3),
             "vs_engine_level_value": round(v / engine_value, 4) if engine_value else None,
+            "without_confidence_model": {"value": round(v2, 2), "s_total": round(dt2, 3),
+                                         "vs_engine_level_value": round(v2 / engine_value, 4) if engine_value else None},
             "confidences_finite": bool(torch.isfinite(conf).all()), "mean_final_centroid_distance_from_pocket_A": round(drift, 2)}
 
 

@@ -39,6 +39,7 @@ struct cbd_conf_engine {
   cbd_conf_config cfg{};
   std::map<std::string, HostTensor> host_w;
   bool weights_ready = false, complex_ready = false;
+  int* overflow_dev = nullptr;      // sticky capacity-overflow flag (cbd_conf_create / cbd_conf_check)
   DevPool wpool, cpool, bpool;
   // ---- weights
   CLayerDev conv[5];
@@ -377,6 +378,10 @@ int cbd_conf_create(const cbd_conf_config* cfg, cbd_conf_engine** out) {
   HIPCHK(hipSetDevice(cfg->device));
   *out = new cbd_conf_engine();
   (*out)->cfg = *cfg;
+  // capacity-overflow flag: lives as long as the engine and is STICKY -- set by any cbd_conf_score since the last cbd_conf_check, so a
+  // caller may score several batches (of several complexes) and check once (sampling(): no host sync per complex)
+  HIPCHK(hipMalloc(reinterpret_cast<void**>(&(*out)->overflow_dev), sizeof(int)));
+  HIPCHK(hipMemset((*out)->overflow_dev, 0, sizeof(int)));
   return 0;
 }
 
@@ -386,6 +391,7 @@ int cbd_conf_destroy(cbd_conf_engine* e) {
   (void)hipDeviceSynchronize();
   for (auto& p : e->ev_pool) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
   e->bpool.release(); e->cpool.release(); e->wpool.release();
+  if (e->overflow_dev) (void)hipFree(e->overflow_dev);
   delete e;
   return 0;
 }
@@ -590,8 +596,7 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
   for (int g = 0; g < CONF_MAX_GROUPS; ++g)   // run_acc: one [nodes of the type][84] buffer per group
     HIPCHK(bp.alloc(&e->racc[g], nodes_of[g] * CN_STRIDE));
   HIPCHK(bp.alloc(&cd.total, CONF_MAX_GROUPS));
-  HIPCHK(bp.alloc(&cd.overflow, 1));
-  HIPCHK(hipMemset(cd.overflow, 0, sizeof(int)));
+  cd.overflow = e->overflow_dev;
   HIPCHK(hipMemset(cd.total, 0, sizeof(int) * CONF_MAX_GROUPS));
   HIPCHK(bp.alloc(&cd.keep_res, nR));
   HIPCHK(bp.alloc(&cd.ll_vec, caps[G_LL] * 4)); HIPCHK(bp.alloc(&cd.ll_dist, caps[G_LL])); HIPCHK(bp.alloc(&cd.ll_bond4, caps[G_LL] * 4));
@@ -637,7 +642,6 @@ int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float cr
   };
   // ---- crop + graphs
   const float crop2 = crop_beyond > 0 ? crop_beyond * crop_beyond : std::numeric_limits<float>::infinity();
-  HIPCHK(hipMemsetAsync(cd.overflow, 0, sizeof(int), s));
   HIPCHK(conf_launch_keep(cs, cd, B, crop2, s));
   CHK(stage("keep"));
   const float r = e->cfg.lig_max_radius;
@@ -736,7 +740,8 @@ int cbd_conf_check(cbd_conf_engine* e) {
   HIPCHK(hipSetDevice(e->cfg.device));
   HIPCHK(hipStreamSynchronize(e->last_stream));
   int flag = 0;
-  HIPCHK(hipMemcpy(&flag, e->cd.overflow, sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(&flag, e->overflow_dev, sizeof(int), hipMemcpyDeviceToHost));
+  if (flag) HIPCHK(hipMemset(e->overflow_dev, 0, sizeof(int)));
   if (flag) return fail(CBD_ERR_CAPACITY, "a ligand atom has more than %d receptor atoms within lig_max_radius", e->cd.la_cap);
   return 0;
 }

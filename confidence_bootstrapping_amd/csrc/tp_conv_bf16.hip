@@ -61,6 +61,7 @@ __device__ __forceinline__ void v2_set_hidden(Act6& h, int m, const f32x16& acc)
 //   * fragment q-1 is re-loaded after the MFMA pair of fragment q has been issued -- one pair late, so that even a load that hits in
 //     L1 (~120 cycles) lands after the pair that read the register has started; the bias follows the second pair, the last fragment
 //     its own pair directly.
+template <int DIAG = 0>
 __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag next, GBias next_bias, int lane, int hf,
                                         const Act6& B0, const Act6& B1, f32x16& acc0, f32x16& acc1) {
   GFrag pa = next;            // uniform: tile base (fragments 0..3: immediate offsets 0..3 KB)
@@ -81,21 +82,23 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag
     // keep the bias registers a live 16-register tuple of their own: otherwise hipcc lets an accumulator take them over after the first
     // pair, loads the next bias somewhere else and copies it back with 16 v_mov behind a vmcnt(0) at the end of every tile
     if (q == 0) asm volatile("" : "+v"(cb));
-    if (q > 0) a[q - 1] = q - 1 < 4 ? pa[lane + (q - 1) * 64] : pb[lane + (q - 5) * 64];
-    if (q == 1) {   // rows (r & 3) + 8 (r >> 2) + 4 hf of the next tile's bias: float4 2q' + hf of its 32 floats
+    if (q > 0 && !(DIAG & 16)) a[q - 1] = q - 1 < 4 ? pa[lane + (q - 1) * 64] : pb[lane + (q - 5) * 64];
+    if (q == 1 && !(DIAG & 8)) {   // rows (r & 3) + 8 (r >> 2) + 4 hf of the next tile's bias: float4 2q' + hf of its 32 floats
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const f32x4 b = pc[hf + 2 * qq];
         cb[4 * qq + 0] = b.x; cb[4 * qq + 1] = b.y; cb[4 * qq + 2] = b.z; cb[4 * qq + 3] = b.w;
       }
     }
-    if (q == V2_NFRAG - 1) a[q] = pb[lane + (q - 4) * 64];
+    if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pb[lane + (q - 4) * 64];
     __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 // DIAG (timing only, WRONG results; CBD_BF16_DIAG=n): 1 = every tile re-reads weight tile 0 (the weight stream becomes L1-resident),
-// 2 = no CG epilogue (the accumulators are only summed up), 3 = both; 4 = correct results + phase stamps (tools/conv_clock.py bf16)
+// 2 = no CG epilogue (the accumulators are only summed up), 3 = both; 4 = correct results + phase stamps (tools/conv_clock.py bf16);
+// 8 = the bias registers are never re-loaded, 9 = 8 + 1, 16 = no weight or bias re-loads at all (the first tile's registers serve every
+// tile: the kernel without its weight stream), 24 = 16 + 8
 template <int IN, int OUT, int DIAG = 0>
 __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #define V2_TILE(BA, BB, NEXT)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    v2_gemm(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)tn_ * 8, lane, hf, BA, BB, acc0, acc1); \
+    v2_gemm<DIAG>(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)tn_ * 8, lane, hf, BA, BB, acc0, acc1); \
     T = tn_;                                                                \
   }
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
@@ -388,6 +391,10 @@ static hipError_t launch_one64(const ConvArgs& a, int grid, hipStream_t s) {
   else if (IN == 3 && diag == 2) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 2 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && diag == 4) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 4 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && diag == 3) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 3 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 8) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 8 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 9) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 9 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 24) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 24 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else if (IN == 3 && diag == 26) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 26 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else
   hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();

@@ -149,8 +149,9 @@ def sampling_distributed(data_list, model, inference_steps, tr_schedule, rot_sch
         c = conf.reshape(-1).float().to(pos.device) if conf is not None else torch.zeros(0, device=pos.device)
     else:
         c = -ids.float().to(pos.device)                      # no confidence model: keep sample order
-    if world > 1 and dist.get_backend() == "nccl":
-        pos, c = pos.to(device), c.to(device)
+    if world > 1:
+        # RCCL gathers device tensors, gloo host tensors (two ranks may share one GPU under gloo: tests/test_gpu_distributed.py)
+        pos, c = (pos.to(device), c.to(device)) if dist.get_backend() == "nccl" else (pos.cpu(), c.cpu())
     rpos, rconf, rid = gather_ranked(pos, c, world, rank, dst, ids=ids, rows=-(-N // world))
     if rank != dst:
         return None

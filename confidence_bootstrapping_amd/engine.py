@@ -64,6 +64,8 @@ SYMBOLS = {
     "cbd_conv_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_pack_conv_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_symm_rmsd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_knn_graph": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P]),
+    "cbd_radius_neighbors": (C.c_int, [C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
     "cbd_conf_create": (C.c_int, [C.POINTER(cbd_conf_config), C.POINTER(_P)]),
     "cbd_conf_destroy": (C.c_int, [_P]),
     "cbd_conf_load_weight": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int32]),
@@ -533,6 +535,11 @@ class ConfidenceEngine:
             if check:
                 _check(self.lib.cbd_conf_check(self.h))
         return conf, atom.unsqueeze(1)
+
+    def check(self):
+        """cbd_conf_check: synchronises and raises if any score() since the last check exceeded a per-atom edge capacity."""
+        with torch.cuda.device(self.device):
+            _check(self.lib.cbd_conf_check(self.h))
 
     def set_option(self, name: str, value: int):
         _check(self.lib.cbd_conf_set_option(self.h, name.encode(), int(value)))

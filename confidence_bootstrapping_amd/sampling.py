@@ -157,6 +157,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     pending_key = None
 
     groups = []           # closed groups (one complex each) waiting to be advanced together
+    conf_engines_used = set()
 
     def flush():
         """close the pending group (consecutive loader batches of one complex); run when `co_schedule` groups are waiting"""
@@ -207,7 +208,9 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 ckey = complex_fingerprint(fbatch) + (fg["atom"].pos.shape[0],)
                 if ceng.complex_key != ckey:
                     ceng.set_complex(fg, ckey)
-                confidence.append(ceng.score(pos, crop)[0])
+                # no host sync per complex: the capacity flag of the confidence engine is sticky, checked once at the end
+                confidence.append(ceng.score(pos, crop, check=False)[0])
+                conf_engines_used.add(ceng)
         groups.clear()
 
     with torch.no_grad():
@@ -249,6 +252,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),
                                   part=1, order=2)
     if conf_model is not None:
+        for ceng in conf_engines_used:
+            ceng.check()          # raises if any of the batches above exceeded a per-atom edge capacity
         confidence = torch.nan_to_num(torch.cat(confidence, dim=0), nan=-1000)
         return data_list, confidence
     return data_list, None

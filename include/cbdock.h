@@ -180,6 +180,16 @@ int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1_ho
 int cbd_symm_rmsd(int32_t B, int32_t N, int32_t K, const float* pos_dev, const float* ref_dev, const int32_t* idx_ref_dev,
                   const int32_t* idx_pos_dev, float* rmsd_out_dev, int32_t* argmin_out_dev, void* stream);
 
+/* Neighbour graphs of the receptor featurisation (reference datasets/process_mols.py:456-479,491-513).
+ * cbd_knn_graph replaces torch_cluster.knn_graph(pos, k) for one example (loop = False): nbr_out[i][r] = the r-th nearest node of
+ * centre i, r < k <= n - 1, ties in distance to the lower index -- the caller forms edge_index = [nbr; centre].
+ * cbd_radius_neighbors replaces the cdist / np.where / np.argsort loop of the non-kNN branch: for centre i the nodes closer than
+ * `cutoff` in index order if at most `cap` (= max_neighbors), else the `cap` nearest by increasing distance; a centre with none gets
+ * its nearest node; cnt_out[i] entries of idx_out[i][0..cap) are valid.  pos [n][3] fp32, device pointers. */
+int cbd_knn_graph(int32_t n, int32_t k, const float* pos_dev, int32_t* nbr_out_dev, void* stream);
+int cbd_radius_neighbors(int32_t n, float cutoff, int32_t cap, const float* pos_dev, int32_t* idx_out_dev, int32_t* cnt_out_dev,
+                         void* stream);
+
 /* ============================ all-atom CONFIDENCE model ===========================================
  * Replaces, for the shipped workdir/pretrained_confidence architecture, the confidence branch of
  * utils/sampling.py:240-261: crop_beyond (utils/utils.py:395-420) + set_time(0) + the all-atom
@@ -214,8 +224,10 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
  * Outputs (device fp32): confidence_dev [B], atom_confidence_dev [B*Nl] (may be NULL).  Asynchronous on `stream`. */
 int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float crop_beyond, float* confidence_dev,
                    float* atom_confidence_dev, void* stream);
-/* After the work of the last cbd_conf_score has completed: 0 if it was valid, CBD_ERR_CAPACITY if a per-atom edge
- * capacity was exceeded (results must be discarded).  Synchronises the stream of that call. */
+/* After the work of the last cbd_conf_score has completed: 0 if EVERY cbd_conf_score since the previous check was valid,
+ * CBD_ERR_CAPACITY if a per-atom edge capacity was exceeded in any of them (their results must be discarded; the flag is sticky
+ * and cleared by this call, so several batches -- also of different complexes -- can be scored back to back and checked once).
+ * Synchronises the stream of the last call. */
 int cbd_conf_check(cbd_conf_engine* e);
 /* Options: "debug" (0/1) keeps per-layer ligand features of the next calls for cbd_conf_debug_fetch (synchronises). */
 int cbd_conf_set_option(cbd_conf_engine* e, const char* name, int64_t value);

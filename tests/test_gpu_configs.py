@@ -195,7 +195,7 @@ def test_config_c5_bootstrapping_round_at_size():
     for i, n in enumerate(names):
         g = add_atoms(make_complex(seed=500 + i, name=n, **WORKLOADS["c2_dockgen_median"]), seed=500 + i)
         g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
-        nums = g["ligand"].x[:, 0].numpy() + 1          # synthetic atom types as "atomic numbers" (0 would be filtered as H)
+        nums = np.minimum(g["ligand"].x[:, 0].numpy() + 1, 118)     # synthetic atom types as "atomic numbers" (0 would be filtered as H)
         g["ligand"].x[:, 0] = torch.from_numpy(nums)
         ei = g["ligand", "ligand"].edge_index.numpy()
         am = np.zeros((len(nums), len(nums)), dtype=int)

@@ -28,7 +28,7 @@ def test_confidence_bootstrapping_round_trip():
     for i, n in enumerate(names):
         g = add_atoms(make_complex(Nl=9 + i, Nr=36 + 4 * i, R=1 + i % 2, knn=8, seed=40 + i, name=n), seed=40 + i)
         g["ligand"].orig_pos = g["ligand"].pos.numpy() + g.original_center.numpy()
-        nums = g["ligand"].x[:, 0].numpy() + 1          # synthetic atom types as "atomic numbers" (0 would be filtered as H)
+        nums = np.minimum(g["ligand"].x[:, 0].numpy() + 1, 118)     # synthetic atom types as "atomic numbers" (0 would be filtered as H)
         g["ligand"].x[:, 0] = torch.from_numpy(nums)
         ei = g["ligand", "ligand"].edge_index.numpy()
         am = np.zeros((len(nums), len(nums)), dtype=int)
