@@ -109,7 +109,7 @@ struct cbd_engine {
   float* proj[2 * 4 + 2] = {};   // node projections of the first Linear: (src, dst) x up to 4 FCBlocks of a layer, + one pair for the side stream
   float *ll_attr = nullptr, *lr_attr = nullptr;
   StepVectors sv{};
-  float* sigma_emb_dev = nullptr;   // [S_max][32]
+  float* sigma_emb_dev = nullptr;   // [S_max][64]: sigma_emb | sigma_emb_t of every step
   int sigma_cap = 0;
   float *tr_out = nullptr, *rot_out = nullptr, *tor_out = nullptr, *dbg_global = nullptr, *dbg_torfeat = nullptr;
   float* center_msg = nullptr;
@@ -251,7 +251,10 @@ static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1
   constexpr int NQ = KDIM / 16;
   constexpr int TILE_BF16 = NQ * 64 * 8;   // 3072 bf16 = 6 KB
   const size_t tile_floats = (size_t)(tr.ntiles + 1) * TILE_BF16 / 2;
-  std::vector<float> out(tile_floats + (size_t)(tr.ntiles + 1) * 32, 0.f);
+  // ... then the bias rows of the 0e tiles once more as a [32 outputs x 48 mids] bf16 MFMA tile (3 fragments of [64 lanes][8 bf16]):
+  // the kernel adds sum_i b_i m_i of the 0e block with one small matrix product instead of feeding a bias to each of its tiles
+  const size_t b0e_floats = 3 * 64 * 8 / 2;
+  std::vector<float> out(tile_floats + (size_t)(tr.ntiles + 1) * 32 + b0e_floats, 0.f);
   uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
   float* const bias = out.data() + tile_floats;
   for (int T = 0; T < tr.ntiles; ++T) {
@@ -276,6 +279,16 @@ static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1
       const TileRow& R = tr.rows[(size_t)T * 32 + r];
       bias[(size_t)T * 32 + r] = R.row < 0 ? 0.f : R.scale * (first ? b1 : b2)[R.row];
     }
+  }
+  {  // A operand of the 0e bias product: lane (o, h), fragment s holds b[tile 3 + i][row o] for the mids i = 16 s + 8 h + j
+    const int fan0e = conv_shape(IN, OUT).fan0e;
+    uint16_t* const bt = reinterpret_cast<uint16_t*>(bias + (size_t)(tr.ntiles + 1) * 32);
+    for (int s3 = 0; s3 < 3; ++s3)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int o = lane & 31, i = 16 * s3 + 8 * (lane >> 5) + j;
+          bt[((size_t)s3 * 64 + lane) * 8 + j] = f32_to_bf16_rne(i < fan0e ? bias[(size_t)(3 + i) * 32 + o] : 0.f);
+        }
   }
   return out;
 }
@@ -629,7 +642,11 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++used;
     CHK(record_event(e0, s, cap));
   }
-  if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  // bf16 operands: the kernel with workgroup-shared weight tiles (CBD_BF16_KERNEL=0 selects the second generation: one wave per
+  // workgroup, every wave streams its own copy of the weights)
+  static const bool bf16_shared = getenv("CBD_BF16_KERNEL") && atoi(getenv("CBD_BF16_KERNEL")) == 1;   // (not validated on the GPU yet: opt-in)
+  if (e->use_bf16 == 1 && bf16_shared) HIPCHK(launch_tp_conv_bf16s(L.in_level, L.out_level, a, grid, s));
+  else if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) CHK(record_event(e1, s, cap));
@@ -866,7 +883,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&vecs, 7 * 32));
   e->sv = StepVectors{vecs, vecs + 32, vecs + 64, vecs + 96, vecs + 128, vecs + 160, vecs + 192};
   e->sigma_cap = 64;
-  HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)e->sigma_cap * 32));
+  HIPCHK(e->bpool.alloc(&e->sigma_emb_dev, (size_t)e->sigma_cap * 64));
   HIPCHK(e->bpool.alloc(&e->tr_out, (size_t)Bm * 3)); HIPCHK(e->bpool.alloc(&e->rot_out, (size_t)Bm * 3));
   HIPCHK(e->bpool.alloc(&e->tor_out, (size_t)Bm * std::max(R, 1)));
   HIPCHK(e->bpool.alloc(&e->center_msg, (size_t)Bm * Nl * 12));
@@ -1190,7 +1207,7 @@ int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* st
   if (!pos_dev || !step || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-  HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 32 * sizeof(float), hipMemcpyHostToDevice, s));
+  HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 64 * sizeof(float), hipMemcpyHostToDevice, s));   // sigma_emb | sigma_emb_t (adjacent)
   CHK(push_desc(e, B, const_cast<float*>(pos_dev), tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, nullptr, nullptr, nullptr, s));
   cbd_engine* E[1] = {e};
   CHK(forward_multi(E, 1, *step, e->sigma_emb_dev, s));
@@ -1219,11 +1236,11 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
   auto nz = [](const float* const* a, int k) { return a ? a[k] : nullptr; };
   if (S > e0->sigma_cap) {
     HIPCHK(hipStreamSynchronize(s));
-    HIPCHK(e0->bpool.alloc(&e0->sigma_emb_dev, (size_t)S * 32));
+    HIPCHK(e0->bpool.alloc(&e0->sigma_emb_dev, (size_t)S * 64));
     e0->sigma_cap = S;
   }
-  std::vector<float> se((size_t)S * 32);
-  for (int i = 0; i < S; ++i) std::memcpy(se.data() + (size_t)i * 32, steps[i].sigma_emb, 32 * sizeof(float));
+  std::vector<float> se((size_t)S * 64);
+  for (int i = 0; i < S; ++i) std::memcpy(se.data() + (size_t)i * 64, steps[i].sigma_emb, 64 * sizeof(float));
   HIPCHK(hipMemcpyAsync(e0->sigma_emb_dev, se.data(), se.size() * 4, hipMemcpyHostToDevice, s));
   HIPCHK(hipStreamSynchronize(s));   // `se` goes out of scope; also orders the upload before the loop
   int max_nl = 0;
@@ -1238,7 +1255,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
   auto run_steps = [&](float* scores) -> int {
     for (int i = 0; i < S; ++i) {
       const cbd_step& st = steps[i];
-      CHK(forward_multi(E, n, st, e0->sigma_emb_dev + (size_t)i * 32, s));
+      CHK(forward_multi(E, n, st, e0->sigma_emb_dev + (size_t)i * 64, s));
       if (scores) {   // n == 1 only (tests)
         const int R = e0->gs.R, B0 = B[0];
         float* o = scores + (size_t)i * B0 * (6 + R);

@@ -316,10 +316,14 @@ CBD_DEV float dot32(const float* w, const float* x) {
   return s;
 }
 
-__global__ __launch_bounds__(64) void step_prep_kernel(StepWeights w, StepVectors v, const float* __restrict__ se) {
+// `se2` = [sigma_emb | sigma_emb_t] of the step (cbd_step): the receptor side embeds the translation time, everything on the ligand
+// side and the two magnitude heads the common time t -- the same vector unless the model has an asyncronous noise schedule
+__global__ __launch_bounds__(64) void step_prep_kernel(StepWeights w, StepVectors v, const float* __restrict__ se2) {
   __shared__ float hid[32];
+  const float* const se_rec = se2;
+  const float* const se = se2 + 32;
   const int o = threadIdx.x;
-  if (o < 32) hid[o] = fmaxf(dot32(w.rec_sig_w0 + o * 32, se) + w.rec_sig_b0[o], 0.f);
+  if (o < 32) hid[o] = fmaxf(dot32(w.rec_sig_w0 + o * 32, se_rec) + w.rec_sig_b0[o], 0.f);
   __syncthreads();
   if (o < 32) {
     v.rec_sigma_emb[o] = dot32(w.rec_sig_w1 + o * 32, hid) + w.rec_sig_b1[o];

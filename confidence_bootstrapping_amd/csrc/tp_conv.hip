@@ -64,7 +64,10 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   const Frag* gp = reinterpret_cast<const Frag*>(G.wstream) + lane;   // per-lane form (policies without NODE_PROJ)
   Frag a[Ops::NFRAG];
   if constexpr (Ops::NODE_PROJ) {
-    Ops::load_first_u(a, gu, lane);   // the live fragments of all three first-Linear tiles
+    // the live fragments of all three first-Linear tiles (f32_split: tiles 0 and 1 here, tile 2 behind the row gather below -- all 18
+    // of its fragments in flight next to the gathers cost a spill and a wait on it at the very start of the wave)
+    if constexpr (std::is_same<Ops, OpsBf16x3>::value) Ops::template load_first_part<0, 2>(a, gu, lane);
+    else Ops::load_first_u(a, gu, lane);
   } else {
 #pragma unroll
     for (int sg = 0; sg < Ops::NFRAG; ++sg) a[sg] = gp[sg * 64];
@@ -130,6 +133,13 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
         }
     }
     // full destination row -> transposed LDS copy xT[col][j]; lane half hf copies cols 40hf .. 40hf+39
+    // (f32_split: its 18-fragment weight tile + three-plane operands leave no room for the row's 40 registers NEXT TO the 48 start
+    //  values above -- hipcc spilled 12 registers here; a scheduling fence makes the row gather a round of its own.  One extra memory
+    //  round trip per wave, this policy only: the exact-fp32 kernel's code is unchanged.)
+    if constexpr (std::is_same<Ops, OpsBf16x3>::value) {
+      __builtin_amdgcn_sched_barrier(0);
+      Ops::template load_first_part<2, 3>(a, gu, lane);
+    }
     const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)(GV == 12 ? src_r : dst) * NODE_STRIDE + 40 * hf);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {

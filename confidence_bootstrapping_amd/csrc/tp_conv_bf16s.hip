@@ -1,26 +1,22 @@
-// bf16-operand tensor-product message passing for gfx950, second generation (BASELINE.json configs[3]; cbd_set_option("bf16", 1)).
+// bf16-operand tensor-product message passing, third generation: the weight stream SHARED by the eight waves of a workgroup
+// (BASELINE.json configs[3]; cbd_set_option("bf16", 1); CBD_BF16_KERNEL=0 selects the second generation, tp_conv_bf16.hip).
 //
-// Same math as tp_conv.hip (FCBlock -> FasterTensorProduct -> segmented sum, reference models/tensor_layers.py:195-206,66-117),
-// re-tiled for the bf16 matrix pipe, where the fp32-era layout is no longer bound by the MFMAs (one 32x32x16 bf16 MFMA is 8 passes =
-// 32 cycles against 64 for the fp32 k=2 form):
-//   * ONE WAVE OWNS 64 EDGES: every weight fragment is used for two MFMAs (two 32-edge sub-tiles, two independent accumulator
-//     chains), which halves the weight stream per FLOP and the per-tile fixed costs;
-//   * the bias (fp32) is the C operand of a tile's first MFMA pair, kept in 16 registers that are re-loaded in place: 6 k-steps and
-//     6 KB per tile, no accumulator initialisation (an earlier version spent a 7th k-step on it);
-//   * what bounds this kernel is not the matrix core but everything next to it (in-kernel stamps and timing-only diagnostics,
-//     CBD_BF16_DIAG=1..4): every VALU instruction costs matrix-pipe time, so the CG epilogue was trimmed --
-//     -fno-slp-vectorize (packed fp32 FMAs are the most expensive kind), scalar x direction mids factored out of the sums, one-
-//     instruction ReLU, padded slots skipped -- and the per-wave latency phases shortened: gathers in two rounds, vector-block tile
-//     loops fully unrolled so that mids are compile-time constants and their LDS reads batch, run-length reduction with scalar run
-//     masks.  Round 1 137.6 -> round 2 195 poses/s on C4 (64 x 40), 0.27 -> 0.39 of the bf16 peak.  Tried and NOT kept: sharing every
-//     tile between the 4 or 8 waves of a workgroup through an LDS ring with one barrier per tile (122 / 108 poses/s), 4 independent
-//     waves per workgroup (no change), 128 edges per wave at one wave per SIMD (114), global instead of FLAT loads (no change), wave
-//     priorities (round 3: static s_setprio by workgroup number, raised inside or outside the MFMA chains: 196.3-199.1 vs 197.7-198.2
-//     poses/s, profiles/r03_b_prio_sweep.txt -- the two residents of a SIMD are not phase-locked);
-//   * LDS per wave = two transposed row tiles of 9.8 KB (the gathered destination rows, later the message tiles): 8 waves per CU.
-// fp32 everywhere outside the two Linears (gathered rows, CG contraction, messages, reduction), like the first generation.
-// Weight stream (pack_conv_stream_bf16, engine.hip): (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] = 6 KB, then the fp32 bias
-// rows [ntiles + 1][32].
+// Why: timing-only diagnostics of the second-generation kernel (profiles/r03_*): without its weight loads it
+// runs at 0.63 of the bf16 peak, with them at 0.42 -- every wave pulls its own copy of every 6 KB tile through the CU's vector
+// memory path, and at 64 edges per wave that path needs the same 64 B/clk per CU as the matrix cores' operand rate: the L1 return
+// path, not L2 or HBM, is the second saturated resource.  Here a tile enters the CU ONCE per workgroup:
+//   * workgroup = 8 waves = 512 edges of ONE edge group; every wave brings one 1 KB fragment of a tile (waves 6, 7 repeat fragments 0, 1) from L2 straight into LDS
+//     (global_load_lds_dwordx4, no VGPRs), four tiles ahead, into a ring of four 6 KB slots;
+//   * every wave re-fills its six fragment registers from the ring with ds_read_b128, in place and one MFMA pair late exactly like
+//     the second generation did from global memory -- the LDS read path has 4x the bandwidth of the L1 return path and was idle;
+//   * ONE s_barrier per tile: it says "tile p + 1 has landed" (every loader waited for its own DMA before arriving) and "slot p is
+//     free" (every wave finished the chain that read tile p).  The 0e block's software pipeline (the previous tile's epilogue between
+//     the MFMA pairs of the current chain) keeps a wave's own VALU work in its own MFMA shadow, so the lockstep the barrier imposes on
+//     the two residents of a SIMD costs little there;
+//   * LDS: the ring needs 24 KB, so the per-wave gather image shrinks from 19.5 KB to 15 KB: the 32 scalar columns are kept as bf16
+//     (they enter the first Linear as bf16 anyway), the vector columns stay fp32; the message tiles of the two 32-edge sub-tiles are
+//     written and reduced one after the other in the same 15 KB.  8 x 15.25 KB + 24 KB = 146 KB of the CU's 160 KB.
+// Everything else (math, tile order, bias handling, deterministic run-length reduction, stream format) is the second generation's.
 #include <cstdlib>
 #include <type_traits>
 
@@ -28,6 +24,7 @@
 #include "tp_conv_dev.h"
 
 namespace cbd {
+namespace shared_w {
 
 constexpr int V2_NFRAG = 6;                      // 6 k-steps of 16 = the 96 inputs; the bias enters as the C operand of the first pair
 constexpr int V2_TILE_FRAGS = V2_NFRAG * 64;     // 16-byte fragments per tile
@@ -62,12 +59,12 @@ __device__ __forceinline__ void v2_set_hidden(Act6& h, int m, const f32x16& acc)
 //     L1 (~120 cycles) lands after the pair that read the register has started; the bias follows the second pair, the last fragment
 //     its own pair directly.
 template <int DIAG = 0>
-__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag next, GPtr<float> next_bias, float& raw_next, int lane,
+__device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const bf16x8* lnext, GPtr<float> next_bias, float& raw_next, int lane31x4,
                                         int lane4hf, const Act6& B0, const Act6& B1, f32x16& acc0, f32x16& acc1) {
-  GFrag pa = next;            // uniform: tile base (fragments 0..3: immediate offsets 0..3 KB)
-  GFrag pb = next + 4 * 64;   // fragments 4..5 (the immediate field holds < 4 KB)
+  const bf16x8* pl = lnext;   // LDS: the next tile in the ring, this lane's 16 bytes of fragment 0 (fragment q: + q KB)
+  pin(pl);
   GPtr<float> pc = next_bias; // uniform: the next tile's 32 bias floats
-  pin_s(pa); pin_s(pb); pin_s(pc);
+  pin_s(pc);
   float raw_new = 0.f;   // bias of the tile AFTER the next one (`next_bias`), spread one chain from now: two tiles of memory latency
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -85,9 +82,9 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag
     if (q == 0) asm volatile("" : "+v"(cb));
     // the next tile's 32 bias floats: ONE dword per lane (lane l gets float l & 31: 256 B through the vector-memory return path
     // instead of the 4 KB of four broadcast dwordx4 loads -- timing-only diagnostics put those at 11 % of the kernel)
-    if (q == 0 && !(DIAG & 8)) raw_new = pc[lane & 31];
-    if (q > 0 && !(DIAG & 16)) a[q - 1] = q - 1 < 4 ? pa[lane + (q - 1) * 64] : pb[lane + (q - 5) * 64];
-    if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pb[lane + (q - 4) * 64];
+    if (q == 0 && !(DIAG & 8)) asm volatile("global_load_dword %0, %1, %2" : "=v"(raw_new) : "v"(lane31x4), "s"(pc) : "memory");
+    if (q > 0 && !(DIAG & 16)) a[q - 1] = pl[(q - 1) * 64];
+    if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pl[q * 64];
     __builtin_amdgcn_sched_barrier(0);
   }
   // ... spread into the accumulator layout through the LDS crossbar (ds_bpermute_b32, no LDS memory): register r of lane half hf is
@@ -97,6 +94,7 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag
     // inline asm: the builtin takes no offset, and hipcc then keeps 16 address registers (spills); with the instruction's offset
     // field one address register (byte address of lane 4 hf) serves all 16.  The results are NOT tracked by the compiler's waitcnt
     // insertion: bias_ready() (s_waitcnt lgkmcnt(0)) closes the tile's epilogue before cb is read again.
+    asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw_next));   // younger: this step's DMA and this chain's own bias dword
     float t[16];
 #define CBD_BP4(R, O0, O1, O2, O3)                                                                                      \
     asm volatile("ds_bpermute_b32 %0, %4, %5 offset:" #O0 "\n\tds_bpermute_b32 %1, %4, %5 offset:" #O1                \
@@ -121,12 +119,12 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag
 // that no VALU temporary can be placed in a register an issued MFMA has not read yet (tp_conv_dev.h).  The next tile's bias is spread
 // behind pair 3 (the raw dword was requested behind pair 0; its lines are hot in L1) and bias_ready() precedes the next chain.
 template <int DIAG = 0, bool BIAS = true, class Epi>
-__device__ __forceinline__ void v2_gemm_p(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFrag next, GPtr<float> next_bias, float& raw_next, int lane,
+__device__ __forceinline__ void v2_gemm_p(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const bf16x8* lnext, GPtr<float> next_bias, float& raw_next, int lane31x4,
                                           int lane4hf, const Act6& B0, const Act6& B1, f32x16& acc0, f32x16& acc1, Epi epi) {
-  GFrag pa = next;
-  GFrag pb = next + 4 * 64;
+  const bf16x8* pl = lnext;
+  pin(pl);
   GPtr<float> pc = next_bias;
-  pin_s(pa); pin_s(pb); pin_s(pc);
+  pin_s(pc);
   float raw_new = 0.f;   // bias of the tile AFTER the next one (`next_bias`), spread one chain from now: two tiles of memory latency
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -146,12 +144,13 @@ __device__ __forceinline__ void v2_gemm_p(bf16x8 (&a)[V2_NFRAG], f32x16& cb, GFr
     }
     __builtin_amdgcn_sched_barrier(0);
     if (q == 0 && BIAS) asm volatile("" : "+v"(cb));
-    if (q == 0 && BIAS && !(DIAG & 8)) raw_new = pc[lane & 31];
-    if (q > 0 && !(DIAG & 16)) a[q - 1] = q - 1 < 4 ? pa[lane + (q - 1) * 64] : pb[lane + (q - 5) * 64];
-    if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pb[lane + (q - 4) * 64];
+    if (q == 0 && BIAS && !(DIAG & 8)) asm volatile("global_load_dword %0, %1, %2" : "=v"(raw_new) : "v"(lane31x4), "s"(pc) : "memory");
+    if (q > 0 && !(DIAG & 16)) a[q - 1] = pl[(q - 1) * 64];
+    if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pl[q * 64];
     __builtin_amdgcn_sched_barrier(0);
     if (q == 3 && BIAS && !(DIAG & 8)) {
-      float t[16];
+      asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw_next));   // younger: this step's DMA and this chain's own bias dword
+    float t[16];
 #define CBD_BP4(R, O0, O1, O2, O3)                                                                                      \
       asm volatile("ds_bpermute_b32 %0, %4, %5 offset:" #O0 "\n\tds_bpermute_b32 %1, %4, %5 offset:" #O1                \
                    "\n\tds_bpermute_b32 %2, %4, %5 offset:" #O2 "\n\tds_bpermute_b32 %3, %4, %5 offset:" #O3            \
@@ -178,34 +177,83 @@ __device__ __forceinline__ void bias_ready(f32x16& cb) { asm volatile("s_waitcnt
 // 2 = no CG epilogue (the accumulators are only summed up), 3 = both; 4 = correct results + phase stamps (tools/conv_clock.py bf16);
 // 8 = the bias registers are never re-loaded, 9 = 8 + 1, 16 = no weight or bias re-loads at all (the first tile's registers serve every
 // tile: the kernel without its weight stream), 24 = 16 + 8, 32 = the bias bpermutes are not waited for
+constexpr int SW_WAVES = 8;                               // waves per workgroup: 512 edges of one group share every weight tile
+constexpr int SW_RING = 4;                                // ring slots of one 6 KB tile each
+constexpr int SW_VEC_FLOATS = (76 - NS) * 32;             // fp32 part of a sub-tile's gather image: columns 32..75
+constexpr int SW_SUB_BYTES = SW_VEC_FLOATS * 4 + NS * 32 * 2;   // + the 32 scalar columns as bf16: 7680 B
+constexpr int SW_WAVE_BYTES = 2 * SW_SUB_BYTES + 256;     // two sub-tiles + srcl[2][32]
+static_assert(2 * SW_SUB_BYTES >= NODE_DIM * OUT_STRIDE * 4, "one message tile must fit a wave's two gather images");
+constexpr int SW_LDS_BYTES = SW_RING * V2_TILE_FRAGS * 16 + SW_WAVES * SW_WAVE_BYTES;
+
+// bf16 bits -> fp32
+__device__ __forceinline__ float bf_up(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+// One 1 KB fragment global -> LDS without registers: lane l's 16 bytes land at lds_dst + 16 l (global_load_lds_dwordx4; M0 carries the
+// wave-uniform LDS byte address and is restored -- hipcc reserves it).  NOT counted by hipcc's s_waitcnt bookkeeping: the kernel waits
+// with explicit vmcnt counts (cdna_hip_programming.md section 7).
+__device__ __forceinline__ void glds16(const void* gsrc_lane, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
+
 template <int IN, int OUT, int DIAG = 0>
-__global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
+__global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT);
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const xT0 = lds;                                   // sub-tile 0: [col][32] gathered rows, later [col][33] messages
-  float* const xT1 = lds + V2_SUB_FLOATS;
-  int* const srcl = reinterpret_cast<int*>(lds + 2 * V2_SUB_FLOATS);   // [2][32]
-  const int lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   const int j = lane & 31, hf = lane >> 5;
   const int lane4hf = 16 * hf;   // byte address (4 x lane) of lane 4 hf: base of the bias bpermutes (v2_gemm)
+  bf16x8* const ring = reinterpret_cast<bf16x8*>(lds_raw);                         // [SW_RING][6 fragments][64 lanes] x 16 B
+  unsigned char* const mine = lds_raw + SW_RING * V2_TILE_FRAGS * 16 + wave * SW_WAVE_BYTES;
+  // sub-tile s: fp32 [44 cols][32] (columns 32..75) then bf16 [32 cols][32] (columns 0..31).  xc0 / xc1 are biased so that the usual
+  // `xc[col * 32]` addressing works for the VECTOR columns (col >= 32); the scalar columns are read through xs0 / xs1.
+  float* const xv0 = reinterpret_cast<float*>(mine);
+  float* const xv1 = reinterpret_cast<float*>(mine + SW_SUB_BYTES);
+  unsigned short* const xsb0 = reinterpret_cast<unsigned short*>(mine + SW_VEC_FLOATS * 4);
+  unsigned short* const xsb1 = reinterpret_cast<unsigned short*>(mine + SW_SUB_BYTES + SW_VEC_FLOATS * 4);
+  float* const msg = reinterpret_cast<float*>(mine);                              // message tile of ONE sub-tile at a time, [col][33]
+  int* const srcl = reinterpret_cast<int*>(mine + 2 * SW_SUB_BYTES);               // [2][32]
 
-  // ---- which group / edge range does this wave own?  (edge counts live on the device; a wave owns 64 edges = two reduction tiles)
+  // ---- which group / edge range?  A workgroup owns 512 consecutive edges of one group; wave w the 64 from 64 w on.  Waves (and
+  //      lanes) past the end of the group work on its last edge and are dropped through src = -1: they must still take part in the
+  //      workgroup's barriers.
   int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
   {
-    int wave_in_group = 0;
-    if (!find_group(args, blockIdx.x, lane, 64, grp, wave_in_group, cnt)) return;
-    e0 = wave_in_group * 64;
-    tile_local = 2 * wave_in_group;
+    int wg_in_group = 0;
+    if (!find_group(args, blockIdx.x, lane, 64 * SW_WAVES, grp, wg_in_group, cnt)) return;   // workgroup-uniform
+    e0 = (wg_in_group * SW_WAVES + wave) * 64;
+    tile_local = 2 * (wg_in_group * SW_WAVES + wave);
   }
   const ConvGroup G = args.g[grp];
   unsigned long long st_t0 = 0, st_r0 = 0, st_t1 = 0, st_t2 = 0, st_t3 = 0, st_0e = 0;
   if constexpr (DIAG == 4) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
 
-  // ---- start the weight stream
-  const GFrag gp = (GFrag)reinterpret_cast<const bf16x8*>(G.wstream);   // uniform; tile T fragment q of this lane: gp[T * V2_TILE_FRAGS + q * 64 + lane]
-  bf16x8 a[V2_NFRAG];
+  // ---- the tile sequence of this workgroup and the start of the ring
+  const GFrag gp = (GFrag)reinterpret_cast<const bf16x8*>(G.wstream);   // tile T fragment q of lane l: gp[T * V2_TILE_FRAGS + q * 64 + l]
+  const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
+  const bool vec_on = G.vec_on != 0;
+  const int T_vec = 3 + S.t0e;
+  const int n0e = i_hi > i_lo ? i_hi - i_lo : 0;
+  // stream index of the tile at position p of the sequence (first Linear, the 0e tiles of this slice, the vector blocks, then the
+  // zero tile for good): selects only
+  auto seq = [&](int p) {
+    const int v = vec_on ? T_vec + (p - 3 - n0e) : S.ntiles;
+    const int t = p < 3 ? p : (p - 3 < n0e ? 3 + i_lo + (p - 3) : v);
+    return t < S.ntiles ? t : S.ntiles;
+  };
+  int pos = 0;                       // position of the tile whose chain runs next
+  // EVERY wave brings one fragment per tile (waves 6 and 7 repeat fragments 0 and 1: the same bytes to the same place) -- all eight
+  // waves then run the same instruction stream with the same vmcnt arithmetic, and the tile loops stay free of branches
+  const int my_frag = wave < V2_NFRAG ? wave : wave - V2_NFRAG;
+  const unsigned ring_lds = (unsigned)reinterpret_cast<size_t>(lds_raw);   // LDS byte address of the ring: the low 32 bits of a generic LDS pointer
+  auto issue_tile = [&](int p) {     // fragment `my_frag` of tile seq(p) -> slot p % 4 (asynchronous, no registers)
+    const bf16x8* src = reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)seq(p) * V2_TILE_FRAGS + my_frag * 64 + lane;
+    glds16(src, ring_lds + ((p & (SW_RING - 1)) * V2_TILE_FRAGS + my_frag * 64) * 16);
+  };
 #pragma unroll
-  for (int q = 0; q < V2_NFRAG; ++q) a[q] = gp[q * 64 + lane];
+  for (int p = 0; p < SW_RING; ++p) issue_tile(p);
   // fp32 bias rows behind the (ntiles + 1) tiles: [ntiles + 1][32]; this lane half's float4s are 2q' + hf
   const GBias gbias = (GBias)reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)(S.ntiles + 1) * V2_TILE_FRAGS);   // uniform
   f32x16 cb;
@@ -265,26 +313,48 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   }
 #pragma unroll
   for (int sub = 0; sub < 2; ++sub) {
-    float* xT = sub ? xT1 : xT0;
+    float* xv = sub ? xv1 : xv0;
+    unsigned short* xsb = sub ? xsb1 : xsb0;
 #pragma unroll
-    for (int q = 0; q < 10; ++q) {   // transposed LDS copy xT[col][j]
+    for (int q = 0; q < 10; ++q) {   // transposed LDS copy: lane half hf holds columns 40hf + 4q .. + 3 of edge j
       const f32x4 r = tr[q];
       if (sub == 0) tr[q] = pr[1][q];
-      if (40 * hf + 4 * q < 76) {
-        float* o = xT + (40 * hf + 4 * q) * 32 + j;
-        o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
+      const int c0 = 40 * hf + 4 * q;          // runtime through hf only: q < 8 of the lower half are the scalar columns
+      const float rv[4] = {r.x, r.y, r.z, r.w};
+      if (c0 < 76) {
+        if (c0 < NS) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xsb[(c0 + k) * 32 + j] = (unsigned short)(__builtin_bit_cast(unsigned, (float)(__bf16)rv[k]) >> 16);
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) xv[(c0 + k - NS) * 32 + j] = rv[k];
+        }
       }
     }
   }
-  __syncthreads();   // single-wave workgroup: orders the LDS writes above before the reads below
+  // the first four tiles have landed (every loader waits for its own DMAs, then the workgroup meets); tile 0 -> registers
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  bf16x8 a[V2_NFRAG];
+#pragma unroll
+  for (int q = 0; q < V2_NFRAG; ++q) a[q] = ring[q * 64 + lane];
+  const int lane31x4 = 4 * (lane & 31);
   if constexpr (DIAG == 4) st_t1 = stamp();
+  // Start of the step that runs the chain of tile `pos`: tile pos + 1 must be complete in the ring (its fragments are read during this
+  // chain) and the slot of tile pos is free once every wave has left the chain that read it -> ONE barrier, then the DMA of tile pos + 4
+  // into that slot.  vmcnt(2): a wave's two youngest vector-memory operations may still be in flight (the DMAs of tiles pos + 2 and
+  // pos + 3, or younger bias dwords), its DMA of tile pos + 1 has landed; lgkmcnt(0): this wave's own reads of the slot are complete.
+#define SW_SYNC()                                                                   \
+  {                                                                                 \
+    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                     \
+    __builtin_amdgcn_s_barrier();                                                   \
+    issue_tile(pos + SW_RING);                                                      \
+  }
+#define SW_NEXT() (ring + ((pos + 1) & (SW_RING - 1)) * V2_TILE_FRAGS + lane)
 
   int T = 0;
   f32x16 acc0, acc1;
   Act6 h0, h1;
-  const int i_lo = G.i0e_lo, i_hi = G.i0e_hi;
-  const bool vec_on = G.vec_on != 0;
-  const int T_vec = 3 + S.t0e;
   // The bias rows are requested TWO tiles ahead (every chain names the tile after its successor: NEXT2).  This wave's sequence: first
   // Linear 0..2, the 0e tiles [3 + i_lo, 3 + i_hi), the vector blocks if vec_on, then the zero tile S.ntiles.  All selects, no branches.
   const int past0e = vec_on ? T_vec : S.ntiles;                                  // first tile behind the 0e block
@@ -295,7 +365,9 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #define V2_TILE(BA, BB, NEXT, NEXT2)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    v2_gemm<DIAG>(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias + (size_t)(NEXT2) * 32, raw_next, lane, lane4hf, BA, BB, acc0, acc1); \
+    SW_SYNC();                                                              \
+    v2_gemm<DIAG>(a, cb, SW_NEXT(), gbias + (size_t)(NEXT2) * 32, raw_next, lane31x4, lane4hf, BA, BB, acc0, acc1); \
+    ++pos;                                                                  \
     T = tn_;                                                                \
   }
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
@@ -309,8 +381,10 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   }
 
   if constexpr (DIAG == 4) st_t2 = stamp();
-  const float* xc0 = xT0 + j;
-  const float* xc1 = xT1 + j;
+  const float* xc0 = xv0 - NS * 32 + j;     // xc[col * 32] is column col >= 32 of edge j (the scalar columns are NOT behind this pointer)
+  const float* xc1 = xv1 - NS * 32 + j;
+  const unsigned short* xs0 = xsb0 + j;      // bf_up(xs[i * 32]): scalar column i < 32 of edge j
+  const unsigned short* xs1 = xsb1 + j;
   // ---- block 0e: one tile per mid index, 32 output scalars
   // The 0e tiles carry NO bias: sum_i m_i (w_i + b_i) = sum_i m_i w_i + sum_i b_i m_i, and the second sum is ONE small matrix product
   // per block -- A = the block's bias rows as a [32 outputs x 48 mids] bf16 tile (3 fragments behind the bias table of the stream),
@@ -323,6 +397,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     const GFrag gb0e = (GFrag)reinterpret_cast<const bf16x8*>(reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)(S.ntiles + 1) * V2_TILE_FRAGS) + (size_t)(S.ntiles + 1) * 32);
 #pragma unroll
     for (int s3 = 0; s3 < 3; ++s3) ab0e[s3] = gb0e[s3 * 64 + lane];
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(raw_next));   // the bias dword the last first-Linear chain requested (asm load) is abandoned here
     if (vec_on && !(DIAG & 8)) {   // the vector blocks behind this one still take their bias as the C operand: request it now
       const GPtr<f32x4> gb4 = (GPtr<f32x4>)(gbias + (size_t)T_vec * 32);
 #pragma unroll
@@ -352,20 +427,24 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 #define V2_CHAIN_PLAIN(I, X0, X1)                                                                                    \
   {                                                                                                                  \
     const int tn_ = next_of(I);                                                                                      \
-    v2_gemm_p<DIAG, false>(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias, raw_next, lane, lane4hf, h0, h1, \
+    SW_SYNC();                                                                                                       \
+    v2_gemm_p<DIAG, false>(a, cb, SW_NEXT(), gbias, raw_next, lane31x4, lane4hf, h0, h1,                       \
                     X0, X1, [](int) {});                                                                             \
+    ++pos;                                                                                                           \
     T = tn_;                                                                                                         \
   }
 #define V2_CHAIN_EPI(I, X0, X1, Y0, Y1, M0, M1)                                                                      \
   {                                                                                                                  \
     const int tn_ = next_of(I);                                                                                      \
-    v2_gemm_p<DIAG, false>(a, cb, gp + ((DIAG & 1) ? (size_t)0 : (size_t)tn_ * V2_TILE_FRAGS), gbias, raw_next, lane, lane4hf, h0, h1, \
+    SW_SYNC();                                                                                                       \
+    v2_gemm_p<DIAG, false>(a, cb, SW_NEXT(), gbias, raw_next, lane31x4, lane4hf, h0, h1,                       \
                     X0, X1, [&](int q) __attribute__((always_inline)) {                                              \
                       if constexpr (DIAG & 2) { if (q == 0) { o0e0[0] += Y0[0] + M0; o0e1[0] += Y1[0] + M1; } } else { \
                         _Pragma("unroll") for (int r = 0; r < 16; ++r)                                               \
                           if (r >= EPI_LO[q] && r < EPI_LO[q + 1]) { o0e0[r] = fmaf(M0, Y0[r], o0e0[r]); o0e1[r] = fmaf(M1, Y1[r], o0e1[r]); } \
                       }                                                                                              \
                     });                                                                                              \
+    ++pos;                                                                                                           \
     T = tn_;                                                                                                         \
   }
   // tiles [IB, IE) whose mids come from MID(i, m0, m1) (LDS reads, issued one chain before they are used)
@@ -391,7 +470,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
       V2_EPI_ALL(acc0, acc1, ma0, ma1);                                                                              \
     }                                                                                                                \
   }
-#define V2_MID_SCALAR(I, M0, M1) { M0 = xc0[(I) * 32]; M1 = xc1[(I) * 32]; }
+#define V2_MID_SCALAR(I, M0, M1) { M0 = bf_up(xs0[(I) * 32]); M1 = bf_up(xs1[(I) * 32]); }
 #define V2_MID_DOT(I, M0, M1)                                                                                        \
   {                                                                                                                  \
     const float* p0_ = xc0 + (COL_1O + 3 * ((I) - NS)) * 32;                                                          \
@@ -414,7 +493,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
       for (int jj = 0; jj < 8; ++jj) {
         const int i = 16 * s3 + 8 * hf + jj;       // mid index of element jj of this lane half's k-slice (runtime through hf only)
         float m0 = 0.f, m1 = 0.f;
-        if (s3 < 2) { m0 = xc0[i * 32]; m1 = xc1[i * 32]; }
+        if (s3 < 2) { m0 = bf_up(xs0[i * 32]); m1 = bf_up(xs1[i * 32]); }
         else if constexpr (IN >= 1) {
           if (jj < S.n1o) {                         // mids 32 .. 37 live in the lower lane half's slice (i = 32 + jj); the upper half's are padding
             const float* p0 = xc0 + (COL_1O + 3 * jj) * 32;
@@ -478,7 +557,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
         const int i = VEC_TILE_I * t + q;
         if (i >= fan) continue;
         float xa = 0.f, xb = 0.f;
-        if (is_scalar(i)) { xa = scalar_of(xc0, i); xb = scalar_of(xc1, i); }
+        if (is_scalar(i)) { xa = scalar_of(xc0, xs0, i); xb = scalar_of(xc1, xs1, i); }
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float wa = acc0[3 * q + o], wb = acc1[3 * q + o];
@@ -510,11 +589,11 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   };
   if (vec_on) {
     vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
-              [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
+              [](int i) { return i < NS; }, [](const float*, const unsigned short* xs, int i) { return bf_up(xs[i * 32]); },
               std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o0, k1o1);
     if constexpr (OUT >= 2)
       vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
-                [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
+                [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, const unsigned short*, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
                 std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e0, k1e1);
     if constexpr (OUT >= 3) {
 #pragma unroll
@@ -539,39 +618,41 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   }
 #undef V2_TILE
 
-  // ---- messages -> LDS (re-using the gathered-row tiles, stride 33), then run-length sums per aggregating node and sub-tile
+  // ---- messages -> LDS and run-length sums per aggregating node, ONE sub-tile at a time in the wave's 15 KB (the message tile of a
+  //      sub-tile, [74][33] fp32, overlays both gather images: every mid has been read by now)
   if constexpr (DIAG == 4) st_t3 = stamp();
-  __syncthreads();   // every read of xT (mids) is complete before it is overwritten
-#pragma unroll
+  // drains the DMAs of the tiles behind the end of the sequence (nobody reads them; they must not land in the LDS of the NEXT workgroup
+  // on this CU) and the last bias dword (its register is re-used from here on)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(raw_next)::"memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll 1
   for (int sub = 0; sub < 2; ++sub) {
-    float* xT = sub ? xT1 : xT0;
     const f32x16& o0e = sub ? o0e1 : o0e0;
     const float* k1o = sub ? k1o1 : k1o0;
     const float* k1e = sub ? k1e1 : k1e0;
     const float* k0o = sub ? k0o1 : k0o0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xT[((r & 3) + 8 * (r >> 2) + 4 * hf) * OUT_STRIDE + j] = o0e[r];
+    for (int r = 0; r < 16; ++r) msg[((r & 3) + 8 * (r >> 2) + 4 * hf) * OUT_STRIDE + j] = o0e[r];
 #pragma unroll
     for (int o = 0; o < 3; ++o)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        xT[(COL_1O + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1o[3 * o + c];
-        if constexpr (OUT >= 2) xT[(COL_1E + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1e[3 * o + c];
+        msg[(COL_1O + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1o[3 * o + c];
+        if constexpr (OUT >= 2) msg[(COL_1E + 3 * (3 * hf + o) + c) * OUT_STRIDE + j] = k1e[3 * o + c];
       }
     if constexpr (OUT >= 3) {
 #pragma unroll
-      for (int o = 0; o < 3; ++o) xT[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
+      for (int o = 0; o < 3; ++o) msg[(COL_0O + 3 * hf + o) * OUT_STRIDE + j] = k0o[o];
     }
-  }
-  __syncthreads();
-  // Run-length sums per aggregating node and 32-edge reduction tile, exactly the pieces of tp_conv_kernel (reduce_runs, tp_conv_dev.h)
-#pragma unroll 1
-  for (int sub = 0; sub < 2; ++sub)
-    reduce_runs<NODE_STRIDE, OUT_STRIDE>(sub ? xT1 : xT0, srcl + 32 * sub, lane, S.out_dim, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this wave's message stores are in LDS (the tile is wave-private)
+    reduce_runs<NODE_STRIDE, OUT_STRIDE>(msg, srcl + 32 * sub, lane, S.out_dim, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
                 G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // ... and read back before the next sub-tile overwrites them
+  }
   if constexpr (DIAG == 4) {   // same record layout as tp_conv_kernel's CBD_CONV_VARIANT=8 stamps (tools/conv_clock.py)
-    if (lane == 0 && args.stamps && blockIdx.x < 8192) {
-      unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
+    if (lane == 0 && args.stamps && blockIdx.x * SW_WAVES + wave < 8192) {
+      unsigned long long* o = args.stamps + (size_t)(blockIdx.x * SW_WAVES + wave) * 8;
       o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
       o[4] = st_t1; o[5] = st_t2; o[6] = st_t3; o[7] = st_0e;   // slot 7: end of the 0e block (fp32 kernel: end of the first first-Linear tile)
     }
@@ -579,30 +660,30 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 }
 
 template <int IN, int OUT>
-static hipError_t launch_one64(const ConvArgs& a, int grid, hipStream_t s) {
-  constexpr int lds_bytes = (2 * V2_SUB_FLOATS + 64) * 4;
+static hipError_t launch_one64s(const ConvArgs& a, int grid, hipStream_t s) {
   static const int diag = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
-  if (IN == 3 && diag == 1) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 1 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 2) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 2 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 4) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 4 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 3) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 3 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 8) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 8 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 9) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 9 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 24) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 24 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 32) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 32 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else if (IN == 3 && diag == 26) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 26 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else
-  hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
+  static bool attr_done = false;
+  if (!attr_done) {   // > 64 KB of dynamic LDS needs the opt-in
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<IN, OUT, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES);
+    if (IN == 3) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<IN, OUT, (IN == 3 ? 4 : 0)>), hipFuncAttributeMaxDynamicSharedMemorySize, SW_LDS_BYTES);
+    attr_done = true;
+  }
+  if (IN == 3 && diag == 4) hipLaunchKernelGGL((tp_conv64s_kernel<IN, OUT, (IN == 3 ? 4 : 0)>), dim3(grid), dim3(64 * SW_WAVES), SW_LDS_BYTES, s, a);
+  else hipLaunchKernelGGL((tp_conv64s_kernel<IN, OUT>), dim3(grid), dim3(64 * SW_WAVES), SW_LDS_BYTES, s, a);
   return hipGetLastError();
 }
 
-// grid: number of 64-edge waves (sum over groups of ceil(cap / 64))
-hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s) {
-  if (grid <= 0) return hipSuccess;
-  if (in_level == 0 && out_level == 1) return launch_one64<0, 1>(a, grid, s);
-  if (in_level == 1 && out_level == 2) return launch_one64<1, 2>(a, grid, s);
-  if (in_level == 2 && out_level == 3) return launch_one64<2, 3>(a, grid, s);
-  if (in_level == 3 && out_level == 3) return launch_one64<3, 3>(a, grid, s);
+}  // namespace shared_w
+
+// grid64: number of 64-edge waves the capacities of the groups need (sum over groups of ceil(cap / 64), what the second-generation
+// launcher takes): the workgroups of 512 edges are at most grid64 / 8 + one per group
+hipError_t launch_tp_conv_bf16s(int in_level, int out_level, const ConvArgs& a, int grid64, hipStream_t s) {
+  if (grid64 <= 0) return hipSuccess;
+  const int grid = (grid64 + shared_w::SW_WAVES - 1) / shared_w::SW_WAVES + a.n_groups;
+  if (in_level == 0 && out_level == 1) return shared_w::launch_one64s<0, 1>(a, grid, s);
+  if (in_level == 1 && out_level == 2) return shared_w::launch_one64s<1, 2>(a, grid, s);
+  if (in_level == 2 && out_level == 3) return shared_w::launch_one64s<2, 3>(a, grid, s);
+  if (in_level == 3 && out_level == 3) return shared_w::launch_one64s<3, 3>(a, grid, s);
   return hipErrorInvalidValue;
 }
 

@@ -308,6 +308,13 @@ struct OpsBf16x3 {
 #pragma unroll
       for (int s = 0; s < NFRAG / 3; ++s) a[(NFRAG / 3) * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64 + lane];
   }
+  template <int M0, int M1>   // first-Linear tiles [M0, M1) only
+  static __device__ __forceinline__ void load_first_part(Frag (&a)[NFRAG], GPtr<Frag> gp, int lane) {
+#pragma unroll
+    for (int m = M0; m < M1; ++m)
+#pragma unroll
+      for (int s = 0; s < NFRAG / 3; ++s) a[(NFRAG / 3) * m + s] = gp[(size_t)m * TILE_FRAGS + s * 64 + lane];
+  }
   template <int M>
   static __device__ __forceinline__ void gemm_first_u(Frag (&a)[NFRAG], GPtr<Frag> next, int lane, const Act& B, f32x16& acc) {
     constexpr int base = (NFRAG / 3) * M;          // fragments 6M .. 6M+5 of the first second-Linear tile

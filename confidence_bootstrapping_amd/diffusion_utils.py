@@ -54,9 +54,10 @@ def set_time(complex_graphs, t, t_tr, t_rot, t_tor, batchsize, all_atoms, asyncr
              include_miscellaneous_atoms=False):
     """Attach the diffusion time to a batch.  Same fields as the reference (node_t / complex_t dicts of fp32
     tensors) so user code that reads them keeps working; the engine only consumes complex_t."""
-    if all_atoms or asyncronous_noise_schedule or include_miscellaneous_atoms:
-        raise NotImplementedError("all_atoms / asynchronous schedules are outside the MI355X hot path")
+    if all_atoms or include_miscellaneous_atoms:
+        raise NotImplementedError("all_atoms / misc-atom time fields are outside the MI355X hot path (the confidence engine evaluates at t = 0)")
+    kinds = (("tr", t_tr), ("rot", t_rot), ("tor", t_tor)) + ((("t", t),) if asyncronous_noise_schedule else ())
     for nt in ("ligand", "receptor"):
         n = complex_graphs[nt].num_nodes
-        complex_graphs[nt].node_t = {k: v * torch.ones(n, device=device) for k, v in (("tr", t_tr), ("rot", t_rot), ("tor", t_tor))}
-    complex_graphs.complex_t = {k: v * torch.ones(batchsize, device=device) for k, v in (("tr", t_tr), ("rot", t_rot), ("tor", t_tor))}
+        complex_graphs[nt].node_t = {k: v * torch.ones(n, device=device) for k, v in kinds}
+    complex_graphs.complex_t = {k: v * torch.ones(batchsize, device=device) for k, v in kinds}

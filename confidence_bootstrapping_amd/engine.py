@@ -30,7 +30,7 @@ class cbd_step(C.Structure):
     _fields_ = [("t", C.c_float), ("tr_sigma", C.c_float), ("cross_cutoff", C.c_float), ("rot_score_norm", C.c_float),
                 ("tor_score_norm_sqrt", C.c_float), ("tr_score_coef", C.c_float), ("tr_noise_coef", C.c_float),
                 ("rot_score_coef", C.c_float), ("rot_noise_coef", C.c_float), ("tor_score_coef", C.c_float),
-                ("tor_noise_coef", C.c_float), ("sigma_emb", C.c_float * 32)]
+                ("tor_noise_coef", C.c_float), ("sigma_emb", C.c_float * 32), ("sigma_emb_t", C.c_float * 32)]
 
 
 class cbd_conf_config(C.Structure):
@@ -119,12 +119,15 @@ def _hptr(a: np.ndarray):
 
 
 def make_steps(t_schedule, model_args, timestep_emb_func, ode=False, no_random=False, no_final_step_noise=False,
-               temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None):
+               temp_sampling=1.0, temp_psi=0.0, temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None, common_t_schedule=None):
     """Per-step host scalars, computed with the reference's own scalar arithmetic and dtypes
     (utils/sampling.py:94-167; models/score_model.py:338,347,419-420,447).  Returns a ctypes array of cbd_step.
     `t_schedule` is the translation schedule; `rot_schedule` / `tor_schedule` default to it (inference.py:393-396) and differ
     under --different_schedules (inference.py:375-383): the model embeds the TRANSLATION time only (score_model.py:323,499),
-    sigma_rot(t_rot) / sigma_tor(t_tor) enter through the score normalisers and the SDE coefficients of their component."""
+    sigma_rot(t_rot) / sigma_tor(t_tor) enter through the score normalisers and the SDE coefficients of their component.
+    `common_t_schedule`: for a model built with asyncronous_noise_schedule (inference.py:384-388: the three component schedules are
+    beta-quantile images of ONE common time grid t) -- the ligand side and the magnitude heads then embed t instead of t_tr
+    (score_model.py:408,460,497), the receptor side keeps t_tr."""
     S = len(t_schedule)
     scheds = [np.asarray(t_schedule, dtype=np.float64),
               np.asarray(t_schedule if rot_schedule is None else rot_schedule, dtype=np.float64),
@@ -148,8 +151,10 @@ def make_steps(t_schedule, model_args, timestep_emb_func, ode=False, no_random=F
         st.rot_score_norm = float(so3.score_norm(sig_t[1])[0])
         st.tor_score_norm_sqrt = float(torch.sqrt(torch.tensor(torus.score_norm(sig_t[2].numpy())).float())[0])
         emb = timestep_emb_func(cts[0])[0]
+        emb_t = emb if common_t_schedule is None else timestep_emb_func(float(np.asarray(common_t_schedule, dtype=np.float64)[i]) * torch.ones(1))[0]
         for k in range(32):
             st.sigma_emb[k] = float(emb[k])
+            st.sigma_emb_t[k] = float(emb_t[k])
         # sampler side: float64 sigma, fp32 g (0-dim tensor), python/numpy scalars for dt -- per component on its own schedule
         noise_on = not (no_random or ode or (no_final_step_noise and i == S - 1))
         coefs = []
@@ -653,8 +658,14 @@ def score_batch(model, data):
     key = complex_fingerprint(data)
     if eng.complex_key != key:
         eng.set_complex(g, key)
+    common = None
+    if getattr(model, "asyncronous_noise_schedule", False):
+        t_c = ct["t"].detach().cpu()
+        if not bool(torch.all(t_c == t_c[0])):
+            raise NotImplementedError("per-sample diffusion times within one batch are outside the MI355X hot path")
+        common = np.array([float(t_c[0])])
     steps = make_steps(np.array([float(t_tr[0])]), _ArgsFromModel(model), model.timestep_emb_func,
-                       rot_schedule=np.array([float(t_rot[0])]), tor_schedule=np.array([float(t_tor[0])]))
+                       rot_schedule=np.array([float(t_rot[0])]), tor_schedule=np.array([float(t_tor[0])]), common_t_schedule=common)
     pos = data["ligand"].pos.reshape(B, Nl, 3)
     tr, rot, tor = eng.score(pos, steps[0])
     if model.no_torsion or eng.R == 0:

@@ -15,7 +15,7 @@ Differences from the reference that are deliberate and documented (SURVEY.md 8a 
     rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
   * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
     rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
-  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model: not in the shipped yml), asynchronous schedules raise
+  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model: not in the shipped yml) raise
     NotImplementedError (the first three also raise in the reference).
 Confidence scoring (reference utils/sampling.py:240-261): with `confidence_model` set, the final poses of every batch
 are scored by the all-atom confidence engine (cbd_conf_score) -- crop_beyond per pose, t = 0 -- on the all-atom graphs
@@ -122,8 +122,15 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     assert not (return_full_trajectory or return_features or pivot), "Not implemented yet in new inference version"
     if svgd_weight_log_0 is not None and svgd_weight_log_1 is not None:
         raise NotImplementedError("SVGD sampling (O(B^2) host loop in the reference) is outside the MI355X hot path")
-    if asyncronous_noise_schedule or t_schedule is not None:
-        raise NotImplementedError("asynchronous noise schedules are outside the MI355X hot path")
+    # asyncronous_noise_schedule (inference.py:384-388, utils/diffusion_utils.py:172-175): the caller passes the common time grid as
+    # `t_schedule`, the three component schedules are its beta-quantile images; what the flag changes is which time the MODEL embeds,
+    # and that is a property of the model (score_model.py:85) -- a model built without it ignores complex_t['t'] in the reference too
+    model_async = bool(getattr(getattr(model, "module", model), "asyncronous_noise_schedule", False))
+    if model_async and (t_schedule is None or not asyncronous_noise_schedule):
+        raise KeyError("'t': the model embeds the common diffusion time (asyncronous_noise_schedule) -- pass t_schedule and "
+                       "asyncronous_noise_schedule=True, as inference.py does")
+    if t_schedule is not None and len(t_schedule) != inference_steps:
+        raise ValueError("t_schedule length != inference_steps")
     if getattr(model_args, "crop_beyond", None) is not None:
         raise NotImplementedError("crop_beyond is only used by the all-atom / confidence model (SURVEY.md 8f-1)")
     conf_model = getattr(confidence_model, "module", confidence_model)
@@ -142,7 +149,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     # scalar of the step (engine.make_steps), the engine itself is agnostic
     steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
                        no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
-                       temp_sigma_data=temp_sigma_data, rot_schedule=rot_schedule, tor_schedule=tor_schedule)
+                       temp_sigma_data=temp_sigma_data, rot_schedule=rot_schedule, tor_schedule=tor_schedule,
+                       common_t_schedule=t_schedule if model_async else None)
     S = inference_steps
     use_noise = not (no_random or ode)
     if co_schedule is None:

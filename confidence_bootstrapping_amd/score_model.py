@@ -158,7 +158,7 @@ class TensorProductScoreModel(nn.Module):
         unsupported = {
             "sh_lmax != 1": sh_lmax != 1, "use_second_order_repr": use_second_order_repr,
             "confidence_mode": confidence_mode, "separate_noise_schedule": separate_noise_schedule,
-            "asyncronous_noise_schedule": asyncronous_noise_schedule, "smooth_edges": smooth_edges,
+            "smooth_edges": smooth_edges,
             "odd_parity": odd_parity, "include_miscellaneous_atoms": include_miscellaneous_atoms,
             "sidechain_pred": sidechain_pred, "depthwise_convolution": depthwise_convolution,
             "not differentiate_convolutions": not differentiate_convolutions, "tp_weights_layers != 2": tp_weights_layers != 2,
@@ -177,6 +177,9 @@ class TensorProductScoreModel(nn.Module):
         self.t_to_sigma = t_to_sigma
         self.device = device
         self.timestep_emb_func = timestep_emb_func
+        # asyncronous_noise_schedule (score_model.py:85): no parameters of its own -- the ligand side and the tr / rot magnitude heads
+        # embed the common time complex_t['t'] instead of complex_t['tr'] (engine.make_steps: cbd_step.sigma_emb_t)
+        self.asyncronous_noise_schedule = bool(asyncronous_noise_schedule)
         self.in_lig_edge_features = in_lig_edge_features
         self.sigma_embed_dim = sigma_embed_dim
         self.lig_max_radius, self.rec_max_radius = lig_max_radius, rec_max_radius

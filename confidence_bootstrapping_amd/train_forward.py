@@ -44,24 +44,35 @@ def collate(data_list: List[HeteroData], device) -> Batch:
     side = _copy_stream(device)
     keep_alive = []
 
-    def dv(parts, dim=0):
+    def dv(parts, dim=0, static=False):
         """per-graph host-to-device copies, concatenated on the device (a host-side cat of the 2 MB/complex language-model
-        features costs more than the whole GPU step on a many-core host)"""
+        features costs more than the whole GPU step on a many-core host).  static=True: tensors that belong to the COMPLEX, not to the
+        noised sample (receptor features / trace / graph, ligand atom types / bonds) -- the buffer hands out shallow copies that share
+        them, so their device copies are cached across steps (_dev_cached) instead of being uploaded again for every sample."""
         with torch.cuda.stream(side):
-            out = torch.cat([p.to(device, non_blocking=True) for p in parts], dim) if len(parts) > 1 else parts[0].to(device, non_blocking=True)
+            up = [(_dev_cached(p, device) if static else p.to(device, non_blocking=True)) for p in parts]
+            out = torch.cat(up, dim) if len(up) > 1 else (up[0].clone() if static else up[0])
         keep_alive.append(out)
         return out
 
-    b["ligand"].x = dv([d["ligand"].x for d in data_list])
+    def dv_edges(parts, offsets):
+        """edge_index tensors: cached raw copies, per-graph node offsets added on the device"""
+        with torch.cuda.stream(side):
+            up = [_dev_cached(p, device) + o for p, o in zip(parts, offsets)]
+            out = torch.cat(up, 1) if len(up) > 1 else up[0]
+        keep_alive.append(out)
+        return out
+
+    b["ligand"].x = dv([d["ligand"].x for d in data_list], static=True)
     b["ligand"].pos = dv([d["ligand"].pos for d in data_list])
-    b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list])
+    b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list], static=True)
     b["ligand"].batch = dv([torch.repeat_interleave(torch.arange(len(nl)), torch.tensor(nl))])
-    b["ligand", "ligand"].edge_index = dv([d["ligand", "ligand"].edge_index + o for d, o in zip(data_list, lo)], 1)
-    b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list])
-    b["receptor"].x = dv([d["receptor"].x for d in data_list])
-    b["receptor"].pos = dv([d["receptor"].pos for d in data_list])
+    b["ligand", "ligand"].edge_index = dv_edges([d["ligand", "ligand"].edge_index for d in data_list], lo)
+    b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list], static=True)
+    b["receptor"].x = dv([d["receptor"].x for d in data_list], static=True)
+    b["receptor"].pos = dv([d["receptor"].pos for d in data_list], static=True)
     b["receptor"].batch = dv([torch.repeat_interleave(torch.arange(len(nr)), torch.tensor(nr))])
-    b["receptor", "receptor"].edge_index = dv([d["receptor", "receptor"].edge_index + o for d, o in zip(data_list, ro)], 1)
+    b["receptor", "receptor"].edge_index = dv_edges([d["receptor", "receptor"].edge_index for d in data_list], ro)
     b.complex_t = {k: dv([torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list])])
                    for k in ("tr", "rot", "tor")}
     # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
@@ -74,6 +85,28 @@ def collate(data_list: List[HeteroData], device) -> Batch:
 
 
 _COPY_STREAMS = {}
+_DEV_CACHE = {}          # (host storage pointer, shape, dtype, version, device) -> (host tensor kept alive, device copy)
+_DEV_CACHE_BYTES = [0]
+_DEV_CACHE_LIMIT = 4 << 30
+
+
+def _dev_cached(t: torch.Tensor, device):
+    """Device copy of a host tensor that does not change between training steps, uploaded once.  The key holds the tensor's storage
+    address, shape, dtype and version counter; the entry keeps the host tensor alive, so the address cannot be recycled while the
+    entry exists.  Device tensors pass through.  Bounded (4 GB): when full the cache is dropped and refills."""
+    if t.is_cuda:
+        return t
+    key = (t.data_ptr(), tuple(t.shape), t.dtype, t._version, str(device))
+    hit = _DEV_CACHE.get(key)
+    if hit is not None:
+        return hit[1]
+    if _DEV_CACHE_BYTES[0] > _DEV_CACHE_LIMIT:
+        _DEV_CACHE.clear()
+        _DEV_CACHE_BYTES[0] = 0
+    d = t.to(device, non_blocking=True)
+    _DEV_CACHE[key] = (t, d)
+    _DEV_CACHE_BYTES[0] += d.numel() * d.element_size()
+    return d
 
 
 def _copy_stream(device):
@@ -161,7 +194,9 @@ def _bn_maps(irreps: str, device):
         A[torch.arange(D), c2c] = 1.0 / torch.bincount(c2c, minlength=Fc).float()[c2c]
         lo = cols0e[0] if cols0e else 0
         assert cols0e == list(range(lo, lo + len(cols0e))), "the 0e columns of a layout are contiguous"
-        m = {"col2chan": c2c.to(device), "avg": A.to(device), "lo0e": lo, "n0e": len(cols0e), "D": D}
+        expand = torch.zeros(Fc, D)
+        expand[c2c, torch.arange(D)] = 1.0          # [F, D] 0/1: per-channel factor -> per-column factor as a matrix product
+        m = {"col2chan": c2c.to(device), "avg": A.to(device), "expand": expand.to(device), "lo0e": lo, "n0e": len(cols0e), "D": D}
         _BN_MAPS[key] = m
     return m
 
@@ -183,7 +218,9 @@ def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1):
             if has0e:
                 bn.running_mean.mul_(1 - momentum).add_(momentum * mean.detach())
             bn.running_var.mul_(1 - momentum).add_(momentum * var.detach())
-    out = x * ((var + eps).pow(-0.5) * bn.weight).index_select(0, m["col2chan"])
+    # per-channel factor spread over the channel's columns by a 0/1 matrix product (exact: one non-zero term per column) -- an
+    # index_select here has an atomic index_add as its backward (at::native::indexFuncLargeIndex<ReduceAdd> in the step's profile)
+    out = x * (((var + eps).pow(-0.5) * bn.weight) @ m["expand"])
     if has0e:
         out = out + F.pad(bn.bias, (lo, D - lo - n0e))
     return out
@@ -257,6 +294,8 @@ def forward(model, data):
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
+    if getattr(model, "asyncronous_noise_schedule", False):
+        raise NotImplementedError("fine-tuning a model with an asyncronous noise schedule is outside the MI355X training path")
     from .train_ops import clear_csr_cache
     clear_csr_cache()          # edge groupings are per step (the graphs change with the poses)
     data = collate(data, dev)

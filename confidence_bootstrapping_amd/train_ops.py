@@ -60,6 +60,13 @@ class StreamMap:
         src[live] = np.rint(idx[live].astype(np.float64) / scale[live].astype(np.float64)).astype(np.int64) - 1
         assert src.min() >= 0 and src.max() < offs[-1]
         self.n, self.scale_np, self.src_np = n, scale, src
+        # every parameter sits at exactly ONE live stream position, so the backward of the stream gather is itself a gather through
+        # the inverse map (autograd's own backward of index_select is an atomic index_add: at::native::indexFuncLargeIndex<ReduceAdd>)
+        pos = np.flatnonzero(live)
+        assert np.array_equal(np.sort(src[pos]), np.arange(offs[-1])), "the packer maps every FCBlock parameter to one stream slot"
+        inv = np.empty(int(offs[-1]), dtype=np.int64)
+        inv[src[pos]] = pos
+        self.inv_np = inv
         # physical position of (tile T, row r, k-step s, lane half hf) (csrc/engine.hip::pack_rows_f32) and the hidden unit the
         # second Linear's k-step addresses (C/D register layout of the first GEMM)
         T, r, s, hf = np.meshgrid(np.arange(3, self.ntiles), np.arange(32), np.arange(48), np.arange(2), indexing="ij")
@@ -75,6 +82,7 @@ class StreamMap:
         d = self._dev.get(str(device))
         if d is None:
             d = {"src": torch.from_numpy(self.src_np).to(device), "scale": torch.from_numpy(self.scale_np).to(device),
+                 "inv": torch.from_numpy(self.inv_np).to(device),
                  "w2p": torch.from_numpy(self.w2p_np.ravel()).to(device), "b2p": torch.from_numpy(self.b2p_np).to(device)}
             self._dev[str(device)] = d
         return d
@@ -84,7 +92,21 @@ class StreamMap:
         w1, w2 = fc[0], fc[3]
         flat = torch.cat([w1.weight.reshape(-1), w1.bias, w2.weight.reshape(-1), w2.bias])
         d = self.on(flat.device)
-        return flat.index_select(0, d["src"]) * d["scale"]
+        return _StreamFn.apply(flat, d["src"], d["scale"], d["inv"])
+
+
+class _StreamFn(torch.autograd.Function):
+    """stream = scale * flat[src]; backward = (g * scale)[inv]: a gather both ways (bitwise deterministic, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, flat, src, scale, inv):
+        ctx.save_for_backward(scale, inv)
+        return flat.index_select(0, src) * scale
+
+    @staticmethod
+    def backward(ctx, g):
+        scale, inv = ctx.saved_tensors
+        return (g * scale).index_select(0, inv), None, None, None
 
 
 @lru_cache(maxsize=None)

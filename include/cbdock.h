@@ -64,7 +64,12 @@ typedef struct {
   float tr_score_coef, tr_noise_coef;    /* g^2 dt (or 0.5 g^2 dt for ODE) and g sqrt(dt), sampling.py:119-132 */
   float rot_score_coef, rot_noise_coef;
   float tor_score_coef, tor_noise_coef;
-  float sigma_emb[32];     /* sinusoidal_embedding(embedding_scale * t, 32), diffusion_utils.py:99-110   */
+  float sigma_emb[32];     /* sinusoidal_embedding(embedding_scale * t_tr, 32), diffusion_utils.py:99-110: what the RECEPTOR side
+                            * embeds (complex_t['tr'], score_model.py:323)                                */
+  float sigma_emb_t[32];   /* the embedding the LIGAND nodes / edges, the cross and centre edges and the tr / rot magnitude heads use:
+                            * equal to sigma_emb, except for a model built with asyncronous_noise_schedule, where it is the embedding
+                            * of the common time t (node_t['t'] / complex_t['t'], score_model.py:408,460,497;
+                            * utils/diffusion_utils.py:172-175)                                           */
 } cbd_step;
 
 const char* cbd_last_error(void);

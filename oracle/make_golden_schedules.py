@@ -3,6 +3,9 @@
 
 TEST INFRASTRUCTURE ONLY (needs /root/reference and the cached tables of oracle/gen_tables.py).  Output:
   tests/golden/g14_sampling_schedules.npz   pos0, the three schedules, the drawn noise, per-step scores, final poses (tiny, B = 3, S = 8)
+  tests/golden/g16_sampling_async.npz       the same for a model BUILT with asyncronous_noise_schedule (score_model.py:85) and the
+                                            schedules of inference.py:384-388: a common time grid t and its beta-quantile images
+                                            (get_inverse_schedule) for translation / rotation / torsion
 Usage: python oracle/make_golden_schedules.py"""
 from __future__ import annotations
 
@@ -67,6 +70,36 @@ def main():
         torch.normal = real_normal
     assert conf is None and len(drawn) == 3 * S
     npz("g14_sampling_schedules.npz", pos0=pos0, tr_schedule=tr_s, rot_schedule=rot_s, tor_schedule=tor_s,
+        noise_tr=torch.stack(drawn[0::3]), noise_rot=torch.stack(drawn[1::3]), noise_tor=torch.stack(drawn[2::3]),
+        final_pos=torch.stack([d["ligand"].pos for d in out_list]),
+        step_tr=torch.stack([s[0] for s in step_scores]), step_rot=torch.stack([s[1] for s in step_scores]),
+        step_tor=torch.stack([s[2] for s in step_scores]))
+
+    # ---- asyncronous noise schedule: the reference model class built with the flag (same weights: it adds no parameters)
+    from utils.diffusion_utils import get_inverse_schedule
+    async_model, _ = ref_import.reference_score_model(sd, asyncronous_noise_schedule=True)
+    t_s = get_t_schedule(sigma_schedule="expbeta", inference_steps=S, inf_sched_alpha=1, inf_sched_beta=1)
+    tr_a, rot_a, tor_a = get_inverse_schedule(t_s, 1.0, 1.0), get_inverse_schedule(t_s, 2.0, 1.0), get_inverse_schedule(t_s, 1.0, 3.0)
+    assert np.allclose(tr_a, t_s) and not np.allclose(rot_a, t_s)
+    tr_a = get_inverse_schedule(t_s, 1.5, 1.0)          # all three differ from the common grid
+    drawn.clear(); step_scores.clear()
+    orig_async = async_model.forward
+
+    def spy_async(batch):
+        assert "t" in batch.complex_t
+        out = orig_async(batch)
+        step_scores.append([o.clone() for o in out[:3]])
+        return out
+    torch.manual_seed(78)
+    torch.normal = rec_normal
+    try:
+        out_list, conf = ref_sampling.sampling([copy.deepcopy(d) for d in data_list], spy_async, S, tr_a, rot_a, tor_a, torch.device("cpu"),
+                                               partial(t_to_sigma, args=margs), margs, batch_size=B,
+                                               asyncronous_noise_schedule=True, t_schedule=t_s)
+    finally:
+        torch.normal = real_normal
+    assert len(drawn) == 3 * S
+    npz("g16_sampling_async.npz", pos0=pos0, t_schedule=t_s, tr_schedule=tr_a, rot_schedule=rot_a, tor_schedule=tor_a,
         noise_tr=torch.stack(drawn[0::3]), noise_rot=torch.stack(drawn[1::3]), noise_tor=torch.stack(drawn[2::3]),
         final_pos=torch.stack([d["ligand"].pos for d in out_list]),
         step_tr=torch.stack([s[0] for s in step_scores]), step_rot=torch.stack([s[1] for s in step_scores]),

@@ -116,8 +116,9 @@ def sde_coefficients(t_idx, schedule, cfg: ScoreConfig, rot_schedule=None, tor_s
 @torch.no_grad()
 def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreConfig, so3_table, torus_table,
                  noise=None, no_final_step_noise=False, ode=False, record=False, temp_sampling=1.0, temp_psi=0.0,
-                 temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None):
+                 temp_sigma_data=0.5, rot_schedule=None, tor_schedule=None, common_t_schedule=None):
     """Reverse diffusion for b poses of ONE complex: pos0 [b,N,3] -> final pos [b,N,3].
+    common_t_schedule: the common time grid of a model with asyncronous_noise_schedule (utils/sampling.py:110-111).
     noise: dict of 'tr' [S,b,3], 'rot' [S,b,3], 'tor' [S,b*R] (explicit, lifted out of the reference's
     unseeded torch.normal calls, drawn in the reference's order) or None => zeros (no_random)."""
     S = len(schedule)
@@ -127,7 +128,8 @@ def sampling_ref(w, cx: ComplexData, pos0: torch.Tensor, schedule, cfg: ScoreCon
     trace = []
     for s in range(S):
         ts, dts, sig, g = sde_coefficients(s, schedule, cfg, rot_schedule, tor_schedule)
-        out = score_forward(w, cx, pos, ts[0], ts[1], ts[2], cfg, so3_table, torus_table, rec_cache=rec_cache)
+        out = score_forward(w, cx, pos, ts[0], ts[1], ts[2], cfg, so3_table, torus_table, rec_cache=rec_cache,
+                            t_common=None if common_t_schedule is None else float(common_t_schedule[s]))
         tr_s, rot_s, tor_s = out["tr_pred"], out["rot_pred"], out["tor_pred"]
         last = (s == S - 1)
         zero = noise is None or (no_final_step_noise and last)

@@ -105,7 +105,7 @@ def install(scratch_dir="/tmp/cb_tables", torus_seed=0, load_tables=True):
     return hetero
 
 
-def reference_score_model(state_dict=None, dropout=None):
+def reference_score_model(state_dict=None, dropout=None, asyncronous_noise_schedule=False):
     """Construct the REFERENCE TensorProductScoreModel class with the shipped yml's kwargs
     (utils/utils.py:239-283 mapping), optionally loading a state dict produced by the build."""
     from functools import partial
@@ -126,7 +126,7 @@ def reference_score_model(state_dict=None, dropout=None):
                      dropout=args.dropout, use_second_order_repr=args.use_second_order_repr,
                      cross_max_distance=args.cross_max_distance, dynamic_max_cross=args.dynamic_max_cross,
                      separate_noise_schedule=False, smooth_edges=False, odd_parity=False,
-                     lm_embedding_type="precomputed", confidence_mode=False, asyncronous_noise_schedule=False,
+                     lm_embedding_type="precomputed", confidence_mode=False, asyncronous_noise_schedule=asyncronous_noise_schedule,
                      fixed_center_conv=not args.not_fixed_center_conv, no_aminoacid_identities=False,
                      include_miscellaneous_atoms=False, sh_lmax=args.sh_lmax, differentiate_convolutions=True,
                      tp_weights_layers=args.tp_weights_layers, num_prot_emb_layers=args.num_prot_emb_layers,

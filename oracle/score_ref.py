@@ -284,9 +284,11 @@ def receptor_embedding(w: Dict[str, torch.Tensor], cx: ComplexData, cfg: ScoreCo
 @torch.no_grad()
 def score_forward(w: Dict[str, torch.Tensor], cx: ComplexData, pos: torch.Tensor, t_tr: float, t_rot: float,
                   t_tor: float, cfg: ScoreConfig, so3_table, torus_table, rec_cache=None,
-                  keep_intermediates: bool = True):
+                  keep_intermediates: bool = True, t_common=None):
     """Score model forward for B poses `pos [B, Nl, 3]` of one complex at diffusion time (t_tr, t_rot, t_tor).
-    Returns dict with tr_pred [B,3], rot_pred [B,3], tor_pred [B*R] and intermediates."""
+    Returns dict with tr_pred [B,3], rot_pred [B,3], tor_pred [B*R] and intermediates.
+    `t_common`: the common time of a model with asyncronous_noise_schedule -- embedded by the ligand nodes and the graph-level heads
+    (score_model.py:408,460,497) while the receptor keeps t_tr (score_model.py:323); None = an ordinary model."""
     B, Nl, Nr, R = pos.shape[0], cx.Nl, cx.Nr, cx.R
     T: Dict[str, torch.Tensor] = {}
     f32 = torch.float32
@@ -295,7 +297,8 @@ def score_forward(w: Dict[str, torch.Tensor], cx: ComplexData, pos: torch.Tensor
     ct = [float(t) * torch.ones(1) for t in (t_tr, t_rot, t_tor)]
     tr_sigma_t, rot_sigma_t, tor_sigma_t = t_to_sigma(ct[0], ct[1], ct[2], cfg)
     T["tr_sigma"], T["rot_sigma"], T["tor_sigma"] = tr_sigma_t[0], rot_sigma_t[0], tor_sigma_t[0]
-    t_emb_one = sinusoidal_embedding(cfg.embedding_scale * ct[0], cfg.sigma_embed_dim)  # [1,32]
+    t_emb_rec = sinusoidal_embedding(cfg.embedding_scale * ct[0], cfg.sigma_embed_dim)  # [1,32]: complex_t['tr'], receptor side
+    t_emb_one = t_emb_rec if t_common is None else sinusoidal_embedding(cfg.embedding_scale * (float(t_common) * torch.ones(1)), cfg.sigma_embed_dim)
     T["sigma_emb"] = t_emb_one[0]
 
     lig_pos = pos.reshape(B * Nl, 3).to(f32)
@@ -308,7 +311,7 @@ def score_forward(w: Dict[str, torch.Tensor], cx: ComplexData, pos: torch.Tensor
         rec_cache = receptor_embedding(w, cx, cfg)
     rec_node0, rec_edge_attr0, rec_edge_sh0 = rec_cache
     T["rec_node_static"] = rec_node0
-    rec_sigma_emb = mlp2(w, "rec_sigma_embedding", t_emb_one)  # [1,32]
+    rec_sigma_emb = mlp2(w, "rec_sigma_embedding", t_emb_rec)  # [1,32]
     T["rec_sigma_emb"] = rec_sigma_emb[0]
     rec_node = rec_node0.repeat(B, 1)
     rec_node[:, :NS] = rec_node[:, :NS] + rec_sigma_emb
