@@ -94,7 +94,7 @@ __device__ __forceinline__ void v2_gemm(bf16x8 (&a)[V2_NFRAG], f32x16& cb, const
     // inline asm: the builtin takes no offset, and hipcc then keeps 16 address registers (spills); with the instruction's offset
     // field one address register (byte address of lane 4 hf) serves all 16.  The results are NOT tracked by the compiler's waitcnt
     // insertion: bias_ready() (s_waitcnt lgkmcnt(0)) closes the tile's epilogue before cb is read again.
-    asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw_next));   // younger: this step's DMA and this chain's own bias dword
+    asm volatile("s_waitcnt vmcnt(3)" : "+v"(raw_next));   // younger: this step's two DMAs and this chain's own bias dword
     float t[16];
 #define CBD_BP4(R, O0, O1, O2, O3)                                                                                      \
     asm volatile("ds_bpermute_b32 %0, %4, %5 offset:" #O0 "\n\tds_bpermute_b32 %1, %4, %5 offset:" #O1                \
@@ -149,7 +149,7 @@ __device__ __forceinline__ void v2_gemm_p(bf16x8 (&a)[V2_NFRAG], f32x16& cb, con
     if (q == V2_NFRAG - 1 && !(DIAG & 16)) a[q] = pl[q * 64];
     __builtin_amdgcn_sched_barrier(0);
     if (q == 3 && BIAS && !(DIAG & 8)) {
-      asm volatile("s_waitcnt vmcnt(2)" : "+v"(raw_next));   // younger: this step's DMA and this chain's own bias dword
+      asm volatile("s_waitcnt vmcnt(3)" : "+v"(raw_next));   // younger: this step's two DMAs and this chain's own bias dword
     float t[16];
 #define CBD_BP4(R, O0, O1, O2, O3)                                                                                      \
       asm volatile("ds_bpermute_b32 %0, %4, %5 offset:" #O0 "\n\tds_bpermute_b32 %1, %4, %5 offset:" #O1                \
@@ -177,8 +177,10 @@ __device__ __forceinline__ void bias_ready(f32x16& cb) { asm volatile("s_waitcnt
 // 2 = no CG epilogue (the accumulators are only summed up), 3 = both; 4 = correct results + phase stamps (tools/conv_clock.py bf16);
 // 8 = the bias registers are never re-loaded, 9 = 8 + 1, 16 = no weight or bias re-loads at all (the first tile's registers serve every
 // tile: the kernel without its weight stream), 24 = 16 + 8, 32 = the bias bpermutes are not waited for
-constexpr int SW_WAVES = 8;                               // waves per workgroup: 512 edges of one group share every weight tile
-constexpr int SW_RING = 4;                                // ring slots of one 6 KB tile each
+constexpr int SW_WAVES = 4;                               // waves per workgroup: 256 edges of one group share every weight tile; TWO
+                                                          // workgroups per CU (one wave of each per SIMD), so the residents of a SIMD
+                                                          // are NOT in lockstep and a workgroup's prologue overlaps the other's tiles
+constexpr int SW_RING = 3;                                // ring slots of one 6 KB tile each
 constexpr int SW_VEC_FLOATS = (76 - NS) * 32;             // fp32 part of a sub-tile's gather image: columns 32..75
 constexpr int SW_SUB_BYTES = SW_VEC_FLOATS * 4 + NS * 32 * 2;   // + the 32 scalar columns as bf16: 7680 B
 constexpr int SW_WAVE_BYTES = 2 * SW_SUB_BYTES + 256;     // two sub-tiles + srcl[2][32]
@@ -188,12 +190,12 @@ constexpr int SW_LDS_BYTES = SW_RING * V2_TILE_FRAGS * 16 + SW_WAVES * SW_WAVE_B
 // bf16 bits -> fp32
 __device__ __forceinline__ float bf_up(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 
-// One 1 KB fragment global -> LDS without registers: lane l's 16 bytes land at lds_dst + 16 l (global_load_lds_dwordx4; M0 carries the
+// One 1 KB fragment global -> LDS without registers: lane l's 12 bytes land at lds_dst + 12 l (global_load_lds_dwordx3: 4 waves x 2 x 768 B = one 6 KB tile; M0 carries the
 // wave-uniform LDS byte address and is restored -- hipcc reserves it).  NOT counted by hipcc's s_waitcnt bookkeeping: the kernel waits
 // with explicit vmcnt counts (cdna_hip_programming.md section 7).
-__device__ __forceinline__ void glds16(const void* gsrc_lane, unsigned lds_dst) {
+__device__ __forceinline__ void glds12(const void* gsrc_lane, unsigned lds_dst) {   // lane l's 12 bytes land at lds_dst + 12 l
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx3 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc_lane), "s"(lds_dst) : "memory");
 }
 
@@ -244,13 +246,14 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
     return t < S.ntiles ? t : S.ntiles;
   };
   int pos = 0;                       // position of the tile whose chain runs next
-  // EVERY wave brings one fragment per tile (waves 6 and 7 repeat fragments 0 and 1: the same bytes to the same place) -- all eight
-  // waves then run the same instruction stream with the same vmcnt arithmetic, and the tile loops stay free of branches
-  const int my_frag = wave < V2_NFRAG ? wave : wave - V2_NFRAG;
+  // EVERY wave brings a quarter of each tile: two DMAs of 64 x 12 B (bytes [1536 w, 1536 w + 1536) of the tile) -- all four waves run
+  // the same instruction stream with the same vmcnt arithmetic, and the tile loops stay free of branches
   const unsigned ring_lds = (unsigned)reinterpret_cast<size_t>(lds_raw);   // LDS byte address of the ring: the low 32 bits of a generic LDS pointer
-  auto issue_tile = [&](int p) {     // fragment `my_frag` of tile seq(p) -> slot p % 4 (asynchronous, no registers)
-    const bf16x8* src = reinterpret_cast<const bf16x8*>(G.wstream) + (size_t)seq(p) * V2_TILE_FRAGS + my_frag * 64 + lane;
-    glds16(src, ring_lds + ((p & (SW_RING - 1)) * V2_TILE_FRAGS + my_frag * 64) * 16);
+  auto issue_tile = [&](int p) {     // this wave's quarter of tile seq(p) -> slot p % 3 (asynchronous, no registers)
+    const unsigned char* src = reinterpret_cast<const unsigned char*>(G.wstream) + (size_t)seq(p) * (V2_TILE_FRAGS * 16) + wave * 1536 + lane * 12;
+    const unsigned dst = ring_lds + (p % SW_RING) * (V2_TILE_FRAGS * 16) + wave * 1536;
+    glds12(src, dst);
+    glds12(src + 768, dst + 768);
   };
 #pragma unroll
   for (int p = 0; p < SW_RING; ++p) issue_tile(p);
@@ -341,16 +344,17 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
   const int lane31x4 = 4 * (lane & 31);
   if constexpr (DIAG == 4) st_t1 = stamp();
   // Start of the step that runs the chain of tile `pos`: tile pos + 1 must be complete in the ring (its fragments are read during this
-  // chain) and the slot of tile pos is free once every wave has left the chain that read it -> ONE barrier, then the DMA of tile pos + 4
-  // into that slot.  vmcnt(2): a wave's two youngest vector-memory operations may still be in flight (the DMAs of tiles pos + 2 and
-  // pos + 3, or younger bias dwords), its DMA of tile pos + 1 has landed; lgkmcnt(0): this wave's own reads of the slot are complete.
-#define SW_SYNC()                                                                   \
+  // chain) and the slot of tile pos is free once every wave has left the chain that read it -> ONE barrier, then the DMAs of tile pos + 3
+  // into that slot.  A step issues two DMAs (tile pos + 3) and, outside the 0e block, one bias dword behind them; what may still be in
+  // flight at the next step's start is exactly that step's operations -- vmcnt(3) if it issued a bias dword (RAWPREV), else vmcnt(2):
+  // the DMAs of tile pos + 1, issued two steps ago, have landed.  lgkmcnt(0): this wave's own reads of the slot are complete.
+#define SW_SYNC(RAWPREV)                                                            \
   {                                                                                 \
-    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");                     \
+    if constexpr (RAWPREV) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); \
     __builtin_amdgcn_s_barrier();                                                   \
     issue_tile(pos + SW_RING);                                                      \
   }
-#define SW_NEXT() (ring + ((pos + 1) & (SW_RING - 1)) * V2_TILE_FRAGS + lane)
+#define SW_NEXT() (ring + ((pos + 1) % SW_RING) * V2_TILE_FRAGS + lane)
 
   int T = 0;
   f32x16 acc0, acc1;
@@ -362,10 +366,10 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
   const int past0e_1 = vec_on ? (T_vec + 1 < S.ntiles ? T_vec + 1 : S.ntiles) : S.ntiles;   // ... and the one behind `past0e`
   const int second0e = i_lo < i_hi ? (i_lo + 1 < i_hi ? 4 + i_lo : past0e) : past0e_1;     // tile behind `first0e`
   float raw_next = gbias[32 + (lane & 31)];   // bias of tile 1
-#define V2_TILE(BA, BB, NEXT, NEXT2)                                               \
+#define V2_TILE(RAWPREV, BA, BB, NEXT, NEXT2)                                               \
   {                                                                         \
     const int tn_ = (NEXT);                                                 \
-    SW_SYNC();                                                              \
+    SW_SYNC(RAWPREV);                                                       \
     v2_gemm<DIAG>(a, cb, SW_NEXT(), gbias + (size_t)(NEXT2) * 32, raw_next, lane31x4, lane4hf, BA, BB, acc0, acc1); \
     ++pos;                                                                  \
     T = tn_;                                                                \
@@ -373,7 +377,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
   // ---- first Linear (3 tiles): h = ReLU(W1 x + b1), kept in the C/D register layout = B operand of the second Linear
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
-    V2_TILE(Bx0, Bx1, m < 2 ? T + 1 : first0e, m == 0 ? 2 : (m == 1 ? first0e : second0e));
+    if (m == 0) { V2_TILE(false, Bx0, Bx1, T + 1, 2); } else { V2_TILE(true, Bx0, Bx1, m < 2 ? T + 1 : first0e, m == 1 ? first0e : second0e); }
     if (m == 2) mfma_operand_guard();   // the first-Linear operands die here without a refill
     v2_set_hidden(h0, m, acc0);
     v2_set_hidden(h1, m, acc1);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
 #define V2_CHAIN_PLAIN(I, X0, X1)                                                                                    \
   {                                                                                                                  \
     const int tn_ = next_of(I);                                                                                      \
-    SW_SYNC();                                                                                                       \
+    SW_SYNC(false);                                                                                                  \
     v2_gemm_p<DIAG, false>(a, cb, SW_NEXT(), gbias, raw_next, lane31x4, lane4hf, h0, h1,                       \
                     X0, X1, [](int) {});                                                                             \
     ++pos;                                                                                                           \
@@ -436,7 +440,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
 #define V2_CHAIN_EPI(I, X0, X1, Y0, Y1, M0, M1)                                                                      \
   {                                                                                                                  \
     const int tn_ = next_of(I);                                                                                      \
-    SW_SYNC();                                                                                                       \
+    SW_SYNC(false);                                                                                                  \
     v2_gemm_p<DIAG, false>(a, cb, SW_NEXT(), gbias, raw_next, lane31x4, lane4hf, h0, h1,                       \
                     X0, X1, [&](int q) __attribute__((always_inline)) {                                              \
                       if constexpr (DIAG & 2) { if (q == 0) { o0e0[0] += Y0[0] + M0; o0e1[0] += Y1[0] + M1; } } else { \
@@ -550,7 +554,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
           mid_fn(xc0, i, v0, ma[q]); mid_fn(xc1, i, v1, mb[q]);
         }
       }
-      V2_TILE(h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles);
+      if (t == 0) { V2_TILE(false, h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles); } else { V2_TILE(true, h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles); }
       if constexpr (DIAG & 2) { keep0[0] += acc0[0]; keep1[0] += acc1[0]; if constexpr (!(DIAG & 40)) bias_ready(cb); continue; }
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(64 * SW_WAVES, 2) void tp_conv64s_kernel(ConvArgs a
           if (VEC_TILE_I * t + q >= S.fan0o) continue;
           ma[q] = mid0o<IN>(xc0, VEC_TILE_I * t + q, v0); mb[q] = mid0o<IN>(xc1, VEC_TILE_I * t + q, v1);
         }
-        V2_TILE(h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles);
+        if (t == 0) { V2_TILE(false, h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles); } else { V2_TILE(true, h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles); }
         if constexpr (DIAG & 2) { k0o0[0] += acc0[0]; k0o1[0] += acc1[0]; if constexpr (!(DIAG & 40)) bias_ready(cb); continue; }
 #pragma unroll
         for (int q = 0; q < VEC_TILE_I; ++q) {
@@ -676,7 +680,7 @@ static hipError_t launch_one64s(const ConvArgs& a, int grid, hipStream_t s) {
 }  // namespace shared_w
 
 // grid64: number of 64-edge waves the capacities of the groups need (sum over groups of ceil(cap / 64), what the second-generation
-// launcher takes): the workgroups of 512 edges are at most grid64 / 8 + one per group
+// launcher takes): the workgroups of 512 edges are at most grid64 / 4 + one per group
 hipError_t launch_tp_conv_bf16s(int in_level, int out_level, const ConvArgs& a, int grid64, hipStream_t s) {
   if (grid64 <= 0) return hipSuccess;
   const int grid = (grid64 + shared_w::SW_WAVES - 1) / shared_w::SW_WAVES + a.n_groups;
