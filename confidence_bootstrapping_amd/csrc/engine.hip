@@ -642,11 +642,7 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++used;
     CHK(record_event(e0, s, cap));
   }
-  // bf16 operands: the kernel with workgroup-shared weight tiles (CBD_BF16_KERNEL=0 selects the second generation: one wave per
-  // workgroup, every wave streams its own copy of the weights)
-  static const bool bf16_shared = getenv("CBD_BF16_KERNEL") && atoi(getenv("CBD_BF16_KERNEL")) == 1;   // (not validated on the GPU yet: opt-in)
-  if (e->use_bf16 == 1 && bf16_shared) HIPCHK(launch_tp_conv_bf16s(L.in_level, L.out_level, a, grid, s));
-  else if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (e->timing) CHK(record_event(e1, s, cap));

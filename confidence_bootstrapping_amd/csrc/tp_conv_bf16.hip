@@ -16,7 +16,9 @@
 //     tile between the 4 or 8 waves of a workgroup through an LDS ring with one barrier per tile (122 / 108 poses/s), 4 independent
 //     waves per workgroup (no change), 128 edges per wave at one wave per SIMD (114), global instead of FLAT loads (no change), wave
 //     priorities (round 3: static s_setprio by workgroup number, raised inside or outside the MFMA chains: 196.3-199.1 vs 197.7-198.2
-//     poses/s, profiles/r03_b_prio_sweep.txt -- the two residents of a SIMD are not phase-locked);
+//     poses/s, profiles/r03_b_prio_sweep.txt -- the two residents of a SIMD are not phase-locked), and again round 3: workgroup-shared
+//     tiles through an LDS ring filled by LDS-DMA with one barrier per tile (8-wave workgroups: 159 vs 214 poses/s,
+//     profiles/r03_k_bf16_shared_weights_experiment.txt);
 //   * LDS per wave = two transposed row tiles of 9.8 KB (the gathered destination rows, later the message tiles): 8 waves per CU.
 // fp32 everywhere outside the two Linears (gathered rows, CG contraction, messages, reduction), like the first generation.
 // Weight stream (pack_conv_stream_bf16, engine.hip): (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] = 6 KB, then the fp32 bias
