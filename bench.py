@@ -199,7 +199,8 @@ def finetune_leg(dev, batch=8, warm=3, steps=6):
     state = (np.random.get_state(), torch.random.get_rng_state())
     np.random.seed(0)
     torch.manual_seed(0)
-    batches = [[nt(copy.deepcopy(c)) for c in base] for _ in range(warm + steps)]
+    # the loop's buffer hands out shallow copies that share the complex's tensors (bootstrapping/buffer.py::get): the same here
+    batches = [[nt(c.shallow_copy()) for c in base] for _ in range(warm + steps)]
     np.random.set_state(state[0])
     torch.random.set_rng_state(state[1])
     for k in range(warm):

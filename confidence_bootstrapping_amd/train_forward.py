@@ -77,7 +77,7 @@ def collate(data_list: List[HeteroData], device) -> Batch:
                    for k in ("tr", "rot", "tor")}
     # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
     b.host = {"t": {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list]) for k in ("tr", "rot", "tor")},
-              "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list]}
+              "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl}
     torch.cuda.current_stream(device).wait_stream(side)
     for t in keep_alive:
         t.record_stream(torch.cuda.current_stream(device))
@@ -114,6 +114,21 @@ def _copy_stream(device):
     if key not in _COPY_STREAMS:
         _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
     return _COPY_STREAMS[key]
+
+
+def upload(t: torch.Tensor, device):
+    """Host tensor -> device WITHOUT stalling the host on the compute stream.  A copy from pageable memory blocks the host until the
+    stream it is issued on has drained; issued on the compute stream in the middle of a step that is a full pipeline flush (the
+    host then enqueues the rest of the step with the GPU idle).  Here the copy goes through the side stream -- idle but for such
+    copies -- and the compute stream waits for it on the device."""
+    if t.is_cuda:
+        return t
+    side, main = _copy_stream(device), torch.cuda.current_stream(device)
+    with torch.cuda.stream(side):
+        d = t.to(device, non_blocking=True)
+    main.wait_stream(side)
+    d.record_stream(main)
+    return d
 
 
 # ----------------------------------------------------------------------------- graph ops (torch_cluster / torch_scatter semantics)
@@ -303,31 +318,44 @@ def forward(model, data):
     lig, rec = data["ligand"], data["receptor"]
     B = data.num_graphs
     ct = data.complex_t
-    tr_sigma, rot_sigma, tor_sigma = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
     lig_batch, rec_batch = lig.batch, rec.batch
-    lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
 
-    # ---- everything that needs a device->host read-back (edge counts of the three radius graphs) or a host table look-up happens
-    #      first, while the GPU is still busy with the previous step: the rest of the step is enqueued without a single sync
+    # ---- everything that needs a device->host read-back (edge counts of the three radius graphs, boolean masks) or a host table
+    #      look-up depends on the step's INPUTS only, so it runs on the side stream: the read-backs wait for that stream, not for the
+    #      previous step's backward pass on the compute stream, and the host enqueues the rest of the step without a single stall
     host = getattr(data, "host", None)
-    t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
-    n_rot = host["n_rot"] if host else torch.bincount(lig_batch[data["ligand", "ligand"].edge_index[0][lig.edge_mask.bool()]], minlength=B).tolist()
-    _, rot_sigma_h, tor_sigma_h = model.t_to_sigma(t_host["tr"], t_host["rot"], t_host["tor"])
-    so3_norm = so3.score_norm(rot_sigma_h).unsqueeze(1).to(dev, non_blocking=True)
-    tor_sigma_edge = np.repeat(tor_sigma_h.numpy(), n_rot)
-    torus_norm = torch.sqrt(torch.tensor(torus.score_norm(tor_sigma_edge)).float()).to(dev, non_blocking=True) if sum(n_rot) else None
-    bond_ei = data["ligand", "ligand"].edge_index.long()
-    edge_mask = lig.edge_mask.bool()
-    radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
-    cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
-    lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
-    if sum(n_rot):
-        bonds = bond_ei[:, edge_mask]
-        bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
-        t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
+    main, side = torch.cuda.current_stream(dev), _copy_stream(dev)
+    if host is None:                # a batch collated elsewhere: its tensors may still be in flight on the compute stream
+        side.wait_stream(main)
+    with torch.cuda.stream(side):
+        tr_sigma, rot_sigma, tor_sigma = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
+        lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
+        t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
+        n_rot = host["n_rot"] if host else torch.bincount(lig_batch[data["ligand", "ligand"].edge_index[0][lig.edge_mask.bool()]], minlength=B).tolist()
+        _, rot_sigma_h, tor_sigma_h = model.t_to_sigma(t_host["tr"], t_host["rot"], t_host["tor"])
+        so3_norm = so3.score_norm(rot_sigma_h).unsqueeze(1).to(dev, non_blocking=True)
+        tor_sigma_edge = np.repeat(tor_sigma_h.numpy(), n_rot)
+        torus_norm = torch.sqrt(torch.tensor(torus.score_norm(tor_sigma_edge)).float()).to(dev, non_blocking=True) if sum(n_rot) else None
+        bond_ei = data["ligand", "ligand"].edge_index.long()
+        edge_mask = lig.edge_mask.bool()
+        radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
+        cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
+        lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
+        bonds = bond_pos = t_ei = None
+        if sum(n_rot):
+            bonds = bond_ei[:, edge_mask]
+            bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
+            t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
+        # atoms per graph: known on the host (collate); torch.bincount would read its output size back from the device
+        counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
+        r_ei = data["receptor", "receptor"].edge_index.long()
+    main.wait_stream(side)
+    for t in (tr_sigma, rot_sigma, tor_sigma, lig_pos, rec_pos, so3_norm, torus_norm, bond_ei, edge_mask, radius_edges, cutoff, lr, bonds,
+              bond_pos, t_ei, counts, r_ei):
+        if t is not None:
+            t.record_stream(main)
 
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
-    r_ei = data["receptor", "receptor"].edge_index.long()
     r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
     rec_edge_attr = model.rec_edge_embedding(gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1)))
     r_vec4 = unit4(r_vec)
@@ -381,7 +409,6 @@ def forward(model, data):
     lig_node = node[:nL]
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
-    counts = torch.bincount(lig_batch, minlength=B).unsqueeze(1)
     center = scatter_sum(lig_pos, lig_batch, B) / counts
     c_vec2 = lig_pos - center[lig_batch]
     c_attr = torch.cat([gaussian_smearing(model.center_distance_expansion, c_vec2.norm(dim=-1)), node_sigma_emb], 1)

@@ -271,16 +271,33 @@ def first_linear(x, linear):
 # differ from run to run in the last bits.  Here every scatter is a segmented sum over edges grouped by target row (`cbd_segment_sum`,
 # fixed order), so a training step is bitwise repeatable; the grouping (stable argsort + row pointers) is cached per index tensor.
 class Csr:
-    """Edges grouped by target row: perm = stable argsort of `index`, rowptr = exclusive scan of the per-row counts."""
+    """Edges grouped by target row: perm = stable argsort of `index`, rowptr = first sorted position of every row -- one `cbd_csr_build`
+    call (radix sort over the bits the row count needs + binary searches, all enqueued on the current stream).  torch.argsort(stable=True)
+    synchronises the stream and torch.bincount reads its output size back: 33 + 34 pipeline flushes per training step in the profiles of
+    round 3, which is what kept the host from running ahead of the GPU."""
 
     def __init__(self, index: torch.Tensor, n_rows: int):
-        index = index.long()
+        if not index.is_cuda:
+            raise RuntimeError("edge grouping runs on the MI355X only (HIP kernels, no CPU fallback)")
+        index = index.long().contiguous()
+        lib = _bind(load_library())
         self.n_rows = int(n_rows)
         self.index = index
-        self.perm = torch.argsort(index, stable=True)
-        counts = torch.bincount(index, minlength=self.n_rows)
-        self.counts = counts
-        self.rowptr = torch.cat([counts.new_zeros(1), torch.cumsum(counts, 0)])
+        n = int(index.shape[0])
+        need = C.c_size_t(0)
+        _check(lib.cbd_csr_build(n, self.n_rows, None, None, None, None, 0, C.byref(need), None))
+        scratch = torch.empty(need.value, dtype=torch.uint8, device=index.device)
+        self.perm = torch.empty(n, dtype=torch.long, device=index.device)
+        self.rowptr = torch.empty(self.n_rows + 1, dtype=torch.long, device=index.device)
+        _check(lib.cbd_csr_build(n, self.n_rows, _ptr(index), _ptr(self.perm), _ptr(self.rowptr), _ptr(scratch), need.value, None,
+                                 _stream_handle()))
+        self._counts = None
+
+    @property
+    def counts(self):
+        if self._counts is None:
+            self._counts = self.rowptr[1:] - self.rowptr[:-1]
+        return self._counts
 
 
 _CSR_CACHE = {}

@@ -28,6 +28,11 @@ def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma,
     if backbone_weight > 0 or sidechain_weight > 0:
         raise NotImplementedError("side-chain / backbone losses are outside the score-model fine-tuning path")
     dev = tr_pred.device
+    if dev.type == "cuda":          # host -> device copies that do not stall the host on the compute stream (train_forward.upload)
+        from .train_forward import upload
+        up = lambda t: upload(t, dev)
+    else:
+        up = lambda t: t.to(dev)
     lst = isinstance(data, (list, tuple))
     ct = {k: (torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data]) if lst else data.complex_t[k])
           for k in ("tr", "rot", "tor")}
@@ -35,28 +40,28 @@ def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma,
     mean_dims = (0, 1) if apply_mean else 1
     zeros = lambda: torch.zeros(1 if apply_mean else tr_pred.shape[0], dtype=torch.float, device=dev)
 
-    tr_score = _cat(data, "tr_score").to(dev)
-    tr_sigma = tr_sigma.to(dev).unsqueeze(-1)
+    tr_score = up(_cat(data, "tr_score"))
+    tr_sigma = up(tr_sigma).unsqueeze(-1)
     tr_loss = ((tr_pred - tr_score) ** 2 * tr_sigma ** 2).mean(dim=mean_dims)
     tr_base_loss = (tr_score ** 2 * tr_sigma ** 2).mean(dim=mean_dims).detach()
 
-    rot_score = _cat(data, "rot_score").to(dev)
-    rot_score_norm = so3.score_norm(rot_sigma.cpu()).unsqueeze(-1).to(dev)
+    rot_score = up(_cat(data, "rot_score"))
+    rot_score_norm = up(so3.score_norm(rot_sigma.cpu()).unsqueeze(-1))
     rot_loss = (((rot_pred - rot_score) / rot_score_norm) ** 2).mean(dim=mean_dims)
     rot_base_loss = ((rot_score / rot_score_norm) ** 2).mean(dim=mean_dims).detach()
 
     if not no_torsion:
         sig = [d.tor_sigma_edge for d in data] if lst else data.tor_sigma_edge
         edge_tor_sigma = np.concatenate(sig) if isinstance(sig, (list, tuple)) else np.asarray(sig)
-        tor_score = _cat(data, "tor_score").to(dev)
-        tor_score_norm2 = torch.tensor(torus.score_norm(edge_tor_sigma)).float().to(dev)
+        tor_score = up(_cat(data, "tor_score"))
+        tor_score_norm2 = up(torch.tensor(torus.score_norm(edge_tor_sigma)).float())
         tor_loss = (tor_pred - tor_score) ** 2 / tor_score_norm2
         tor_base_loss = (tor_score ** 2 / tor_score_norm2).detach()
         if apply_mean:
             tor_loss, tor_base_loss = tor_loss.mean() * torch.ones(1, device=dev), tor_base_loss.mean() * torch.ones(1, device=dev)
         else:
             if lst:
-                index = torch.cat([torch.full((int(d["ligand"].edge_mask.sum()),), i, dtype=torch.long) for i, d in enumerate(data)]).to(dev)
+                index = up(torch.cat([torch.full((int(d["ligand"].edge_mask.sum()),), i, dtype=torch.long) for i, d in enumerate(data)]))
                 n = len(data)
             else:
                 index = data["ligand"].batch[data["ligand", "ligand"].edge_index[0][data["ligand"].edge_mask]].to(dev)
@@ -77,16 +82,19 @@ class AverageMeter:
 
     def __init__(self, types):
         self.types = types
-        self.acc = {t: 0.0 for t in types}
+        self.acc = None         # one tensor of running sums on the values' device: no read-back per step, one in summary()
         self.count = 0
 
     def add(self, vals):
         self.count += 1
-        for t, v in zip(self.types, vals):
-            self.acc[t] += float(torch.as_tensor(v).float().mean())
+        dev = next((v.device for v in vals if torch.is_tensor(v)), torch.device("cpu"))
+        row = torch.stack([torch.as_tensor(v, device=dev).detach().float().mean() for v in vals])
+        self.acc = row if self.acc is None else self.acc + row
 
     def summary(self):
-        return {t: self.acc[t] / max(self.count, 1) for t in self.types}
+        if self.acc is None:
+            return {t: 0.0 for t in self.types}
+        return {t: v / max(self.count, 1) for t, v in zip(self.types, self.acc.tolist())}
 
 
 _METRICS = ["loss", "tr_loss", "rot_loss", "tor_loss", "backbone_loss", "sidechain_loss", "tr_base_loss", "rot_base_loss",
@@ -163,10 +171,12 @@ def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=
         tr_pred, rot_pred, tor_pred, sc = forward_fn(model, data)
         loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sc, data=data, t_to_sigma=t_to_sigma, device=device)
         loss = loss_tuple[0]
-        if torch.any(torch.isnan(loss)):
+        # the backward pass is enqueued BEFORE the loss is read back: checking first (as the reference does, utils/training.py:201)
+        # flushes the pipeline in the middle of the step and the host then enqueues the whole backward pass with the GPU idle.  A
+        # NaN loss gives NaN gradients, which are discarded below exactly as if backward had not run.
+        loss.backward()
+        if torch.any(torch.isnan(loss.detach())):
             skip = True
-        else:
-            loss.backward()
     if not allreduce_gradients(model, skip=skip):
         optimizer.zero_grad()
         return None

@@ -16,6 +16,7 @@
 #ifndef CBDOCK_H
 #define CBDOCK_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -286,6 +287,14 @@ int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n
  * rowptr [n_rows + 1]; out [n_rows][width].  Device pointers, int64 indices (torch's index dtype). */
 int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
                     float* out_dev, void* stream);
+
+
+/* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
+ * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training
+ * graph of utils/training.py:198-205; torch's stable sort synchronises the stream).  Everything is enqueued on `stream`; scratch is the
+ * caller's: call once with scratch_dev = NULL to get *scratch_needed, then with a device buffer of at least that size. */
+int cbd_csr_build(int64_t n, int64_t n_rows, const int64_t* index_dev, int64_t* perm_dev, int64_t* rowptr_dev, void* scratch_dev,
+                  size_t scratch_bytes, size_t* scratch_needed, void* stream);
 
 #ifdef __cplusplus
 }

@@ -266,3 +266,24 @@ def test_segment_sum_matches_index_add():
             x.grad = None
             (gather_rows(x, idx) * wgt).sum().backward()
             assert torch.equal(g1, x.grad)
+
+
+def test_csr_build_is_a_stable_argsort_with_row_pointers():
+    """cbd_csr_build (rocPRIM radix sort over the bits the row count needs + binary searches, no host synchronisation) against
+    torch.argsort(stable=True) / bincount, bit for bit: empty lists, one row, row counts at and around powers of two, rows that no edge
+    targets, already sorted input, and a list larger than one sort block."""
+    from confidence_bootstrapping_amd.train_ops import Csr
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(1)
+    for E, N in ((0, 0), (0, 5), (1, 1), (7, 1), (1000, 2), (1000, 3), (5000, 256), (5000, 257), (4097, 1 << 15), (300000, 3300), (70000, 70001)):
+        idx = torch.randint(0, max(N, 1), (E,), generator=g)
+        if E > 10:
+            idx[idx == 1] = 0                      # a row without edges
+        for index in (idx, torch.sort(idx)[0]):
+            c = Csr(index.to(dev), N)
+            assert c.perm.dtype == torch.long and c.rowptr.shape == (N + 1,)
+            assert torch.equal(c.perm.cpu(), torch.argsort(index, stable=True))
+            want = torch.zeros(N + 1, dtype=torch.long)
+            want[1:] = torch.cumsum(torch.bincount(index, minlength=N)[:N], 0)
+            assert torch.equal(c.rowptr.cpu(), want)
+            assert torch.equal(c.counts.cpu(), want[1:] - want[:-1])

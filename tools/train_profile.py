@@ -36,7 +36,7 @@ def main():
     base = [make_complex(name=f"cplx{i}", seed=1234 + i, **WORKLOADS["c2_dockgen_median"]) for i in range(a.batch)]
     nt = NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False)
     np.random.seed(0); torch.manual_seed(0)
-    batches = [[nt(copy.deepcopy(c)) for c in base] for _ in range(8)]
+    batches = [[nt(c.shallow_copy()) for c in base] for _ in range(8)]   # like CBBuffer.get: shallow copies sharing the complex's tensors
     sync = torch.cuda.synchronize
 
     def step(data, tm=None):
