@@ -178,7 +178,7 @@ def confidence_leg(workload, samples, cplx_seed, final_pos, dev, geometry):
             "frac": round(tf / PEAK_FP32_MFMA_TFLOPS, 4)}
 
 
-def finetune_leg(dev, batch=8, warm=3, steps=6):
+def finetune_leg(dev, batch=8, warm=8, steps=16):
     """One confidence-bootstrapping fine-tuning step (BASELINE.json configs[4]) measured OUTSIDE the timed region of
     the headline metric: train-mode forward on the HIP tensor-product op, score-matching loss, HIP backward kernels, Adam, EMA on a
     batch of `batch` different C2-sized complexes noised by NoiseTransform (same code path as tools/train_bench.py)."""
@@ -200,15 +200,15 @@ def finetune_leg(dev, batch=8, warm=3, steps=6):
     np.random.seed(0)
     torch.manual_seed(0)
     # the loop's buffer hands out shallow copies that share the complex's tensors (bootstrapping/buffer.py::get): the same here
-    batches = [[nt(c.shallow_copy()) for c in base] for _ in range(warm + steps)]
+    batches = [[nt(c.shallow_copy()) for c in base] for _ in range(8)]      # cycled: warm-up also settles the caching allocator
     np.random.set_state(state[0])
     torch.random.set_rng_state(state[1])
     for k in range(warm):
-        train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
+        train_step(model, batches[k % 8], opt, dev, t2s, loss_fn, ema)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(warm, warm + steps):
-        out = train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
+        out = train_step(model, batches[k % 8], opt, dev, t2s, loss_fn, ema)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     return {"what": "fine-tuning step (train-mode forward + HIP backward kernels + Adam + EMA), not part of `value`", "batch": batch,

@@ -442,6 +442,7 @@ namespace cbd {
 // the mean divides afterwards) and for the backward of the node gathers `node_attr[edge_dst]` (an index_add in autograd) in the
 // fine-tuning step: with every scatter in a fixed order the training step is bitwise repeatable.
 // One wave per output row, lanes over columns (rows of <= 128 floats are read as coalesced segments), 4 gathered rows in flight.
+template <bool MEAN>
 __global__ __launch_bounds__(256) void segment_sum_kernel(int64_t n_rows, int width, const float* __restrict__ vals,
                                                           const int64_t* __restrict__ perm, const int64_t* __restrict__ rowptr,
                                                           float* __restrict__ out) {
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(int64_t n_rows, int wi
       acc += v3;
     }
     for (; k < hi; ++k) acc += vals[perm[k] * width + c];
+    if (MEAN) acc = acc / (float)(hi - lo > 1 ? hi - lo : 1);      // torch_scatter's mean: sum / clamp(count, min = 1)
     out[row * width + c] = acc;
   }
 }
@@ -532,10 +534,21 @@ int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const 
                     float* out_dev, void* stream) {
   if (n_rows < 0 || width <= 0 || !rowptr_dev || !out_dev) return fail(CBD_ERR_ARG, "bad argument");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(cbd::segment_sum_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(cbd::segment_sum_kernel<false>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                      n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev);
   const hipError_t r = hipGetLastError();
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_segment_sum: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_segment_mean(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
+                     float* out_dev, void* stream) {
+  if (n_rows < 0 || width <= 0 || !rowptr_dev || !out_dev) return fail(CBD_ERR_ARG, "bad argument");
+  if (n_rows == 0) return 0;
+  hipLaunchKernelGGL(cbd::segment_sum_kernel<true>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_segment_mean: %s", hipGetErrorString(r));
   return 0;
 }
 

@@ -12,6 +12,7 @@ Works in eval mode too (running statistics, no dropout), which the tests use to 
 from __future__ import annotations
 
 import math
+import weakref
 from typing import List
 
 import numpy as np
@@ -21,7 +22,8 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import LEVEL_DIMS, NODE_STRIDE, csr_of, first_linear, gather_rows, scatter_sum, stream_map, tensor_product
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, IrrepsBatchNormFn, StreamHub, TensorProductHubFn, csr_of, first_linear, gather_rows, scatter_mean as _scatter_mean_op,
+                        scatter_sum, stream_map, tensor_product)
 
 SQ3 = math.sqrt(3.0)
 
@@ -153,11 +155,9 @@ def radius_graph(x, r, batch, max_num_neighbors=32):
 
 
 def scatter_mean(src, index, dim_size):
-    """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce='mean') with the sum in a fixed order (train_ops.scatter_sum:
-    `cbd_segment_sum`, no atomics)."""
-    out = scatter_sum(src, index, dim_size)
-    cnt = csr_of(index, dim_size).counts.to(src.dtype) if index.shape[0] else torch.zeros(dim_size, dtype=src.dtype, device=src.device)
-    return out / cnt.clamp(min=1).reshape((dim_size,) + (1,) * (src.dim() - 1))
+    """torch_scatter.scatter(src, index, dim=0, dim_size=dim_size, reduce='mean') with the sum in a fixed order and the division by the
+    clamped count inside the kernel (train_ops.scatter_mean: `cbd_segment_mean`, no atomics)."""
+    return _scatter_mean_op(src, index, dim_size)
 
 
 def take(x, idx):
@@ -178,14 +178,28 @@ def unit4(vec):
 
 
 def atom_encoder(enc, x_cat, extra):
-    emb = 0
-    for i, table in enumerate(enc.atom_embedding_list):
-        emb = emb + take(table.weight, x_cat[:, i].long())
+    """AtomEncoder.forward (models/score_model.py:30-41): sum of the categorical embeddings (+ Linear over [sum, extra features]).  All
+    tables are looked up with ONE gather over a concatenated table (one edge grouping for its fixed-order backward instead of one per
+    feature: 16 for the ligand)."""
+    tables = enc.atom_embedding_list
+    nf = len(tables)
+    if nf == 1:
+        emb = take(tables[0].weight, x_cat[:, 0].long())
+    else:
+        key = (id(enc), str(x_cat.device))
+        offs = _TABLE_OFFSETS.get(key)
+        if offs is None:
+            sizes = [t.weight.shape[0] for t in tables]
+            offs = _TABLE_OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.long).to(x_cat.device)
+        big = torch.cat([t.weight for t in tables], 0)
+        idx = (x_cat[:, :nf].long() + offs).reshape(-1)
+        emb = take(big, idx).view(x_cat.shape[0], nf, -1).sum(1)
     if enc.additional_features_dim > 0:
         emb = enc.additional_features_embedder(torch.cat([emb, extra], dim=1))
     return emb
 
 
+_TABLE_OFFSETS = {}
 _BN_MAPS = {}
 
 
@@ -211,16 +225,34 @@ def _bn_maps(irreps: str, device):
         assert cols0e == list(range(lo, lo + len(cols0e))), "the 0e columns of a layout are contiguous"
         expand = torch.zeros(Fc, D)
         expand[c2c, torch.arange(D)] = 1.0          # [F, D] 0/1: per-channel factor -> per-column factor as a matrix product
-        m = {"col2chan": c2c.to(device), "avg": A.to(device), "expand": expand.to(device), "lo0e": lo, "n0e": len(cols0e), "D": D}
+        fields, col, i0 = [], 0, 0
+        for mul, l, p in parse_irreps(irreps):
+            for u in range(mul):
+                fields.append([col, 2 * l + 1, i0 if (l == 0 and p == 1) else -1])
+                i0 += 1 if (l == 0 and p == 1) else 0
+                col += 2 * l + 1
+        m = {"col2chan": c2c.to(device), "avg": A.to(device), "expand": expand.to(device), "lo0e": lo, "n0e": len(cols0e), "D": D,
+             "fields": torch.tensor(fields, dtype=torch.int32).to(device)}
         _BN_MAPS[key] = m
     return m
 
 
-def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1):
+def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1, residual=None):
     """e3nn.nn.BatchNorm (0.5.0: affine, normalization='component', reduce='mean').  Training: per-channel batch mean of the 0e
-    fields and batch mean of the squared (centred) components of every field, running averages updated with `momentum`;
-    eval: running statistics.  Vectorised over the irreps blocks (one mean, one squared mean, one [D]x[D,F] product) -- the
-    block-by-block form costs ~35 launches per call, and the step is host-bound at the reference's batch size."""
+    fields and batch mean of the squared (centred) components of every field, running averages updated with `momentum` -- one HIP
+    launch forward, one backward (train_ops.IrrepsBatchNormFn; as torch ops ~14 + ~25 launches per call, and the step is host-bound
+    at the reference's batch size); eval: running statistics, torch ops.  `residual` [N, <= D] is added to the leading columns of the
+    result (the layer's  out + pad(node_attr), models/tensor_layers.py:211-213)."""
+    m = _bn_maps(bn.irreps, x.device)
+    if bn.training and x.shape[0] > 0:
+        return IrrepsBatchNormFn.apply(x, m["D"], bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, m["fields"], momentum, eps)
+    out = irreps_batch_norm_torch(bn, x[:, :m["D"]], eps, momentum)
+    return out if residual is None else out + F.pad(residual, (0, out.shape[1] - residual.shape[1]))
+
+
+def irreps_batch_norm_torch(bn, x, eps=1e-5, momentum=0.1):
+    """The same BatchNorm as torch ops: the eval-mode path (running statistics), and the formulation the HIP kernels are tested
+    against in training mode (tests/test_gpu_train_step.py)."""
     m = _bn_maps(bn.irreps, x.device)
     lo, n0e, D = m["lo0e"], m["n0e"], m["D"]
     has0e = n0e > 0
@@ -247,7 +279,7 @@ def _fc_hidden(fc, x):
     return fc[2](fc[1](first_linear(x, fc[0])))
 
 
-def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, out_level):
+def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, out_level, hub=None):
     """TensorProductConvLayer.forward (models/tensor_layers.py:195-217) with FasterTensorProduct on the HIP op."""
     n, din = node_attr.shape
     dout = LEVEL_DIMS[out_level]
@@ -263,10 +295,15 @@ def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, o
         # FCBlock (+ ReLU + Dropout) stays a torch op
         live = [(fc, ea) for fc, ea in zip(fcs, groups) if ea.shape[0] > 0]
         hid = torch.cat([_fc_hidden(fc, ea) for fc, ea in live], dim=0) if len(live) > 1 else _fc_hidden(*live[0])
-        msg = tensor_product(take(xpad, dst), vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level,
-                             [ea.shape[0] for _, ea in live])[:, :dout]
-        out = scatter_mean(msg, src, n)
-        out = irreps_batch_norm(layer.batch_norm, out)
+        if hub is not None:     # the model's streams packed once per step (train_ops.StreamHub)
+            msg = TensorProductHubFn.apply(take(xpad, dst), vec4, hid, hub.big, hub, in_level, out_level, tuple(ea.shape[0] for _, ea in live),
+                                           tuple(hub.block(fc) for fc, _ in live))
+        else:
+            msg = tensor_product(take(xpad, dst), vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level,
+                                 [ea.shape[0] for _, ea in live])
+        # the 80-float message rows go through the segmented mean and into the BatchNorm kernel as they are (it reads the layout's
+        # `dout` columns): no slice copy of the [E, 80] tensor
+        return irreps_batch_norm(layer.batch_norm, scatter_mean(msg, src, n), residual=node_attr)
     return out + F.pad(node_attr, (0, dout - din))
 
 
@@ -304,6 +341,23 @@ def bond_tensor_product(x, edge_vec, bond_vec, w):
 
 
 # ----------------------------------------------------------------------------- the model
+_HUBS = weakref.WeakKeyDictionary()
+
+
+def _stream_hub(model, dev) -> StreamHub:
+    """the model's StreamHub (every FCBlock that feeds a FasterTensorProduct, with the irreps levels of its layer), built once"""
+    hub = _HUBS.get(model)          # kept beside the model, not on it: a hub holds non-leaf tensors, which copy.deepcopy(model) refuses
+    if hub is None or hub.src.device != dev:
+        blocks = []
+        for layers in (model.rec_emb_layers, model.lig_emb_layers):
+            for l, layer in enumerate(layers):
+                blocks.append((layer.fc, min(l, 3), min(l + 1, 3)))
+        for layer in model.conv_layers:
+            blocks += [(fc, 3, 3) for fc in ([layer.fc] if layer.edge_groups == 1 else list(layer.fc))]
+        hub = _HUBS[model] = StreamHub(blocks, dev)
+    return hub
+
+
 def forward(model, data):
     """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449)."""
     dev = next(model.parameters()).device
@@ -355,6 +409,9 @@ def forward(model, data):
         if t is not None:
             t.record_stream(main)
 
+    hub = _stream_hub(model, dev)
+    hub.pack()
+
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
     r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
     rec_edge_attr = model.rec_edge_embedding(gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1)))
@@ -362,7 +419,7 @@ def forward(model, data):
     rec_node = atom_encoder(model.rec_node_embedding, rec.x[:, :1], rec.x[:, 1:].float())
     for l, layer in enumerate(model.rec_emb_layers):
         ea = torch.cat([rec_edge_attr, take(rec_node[:, :ns], r_ei[0]), take(rec_node[:, :ns], r_ei[1])], -1)
-        rec_node = conv_layer(layer, rec_node, r_ei, ea, r_vec4, min(l, 3), min(l + 1, 3))
+        rec_node = conv_layer(layer, rec_node, r_ei, ea, r_vec4, min(l, 3), min(l + 1, 3), hub)
     graph_sigma_emb = model.timestep_emb_func(ct["tr"])
     rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
     rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
@@ -380,7 +437,7 @@ def forward(model, data):
     lig_edge_attr = model.lig_edge_embedding(l_attr)
     for l, layer in enumerate(model.lig_emb_layers):
         ea = torch.cat([lig_edge_attr, take(lig_node[:, :ns], l_ei[0]), take(lig_node[:, :ns], l_ei[1])], -1)
-        lig_node = conv_layer(layer, lig_node, l_ei, ea, l_vec4, min(l, 3), min(l + 1, 3))
+        lig_node = conv_layer(layer, lig_node, l_ei, ea, l_vec4, min(l, 3), min(l + 1, 3), hub)
 
     # ---- cross graph (score_model.py:345-352, 564-587)
     c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
@@ -392,7 +449,7 @@ def forward(model, data):
     nL = lig_node.shape[0]
     node = torch.cat([lig_node, rec_node], 0)
     lr_j = torch.stack([lr[0], lr[1] + nL], 0)
-    edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.flip(lr_j, dims=[0])], 1)
+    edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.stack([lr_j[1], lr_j[0]], 0)], 1)
     edge_attr = torch.cat([lig_edge_attr, lr_edge_attr, rec_edge_attr, lr_edge_attr], 0)
     vec4 = torch.cat([l_vec4, lr_vec4, r_vec4, -lr_vec4], 0)
     s1 = l_ei.shape[1]
@@ -402,10 +459,10 @@ def forward(model, data):
     for l, layer in enumerate(model.conv_layers):
         if l < nconv - 1:
             ea = torch.cat([edge_attr, take(node[:, :ns], edge_index[0]), take(node[:, :ns], edge_index[1])], -1)
-            node = conv_layer(layer, node, edge_index, [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]], vec4, 3, 3)
+            node = conv_layer(layer, node, edge_index, [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]], vec4, 3, 3, hub)
         else:
             ea = torch.cat([edge_attr[:s2], take(node[:, :ns], edge_index[0, :s2]), take(node[:, :ns], edge_index[1, :s2])], -1)
-            node = conv_layer(layer, node, edge_index[:, :s2], [ea[:s1], ea[s1:s2]], vec4[:s2], 3, 3)
+            node = conv_layer(layer, node, edge_index[:, :s2], [ea[:s1], ea[s1:s2]], vec4[:s2], 3, 3, hub)
     lig_node = node[:nL]
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)

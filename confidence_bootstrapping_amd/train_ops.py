@@ -161,7 +161,14 @@ def _cg_flops(in_level, out_level):
 TIMER = KernelTimer()
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream_handle():
+    """HIP stream torch is currently enqueueing on, as a raw handle.  torch.cuda.current_stream() builds a Stream object through
+    several Python layers (40 us per call, ~70 calls per training step); the C accessor the compiler back-ends use costs < 1 us."""
+    if _RAW_STREAM is not None:
+        return C.c_void_p(_RAW_STREAM(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -229,6 +236,153 @@ def tensor_product(xrow, vec4, h, streams, in_level, out_level, group_edges=None
     return TensorProductFn.apply(xrow, vec4, h, in_level, out_level, tuple(int(x) for x in group_edges), *streams)
 
 
+class StreamHub:
+    """The tile streams of ALL FCBlocks of the model, packed once per training step (the weights change every step), and the way back
+    for their gradients.  Per block and step this replaces cat + gather + scale forward, the W2 gather / zero-fill / two scatters of
+    the tensor-product backward and the stream gather's own backward (~12 launches x 28 blocks) by seven launches for the whole
+    model -- the step is launch-bound at the reference's batch sizes.
+
+    Only the second Linear's parameters enter the training kernels through the stream (the first Linear is a torch op with its own
+    backward, FirstLinearFn), so the hub gathers from fc[3].weight / fc[3].bias; the first Linear's slots of the stream stay zero."""
+
+    def __init__(self, blocks, device):
+        """blocks: [(fc, in_level, out_level)] in a fixed order; fc = nn.Sequential(Linear, ReLU, Dropout, Linear)"""
+        self.blocks = [(fc, stream_map(i, o)) for fc, i, o in blocks]
+        self.index = {id(fc): b for b, (fc, _) in enumerate(self.blocks)}
+        src, scale, w2p, b2p, p2g, pscale = [], [], [], [], [], []
+        self.stream_off, self.flat_off, self.g_off, self.gb_off = [], [], [], []
+        so = fo = 0
+        go = 0
+        for fc, sm in self.blocks:
+            W = sm.weight_numel
+            lo2 = KDIM * KDIM + KDIM                          # [w1 | b1 | w2 | b2]: the second Linear starts here
+            live2 = (sm.scale_np != 0) & (sm.src_np >= lo2)
+            src.append(np.where(live2, sm.src_np - lo2 + fo, 0))
+            scale.append(np.where(live2, sm.scale_np, 0.0).astype(np.float32))
+            w2p.append(sm.w2p_np.ravel() + so)
+            self.stream_off.append(so)
+            self.flat_off.append(fo)
+            self.g_off.append(go)
+            so += sm.n
+            fo += W * KDIM + W
+            go += sm.wp * KDIM
+        gbo = go
+        for fc, sm in self.blocks:
+            self.gb_off.append(gbo)
+            gbo += sm.wp
+        self.n_stream, self.n_flat, self.n_grad = so, fo, gbo
+        # parameter element -> its slot in the gradient buffer [dW2p of every block | db2p of every block] and the packer's scale
+        for b, (fc, sm) in enumerate(self.blocks):
+            W = sm.weight_numel
+            lo2 = KDIM * KDIM + KDIM
+            pos = sm.inv_np[lo2:]                             # stream slot of every second-Linear parameter
+            slot = np.full(sm.n, -1, dtype=np.int64)
+            slot[sm.w2p_np.ravel()] = self.g_off[b] + np.arange(sm.wp * KDIM)
+            slot[sm.b2p_np] = self.gb_off[b] + np.arange(sm.wp)
+            assert (slot[pos] >= 0).all(), "every second-Linear parameter sits in the W2p matrix or the bias table of its stream"
+            p2g.append(slot[pos])
+            pscale.append(sm.scale_np[pos])
+        t = lambda a, dt: torch.from_numpy(np.concatenate(a).astype(dt)).to(device)
+        self.src, self.scale = t(src, np.int64), t(scale, np.float32)
+        self.w2p_idx = t(w2p, np.int64)
+        self.p2g, self.pscale = t(p2g, np.int64), t(pscale, np.float32)
+        self.big = self.w2p_all = self.grads = None
+        self.used = set()
+
+    def pack(self):
+        """-> the packed streams of this step (autograd-connected to every fc[3].weight / fc[3].bias)"""
+        flat = torch.cat([p.reshape(-1) for fc, _ in self.blocks for p in (fc[3].weight, fc[3].bias)])
+        self.big = _HubFn.apply(flat, self)
+        with torch.no_grad():
+            self.w2p_all = self.big.index_select(0, self.w2p_idx)          # W2p matrices for the g_h GEMMs of the backward pass
+            self.grads = torch.zeros(self.n_grad, device=flat.device, dtype=torch.float32)
+        self.used = set()
+        return self.big
+
+    def block(self, fc) -> int:
+        return self.index[id(fc)]
+
+    def stream_ptr(self, b):
+        return self.big.data_ptr() + 4 * self.stream_off[b]
+
+    def w2p(self, b):
+        sm = self.blocks[b][1]
+        return self.w2p_all[self.g_off[b]:self.g_off[b] + sm.wp * KDIM].view(sm.wp, KDIM)
+
+    def grad_views(self, b):
+        sm = self.blocks[b][1]
+        if b in self.used:
+            raise RuntimeError("an FCBlock feeds one tensor-product call per step")
+        self.used.add(b)
+        return (self.grads[self.g_off[b]:self.g_off[b] + sm.wp * KDIM].view(sm.wp, KDIM), self.grads[self.gb_off[b]:self.gb_off[b] + sm.wp])
+
+
+class _HubFn(torch.autograd.Function):
+    """big = scale * flat[src]; the gradient does not arrive through `big` (the tensor-product calls write dW2p / db2p of their blocks
+    into hub.grads and return nothing for it) -- backward maps that buffer to the parameters: a gather and a scale."""
+
+    @staticmethod
+    def forward(ctx, flat, hub):
+        ctx.hub = hub
+        ctx.set_materialize_grads(False)
+        return flat.index_select(0, hub.src) * hub.scale
+
+    @staticmethod
+    def backward(ctx, g):
+        hub = ctx.hub
+        return hub.grads.index_select(0, hub.p2g) * hub.pscale, None
+
+
+class TensorProductHubFn(torch.autograd.Function):
+    """TensorProductFn with the weight streams (and the way back for their gradients) in a StreamHub: `big` is an input only so that
+    autograd runs the hub's backward after every tensor-product backward."""
+
+    @staticmethod
+    def forward(ctx, xrow, vec4, h, big, hub, in_level, out_level, group_edges, blocks):
+        lib = _bind(load_library())
+        xrow, vec4, h = xrow.contiguous().float(), vec4.contiguous().float(), h.contiguous().float()
+        E = xrow.shape[0]
+        assert xrow.shape == (E, NODE_STRIDE) and vec4.shape == (E, 4) and h.shape == (E, KDIM)
+        assert len(group_edges) == len(blocks) and sum(group_edges) == E
+        n = len(blocks)
+        ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
+        ws = (C.c_void_p * n)(*[hub.stream_ptr(b) for b in blocks])
+        msg = torch.empty(E, NODE_STRIDE, device=xrow.device, dtype=torch.float32)
+        TIMER.wrap("fwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_forward(
+            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(msg), _stream_handle())))
+        ctx.save_for_backward(xrow, vec4, h, big)
+        ctx.meta = (hub, in_level, out_level, list(group_edges), list(blocks))
+        return msg
+
+    @staticmethod
+    def backward(ctx, gmsg):
+        xrow, vec4, h, big = ctx.saved_tensors
+        hub, in_level, out_level, group_edges, blocks = ctx.meta
+        lib = _bind(load_library())
+        sm = stream_map(in_level, out_level)
+        E, n = xrow.shape[0], len(blocks)
+        gmsg = gmsg.contiguous().float()
+        gx = torch.empty_like(xrow)
+        gw = torch.empty(E, sm.wp, device=xrow.device, dtype=torch.float32)
+        ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
+        ws = (C.c_void_p * n)(*[hub.stream_ptr(b) for b in blocks])
+        TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
+            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), _ptr(gw), _stream_handle())))
+        gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
+        lo = 0
+        for ne, b in zip(group_edges, blocks):
+            hi = lo + ne
+            if ne:
+                gwg = gw[lo:hi]
+                if gh is not None:
+                    torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
+                dw, db = hub.grad_views(b)
+                torch.mm(gwg.t(), h[lo:hi], out=dw)
+                torch.sum(gwg, 0, out=db)
+            lo = hi
+        return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
+
+
 class FirstLinearFn(torch.autograd.Function):
     """y = x W^T + b for the FCBlock's first Linear (96 -> 96) with the weight / bias gradient on `cbd_outer_accum`: the reduction
     over 10^5..10^6 edges into a 96 x 96 matrix that library GEMMs run at ~10 TFLOP/s (csrc/tp_train.hip::outer_accum_kernel)."""
@@ -270,6 +424,13 @@ def first_linear(x, linear):
 # (models/tensor_layers.py:206) and autograd's index_add for every `node_attr[edge_index]` gather.  Atomic float adds make the step
 # differ from run to run in the last bits.  Here every scatter is a segmented sum over edges grouped by target row (`cbd_segment_sum`,
 # fixed order), so a training step is bitwise repeatable; the grouping (stable argsort + row pointers) is cached per index tensor.
+@lru_cache(maxsize=None)
+def _csr_scratch_bytes(n: int, n_rows: int) -> int:
+    need = C.c_size_t(0)
+    _check(_bind(load_library()).cbd_csr_build(n, n_rows, None, None, None, None, 0, C.byref(need), None))
+    return int(need.value)
+
+
 class Csr:
     """Edges grouped by target row: perm = stable argsort of `index`, rowptr = first sorted position of every row -- one `cbd_csr_build`
     call (radix sort over the bits the row count needs + binary searches, all enqueued on the current stream).  torch.argsort(stable=True)
@@ -284,12 +445,11 @@ class Csr:
         self.n_rows = int(n_rows)
         self.index = index
         n = int(index.shape[0])
-        need = C.c_size_t(0)
-        _check(lib.cbd_csr_build(n, self.n_rows, None, None, None, None, 0, C.byref(need), None))
-        scratch = torch.empty(need.value, dtype=torch.uint8, device=index.device)
+        need = _csr_scratch_bytes(1 << max(n - 1, 0).bit_length(), self.n_rows)        # sized for the next power of two: cacheable
+        scratch = torch.empty(need, dtype=torch.uint8, device=index.device)
         self.perm = torch.empty(n, dtype=torch.long, device=index.device)
         self.rowptr = torch.empty(self.n_rows + 1, dtype=torch.long, device=index.device)
-        _check(lib.cbd_csr_build(n, self.n_rows, _ptr(index), _ptr(self.perm), _ptr(self.rowptr), _ptr(scratch), need.value, None,
+        _check(lib.cbd_csr_build(n, self.n_rows, _ptr(index), _ptr(self.perm), _ptr(self.rowptr), _ptr(scratch), need, None,
                                  _stream_handle()))
         self._counts = None
 
@@ -319,7 +479,7 @@ def clear_csr_cache():
     _CSR_CACHE.clear()
 
 
-def _segment_sum(vals: torch.Tensor, csr: Csr) -> torch.Tensor:
+def _segment_sum(vals: torch.Tensor, csr: Csr, mean: bool = False) -> torch.Tensor:
     if not vals.is_cuda:
         raise RuntimeError("segment_sum runs on the MI355X only (HIP kernel, no CPU fallback)")
     lib = _bind(load_library())
@@ -328,7 +488,8 @@ def _segment_sum(vals: torch.Tensor, csr: Csr) -> torch.Tensor:
     out = torch.empty(csr.n_rows, v2.shape[1], device=v.device, dtype=torch.float32)
     if v2.shape[1] == 0 or csr.n_rows == 0:
         return out.reshape((csr.n_rows,) + tuple(v.shape[1:]))
-    _check(lib.cbd_segment_sum(csr.n_rows, v2.shape[1], _ptr(v2), _ptr(csr.perm), _ptr(csr.rowptr), _ptr(out), _stream_handle()))
+    fn = lib.cbd_segment_mean if mean else lib.cbd_segment_sum
+    _check(fn(csr.n_rows, v2.shape[1], _ptr(v2), _ptr(csr.perm), _ptr(csr.rowptr), _ptr(out), _stream_handle()))
     return out.reshape((csr.n_rows,) + tuple(v.shape[1:]))
 
 
@@ -345,6 +506,63 @@ class ScatterSumFn(torch.autograd.Function):
         return g.index_select(0, ctx.csr.index), None
 
 
+class ScatterMeanFn(torch.autograd.Function):
+    """torch_scatter.scatter(src, index, reduce='mean'): out[n] = sum_{e: index[e] = n} src[e] / max(count[n], 1), fixed order, the
+    division inside the kernel; backward = gather of g / count."""
+
+    @staticmethod
+    def forward(ctx, src, csr):
+        ctx.csr = csr
+        return _segment_sum(src, csr, mean=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        csr = ctx.csr
+        if getattr(csr, "_inv_counts", None) is None:
+            csr._inv_counts = 1.0 / csr.counts.clamp(min=1).to(torch.float32)
+        scale = csr._inv_counts.reshape((-1,) + (1,) * (g.dim() - 1))
+        return (g * scale).index_select(0, csr.index), None
+
+
+class IrrepsBatchNormFn(torch.autograd.Function):
+    """Train-mode e3nn BatchNorm (+ the layer's residual) on cbd_irreps_bn_forward / _backward: one launch each way.  `x` may be wider
+    than the irreps layout (`dim` columns are read, e.g. the 80-float message rows): no slice copy before, no padding op behind."""
+
+    @staticmethod
+    def forward(ctx, x, dim, weight, bias, res, running_mean, running_var, fields, momentum, eps):
+        lib = _bind(load_library())
+        x = x.contiguous().float()
+        n, ldx = x.shape
+        nf = int(fields.shape[0])
+        out = torch.empty(n, dim, device=x.device, dtype=torch.float32)
+        stats = torch.empty(2, nf, device=x.device, dtype=torch.float32)
+        r = None if res is None else res.contiguous().float()
+        _check(lib.cbd_irreps_bn_forward(n, dim, ldx, nf, _ptr(fields), _ptr(x), None if r is None else _ptr(r),
+                                         0 if r is None else int(r.shape[1]), _ptr(weight), _ptr(bias) if bias.numel() else None,
+                                         _ptr(running_mean) if running_mean.numel() else None, _ptr(running_var), float(momentum),
+                                         float(eps), _ptr(out), _ptr(stats[0]), _ptr(stats[1]), _stream_handle()))
+        ctx.save_for_backward(x, weight, stats, fields)
+        ctx.res_dim = None if r is None else int(r.shape[1])
+        ctx.n_bias = int(bias.numel())
+        ctx.dim = dim
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _bind(load_library())
+        x, weight, stats, fields = ctx.saved_tensors
+        g = g.contiguous().float()
+        n, ldx = x.shape
+        nf = int(fields.shape[0])
+        gx = torch.empty_like(x)
+        gw = torch.empty(nf, device=x.device, dtype=torch.float32)
+        gb = torch.empty(ctx.n_bias, device=x.device, dtype=torch.float32)
+        _check(lib.cbd_irreps_bn_backward(n, ctx.dim, ldx, nf, _ptr(fields), _ptr(g), _ptr(x), _ptr(weight), _ptr(stats[0]), _ptr(stats[1]),
+                                          _ptr(gx), _ptr(gw), _ptr(gb) if ctx.n_bias else None, _stream_handle()))
+        gres = None if ctx.res_dim is None else g[:, :ctx.res_dim]
+        return gx, None, gw, gb, gres, None, None, None, None, None
+
+
 class GatherFn(torch.autograd.Function):
     """x[index]; backward = segmented sum of the incoming gradient rows per source row (fixed order) instead of an atomic index_add."""
 
@@ -356,6 +574,12 @@ class GatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return _segment_sum(g, ctx.csr), None
+
+
+def scatter_mean(src, index, dim_size):
+    if src.shape[0] == 0:
+        return src.new_zeros((dim_size,) + tuple(src.shape[1:]))
+    return ScatterMeanFn.apply(src, csr_of(index, dim_size))
 
 
 def scatter_sum(src, index, dim_size):

@@ -288,6 +288,25 @@ int cbd_outer_accum(int64_t E, const float* g_dev, const float* x_dev, int32_t n
 int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
                     float* out_dev, void* stream);
 
+/* The same with every row divided by max(rowptr[n+1] - rowptr[n], 1): torch_scatter.scatter(..., reduce='mean') of
+ * TensorProductConvLayer.forward (models/tensor_layers.py:206). */
+int cbd_segment_mean(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
+                     float* out_dev, void* stream);
+
+/* Train-mode e3nn.nn.BatchNorm (0.5.0: affine, normalization='component', reduce='mean') of the fine-tuning step, as the reference's
+ * TensorProductConvLayer applies it (models/tensor_layers.py:191-193, 208-209) under model.train() (utils/training.py:186), fused with
+ * the layer's residual  out + pad(node_attr)  (:211-213).  x [n][ldx >= dim] (columns >= dim ignored; their gx is zero), out [n][dim] fp32; fields [n_fields][3] int32 = {first column, components,
+ * index among the 0e (scalar, even) fields or -1}; weight / running_var / save_* [n_fields]; bias / running_mean [#0e fields] (may be
+ * NULL when there is none).  0e fields are centred and biased; every field is scaled by weight / sqrt(mean of its squared components
+ * over rows and components + eps); running statistics are updated in place with `momentum`.  res_dev (or NULL): [n][res_dim], added to
+ * the first res_dim output columns.  save_mean / save_inv feed the backward pass, which takes g [n][dim] and returns gx [n][ldx], gw [n_fields], gb [#0e]
+ * (the residual's gradient is g[:, :res_dim] itself).  Sums in a fixed order: bitwise repeatable. */
+int cbd_irreps_bn_forward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields, const int32_t* fields_dev, const float* x_dev, const float* res_dev,
+                          int32_t res_dim, const float* weight_dev, const float* bias_dev, float* running_mean_dev, float* running_var_dev,
+                          float momentum, float eps, float* out_dev, float* save_mean_dev, float* save_inv_dev, void* stream);
+int cbd_irreps_bn_backward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields, const int32_t* fields_dev, const float* g_dev, const float* x_dev,
+                           const float* weight_dev, const float* save_mean_dev, const float* save_inv_dev, float* gx_dev, float* gw_dev,
+                           float* gb_dev, void* stream);
 
 /* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
  * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training

@@ -287,3 +287,45 @@ def test_csr_build_is_a_stable_argsort_with_row_pointers():
             want[1:] = torch.cumsum(torch.bincount(index, minlength=N)[:N], 0)
             assert torch.equal(c.rowptr.cpu(), want)
             assert torch.equal(c.counts.cpu(), want[1:] - want[:-1])
+
+
+def test_irreps_batch_norm_kernels_match_the_torch_formulation():
+    """cbd_irreps_bn_forward / _backward (one launch each) against the torch-op formulation of e3nn's train-mode BatchNorm that the
+    reference golden g11 pinned in round 2: outputs, running statistics, and the gradients of input, weight, bias and residual; wide
+    input rows (80-float message rows), layouts with and without 0e fields, a batch of two rows."""
+    import copy
+    from confidence_bootstrapping_amd.score_model import IrrepsBatchNorm
+    from confidence_bootstrapping_amd.train_forward import irreps_batch_norm, irreps_batch_norm_torch
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    for irreps, n, wide, res_dim in (("32x0e+6x1o+6x1e+6x0o", 3301, 80, 74), ("32x0e+6x1o", 500, 80, 32), ("2x1o+2x1e", 8, 12, None),
+                                      ("32x0o+32x0e", 97, 64, None), ("32x0e+6x1o+6x1e", 2, 80, 50)):
+        bn_a = IrrepsBatchNorm(irreps).to(dev).train()
+        with torch.no_grad():
+            bn_a.weight.copy_(torch.rand(bn_a.weight.shape, generator=g) + 0.5)
+            bn_a.bias.copy_(torch.randn(bn_a.bias.shape, generator=g))
+            bn_a.running_var.copy_(torch.rand(bn_a.running_var.shape, generator=g) + 0.5)
+            bn_a.running_mean.copy_(torch.randn(bn_a.running_mean.shape, generator=g))
+        bn_b = copy.deepcopy(bn_a)
+        D = sum(m * (2 * l + 1) for m, l, p in __import__("confidence_bootstrapping_amd.score_model", fromlist=["parse_irreps"]).parse_irreps(irreps))
+        x0 = (torch.randn(n, wide, generator=g) * 2 + 0.3).to(dev)
+        r0 = torch.randn(n, res_dim, generator=g).to(dev) if res_dim else None
+        wgt = torch.randn(n, D, generator=g).to(dev)
+        outs = []
+        for bn, kernel in ((bn_a, True), (bn_b, False)):
+            x = x0.clone().requires_grad_()
+            r = r0.clone().requires_grad_() if r0 is not None else None
+            if kernel:
+                y = irreps_batch_norm(bn, x, residual=r)
+            else:
+                y = irreps_batch_norm_torch(bn, x[:, :D])
+                if r is not None:
+                    y = y + torch.nn.functional.pad(r, (0, D - res_dim))
+            (y * wgt).sum().backward()
+            outs.append((y.detach(), x.grad, bn.weight.grad, bn.bias.grad, None if r is None else r.grad, bn.running_mean.clone(), bn.running_var.clone()))
+        for name, a, b in zip(("out", "gx", "gw", "gb", "gres", "running_mean", "running_var"), *outs):
+            if a is None or a.numel() == 0:
+                continue
+            scale = max(1.0, float(b.abs().max()))
+            assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * scale, (irreps, name, float((a - b).abs().max()), scale)
+        assert float(outs[0][1][:, D:].abs().max() if wide > D else 0.0) == 0.0

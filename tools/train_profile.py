@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rows", type=int, default=45)
+    ap.add_argument("--cprofile", action="store_true", help="Python-level profile (cProfile) of 16 free-running steps instead of the op table")
     a = ap.parse_args()
     from confidence_bootstrapping_amd.synthetic import make_complex, WORKLOADS
     from confidence_bootstrapping_amd.utils import make_score_model, load_model_args, ExponentialMovingAverage
@@ -59,18 +60,31 @@ def main():
         ema.update(model.parameters())
         t = lap("ema", t)
 
-    for k in range(3):
-        step(batches[k])
+    for k in range(12):             # the caching allocator needs a few steps of every size before it stops calling hipMalloc
+        step(batches[k % 8])
     sync()
-    t0 = time.perf_counter()
-    for k in range(3, 7):
-        step(batches[k])
-    sync()
-    print(f"batch {a.batch}: {(time.perf_counter() - t0) / 4 * 1e3:.1f} ms per step (free-running)")
+    for rep in range(3):
+        t0 = time.perf_counter()
+        for k in range(16):
+            step(batches[k % 8])
+        sync()
+        print(f"batch {a.batch}: {(time.perf_counter() - t0) / 16 * 1e3:.1f} ms per step (free-running, 16 steps)")
+    if a.cprofile:
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for k in range(16):
+            step(batches[k % 8])
+        sync()
+        pr.disable()
+        st = pstats.Stats(pr)
+        st.sort_stats("tottime").print_stats(a.rows)
+        st.sort_stats("cumtime").print_stats(a.rows)
+        return
     tm = {}
-    for k in range(3, 7):
+    for k in range(8):
         step(batches[k], tm)
-    print("with a synchronisation after every phase (ms per step):", {k: round(v / 4 * 1e3, 2) for k, v in tm.items()})
+    print("with a synchronisation after every phase (ms per step):", {k: round(v / 8 * 1e3, 2) for k, v in tm.items()})
     # host time of enqueueing alone: the same step with the GPU made irrelevant is not possible, so count ops instead
     from torch.profiler import profile, ProfilerActivity
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
@@ -79,6 +93,8 @@ def main():
     ka = prof.key_averages()
     n_ops = sum(e.count for e in ka if e.device_type == torch.autograd.DeviceType.CPU)
     print("CPU-side op calls in one step:", n_ops)
+    launches = sum(e.count for e in ka if e.key in ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync"))
+    print(f"GPU launches (kernels + async copies / memsets) in one step: {launches}")
     print(ka.table(sort_by="self_cpu_time_total", row_limit=a.rows, max_name_column_width=70))
 
 
