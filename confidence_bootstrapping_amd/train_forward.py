@@ -12,6 +12,7 @@ Works in eval mode too (running statistics, no dropout), which the tests use to 
 from __future__ import annotations
 
 import math
+import os
 import weakref
 from typing import List
 
@@ -22,7 +23,9 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, IrrepsBatchNormFn, StreamHub, TensorProductHubFn, csr_of, first_linear, gather_rows, scatter_mean as _scatter_mean_op,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
+                        grouped_first_linear,
+                        gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
 
 SQ3 = math.sqrt(3.0)
@@ -57,32 +60,60 @@ def collate(data_list: List[HeteroData], device) -> Batch:
         keep_alive.append(out)
         return out
 
-    def dv_edges(parts, offsets):
-        """edge_index tensors: cached raw copies, per-graph node offsets added on the device"""
+    # Everything that changes from step to step (noised ligand positions, diffusion times, and the host-built index vectors) travels in
+    # TWO pinned staging buffers -- one float32, one int64 -- i.e. two truly asynchronous copies per step instead of ~25 blocking
+    # copies from pageable memory (4.6 ms of host time per step in the profile of round 3); the device tensors are views of the two.
+    ne_l = [d["ligand", "ligand"].edge_index.shape[1] for d in data_list]
+    ne_r = [d["receptor", "receptor"].edge_index.shape[1] for d in data_list]
+    t_host = {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list]) for k in ("tr", "rot", "tor")}
+    eo = np.concatenate([[0], np.cumsum(ne_l)[:-1]])
+    rot = np.concatenate([np.flatnonzero(d["ligand"].edge_mask.numpy()) + o for d, o in zip(data_list, eo)]).astype(np.int64)
+    fparts = [d["ligand"].pos.reshape(-1).float() for d in data_list] + [t_host["tr"], t_host["rot"], t_host["tor"]]
+    iparts = [torch.from_numpy(a) for a in (np.repeat(np.arange(len(nl)), nl), np.repeat(np.arange(len(nr)), nr), rot,
+                                            np.repeat(np.asarray(lo, dtype=np.int64), ne_l), np.repeat(np.asarray(ro, dtype=np.int64), ne_r))]
+
+    def stage(parts, dtype):
+        n = sum(int(p.numel()) for p in parts)
+        host = torch.empty(n, dtype=dtype, pin_memory=True)
+        torch.cat([p.to(dtype) for p in parts], out=host)
         with torch.cuda.stream(side):
-            up = [_dev_cached(p, device) + o for p, o in zip(parts, offsets)]
-            out = torch.cat(up, 1) if len(up) > 1 else up[0]
+            dev_t = host.to(device, non_blocking=True)
+        keep_alive.append(dev_t)
+        out, o = [], 0
+        for p in parts:
+            out.append(dev_t[o:o + p.numel()])
+            o += p.numel()
+        return out, dev_t
+
+    (fdev, fall), (idev, _) = stage(fparts, torch.float32), stage(iparts, torch.int64)
+    B = len(data_list)
+
+    def edges(parts, per_edge_offset):
+        """edge_index tensors: cached raw copies concatenated on the device, per-graph node offsets added with one op"""
+        with torch.cuda.stream(side):
+            up = [_dev_cached(p, device) for p in parts]
+            out = (torch.cat(up, 1) if len(up) > 1 else up[0]) + per_edge_offset
         keep_alive.append(out)
         return out
 
     b["ligand"].x = dv([d["ligand"].x for d in data_list], static=True)
-    b["ligand"].pos = dv([d["ligand"].pos for d in data_list])
+    b["ligand"].pos = fall[:3 * sum(nl)].view(-1, 3)
     b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list], static=True)
-    b["ligand"].batch = dv([torch.repeat_interleave(torch.arange(len(nl)), torch.tensor(nl))])
-    b["ligand", "ligand"].edge_index = dv_edges([d["ligand", "ligand"].edge_index for d in data_list], lo)
+    b["ligand"].batch = idev[0]
+    b["ligand", "ligand"].edge_index = edges([d["ligand", "ligand"].edge_index for d in data_list], idev[3])
     b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list], static=True)
     b["receptor"].x = dv([d["receptor"].x for d in data_list], static=True)
     b["receptor"].pos = dv([d["receptor"].pos for d in data_list], static=True)
-    b["receptor"].batch = dv([torch.repeat_interleave(torch.arange(len(nr)), torch.tensor(nr))])
-    b["receptor", "receptor"].edge_index = dv_edges([d["receptor", "receptor"].edge_index for d in data_list], ro)
-    b.complex_t = {k: dv([torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list])])
-                   for k in ("tr", "rot", "tor")}
+    b["receptor"].batch = idev[1]
+    b["receptor", "receptor"].edge_index = edges([d["receptor", "receptor"].edge_index for d in data_list], idev[4])
+    b.complex_t = {"tr": fdev[B], "rot": fdev[B + 1], "tor": fdev[B + 2]}
     # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
-    b.host = {"t": {k: torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data_list]) for k in ("tr", "rot", "tor")},
-              "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl}
+    b.host = {"t": t_host, "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl}
+    # columns of the batch's bond list that are rotatable bonds (the mask is host data: no boolean indexing on the device, which would
+    # read the count back)
+    b.rot_bond_cols = idev[2]
     torch.cuda.current_stream(device).wait_stream(side)
-    for t in keep_alive:
-        t.record_stream(torch.cuda.current_stream(device))
+    _keep_until_main_passes(keep_alive, device)
     return b
 
 
@@ -114,8 +145,47 @@ def _dev_cached(t: torch.Tensor, device):
 def _copy_stream(device):
     key = str(device)
     if key not in _COPY_STREAMS:
-        _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+        # high priority: its small kernels and copies (and the host read-backs that wait for them) must not queue behind the compute
+        # stream's millisecond kernels of the previous step
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if os.environ.get("CBD_TRAIN_SIDE_PRIO", "1") == "1" else 0)
     return _COPY_STREAMS[key]
+
+
+# Tensors allocated on the side stream and read by the compute stream.  The caching allocator would hand their memory back to the side
+# stream as soon as the last Python reference dies, possibly while the compute stream still reads it.  Tensor.record_stream() is the
+# textbook answer, but with ~300 such tensors per step it leaves the side stream's pool permanently short of reusable blocks (every block
+# waits for a compute-stream event) and the allocator falls back to hipMalloc: steps of 36..65 ms with the same kernels.  Instead the
+# tensors of a step are kept alive here until an event recorded on the compute stream at the START OF THE NEXT STEP has completed -- all
+# their uses (forward, loss, backward) are enqueued before that point -- and are then freed to the side pool in one go.
+_KEEP_NOW = {}          # device -> tensors of the running step
+_KEEP_OLD = {}          # device -> deque of (event, tensors)
+
+
+def _keep_until_main_passes(tensors, device):
+    if os.environ.get("CBD_TRAIN_RECORD_STREAM", "0") == "1":       # measurement switch: the textbook scheme
+        main = torch.cuda.current_stream(device)
+        for t in tensors:
+            t.record_stream(main)
+        return
+    _KEEP_NOW.setdefault(str(device), []).extend(tensors)
+
+
+def _rotate_keep(device):
+    """called at the start of every step: closes the previous step's set behind an event, frees the sets whose event has completed"""
+    import collections
+    key = str(device)
+    old = _KEEP_OLD.setdefault(key, collections.deque())
+    cur = _KEEP_NOW.get(key)
+    if cur:
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(device))
+        old.append((ev, cur))
+        _KEEP_NOW[key] = []
+    while old and old[0][0].query():
+        old.popleft()
+    while len(old) > 8:         # a host that runs eight steps ahead of the GPU: wait rather than grow
+        old[0][0].synchronize()
+        old.popleft()
 
 
 def upload(t: torch.Tensor, device):
@@ -129,29 +199,44 @@ def upload(t: torch.Tensor, device):
     with torch.cuda.stream(side):
         d = t.to(device, non_blocking=True)
     main.wait_stream(side)
-    d.record_stream(main)
+    _keep_until_main_passes([d], device)
     return d
 
 
 # ----------------------------------------------------------------------------- graph ops (torch_cluster / torch_scatter semantics)
-def radius(x, y, r, batch_x, batch_y, max_num_neighbors=32):
-    """For every y the x's of the same graph with |x - y|^2 < r^2, first `max_num_neighbors` in index order
-    (torch_cluster.radius; row 0 = index into y, row 1 = index into x)."""
+def radius_mask(x, y, r, batch_x, batch_y, max_num_neighbors=32):
+    """[len(y), len(x)] mask of torch_cluster.radius: for every y the x's of the same graph with |x - y|^2 < r^2, first
+    `max_num_neighbors` in index order."""
     d2 = torch.zeros(y.shape[0], x.shape[0], dtype=x.dtype, device=x.device)
     for k in range(x.shape[1]):
         diff = x[None, :, k] - y[:, None, k]
         d2 = d2 + diff * diff
     ok = (d2 < r * r) & (batch_y[:, None] == batch_x[None, :])
     rank = torch.cumsum(ok.to(torch.int32), dim=1)
-    ok = ok & (rank <= max_num_neighbors)
-    row, col = torch.nonzero(ok, as_tuple=True)
-    return torch.stack([row, col], dim=0)
+    return ok & (rank <= max_num_neighbors)
+
+
+def mask_edges(ok, count=None):
+    """[2, E] (row 0 = index into y, row 1 = index into x) of a radius mask, row-major order.  With `count` (the number of set
+    entries, already on the host) there is no device->host read-back here."""
+    nz = torch.nonzero(ok) if count is None else torch.nonzero_static(ok, size=int(count))
+    return nz.t().contiguous()
+
+
+def radius(x, y, r, batch_x, batch_y, max_num_neighbors=32):
+    """torch_cluster.radius (row 0 = index into y, row 1 = index into x)."""
+    return mask_edges(radius_mask(x, y, r, batch_x, batch_y, max_num_neighbors))
+
+
+def radius_graph_mask(x, r, batch, max_num_neighbors=32):
+    """mask [centre, neighbour] of torch_cluster.radius_graph: the capped scan counts the centre itself, which is then dropped"""
+    ok = radius_mask(x, x, r, batch, batch, max_num_neighbors + 1)
+    return ok & ~torch.eye(x.shape[0], dtype=torch.bool, device=x.device)
 
 
 def radius_graph(x, r, batch, max_num_neighbors=32):
-    ei = radius(x, x, r, batch, batch, max_num_neighbors + 1)
-    keep = ei[0] != ei[1]
-    return torch.stack([ei[1][keep], ei[0][keep]], dim=0)   # [neighbour; centre]
+    ei = mask_edges(radius_graph_mask(x, r, batch, max_num_neighbors))
+    return torch.stack([ei[1], ei[0]], dim=0)   # [neighbour; centre]
 
 
 def scatter_mean(src, index, dim_size):
@@ -177,23 +262,28 @@ def unit4(vec):
     return F.pad(F.normalize(vec, dim=-1), (0, 1))
 
 
-def atom_encoder(enc, x_cat, extra):
-    """AtomEncoder.forward (models/score_model.py:30-41): sum of the categorical embeddings (+ Linear over [sum, extra features]).  All
-    tables are looked up with ONE gather over a concatenated table (one edge grouping for its fixed-order backward instead of one per
-    feature: 16 for the ligand)."""
+def atom_encoder_index(enc, x_cat):
+    """flat row index into the concatenation of the encoder's embedding tables, [N * n_tables] (input-only: built in `_prepare`)"""
     tables = enc.atom_embedding_list
     nf = len(tables)
-    if nf == 1:
-        emb = take(tables[0].weight, x_cat[:, 0].long())
-    else:
-        key = (id(enc), str(x_cat.device))
-        offs = _TABLE_OFFSETS.get(key)
-        if offs is None:
-            sizes = [t.weight.shape[0] for t in tables]
-            offs = _TABLE_OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.long).to(x_cat.device)
-        big = torch.cat([t.weight for t in tables], 0)
-        idx = (x_cat[:, :nf].long() + offs).reshape(-1)
-        emb = take(big, idx).view(x_cat.shape[0], nf, -1).sum(1)
+    key = (id(enc), str(x_cat.device))
+    offs = _TABLE_OFFSETS.get(key)
+    if offs is None:
+        sizes = [t.weight.shape[0] for t in tables]
+        offs = _TABLE_OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.long).to(x_cat.device)
+    return (x_cat[:, :nf].long() + offs).reshape(-1)
+
+
+def atom_encoder(enc, idx, extra):
+    """AtomEncoder.forward (models/score_model.py:30-41): sum of the categorical embeddings (+ Linear over [sum, extra features]).  All
+    tables are looked up with ONE gather over a concatenated table (`idx` from atom_encoder_index: one edge grouping for its
+    fixed-order backward instead of one per feature: 16 for the ligand)."""
+    tables = enc.atom_embedding_list
+    nf = len(tables)
+    big = torch.cat([t.weight for t in tables], 0) if nf > 1 else tables[0].weight
+    emb = take(big, idx)
+    if nf > 1:
+        emb = emb.view(idx.shape[0] // nf, nf, -1).sum(1)
     if enc.additional_features_dim > 0:
         emb = enc.additional_features_embedder(torch.cat([emb, extra], dim=1))
     return emb
@@ -274,12 +364,7 @@ def irreps_batch_norm_torch(bn, x, eps=1e-5, momentum=0.1):
 
 
 # ----------------------------------------------------------------------------- layers
-def _fc_hidden(fc, x):
-    # Linear -> ReLU -> Dropout; the last Linear lives inside the HIP op, the first one's weight gradient on cbd_outer_accum
-    return fc[2](fc[1](first_linear(x, fc[0])))
-
-
-def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, out_level, hub=None):
+def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_level, hub=None, group_sizes=None):
     """TensorProductConvLayer.forward (models/tensor_layers.py:195-217) with FasterTensorProduct on the HIP op."""
     n, din = node_attr.shape
     dout = LEVEL_DIMS[out_level]
@@ -287,20 +372,22 @@ def conv_layer(layer, node_attr, edge_index, edge_attr_groups, vec4, in_level, o
         out = torch.zeros(n, dout, dtype=node_attr.dtype, device=node_attr.device)
     else:
         src, dst = edge_index[0], edge_index[1]
-        xpad = F.pad(node_attr, (0, NODE_STRIDE - din))
+        xrow = gather_pad(node_attr, dst)           # node_attr[edge_dst] as the kernels' zero-padded 80-float rows
         sm = stream_map(in_level, out_level)
-        groups = edge_attr_groups if isinstance(edge_attr_groups, (list, tuple)) else [edge_attr_groups]
         fcs = [layer.fc] if layer.edge_groups == 1 else list(layer.fc)
-        # all edge groups of the layer in ONE launch of the HIP op (forward and backward); the first Linear of every group's
-        # FCBlock (+ ReLU + Dropout) stays a torch op
-        live = [(fc, ea) for fc, ea in zip(fcs, groups) if ea.shape[0] > 0]
-        hid = torch.cat([_fc_hidden(fc, ea) for fc, ea in live], dim=0) if len(live) > 1 else _fc_hidden(*live[0])
+        # all edge groups of the layer in ONE launch of the HIP op (forward and backward); the first Linear of every group's FCBlock
+        # runs per group on slices of one buffer (train_ops.GroupedFirstLinearFn), ReLU and Dropout once over all rows (the groups of
+        # a layer share the dropout rate)
+        sizes = list(group_sizes) if group_sizes is not None else [edge_attr.shape[0]]
+        live = [(fc, ne) for fc, ne in zip(fcs, sizes) if ne > 0]
+        pre = grouped_first_linear(edge_attr, [ne for _, ne in live], [fc[0] for fc, _ in live])
+        drop = live[0][0][2]
+        hid = F.dropout(F.relu(pre), p=drop.p, training=drop.training)
         if hub is not None:     # the model's streams packed once per step (train_ops.StreamHub)
-            msg = TensorProductHubFn.apply(take(xpad, dst), vec4, hid, hub.big, hub, in_level, out_level, tuple(ea.shape[0] for _, ea in live),
+            msg = TensorProductHubFn.apply(xrow, vec4, hid, hub.big, hub, in_level, out_level, tuple(ne for _, ne in live),
                                            tuple(hub.block(fc) for fc, _ in live))
         else:
-            msg = tensor_product(take(xpad, dst), vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level,
-                                 [ea.shape[0] for _, ea in live])
+            msg = tensor_product(xrow, vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level, [ne for _, ne in live])
         # the 80-float message rows go through the segmented mean and into the BatchNorm kernel as they are (it reads the layout's
         # `dout` columns): no slice copy of the [E, 80] tensor
         return irreps_batch_norm(layer.batch_norm, scatter_mean(msg, src, n), residual=node_attr)
@@ -358,6 +445,106 @@ def _stream_hub(model, dev) -> StreamHub:
     return hub
 
 
+class _Prepared:
+    """input-only tensors of one step (see `_prepare`)"""
+
+    def tensors(self):
+        out = []
+        for v in self.__dict__.values():
+            if torch.is_tensor(v):
+                out.append(v)
+            elif isinstance(v, Csr):
+                out += [v.index, v.perm, v.rowptr]
+        return out
+
+
+def _prepare(model, data, host, dev) -> _Prepared:
+    """Everything of the forward pass that depends on the batch alone, not on the weights (called under the side stream)."""
+    g = _Prepared()
+    lig, rec = data["ligand"], data["receptor"]
+    B = data.num_graphs
+    ct = data.complex_t
+    lig_batch, rec_batch = lig.batch, rec.batch
+    g.tr_sigma, _, _ = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
+    lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
+    g.lig_pos = lig_pos
+    t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
+    n_rot = host["n_rot"] if host else torch.bincount(lig_batch[data["ligand", "ligand"].edge_index[0][lig.edge_mask.bool()]], minlength=B).tolist()
+    g.n_rot = n_rot
+    _, rot_sigma_h, tor_sigma_h = model.t_to_sigma(t_host["tr"], t_host["rot"], t_host["tor"])
+    g.so3_norm = so3.score_norm(rot_sigma_h).unsqueeze(1).to(dev, non_blocking=True)
+    tor_sigma_edge = np.repeat(tor_sigma_h.numpy(), n_rot)
+    g.torus_norm = torch.sqrt(torch.tensor(torus.score_norm(tor_sigma_edge)).float()).to(dev, non_blocking=True) if sum(n_rot) else None
+    bond_ei = data["ligand", "ligand"].edge_index.long()
+    edge_mask = lig.edge_mask.bool()
+    # the three radius graphs of the step: masks first, ONE read-back of the three edge counts, then compaction without read-backs
+    cutoff = (g.tr_sigma * 3 + 20).unsqueeze(1)
+    m_ll = radius_graph_mask(lig_pos, model.lig_max_radius, lig_batch)
+    m_lr = radius_mask(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
+    bonds = bond_pos = m_t = None
+    if sum(n_rot):
+        cols = getattr(data, "rot_bond_cols", None)
+        bonds = bond_ei.index_select(1, cols) if cols is not None else bond_ei[:, edge_mask]
+        bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
+        m_t = radius_mask(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
+    n_edges = torch.stack([m.sum() for m in (m_ll, m_lr, m_t) if m is not None]).tolist()
+    ei = mask_edges(m_ll, n_edges[0])
+    radius_edges = torch.stack([ei[1], ei[0]], dim=0)          # [neighbour; centre]
+    lr = g.lr = mask_edges(m_lr, n_edges[1])
+    r_ei = g.r_ei = data["receptor", "receptor"].edge_index.long()
+    nL, nR = lig_pos.shape[0], rec_pos.shape[0]
+    g.nL = nL
+
+    # receptor graph (score_model.py:524-546)
+    r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
+    g.r_smear = gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1))
+    g.r_vec4 = unit4(r_vec)
+    g.rec_cat = atom_encoder_index(model.rec_node_embedding, rec.x)
+    g.rec_batch_src = rec_batch[r_ei[0]]
+    # ligand graph (score_model.py:492-522)
+    l_ei = g.l_ei = torch.cat([bond_ei, radius_edges], 1)
+    g.l_attr0 = torch.cat([data["ligand", "ligand"].edge_attr.float(),
+                           torch.zeros(radius_edges.shape[1], model.in_lig_edge_features, device=dev)], 0)
+    l_vec = lig_pos[l_ei[1]] - lig_pos[l_ei[0]]
+    g.l_smear = gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))
+    g.l_vec4 = unit4(l_vec)
+    g.lig_cat = atom_encoder_index(model.lig_node_embedding, lig.x)
+    # cross graph (score_model.py:564-587), joint graph (score_model.py:354-362)
+    c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
+    g.c_smear = gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))
+    lr_vec4 = unit4(c_vec)
+    lr_j = torch.stack([lr[0], lr[1] + nL], 0)
+    g.edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.stack([lr_j[1], lr_j[0]], 0)], 1)
+    g.vec4 = torch.cat([g.l_vec4, lr_vec4, g.r_vec4, -lr_vec4], 0)
+    g.s1 = l_ei.shape[1]
+    g.s2 = g.s1 + lr_j.shape[1]
+    g.s3 = g.s2 + r_ei.shape[1]
+    g.ei2 = g.edge_index[:, :g.s2].contiguous()          # the last interaction layer updates the ligand side only
+    g.vec4_2 = g.vec4[:g.s2]
+    # centre geometry (score_model.py:635-648)
+    counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
+    center = torch.zeros(B, 3, device=dev, dtype=lig_pos.dtype).index_add_(0, lig_batch, lig_pos) / counts
+    g.c_vec2 = lig_pos - center[lig_batch]
+    g.center_smear = gaussian_smearing(model.center_distance_expansion, g.c_vec2.norm(dim=-1))
+    # torsion graph (score_model.py:650-664)
+    g.bonds, g.t_ei = bonds, None
+    if m_t is not None:
+        t_ei = g.t_ei = mask_edges(m_t, n_edges[2])
+        g.t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
+        g.t_smear = gaussian_smearing(model.lig_distance_expansion, g.t_vec.norm(dim=-1))
+        g.bond_vec_e = (lig_pos[bonds[1]] - lig_pos[bonds[0]])[t_ei[0]]
+    # edge groupings of every index tensor the step gathers / scatters through (cached per tensor: the later csr_of calls hit)
+    nJ = nL + nR
+    n_tab = lambda enc: sum(t.weight.shape[0] for t in enc.atom_embedding_list)
+    warm = [(g.rec_cat, n_tab(model.rec_node_embedding)), (g.lig_cat, n_tab(model.lig_node_embedding)), (r_ei[0], nR), (r_ei[1], nR), (rec_batch, B), (g.rec_batch_src, B), (lig_batch, B), (l_ei[0], nL), (l_ei[1], nL), (lr[0], nL),
+            (g.edge_index[0], nJ), (g.edge_index[1], nJ), (g.ei2[0], nJ), (g.ei2[1], nJ)]
+    if g.t_ei is not None:
+        warm += [(g.bonds[0], nL), (g.bonds[1], nL), (g.t_ei[1], nL), (g.t_ei[0], int(g.bonds.shape[1]))]
+    for k, (idx, n) in enumerate(warm):
+        setattr(g, f"_csr{k}", csr_of(idx, n))
+    return g
+
+
 def forward(model, data):
     """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449)."""
     dev = next(model.parameters()).device
@@ -367,6 +554,7 @@ def forward(model, data):
         raise NotImplementedError("fine-tuning a model with an asyncronous noise schedule is outside the MI355X training path")
     from .train_ops import clear_csr_cache
     clear_csr_cache()          # edge groupings are per step (the graphs change with the poses)
+    _rotate_keep(dev)
     data = collate(data, dev)
     ns = model.ns
     lig, rec = data["ligand"], data["receptor"]
@@ -374,103 +562,65 @@ def forward(model, data):
     ct = data.complex_t
     lig_batch, rec_batch = lig.batch, rec.batch
 
-    # ---- everything that needs a device->host read-back (edge counts of the three radius graphs, boolean masks) or a host table
-    #      look-up depends on the step's INPUTS only, so it runs on the side stream: the read-backs wait for that stream, not for the
-    #      previous step's backward pass on the compute stream, and the host enqueues the rest of the step without a single stall
+    # ---- everything that depends on the step's INPUTS only -- the three radius graphs (their edge counts are read back to the host),
+    #      boolean masks, host table look-ups, the joint edge list, edge vectors / distance expansions / centre geometry, and the edge
+    #      groupings (stable sorts) of every index tensor the step gathers or scatters through -- runs on the SIDE stream: the read-backs
+    #      wait for that stream, not for the previous step's backward pass, the ~250 small launches overlap with it instead of
+    #      lengthening the compute stream, and the host enqueues the rest of the step without a single stall
     host = getattr(data, "host", None)
     main, side = torch.cuda.current_stream(dev), _copy_stream(dev)
     if host is None:                # a batch collated elsewhere: its tensors may still be in flight on the compute stream
         side.wait_stream(main)
     with torch.cuda.stream(side):
-        tr_sigma, rot_sigma, tor_sigma = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
-        lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
-        t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
-        n_rot = host["n_rot"] if host else torch.bincount(lig_batch[data["ligand", "ligand"].edge_index[0][lig.edge_mask.bool()]], minlength=B).tolist()
-        _, rot_sigma_h, tor_sigma_h = model.t_to_sigma(t_host["tr"], t_host["rot"], t_host["tor"])
-        so3_norm = so3.score_norm(rot_sigma_h).unsqueeze(1).to(dev, non_blocking=True)
-        tor_sigma_edge = np.repeat(tor_sigma_h.numpy(), n_rot)
-        torus_norm = torch.sqrt(torch.tensor(torus.score_norm(tor_sigma_edge)).float()).to(dev, non_blocking=True) if sum(n_rot) else None
-        bond_ei = data["ligand", "ligand"].edge_index.long()
-        edge_mask = lig.edge_mask.bool()
-        radius_edges = radius_graph(lig_pos, model.lig_max_radius, lig_batch)
-        cutoff = (tr_sigma * 3 + 20).unsqueeze(1)
-        lr = radius(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
-        bonds = bond_pos = t_ei = None
-        if sum(n_rot):
-            bonds = bond_ei[:, edge_mask]
-            bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
-            t_ei = radius(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
-        # atoms per graph: known on the host (collate); torch.bincount would read its output size back from the device
-        counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
-        r_ei = data["receptor", "receptor"].edge_index.long()
+        g = _prepare(model, data, host, dev)
     main.wait_stream(side)
-    for t in (tr_sigma, rot_sigma, tor_sigma, lig_pos, rec_pos, so3_norm, torus_norm, bond_ei, edge_mask, radius_edges, cutoff, lr, bonds,
-              bond_pos, t_ei, counts, r_ei):
-        if t is not None:
-            t.record_stream(main)
+    _keep_until_main_passes(g.tensors(), dev)
+    tr_sigma, lig_pos, n_rot, r_ei, l_ei, lr, edge_index = g.tr_sigma, g.lig_pos, g.n_rot, g.r_ei, g.l_ei, g.lr, g.edge_index
+    s1, s2, s3, nL = g.s1, g.s2, g.s3, g.nL
 
     hub = _stream_hub(model, dev)
     hub.pack()
 
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
-    r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
-    rec_edge_attr = model.rec_edge_embedding(gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1)))
-    r_vec4 = unit4(r_vec)
-    rec_node = atom_encoder(model.rec_node_embedding, rec.x[:, :1], rec.x[:, 1:].float())
+    rec_edge_attr = model.rec_edge_embedding(g.r_smear)
+    rec_node = atom_encoder(model.rec_node_embedding, g.rec_cat, rec.x[:, 1:].float())
     for l, layer in enumerate(model.rec_emb_layers):
-        ea = torch.cat([rec_edge_attr, take(rec_node[:, :ns], r_ei[0]), take(rec_node[:, :ns], r_ei[1])], -1)
-        rec_node = conv_layer(layer, rec_node, r_ei, ea, r_vec4, min(l, 3), min(l + 1, 3), hub)
+        ea = edge_cat(rec_edge_attr, rec_node, r_ei[0], r_ei[1])
+        rec_node = conv_layer(layer, rec_node, r_ei, ea, g.r_vec4, min(l, 3), min(l + 1, 3), hub)
     graph_sigma_emb = model.timestep_emb_func(ct["tr"])
     rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
     rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
-    rec_edge_attr = rec_edge_attr + take(rec_sigma_emb, rec_batch[r_ei[0]])
+    rec_edge_attr = rec_edge_attr + take(rec_sigma_emb, g.rec_batch_src)
 
     # ---- ligand graph + embedding (score_model.py:492-522, 282-295)
     node_sigma_emb = take(graph_sigma_emb, lig_batch)
-    l_ei = torch.cat([bond_ei, radius_edges], 1)
-    l_attr = torch.cat([data["ligand", "ligand"].edge_attr.float(),
-                        torch.zeros(radius_edges.shape[1], model.in_lig_edge_features, device=dev)], 0)
-    l_vec = lig_pos[l_ei[1]] - lig_pos[l_ei[0]]
-    l_attr = torch.cat([l_attr, take(node_sigma_emb, l_ei[0]), gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))], 1)
-    l_vec4 = unit4(l_vec)
-    lig_node = atom_encoder(model.lig_node_embedding, lig.x, node_sigma_emb)
+    l_attr = torch.cat([g.l_attr0, take(node_sigma_emb, l_ei[0]), g.l_smear], 1)
+    lig_node = atom_encoder(model.lig_node_embedding, g.lig_cat, node_sigma_emb)
     lig_edge_attr = model.lig_edge_embedding(l_attr)
     for l, layer in enumerate(model.lig_emb_layers):
-        ea = torch.cat([lig_edge_attr, take(lig_node[:, :ns], l_ei[0]), take(lig_node[:, :ns], l_ei[1])], -1)
-        lig_node = conv_layer(layer, lig_node, l_ei, ea, l_vec4, min(l, 3), min(l + 1, 3), hub)
+        ea = edge_cat(lig_edge_attr, lig_node, l_ei[0], l_ei[1])
+        lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub)
 
     # ---- cross graph (score_model.py:345-352, 564-587)
-    c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
-    lr_attr = torch.cat([take(node_sigma_emb, lr[0]), gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))], 1)
-    lr_edge_attr = model.cross_edge_embedding(lr_attr)
-    lr_vec4 = unit4(c_vec)
+    lr_edge_attr = model.cross_edge_embedding(torch.cat([take(node_sigma_emb, lr[0]), g.c_smear], 1))
 
     # ---- joint graph, interaction layers (score_model.py:354-376)
-    nL = lig_node.shape[0]
     node = torch.cat([lig_node, rec_node], 0)
-    lr_j = torch.stack([lr[0], lr[1] + nL], 0)
-    edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.stack([lr_j[1], lr_j[0]], 0)], 1)
     edge_attr = torch.cat([lig_edge_attr, lr_edge_attr, rec_edge_attr, lr_edge_attr], 0)
-    vec4 = torch.cat([l_vec4, lr_vec4, r_vec4, -lr_vec4], 0)
-    s1 = l_ei.shape[1]
-    s2 = s1 + lr_j.shape[1]
-    s3 = s2 + r_ei.shape[1]
     nconv = len(model.conv_layers)
     for l, layer in enumerate(model.conv_layers):
         if l < nconv - 1:
-            ea = torch.cat([edge_attr, take(node[:, :ns], edge_index[0]), take(node[:, :ns], edge_index[1])], -1)
-            node = conv_layer(layer, node, edge_index, [ea[:s1], ea[s1:s2], ea[s2:s3], ea[s3:]], vec4, 3, 3, hub)
+            ea = edge_cat(edge_attr, node, edge_index[0], edge_index[1])
+            node = conv_layer(layer, node, edge_index, ea, g.vec4, 3, 3, hub, group_sizes=[s1, s2 - s1, s3 - s2, ea.shape[0] - s3])
         else:
-            ea = torch.cat([edge_attr[:s2], take(node[:, :ns], edge_index[0, :s2]), take(node[:, :ns], edge_index[1, :s2])], -1)
-            node = conv_layer(layer, node, edge_index[:, :s2], [ea[:s1], ea[s1:s2]], vec4[:s2], 3, 3, hub)
+            ea = edge_cat(edge_attr[:s2], node, g.ei2[0], g.ei2[1])
+            node = conv_layer(layer, node, g.ei2, ea, g.vec4_2, 3, 3, hub, group_sizes=[s1, s2 - s1])
     lig_node = node[:nL]
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
-    center = scatter_sum(lig_pos, lig_batch, B) / counts
-    c_vec2 = lig_pos - center[lig_batch]
-    c_attr = torch.cat([gaussian_smearing(model.center_distance_expansion, c_vec2.norm(dim=-1)), node_sigma_emb], 1)
+    c_attr = torch.cat([g.center_smear, node_sigma_emb], 1)
     c_attr = torch.cat([model.center_edge_embedding(c_attr), lig_node[:, :ns]], -1)
-    gp = scatter_mean(center_tensor_product(lig_node, c_vec2, model.final_conv.fc(c_attr)), lig_batch, B)
+    gp = scatter_mean(center_tensor_product(lig_node, g.c_vec2, model.final_conv.fc(c_attr)), lig_batch, B)
     gp = irreps_batch_norm(model.final_conv.batch_norm, gp)
     tr_pred = gp[:, :3] + gp[:, 6:9]
     rot_pred = gp[:, 3:6] + gp[:, 9:]
@@ -479,20 +629,19 @@ def forward(model, data):
     rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
     rot_pred = rot_pred / rot_norm * model.rot_final_layer(torch.cat([rot_norm, graph_sigma_emb], dim=1))
     tr_pred = tr_pred / tr_sigma.unsqueeze(1)
-    rot_pred = rot_pred * so3_norm
+    rot_pred = rot_pred * g.so3_norm
 
     if model.no_torsion or sum(n_rot) == 0:
         return tr_pred, rot_pred, torch.empty(0, device=dev), None
 
     # ---- torsion head (score_model.py:431-448, 650-664)
-    t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
-    t_attr = model.final_edge_embedding(gaussian_smearing(model.lig_distance_expansion, t_vec.norm(dim=-1)))
+    t_ei, bonds = g.t_ei, g.bonds
+    t_attr = model.final_edge_embedding(g.t_smear)
     bond_attr = take(lig_node, bonds[0]) + take(lig_node, bonds[1])
     t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
-    bond_vec = lig_pos[bonds[1]] - lig_pos[bonds[0]]
-    msg = bond_tensor_product(take(lig_node, t_ei[1]), t_vec, bond_vec[t_ei[0]], model.tor_bond_conv.fc(t_attr))
+    msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, model.tor_bond_conv.fc(t_attr))
     tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
     tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor)
     tor_pred = model.tor_final_layer(tor).squeeze(1)
-    tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
+    tor_pred = tor_pred * g.torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
     return tr_pred, rot_pred, tor_pred, None

@@ -250,9 +250,8 @@ class StreamHub:
         self.blocks = [(fc, stream_map(i, o)) for fc, i, o in blocks]
         self.index = {id(fc): b for b, (fc, _) in enumerate(self.blocks)}
         src, scale, w2p, b2p, p2g, pscale = [], [], [], [], [], []
-        self.stream_off, self.flat_off, self.g_off, self.gb_off = [], [], [], []
-        so = fo = 0
-        go = 0
+        self.stream_off, self.flat_off, self.g_off, self.w_off = [], [], [], []
+        so = fo = go = wo = 0
         for fc, sm in self.blocks:
             W = sm.weight_numel
             lo2 = KDIM * KDIM + KDIM                          # [w1 | b1 | w2 | b2]: the second Linear starts here
@@ -263,20 +262,24 @@ class StreamHub:
             self.stream_off.append(so)
             self.flat_off.append(fo)
             self.g_off.append(go)
+            self.w_off.append(wo)
+            wo += sm.wp * KDIM
             so += sm.n
             fo += W * KDIM + W
             go += sm.wp * KDIM
-        gbo = go
+        self.gb_off = []
         for fc, sm in self.blocks:
-            self.gb_off.append(gbo)
-            gbo += sm.wp
-        self.n_stream, self.n_flat, self.n_grad = so, fo, gbo
+            self.gb_off.append(go)
+            go += sm.wp
+        self.n_stream, self.n_flat, self.n_grad = so, fo, go
         # parameter element -> its slot in the gradient buffer [dW2p of every block | db2p of every block] and the packer's scale
         for b, (fc, sm) in enumerate(self.blocks):
             W = sm.weight_numel
             lo2 = KDIM * KDIM + KDIM
             pos = sm.inv_np[lo2:]                             # stream slot of every second-Linear parameter
             slot = np.full(sm.n, -1, dtype=np.int64)
+            # gradient buffer: [dW2p (wp x 96) of every block | db2p (wp) of every block].  (db2p as a 97th column of the dW2p GEMM,
+            # g_w^T [h | 1], was measured: the N = 97 GEMM costs 1.9 ms more per step than N = 96, the column sum it saves 1.3 ms.)
             slot[sm.w2p_np.ravel()] = self.g_off[b] + np.arange(sm.wp * KDIM)
             slot[sm.b2p_np] = self.gb_off[b] + np.arange(sm.wp)
             assert (slot[pos] >= 0).all(), "every second-Linear parameter sits in the W2p matrix or the bias table of its stream"
@@ -307,9 +310,10 @@ class StreamHub:
 
     def w2p(self, b):
         sm = self.blocks[b][1]
-        return self.w2p_all[self.g_off[b]:self.g_off[b] + sm.wp * KDIM].view(sm.wp, KDIM)
+        return self.w2p_all[self.w_off[b]:self.w_off[b] + sm.wp * KDIM].view(sm.wp, KDIM)
 
     def grad_views(self, b):
+        """slots of block b in the gradient buffer: dW2p [wp, 96], db2p [wp]"""
         sm = self.blocks[b][1]
         if b in self.used:
             raise RuntimeError("an FCBlock feeds one tensor-product call per step")
@@ -408,6 +412,54 @@ class FirstLinearFn(torch.autograd.Function):
             tot = parts.sum(0)
             gw, gb = tot[:KDIM * KDIM].view(KDIM, KDIM), tot[KDIM * KDIM:]
         return gx, gw, gb
+
+
+class GroupedFirstLinearFn(torch.autograd.Function):
+    """The first Linear of every edge group's FCBlock over ONE [E, 96] tensor of edge rows: group g owns the contiguous rows
+    [lo_g, hi_g) and its own (W_g, b_g).  Results and input gradients are written into slices of one buffer -- slicing the input per
+    group in autograd instead costs a zero-filled [E, 96] tensor, a copy and an accumulation per group in the backward pass
+    (SliceBackward0: 116 launches per step in the profile of round 3)."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, *wb):
+        x = x.contiguous().float()
+        out = torch.empty(x.shape[0], wb[0].shape[0], device=x.device, dtype=torch.float32)
+        lo = 0
+        for g, ne in enumerate(sizes):
+            torch.addmm(wb[2 * g + 1], x[lo:lo + ne], wb[2 * g].t(), out=out[lo:lo + ne])
+            lo += ne
+        ctx.save_for_backward(x, *wb[0::2])
+        ctx.sizes = sizes
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, *ws = ctx.saved_tensors
+        lib = _bind(load_library())
+        g = g.contiguous().float()
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        pf = int(lib.cbd_outer_accum_part_floats())
+        grads, lo = [], 0
+        for k, ne in enumerate(ctx.sizes):
+            gg, xg = g[lo:lo + ne], x[lo:lo + ne]
+            if gx is not None:
+                torch.mm(gg, ws[k], out=gx[lo:lo + ne])
+            n_parts = max(1, min(1024, (ne + 63) // 64))
+            parts = torch.empty(n_parts, pf, device=x.device, dtype=torch.float32)
+            _check(lib.cbd_outer_accum(ne, _ptr(gg), _ptr(xg), n_parts, _ptr(parts), _stream_handle()))
+            tot = parts.sum(0)
+            grads += [tot[:KDIM * KDIM].view(KDIM, KDIM), tot[KDIM * KDIM:]]
+            lo += ne
+        return (gx, None, *grads)
+
+
+def grouped_first_linear(x, sizes, linears):
+    """[linear_g(x[lo_g:hi_g])] concatenated, for nn.Linear(96, 96) modules and group sizes that add up to x.shape[0] (all > 0)."""
+    if not x.is_cuda:
+        raise RuntimeError("grouped_first_linear runs on the MI355X only (HIP weight-gradient kernel, no CPU fallback)")
+    assert sum(sizes) == x.shape[0] and all(n > 0 for n in sizes) and len(sizes) == len(linears)
+    wb = [p for lin in linears for p in (lin.weight, lin.bias)]
+    return GroupedFirstLinearFn.apply(x, tuple(int(n) for n in sizes), *wb)
 
 
 def first_linear(x, linear):
@@ -518,6 +570,13 @@ class ScatterMeanFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         csr = ctx.csr
+        g = g.contiguous().float()
+        width = int(np.prod(g.shape[1:]))
+        if width % 4 == 0:      # one launch: gather + division by the clamped count
+            out = torch.empty((csr.index.shape[0],) + tuple(g.shape[1:]), device=g.device, dtype=torch.float32)
+            _check(_bind(load_library()).cbd_segment_mean_backward(int(csr.index.shape[0]), width, _ptr(g), _ptr(csr.index), _ptr(csr.rowptr),
+                                                                   _ptr(out), _stream_handle()))
+            return out, None
         if getattr(csr, "_inv_counts", None) is None:
             csr._inv_counts = 1.0 / csr.counts.clamp(min=1).to(torch.float32)
         scale = csr._inv_counts.reshape((-1,) + (1,) * (g.dim() - 1))
@@ -574,6 +633,76 @@ class GatherFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return _segment_sum(g, ctx.csr), None
+
+
+class EdgeCatFn(torch.autograd.Function):
+    """[edge_attr | node[src][:32] | node[dst][:32]] (the FCBlock input of a layer) on cbd_edge_cat; backward on
+    cbd_edge_cat_backward: both node gathers' gradients as ONE fixed-order pass into a zero-padded [N, D] tensor."""
+
+    @staticmethod
+    def forward(ctx, edge_attr, node, csr_src, csr_dst):
+        lib = _bind(load_library())
+        edge_attr, node = edge_attr.contiguous().float(), node.contiguous().float()
+        E = edge_attr.shape[0]
+        assert edge_attr.shape[1] == 32 and node.shape[1] >= 32 and csr_src.index.shape[0] == E and csr_dst.index.shape[0] == E
+        out = torch.empty(E, KDIM, device=node.device, dtype=torch.float32)
+        _check(lib.cbd_edge_cat(E, _ptr(edge_attr), _ptr(node), int(node.shape[1]), _ptr(csr_src.index), _ptr(csr_dst.index), _ptr(out),
+                                _stream_handle()))
+        ctx.csrs = (csr_src, csr_dst)
+        ctx.node_shape = tuple(node.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _bind(load_library())
+        cs, cd = ctx.csrs
+        g = g.contiguous().float()
+        N, D = ctx.node_shape
+        g_node = None
+        if ctx.needs_input_grad[1]:
+            g_node = torch.empty(N, D, device=g.device, dtype=torch.float32)
+            _check(lib.cbd_edge_cat_backward(N, D, _ptr(g), _ptr(cs.perm), _ptr(cs.rowptr), _ptr(cd.perm), _ptr(cd.rowptr), _ptr(g_node),
+                                             _stream_handle()))
+        return (g[:, :32] if ctx.needs_input_grad[0] else None), g_node, None, None
+
+
+def edge_cat(edge_attr, node, src, dst):
+    if not node.is_cuda:
+        raise RuntimeError("edge_cat runs on the MI355X only (HIP kernels, no CPU fallback)")
+    n = node.shape[0]
+    return EdgeCatFn.apply(edge_attr, node, csr_of(src, n), csr_of(dst, n))
+
+
+class GatherPadFn(torch.autograd.Function):
+    """node[index] widened to the kernels' 80-float rows (zero padded) on cbd_gather_pad; backward = cbd_segment_sum_ld."""
+
+    @staticmethod
+    def forward(ctx, node, csr):
+        lib = _bind(load_library())
+        node = node.contiguous().float()
+        E = int(csr.index.shape[0])
+        out = torch.empty(E, NODE_STRIDE, device=node.device, dtype=torch.float32)
+        _check(lib.cbd_gather_pad(E, int(node.shape[1]), NODE_STRIDE, _ptr(node), _ptr(csr.index), _ptr(out), _stream_handle()))
+        ctx.csr = csr
+        ctx.node_shape = tuple(node.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _bind(load_library())
+        csr = ctx.csr
+        g = g.contiguous().float()
+        N, D = ctx.node_shape
+        out = torch.empty(N, D, device=g.device, dtype=torch.float32)
+        if N:
+            _check(lib.cbd_segment_sum_ld(N, D, int(g.shape[1]), _ptr(g), _ptr(csr.perm), _ptr(csr.rowptr), _ptr(out), _stream_handle()))
+        return out, None
+
+
+def gather_pad(node, index):
+    if not node.is_cuda:
+        raise RuntimeError("gather_pad runs on the MI355X only (HIP kernels, no CPU fallback)")
+    return GatherPadFn.apply(node, csr_of(index, node.shape[0]))
 
 
 def scatter_mean(src, index, dim_size):

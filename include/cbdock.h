@@ -293,6 +293,10 @@ int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const 
 int cbd_segment_mean(int64_t n_rows, int32_t width, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
                      float* out_dev, void* stream);
 
+/* Backward of cbd_segment_mean: out[e] = g[index[e]] / max(rowptr[index[e] + 1] - rowptr[index[e]], 1); width a multiple of 4. */
+int cbd_segment_mean_backward(int64_t n_edges, int32_t width, const float* g_dev, const int64_t* index_dev, const int64_t* rowptr_dev,
+                              float* out_dev, void* stream);
+
 /* Train-mode e3nn.nn.BatchNorm (0.5.0: affine, normalization='component', reduce='mean') of the fine-tuning step, as the reference's
  * TensorProductConvLayer applies it (models/tensor_layers.py:191-193, 208-209) under model.train() (utils/training.py:186), fused with
  * the layer's residual  out + pad(node_attr)  (:211-213).  x [n][ldx >= dim] (columns >= dim ignored; their gx is zero), out [n][dim] fp32; fields [n_fields][3] int32 = {first column, components,
@@ -307,6 +311,23 @@ int cbd_irreps_bn_forward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields,
 int cbd_irreps_bn_backward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields, const int32_t* fields_dev, const float* g_dev, const float* x_dev,
                            const float* weight_dev, const float* save_mean_dev, const float* save_inv_dev, float* gx_dev, float* gw_dev,
                            float* gb_dev, void* stream);
+/* cbd_segment_sum over rows of stride ld >= width (only the first `width` columns are summed): the backward of cbd_gather_pad. */
+int cbd_segment_sum_ld(int64_t n_rows, int32_t width, int32_t ld, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
+                       float* out_dev, void* stream);
+
+/* Edge-row assembly of the fine-tuning step, one launch each way.
+ * cbd_edge_cat: out[e] = [edge_attr[e] (32) | node[src[e]][:32] | node[dst[e]][:32]] -- the FCBlock input of a layer, reference
+ *   models/score_model.py:319,327,367.  node rows have stride node_ld (even, >= 32).  Backward: g [E][96] -> g_node [n_nodes][node_dim]
+ *   = fixed-order sums of g[:, 32:64] over the edges grouped by src plus g[:, 64:96] over the edges grouped by dst (perm / rowptr from
+ *   cbd_csr_build), columns >= 32 zero; the gradient of edge_attr is g[:, :32] itself.
+ * cbd_gather_pad: out[e][:node_dim] = node[index[e]], out[e][node_dim:out_ld] = 0 -- `node_attr[edge_dst]` of
+ *   models/tensor_layers.py:203 as the 80-float rows cbd_tp_forward reads; its backward is cbd_segment_sum_ld. */
+int cbd_edge_cat(int64_t n_edges, const float* edge_attr_dev, const float* node_dev, int32_t node_ld, const int64_t* src_dev,
+                 const int64_t* dst_dev, float* out_dev, void* stream);
+int cbd_edge_cat_backward(int64_t n_nodes, int32_t node_dim, const float* g_dev, const int64_t* perm_src_dev, const int64_t* rowptr_src_dev,
+                          const int64_t* perm_dst_dev, const int64_t* rowptr_dst_dev, float* g_node_dev, void* stream);
+int cbd_gather_pad(int64_t n_edges, int32_t node_dim, int32_t out_ld, const float* node_dev, const int64_t* index_dev, float* out_dev,
+                   void* stream);
 
 /* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
  * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training

@@ -329,3 +329,54 @@ def test_irreps_batch_norm_kernels_match_the_torch_formulation():
             scale = max(1.0, float(b.abs().max()))
             assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-5 * scale, (irreps, name, float((a - b).abs().max()), scale)
         assert float(outs[0][1][:, D:].abs().max() if wide > D else 0.0) == 0.0
+
+
+def test_edge_row_kernels_match_the_torch_formulation():
+    """cbd_edge_cat / cbd_gather_pad and their backward passes against torch.cat of index_selects / F.pad + index_select with autograd's
+    own backward (fp64 index_add as the yardstick for the fixed-order sums); nodes without edges, repeated edges, every irreps width."""
+    from confidence_bootstrapping_amd.train_ops import edge_cat, gather_pad
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    for N, D, E in ((1, 32, 1), (50, 32, 400), (300, 50, 5000), (1200, 68, 20000), (3300, 74, 60000), (7, 74, 0)):
+        node0 = torch.randn(N, D, generator=g).to(dev)
+        ea0 = torch.randn(E, 32, generator=g).to(dev)
+        src = torch.randint(0, max(N - 1, 1), (E,), generator=g).to(dev)        # the last node never sends
+        dst = torch.randint(0, N, (E,), generator=g).to(dev)
+        w = torch.randn(E, 96, generator=g).to(dev)
+        w80 = torch.randn(E, 80, generator=g).to(dev)
+        res = []
+        for kernel in (True, False):
+            node, ea = node0.clone().requires_grad_(), ea0.clone().requires_grad_()
+            if kernel:
+                out = edge_cat(ea, node, src, dst) if E else torch.zeros(0, 96, device=dev)
+                rows = gather_pad(node, dst)
+            else:
+                out = torch.cat([ea, node[:, :32][src], node[:, :32][dst]], -1)
+                rows = torch.nn.functional.pad(node, (0, 80 - D))[dst]
+            if E:
+                ((out.double() * w.double()).sum() + (rows.double() * w80.double()).sum()).backward()
+            res.append((out.detach(), rows.detach(), node.grad, ea.grad))
+        (o1, r1, gn1, ge1), (o2, r2, gn2, ge2) = res
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and r1.shape == (E, 80)
+        if E:
+            assert torch.equal(ge1, ge2)
+            assert float((gn1 - gn2).abs().max()) <= 1e-5 * max(1.0, float(gn2.abs().max()))
+
+
+def test_scatter_mean_matches_torch_scatter_semantics():
+    """cbd_segment_mean / cbd_segment_mean_backward against sum / clamp(count, 1) built from index_add in fp64, rows without edges
+    included; widths with (80, 12, 64) and without (3) the one-launch backward."""
+    from confidence_bootstrapping_amd.train_ops import scatter_mean
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for E, N, W in ((1, 1, 80), (5000, 300, 80), (64, 8, 12), (997, 130, 64), (500, 40, 3)):
+        idx = torch.randint(0, max(N - 1, 1), (E,), generator=g).to(dev)
+        src = torch.randn(E, W, generator=g).to(dev).requires_grad_()
+        wgt = torch.randn(N, W, generator=g).to(dev)
+        out = scatter_mean(src, idx, N)
+        cnt = torch.bincount(idx, minlength=N).clamp(min=1).double()[:, None]
+        ref = torch.zeros(N, W, device=dev, dtype=torch.float64).index_add(0, idx, src.detach().double()) / cnt
+        assert float((out.double() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max()))
+        (out * wgt).sum().backward()
+        refg = (wgt.double() / cnt)[idx]
+        assert float((src.grad.double() - refg).abs().max()) <= 1e-6 * max(1.0, float(refg.abs().max()))

@@ -18,6 +18,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--rows", type=int, default=45)
+    ap.add_argument("--fused-adam", action="store_true")
+    ap.add_argument("--blas", default=None, help="torch.backends.cuda.preferred_blas_library: cublas (= rocBLAS) | cublaslt (= hipBLASLt)")
+    ap.add_argument("--regions", action="store_true", help="GPU launches per forward region and per backward node type")
+    ap.add_argument("--plain", action="store_true", help="free-running steps only (for rocprofv3 --kernel-trace; see tools/gap_stats.py)")
     ap.add_argument("--cprofile", action="store_true", help="Python-level profile (cProfile) of 16 free-running steps instead of the op table")
     a = ap.parse_args()
     from confidence_bootstrapping_amd.synthetic import make_complex, WORKLOADS
@@ -30,7 +34,9 @@ def main():
     margs = load_model_args()
     model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    if a.blas:
+        torch.backends.cuda.preferred_blas_library(a.blas)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, **({"fused": True} if a.fused_adam else {}))
     ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
     t2s = partial(t_to_sigma, args=margs)
     loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
@@ -39,6 +45,9 @@ def main():
     np.random.seed(0); torch.manual_seed(0)
     batches = [[nt(c.shallow_copy()) for c in base] for _ in range(8)]   # like CBBuffer.get: shallow copies sharing the complex's tensors
     sync = torch.cuda.synchronize
+    from contextlib import nullcontext
+    from torch.profiler import record_function
+    reg = (lambda n: record_function("R:" + n)) if a.regions else (lambda n: nullcontext())
 
     def step(data, tm=None):
         def lap(name, t0):
@@ -47,28 +56,41 @@ def main():
                 tm[name] = tm.get(name, 0.0) + time.perf_counter() - t0
             return time.perf_counter()
         t = time.perf_counter()
-        opt.zero_grad()
+        with reg("zero_grad"):
+            opt.zero_grad()
         t = lap("zero_grad", t)
-        out = forward(model, data)
+        with reg("forward_other"):
+            out = forward(model, data)
         t = lap("forward (incl. collate)", t)
-        lt = loss_fn(*out, data=data, t_to_sigma=t2s, device=dev)
+        with reg("loss"):
+            lt = loss_fn(*out, data=data, t_to_sigma=t2s, device=dev)
         t = lap("loss", t)
         lt[0].backward()
         t = lap("backward", t)
-        opt.step()
+        with reg("adam"):
+            opt.step()
         t = lap("adam", t)
-        ema.update(model.parameters())
+        with reg("ema"):
+            ema.update(model.parameters())
         t = lap("ema", t)
 
     for k in range(12):             # the caching allocator needs a few steps of every size before it stops calling hipMalloc
         step(batches[k % 8])
     sync()
-    for rep in range(3):
+    reps = []
+    for rep in range(10 if a.plain else 3):
         t0 = time.perf_counter()
         for k in range(16):
             step(batches[k % 8])
         sync()
-        print(f"batch {a.batch}: {(time.perf_counter() - t0) / 16 * 1e3:.1f} ms per step (free-running, 16 steps)")
+        reps.append((time.perf_counter() - t0) / 16 * 1e3)
+        if not a.plain:
+            print(f"batch {a.batch}: {reps[-1]:.1f} ms per step (free-running, 16 steps)")
+    if a.plain:
+        print(f"batch {a.batch}: free-running ms per step over {len(reps)} x 16 steps: min {min(reps):.1f} median {sorted(reps)[len(reps) // 2]:.1f} all",
+              " ".join(f"{r:.1f}" for r in reps))
+    if a.plain:
+        return
     if a.cprofile:
         import cProfile, pstats
         pr = cProfile.Profile()
@@ -85,8 +107,52 @@ def main():
     for k in range(8):
         step(batches[k], tm)
     print("with a synchronisation after every phase (ms per step):", {k: round(v / 8 * 1e3, 2) for k, v in tm.items()})
-    # host time of enqueueing alone: the same step with the GPU made irrelevant is not possible, so count ops instead
     from torch.profiler import profile, ProfilerActivity
+    if a.regions:
+        import collections
+        from torch.profiler import record_function
+        import confidence_bootstrapping_amd.train_forward as tf
+        import confidence_bootstrapping_amd.train_ops as to
+        import confidence_bootstrapping_amd.training as tr
+
+        def wrap(mod, name):
+            fn = getattr(mod, name)
+
+            def inner(*x, **k):
+                with record_function("R:" + name):
+                    return fn(*x, **k)
+            setattr(mod, name, inner)
+        for name in ("collate", "radius", "radius_graph", "conv_layer", "atom_encoder", "center_tensor_product", "bond_tensor_product",
+                     "irreps_batch_norm", "gaussian_smearing", "edge_cat", "gather_pad", "take"):
+            wrap(tf, name)
+        wrap(to, "csr_of")
+
+        to.StreamHub.pack = (lambda f: (lambda self: (lambda r: r)(f(self))))(to.StreamHub.pack)
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            with record_function("R:step"):
+                step(batches[7])
+            sync()
+        LAUNCH = ("hipLaunchKernel", "hipExtModuleLaunchKernel", "hipMemcpyAsync", "hipMemsetAsync")
+        evs = [e for e in prof.events()]
+        launches = sorted((e.time_range.start, e) for e in evs if e.name in LAUNCH)
+        named = [e for e in evs if e.name.startswith("R:") or e.name.startswith("autograd::engine::evaluate_function")]
+        named.sort(key=lambda e: (e.time_range.start, -e.time_range.end))
+        count = collections.Counter()
+        ncall = collections.Counter()
+        for e in named:
+            ncall[e.name] += 1
+        for t, l in launches:
+            owner = None
+            for e in named:                     # innermost enclosing named range on the same thread
+                if e.thread == l.thread and e.time_range.start <= t <= e.time_range.end:
+                    if owner is None or e.time_range.start >= owner.time_range.start:
+                        owner = e
+            count[owner.name if owner else "(outside)"] += 1
+        print("GPU launches by innermost forward region / backward node type (one step):")
+        for name, n in count.most_common(60):
+            print(f"  {n:6d}  calls {ncall[name]:5d}  {name}")
+        print("  total", sum(count.values()))
+        return
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         step(batches[7])
         sync()
