@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, radius_queries, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
                         grouped_first_linear,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
@@ -70,7 +70,8 @@ def collate(data_list: List[HeteroData], device) -> Batch:
     rot = np.concatenate([np.flatnonzero(d["ligand"].edge_mask.numpy()) + o for d, o in zip(data_list, eo)]).astype(np.int64)
     fparts = [d["ligand"].pos.reshape(-1).float() for d in data_list] + [t_host["tr"], t_host["rot"], t_host["tor"]]
     iparts = [torch.from_numpy(a) for a in (np.repeat(np.arange(len(nl)), nl), np.repeat(np.arange(len(nr)), nr), rot,
-                                            np.repeat(np.asarray(lo, dtype=np.int64), ne_l), np.repeat(np.asarray(ro, dtype=np.int64), ne_r))]
+                                            np.repeat(np.asarray(lo, dtype=np.int64), ne_l), np.repeat(np.asarray(ro, dtype=np.int64), ne_r),
+                                            np.concatenate([[0], np.cumsum(nl)]).astype(np.int64), np.concatenate([[0], np.cumsum(nr)]).astype(np.int64))]
 
     def stage(parts, dtype):
         n = sum(int(p.numel()) for p in parts)
@@ -112,6 +113,7 @@ def collate(data_list: List[HeteroData], device) -> Batch:
     # columns of the batch's bond list that are rotatable bonds (the mask is host data: no boolean indexing on the device, which would
     # read the count back)
     b.rot_bond_cols = idev[2]
+    b.lig_ptr, b.rec_ptr = idev[5], idev[6]        # node offsets of the graphs: the batched radius searches scan [ptr[b], ptr[b + 1])
     torch.cuda.current_stream(device).wait_stream(side)
     _keep_until_main_passes(keep_alive, device)
     return b
@@ -479,18 +481,29 @@ def _prepare(model, data, host, dev) -> _Prepared:
     edge_mask = lig.edge_mask.bool()
     # the three radius graphs of the step: masks first, ONE read-back of the three edge counts, then compaction without read-backs
     cutoff = (g.tr_sigma * 3 + 20).unsqueeze(1)
-    m_ll = radius_graph_mask(lig_pos, model.lig_max_radius, lig_batch)
-    m_lr = radius_mask(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
-    bonds = bond_pos = m_t = None
+    bonds = bond_pos = None
     if sum(n_rot):
         cols = getattr(data, "rot_bond_cols", None)
         bonds = bond_ei.index_select(1, cols) if cols is not None else bond_ei[:, edge_mask]
         bond_pos = (lig_pos[bonds[0]] + lig_pos[bonds[1]]) / 2
-        m_t = radius_mask(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]])
-    n_edges = torch.stack([m.sum() for m in (m_ll, m_lr, m_t) if m is not None]).tolist()
-    ei = mask_edges(m_ll, n_edges[0])
+    lig_ptr, rec_ptr = getattr(data, "lig_ptr", None), getattr(data, "rec_ptr", None)
+    if lig_ptr is not None:         # HIP searches: count, one read-back for all three graphs, fill (train_ops.RadiusQuery)
+        qs = [RadiusQuery(lig_pos, lig_pos, model.lig_max_radius, lig_ptr, lig_batch, 32 + 1, drop_self=True),
+              RadiusQuery(rec_pos, lig_pos, 1.0, rec_ptr, lig_batch, 10000, cutoff=cutoff)]
+        if bonds is not None:
+            qs.append(RadiusQuery(lig_pos, bond_pos, model.lig_max_radius, lig_ptr, lig_batch[bonds[0]], 32))
+        found = radius_queries(qs)
+        ei, lr = found[0], found[1]
+        t_edges = found[2] if bonds is not None else None
+    else:                           # a batch collated elsewhere: dense masks, one read-back of their three counts
+        m_ll = radius_graph_mask(lig_pos, model.lig_max_radius, lig_batch)
+        m_lr = radius_mask(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
+        m_t = radius_mask(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]]) if bonds is not None else None
+        n_edges = torch.stack([m.sum() for m in (m_ll, m_lr, m_t) if m is not None]).tolist()
+        ei, lr = mask_edges(m_ll, n_edges[0]), mask_edges(m_lr, n_edges[1])
+        t_edges = mask_edges(m_t, n_edges[2]) if m_t is not None else None
     radius_edges = torch.stack([ei[1], ei[0]], dim=0)          # [neighbour; centre]
-    lr = g.lr = mask_edges(m_lr, n_edges[1])
+    g.lr = lr
     r_ei = g.r_ei = data["receptor", "receptor"].edge_index.long()
     nL, nR = lig_pos.shape[0], rec_pos.shape[0]
     g.nL = nL
@@ -528,8 +541,8 @@ def _prepare(model, data, host, dev) -> _Prepared:
     g.center_smear = gaussian_smearing(model.center_distance_expansion, g.c_vec2.norm(dim=-1))
     # torsion graph (score_model.py:650-664)
     g.bonds, g.t_ei = bonds, None
-    if m_t is not None:
-        t_ei = g.t_ei = mask_edges(m_t, n_edges[2])
+    if t_edges is not None:
+        t_ei = g.t_ei = t_edges
         g.t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
         g.t_smear = gaussian_smearing(model.lig_distance_expansion, g.t_vec.norm(dim=-1))
         g.bond_vec_e = (lig_pos[bonds[1]] - lig_pos[bonds[0]])[t_ei[0]]

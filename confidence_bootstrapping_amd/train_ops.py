@@ -721,3 +721,40 @@ def gather_rows(x, index):
     if index.shape[0] == 0:
         return x.index_select(0, index)
     return GatherFn.apply(x, csr_of(index, x.shape[0]))
+
+
+# ----------------------------------------------------------------------------- radius graphs
+class RadiusQuery:
+    """One batched radius search (cbd_radius_count now, cbd_radius_fill after the edge counts of ALL searches of the step have been read
+    back together).  x, y: [n, 3] fp32; xptr [B + 1] node offsets of the graphs in x; ybatch [len(y)] graph of every query."""
+
+    def __init__(self, x, y, r, xptr, ybatch, cap, drop_self=False, cutoff=None):
+        if not x.is_cuda:
+            raise RuntimeError("the radius search runs on the MI355X only (HIP kernels, no CPU fallback)")
+        self.x, self.y = x.contiguous().float(), y.contiguous().float()
+        self.cut = None if cutoff is None else cutoff.contiguous().float().reshape(-1)
+        self.r2, self.cap, self.drop = float(np.float32(r) * np.float32(r)), int(cap), int(bool(drop_self))
+        self.xptr, self.ybatch = xptr.contiguous(), ybatch.contiguous()
+        assert self.xptr.dtype == torch.long and self.ybatch.dtype == torch.long
+        self.ny = int(self.y.shape[0])
+        self.counts = torch.empty(self.ny, dtype=torch.long, device=x.device)
+        _check(_bind(load_library()).cbd_radius_count(self.ny, _ptr(self.x), _ptr(self.y), None if self.cut is None else _ptr(self.cut), self.r2,
+                                                      _ptr(self.xptr), _ptr(self.ybatch), self.cap, self.drop, _ptr(self.counts), _stream_handle()))
+        incl = torch.cumsum(self.counts, 0)
+        self.offsets = incl - self.counts
+        self.total = incl[-1] if self.ny else torch.zeros((), dtype=torch.long, device=x.device)
+
+    def edges(self, n_edges: int) -> torch.Tensor:
+        """[2, n_edges]: row 0 = query index, row 1 = point index (torch_cluster.radius order)"""
+        out = torch.empty(2, int(n_edges), dtype=torch.long, device=self.x.device)
+        if n_edges:
+            _check(_bind(load_library()).cbd_radius_fill(self.ny, _ptr(self.x), _ptr(self.y), None if self.cut is None else _ptr(self.cut), self.r2,
+                                                         _ptr(self.xptr), _ptr(self.ybatch), self.cap, self.drop, _ptr(self.offsets), _ptr(out[0]),
+                                                         _ptr(out[1]), _stream_handle()))
+        return out
+
+
+def radius_queries(queries):
+    """edge lists of several RadiusQuery objects with ONE device->host read-back (their edge counts)"""
+    totals = torch.stack([q.total for q in queries]).tolist()
+    return [q.edges(n) for q, n in zip(queries, totals)]

@@ -329,6 +329,19 @@ int cbd_edge_cat_backward(int64_t n_nodes, int32_t node_dim, const float* g_dev,
 int cbd_gather_pad(int64_t n_edges, int32_t node_dim, int32_t out_ld, const float* node_dev, const int64_t* index_dev, float* out_dev,
                    void* stream);
 
+/* Batched radius search of the fine-tuning step: torch_cluster.radius / radius_graph as the reference's training forward calls them
+ * (models/score_model.py:498-503, 573-580, 652-656).  For every query y[q] (graph ybatch[q]) the points x[j], j in
+ * [xptr[b], xptr[b+1]) of the same graph with |x/c - y/c|^2 < r2 (c = cutoff[b], or 1 when cutoff_dev is NULL), the first `cap` of them
+ * in index order; with drop_self the point j == q counts towards the cap but is not returned (radius_graph: cap = max_neighbors + 1).
+ * cbd_radius_count writes the number of edges per query; the caller scans them (exclusive) and passes the offsets to cbd_radius_fill,
+ * which writes (query, point) pairs, sorted by query then point.  x, y: [n][3] fp32.  The distance arithmetic rounds like the torch
+ * ops of the mask formulation (x - y, separate multiply and add, IEEE division), so the edge set is identical bit for bit. */
+int cbd_radius_count(int64_t n_query, const float* x_dev, const float* y_dev, const float* cutoff_dev, float r2, const int64_t* xptr_dev,
+                     const int64_t* ybatch_dev, int64_t cap, int32_t drop_self, int64_t* counts_dev, void* stream);
+int cbd_radius_fill(int64_t n_query, const float* x_dev, const float* y_dev, const float* cutoff_dev, float r2, const int64_t* xptr_dev,
+                    const int64_t* ybatch_dev, int64_t cap, int32_t drop_self, const int64_t* offsets_dev, int64_t* out_query_dev,
+                    int64_t* out_point_dev, void* stream);
+
 /* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
  * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training
  * graph of utils/training.py:198-205; torch's stable sort synchronises the stream).  Everything is enqueued on `stream`; scratch is the

