@@ -536,7 +536,7 @@ def _prepare(model, data, host, dev) -> _Prepared:
     g.vec4_2 = g.vec4[:g.s2]
     # centre geometry (score_model.py:635-648)
     counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
-    center = torch.zeros(B, 3, device=dev, dtype=lig_pos.dtype).index_add_(0, lig_batch, lig_pos) / counts
+    center = scatter_sum(lig_pos, lig_batch, B) / counts          # fixed-order segmented sum (an index_add_ here would be atomic)
     g.c_vec2 = lig_pos - center[lig_batch]
     g.center_smear = gaussian_smearing(model.center_distance_expansion, g.c_vec2.norm(dim=-1))
     # torsion graph (score_model.py:650-664)
