@@ -37,11 +37,20 @@ __host__ __device__ constexpr size_t fctp_stream_floats(int ntiles) { return (si
 struct FctpShape {
   int n1o, n1e, n0o;
   int fan0e, fan1o, fan1e, fan0o;
-  int g0e, t1o, t1e, g0o;     // scalar blocks: groups of 4 mids (3 tiles each); vector blocks: tiles of 5 mids
+  int g0e, t1o, t1e, g0o;     // scalar blocks: groups of 4 mids (3 tiles each; 2 for a tail of <= 2 mids); vector blocks: tiles of 5 mids
   int ntiles;
   int weight_numel;           // 720 / 972 / 1224 / 1944
   int in_dim, out_dim;
 };
+
+// Tiles of a scalar block with `fan` mids: three per full group of 4 mids; a TAIL group of one or two mids takes two denser tiles instead
+// of three half-empty ones -- tile A = slots (mid0, outputs 0..7) (mid1, 0..7) (mid0, 8..15) (mid1, 8..15), tile B = (mid0, 16..23)
+// (mid1, 16..23) + 16 zero rows.  (Every tail of the shipped architecture has two mids: fan = 30.)
+__host__ __device__ constexpr bool sc_tail_dense(int fan, int g) { return fan - C_SC_TILE_I * g >= 1 && fan - C_SC_TILE_I * g <= 2; }
+__host__ __device__ constexpr int sc_block_tiles(int fan) {
+  const int groups = (fan + C_SC_TILE_I - 1) / C_SC_TILE_I;
+  return groups == 0 ? 0 : 3 * (groups - 1) + (sc_tail_dense(fan, groups - 1) ? 2 : 3);
+}
 
 __host__ __device__ constexpr FctpShape fctp_shape(int IN, int OUT) {
   FctpShape s{};
@@ -56,7 +65,7 @@ __host__ __device__ constexpr FctpShape fctp_shape(int IN, int OUT) {
   s.t1o = (s.fan1o + C_VEC_TILE_I - 1) / C_VEC_TILE_I;
   s.t1e = (s.fan1e + C_VEC_TILE_I - 1) / C_VEC_TILE_I;
   s.g0o = (s.fan0o + C_SC_TILE_I - 1) / C_SC_TILE_I;
-  s.ntiles = 3 + 3 * s.g0e + s.t1o + s.t1e + 3 * s.g0o;
+  s.ntiles = 3 + sc_block_tiles(s.fan0e) + s.t1o + s.t1e + sc_block_tiles(s.fan0o);
   s.weight_numel = s.fan0e * CNS + s.fan1o * CNV + s.fan1e * CNV + s.fan0o * CNS;
   s.in_dim = CNS + 3 * s.n1o + 3 * s.n1e + s.n0o;
   s.out_dim = CNS + 3 * CNV + (OUT >= 2 ? 3 * CNV : 0) + (OUT >= 3 ? CNS : 0);

@@ -166,14 +166,22 @@ static std::vector<float> pack_fctp_stream(int IN, int OUT, const float* W1, con
   int wc[32];
   float sc[32];
   auto scalar_block = [&](int out_kind, const std::vector<MidSeg>& segs, int fan, int ngroups) {
-    for (int g = 0; g < ngroups; ++g)
-      for (int q = 0; q < 3; ++q, ++T) {
+    for (int g = 0; g < ngroups; ++g) {
+      const bool dense = sc_tail_dense(fan, g);       // tail of <= 2 mids: two denser tiles (conf_common.h)
+      for (int q = 0; q < (dense ? 2 : 3); ++q, ++T) {
         for (int r = 0; r < 32; ++r) {
-          const int i = C_SC_TILE_I * g + (r >> 3), w = 8 * q + (r & 7);
+          const int slot = r >> 3;
+          int i = C_SC_TILE_I * g + slot, w = 8 * q + (r & 7);
+          if (dense) {
+            i = C_SC_TILE_I * g + (slot & 1);
+            w = (q == 0 ? 8 * (slot >> 1) : 16) + (r & 7);
+            if (q == 1 && slot >= 2) i = fan;         // zero rows
+          }
           if (!column(out_kind, segs, fan, i, w, &wc[r], &sc[r])) { wc[r] = -1; sc[r] = 0.f; }
         }
         fill_tile(T, wc, sc);
       }
+    }
   };
   auto vector_block = [&](int out_kind, const std::vector<MidSeg>& segs, int fan, int ntile) {
     for (int t = 0; t < ntile; ++t, ++T) {

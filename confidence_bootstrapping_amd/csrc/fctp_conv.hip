@@ -233,6 +233,20 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
         for (int c = 0; c < 4; ++c) out[4 * q + c] = fmaf(m[i], acc[4 * i + c], out[4 * q + c]);
     }
   };
+  // tail group of one or two mids in two denser tiles (conf_common.h::sc_tail_dense): tile A carries output octets 0 and 1 of both
+  // mids (slot i = (mid i & 1, octet i >> 1)), tile B octet 2 (slots 0, 1)
+  auto scalar_tail = [&](const float (&m)[4], float (&out)[12]) __attribute__((always_inline)) {
+    CBD_CTILE(h1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[4 * (i >> 1) + c] = fmaf(m[i & 1], acc[4 * i + c], out[4 * (i >> 1) + c]);
+    CBD_CTILE(h1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) out[8 + c] = fmaf(m[i], acc[4 * i + c], out[8 + c]);
+  };
   constexpr int G0E_PLAIN = CNS / 4;   // groups 0 .. G0E_PLAIN-1 of block 0e read x0e[4g .. 4g+3]
 #pragma unroll 1
   for (int g = 0; g < G0E_PLAIN; ++g) {
@@ -244,7 +258,8 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
     float m[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = cmid0e<IN>(xc, 4 * g + i, n);
-    scalar_group(m, o0e);
+    if (sc_tail_dense(S.fan0e, g)) scalar_tail(m, o0e);
+    else scalar_group(m, o0e);
 #pragma unroll
     for (int r = 0; r < 12; ++r) pin(o0e[r]);   // ties the FMAs of an unrolled group to its place (tp_conv.hip)
   }
@@ -310,7 +325,8 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       float m[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
-      scalar_group(m, o0o);
+      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o);
+      else scalar_group(m, o0o);
 #pragma unroll
       for (int r = 0; r < 12; ++r) pin(o0o[r]);
     }
@@ -325,7 +341,8 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       float m[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
-      scalar_group(m, o0o);
+      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o);
+      else scalar_group(m, o0o);
 #pragma unroll
       for (int r = 0; r < 12; ++r) pin(o0o[r]);
     }

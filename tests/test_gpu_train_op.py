@@ -123,3 +123,52 @@ def test_first_linear_weight_gradient_kernel(E):
     rel = lambda a, b: float((a.detach().double() - b.detach()).abs().max() / b.detach().abs().max())
     assert rel(y, y64) < 1e-5 and rel(x.grad, x64.grad) < 1e-5
     assert rel(lin.weight.grad, lin64.weight.grad) < 2e-5 and rel(lin.bias.grad, lin64.bias.grad) < 2e-5
+
+
+def test_stream_hub_path_equals_the_per_block_streams():
+    """The training forward packs the tile streams of all FCBlocks once per step (train_ops.StreamHub) and returns their gradients
+    through one buffer; the per-block form (`StreamMap.stream` + TensorProductFn, checked against the oracle above) must give the same
+    messages and the same gradients for x, h and every fc[3] parameter -- blocks of two different irreps levels, one of them unused
+    in the step (its gradient must be zero, not garbage)."""
+    from confidence_bootstrapping_amd.score_model import FCBlock, faster_tp_weight_numel, get_irrep_seq
+    from confidence_bootstrapping_amd.train_ops import tensor_product, stream_map, StreamHub, TensorProductHubFn
+    seq = get_irrep_seq(32, 6, False, True)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(7)
+    levels = [(3, 3), (3, 3), (1, 2), (3, 3)]                 # block 3 takes no part in the step
+    fcs = [FCBlock(96, 96, faster_tp_weight_numel(seq[i], seq[o]), 0.0).to(dev) for i, o in levels]
+    hub = StreamHub([(fc, i, o) for fc, (i, o) in zip(fcs, levels)], dev)
+    calls = [((3, 3), [0, 1], [300, 41]), ((1, 2), [2], [77])]
+    data = []
+    for (i, o), blocks, sizes in calls:
+        E = sum(sizes)
+        data.append((torch.randn(E, 80, device=dev), F.pad(F.normalize(torch.randn(E, 3, device=dev), dim=-1), (0, 1)),
+                     torch.relu(torch.randn(E, 96, device=dev)), torch.randn(E, 80, device=dev)))
+
+    def run(use_hub):
+        for fc in fcs:
+            fc.zero_grad(set_to_none=True)
+        if use_hub:
+            hub.pack()
+        outs = []
+        for ((i, o), blocks, sizes), (x, v, h, gout) in zip(calls, data):
+            x, h = x.clone().requires_grad_(), h.clone().requires_grad_()
+            if use_hub:
+                msg = TensorProductHubFn.apply(x, v, h, hub.big, hub, i, o, tuple(sizes), tuple(blocks))
+            else:
+                msg = tensor_product(x, v, h, [stream_map(i, o).stream(fcs[b]) for b in blocks], i, o, sizes)
+            outs.append((msg, x, h, gout))
+        sum((m * g).sum() for m, _, _, g in outs).backward()
+        return ([m.detach() for m, _, _, _ in outs], [x.grad for _, x, _, _ in outs], [h.grad for _, _, h, _ in outs],
+                [(fc[3].weight.grad.clone() if fc[3].weight.grad is not None else None, fc[3].bias.grad.clone() if fc[3].bias.grad is not None else None)
+                 for fc in fcs])
+
+    a, b = run(True), run(False)
+    for k in range(3):
+        for t, u in zip(a[k], b[k]):
+            assert torch.equal(t, u)
+    for blk, ((wa, ba), (wb, bb)) in enumerate(zip(a[3], b[3])):
+        if blk == 3:
+            assert float(wa.abs().max()) == 0.0 and float(ba.abs().max()) == 0.0 and wb is None
+            continue
+        assert float((wa - wb).abs().max()) <= 1e-6 * float(wb.abs().max()) and float((ba - bb).abs().max()) <= 1e-6 * float(bb.abs().max()), blk

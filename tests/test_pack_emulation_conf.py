@@ -52,7 +52,9 @@ def quad(a, n):
 
 def emulate(stream, IN, OUT, xin, xrow, n):
     S = shape(IN, OUT)
-    nt = 3 + 3 * S["g0e"] + S["t1o"] + S["t1e"] + 3 * S["g0o"]
+    dense = lambda fan, g: 1 <= fan - 4 * g <= 2          # tail group of <= 2 mids: two denser tiles (conf_common.h::sc_tail_dense)
+    sc_tiles = lambda fan: 0 if fan == 0 else 3 * ((fan + 3) // 4 - 1) + (2 if dense(fan, (fan + 3) // 4 - 1) else 3)
+    nt = 3 + sc_tiles(S["fan0e"]) + S["t1o"] + S["t1e"] + sc_tiles(S["fan0o"])
     assert stream.size == (nt + 1) * TILE_W + nt * 32
     wts, bias = stream[:nt * TILE_W].reshape(nt, TILE_W), stream[(nt + 1) * TILE_W:].reshape(nt, 32)
     tiles = [(wts[k], bias[k]) for k in range(nt)]
@@ -98,10 +100,25 @@ def emulate(stream, IN, OUT, xin, xrow, n):
 
     out = np.zeros((32, STRIDE))
 
-    def scalar_block(ngroups, mid, col0):
+    def scalar_block(ngroups, mid, col0, fan):
         nonlocal T
         keep = np.zeros((12, 64))
         for g in range(ngroups):
+            if dense(fan, g):         # tile A: slot i = (mid i & 1, output octet i >> 1); tile B: slots 0, 1 = octet 2
+                acc = gemm_tile(tiles[T], h1); T += 1
+                for lane in range(64):
+                    for i in range(4):
+                        m = mid(lane & 31, 4 * g + (i & 1))
+                        for c in range(4):
+                            keep[4 * (i >> 1) + c, lane] += m * acc[4 * i + c, lane]
+                acc = gemm_tile(tiles[T], h1); T += 1
+                for lane in range(64):
+                    assert np.all(acc[8:, lane] == 0)
+                    for i in range(2):
+                        m = mid(lane & 31, 4 * g + i)
+                        for c in range(4):
+                            keep[8 + c, lane] += m * acc[4 * i + c, lane]
+                continue
             for q in range(3):
                 acc = gemm_tile(tiles[T], h1); T += 1
                 for lane in range(64):
@@ -129,12 +146,12 @@ def emulate(stream, IN, OUT, xin, xrow, n):
                 oo = 3 * (lane >> 5) + o
                 out[lane & 31, col0 + 3 * oo:col0 + 3 * oo + 3] = keep[o, :, lane]
 
-    scalar_block(S["g0e"], mid0e, 0)
+    scalar_block(S["g0e"], mid0e, 0, S["fan0e"])
     vec_block(S["t1o"], mid1o, C1O)
     if OUT >= 2:
         vec_block(S["t1e"], mid1e, C1E)
     if OUT >= 3:
-        scalar_block(S["g0o"], mid0o, C0O)
+        scalar_block(S["g0o"], mid0o, C0O, S["fan0o"])
     assert T == len(tiles)
     return out
 
