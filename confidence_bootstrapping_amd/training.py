@@ -159,6 +159,28 @@ def sync_batchnorm_buffers(model):
         model.invalidate_engine()
 
 
+_NAN_FLAGS = {}
+
+
+def _async_any_nan(t):
+    """-> callable returning bool(isnan(t).any()); for a device tensor the flag travels through a pinned host buffer behind an event,
+    so calling it later waits for that copy only (not for work enqueued after it)"""
+    bad = torch.isnan(t).any()
+    if not bad.is_cuda:
+        return lambda: bool(bad)
+    buf = _NAN_FLAGS.get(str(t.device))
+    if buf is None:
+        buf = _NAN_FLAGS[str(t.device)] = torch.zeros(1, dtype=torch.bool, pin_memory=True)
+    buf.copy_(bad.reshape(1), non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(t.device))
+
+    def read():
+        ev.synchronize()
+        return bool(buf[0])
+    return read
+
+
 _PARAM_LISTS = __import__("weakref").WeakKeyDictionary()
 
 
@@ -184,11 +206,14 @@ def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=
         tr_pred, rot_pred, tor_pred, sc = forward_fn(model, data)
         loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sc, data=data, t_to_sigma=t_to_sigma, device=device)
         loss = loss_tuple[0]
-        # the backward pass is enqueued BEFORE the loss is read back: checking first (as the reference does, utils/training.py:201)
-        # flushes the pipeline in the middle of the step and the host then enqueues the whole backward pass with the GPU idle.  A
-        # NaN loss gives NaN gradients, which are discarded below exactly as if backward had not run.
+        # NaN check without a pipeline flush.  The reference tests the loss between forward and backward (utils/training.py:201); on an
+        # asynchronous device that read-back drains the GPU and the host then enqueues the whole backward pass with the GPU idle.  Here
+        # the flag is COPIED to pinned host memory asynchronously, the backward pass is enqueued, and only then is the copy waited for:
+        # by that time the forward pass has long finished, so the wait is over the copy alone, not over the backward pass.  A NaN
+        # loss gives NaN gradients, which are discarded below exactly as if backward had not run.
+        nan_flag = _async_any_nan(loss.detach())
         loss.backward()
-        if torch.any(torch.isnan(loss.detach())):
+        if nan_flag():
             skip = True
     if not allreduce_gradients(model, skip=skip):
         optimizer.zero_grad()
