@@ -337,6 +337,24 @@ class _HubFn(torch.autograd.Function):
         return hub.grads.index_select(0, hub.p2g) * hub.pscale, None
 
 
+def _weight_grad(gw, h, dw):
+    """dw = gw^T h  ([Wp, E] x [E, 96]) for E up to 10^5..10^6 edge rows.  The library runs this shape WITHOUT split-K: 19 x 3 macro-tiles
+    = 57 workgroups on 256 CUs, 56-69 TFLOP/s.  Cut into 16 edge chunks as one batched GEMM (912 workgroups) plus a fixed-order sum of the
+    partial products it reaches 112-117 TFLOP/s (tools/micro-benchmarks of round 3: E = 50 000: 0.275 -> 0.155 ms, E = 74 000: 0.378 ->
+    0.231 ms; with only 3-4 chunks it is SLOWER than the plain call)."""
+    E = gw.shape[0]
+    S = 16 if E >= 16384 else 8 if E >= 4096 else 1
+    if S == 1:
+        torch.mm(gw.t(), h, out=dw)
+        return
+    chunk = E // S
+    main = chunk * S
+    part = torch.bmm(gw[:main].view(S, chunk, -1).transpose(1, 2), h[:main].view(S, chunk, -1))
+    torch.sum(part, 0, out=dw)
+    if main < E:
+        dw.addmm_(gw[main:].t(), h[main:])
+
+
 class TensorProductHubFn(torch.autograd.Function):
     """TensorProductFn with the weight streams (and the way back for their gradients) in a StreamHub: `big` is an input only so that
     autograd runs the hub's backward after every tensor-product backward."""
@@ -381,10 +399,8 @@ class TensorProductHubFn(torch.autograd.Function):
                 if gh is not None:
                     torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
                 dw, db = hub.grad_views(b)
-                # measured and dropped (round 3): a manual split-K (bmm over 8-16 edge chunks + sum) is slower than the library's
-                # own choice for [Wp, E] x [E, 96]; the column sums as a matrix-vector product are 10x slower than the reduction
-                torch.mm(gwg.t(), h[lo:hi], out=dw)
-                torch.sum(gwg, 0, out=db)
+                _weight_grad(gwg, h[lo:hi], dw)
+                torch.sum(gwg, 0, out=db)        # (as a matrix-vector product these column sums are 10x slower: measured)
             lo = hi
         return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
 
