@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, radius_queries, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
                         grouped_first_linear,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
@@ -32,7 +32,7 @@ SQ3 = math.sqrt(3.0)
 
 
 # ----------------------------------------------------------------------------- batching
-def collate(data_list: List[HeteroData], device) -> Batch:
+def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
     """Collation of the fields the score model reads (what PyG's Batch gives the reference): node tensors concatenated,
     edge_index offset per graph, `batch` vectors, per-graph diffusion times (utils/diffusion_utils.py:150-179) as tensors.
     Per-graph host-to-device copies on a side stream, concatenated on the device; the input graphs are not copied or modified."""
@@ -114,8 +114,11 @@ def collate(data_list: List[HeteroData], device) -> Batch:
     # read the count back)
     b.rot_bond_cols = idev[2]
     b.lig_ptr, b.rec_ptr = idev[5], idev[6]        # node offsets of the graphs: the batched radius searches scan [ptr[b], ptr[b + 1])
-    torch.cuda.current_stream(device).wait_stream(side)
-    _keep_until_main_passes(keep_alive, device)
+    if keep is None:            # stand-alone use: the compute stream waits here; prepare_batch() hands an event to forward() instead
+        torch.cuda.current_stream(device).wait_stream(side)
+        _keep_until_main_passes(keep_alive, device)
+    else:
+        keep.extend(keep_alive)
     return b
 
 
@@ -460,7 +463,7 @@ class _Prepared:
         return out
 
 
-def _prepare(model, data, host, dev) -> _Prepared:
+def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
     """Everything of the forward pass that depends on the batch alone, not on the weights (called under the side stream)."""
     g = _Prepared()
     lig, rec = data["ligand"], data["receptor"]
@@ -536,7 +539,7 @@ def _prepare(model, data, host, dev) -> _Prepared:
     g.vec4_2 = g.vec4[:g.s2]
     # centre geometry (score_model.py:635-648)
     counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
-    center = scatter_sum(lig_pos, lig_batch, B) / counts          # fixed-order segmented sum (an index_add_ here would be atomic)
+    center = ScatterSumFn.apply(lig_pos, csr_of(lig_batch, B, csr_cache)) / counts    # fixed-order sum (an index_add_ would be atomic)
     g.c_vec2 = lig_pos - center[lig_batch]
     g.center_smear = gaussian_smearing(model.center_distance_expansion, g.c_vec2.norm(dim=-1))
     # torsion graph (score_model.py:650-664)
@@ -554,40 +557,66 @@ def _prepare(model, data, host, dev) -> _Prepared:
     if g.t_ei is not None:
         warm += [(g.bonds[0], nL), (g.bonds[1], nL), (g.t_ei[1], nL), (g.t_ei[0], int(g.bonds.shape[1]))]
     for k, (idx, n) in enumerate(warm):
-        setattr(g, f"_csr{k}", csr_of(idx, n))
+        setattr(g, f"_csr{k}", csr_of(idx, n, csr_cache))
     return g
 
 
+class PreparedBatch:
+    """A batch after `prepare_batch`: collated tensors, the input-only tensors of `_prepare`, the edge groupings, the side-stream
+    tensors to keep alive, and the event the compute stream has to wait for."""
+
+    def __init__(self, batch, g, csr, keep, event, n_graphs):
+        self.batch, self.g, self.csr, self.keep, self.event, self.num_graphs = batch, g, csr, keep, event, n_graphs
+
+
+def prepare_batch(model, data, dev) -> PreparedBatch:
+    """Collation + everything of the forward pass that depends on the batch alone (see `forward`).  Thread-safe with respect to a
+    training step in flight on another host thread: it enqueues on the side stream only, fills its own caches, and does not touch the
+    model's parameters or the CPU random generators."""
+    dev = torch.device(dev)
+    if dev.type != "cuda":
+        raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
+    torch.cuda.set_device(dev)
+    keep, csr = [], {}
+    side = _copy_stream(dev)
+    if isinstance(data, Batch):       # collated elsewhere: its tensors may still be in flight on the compute stream
+        batch = data.to(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+    else:
+        batch = collate(data, dev, keep=keep)
+    with torch.cuda.stream(side):
+        g = _prepare(model, batch, getattr(batch, "host", None), dev, csr)
+        event = torch.cuda.Event()
+        event.record(side)
+    keep.extend(g.tensors())
+    return PreparedBatch(batch, g, csr, keep, event, batch.num_graphs)
+
+
 def forward(model, data):
-    """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449)."""
+    """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449).  `data`: a list of
+    noised graphs (what the reference's DataListLoader yields), their collation, or a `PreparedBatch`."""
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
     if getattr(model, "asyncronous_noise_schedule", False):
         raise NotImplementedError("fine-tuning a model with an asyncronous noise schedule is outside the MI355X training path")
-    from .train_ops import clear_csr_cache
-    clear_csr_cache()          # edge groupings are per step (the graphs change with the poses)
+    # ---- everything that depends on the step's INPUTS only -- collation, the three radius graphs (their edge counts are read back to
+    #      the host), host table look-ups, the joint edge list, edge vectors / distance expansions / centre geometry, and the edge
+    #      groupings (stable sorts) of every index tensor the step gathers or scatters through -- is `prepare_batch`: it runs on the SIDE
+    #      stream (the read-backs wait for that stream, not for the previous step's backward pass; the ~350 small launches overlap with
+    #      it instead of lengthening the compute stream) and may be done AHEAD of the step, on another host thread, while the previous
+    #      step's backward pass is being enqueued (training.train_epoch does).
+    prep = data if isinstance(data, PreparedBatch) else prepare_batch(model, data, dev)
+    use_csr_cache(prep.csr)     # edge groupings are per step (the graphs change with the poses)
     _rotate_keep(dev)
-    data = collate(data, dev)
+    torch.cuda.current_stream(dev).wait_event(prep.event)
+    _keep_until_main_passes(prep.keep, dev)
+    data, g = prep.batch, prep.g
     ns = model.ns
     lig, rec = data["ligand"], data["receptor"]
     B = data.num_graphs
     ct = data.complex_t
     lig_batch, rec_batch = lig.batch, rec.batch
-
-    # ---- everything that depends on the step's INPUTS only -- the three radius graphs (their edge counts are read back to the host),
-    #      boolean masks, host table look-ups, the joint edge list, edge vectors / distance expansions / centre geometry, and the edge
-    #      groupings (stable sorts) of every index tensor the step gathers or scatters through -- runs on the SIDE stream: the read-backs
-    #      wait for that stream, not for the previous step's backward pass, the ~250 small launches overlap with it instead of
-    #      lengthening the compute stream, and the host enqueues the rest of the step without a single stall
-    host = getattr(data, "host", None)
-    main, side = torch.cuda.current_stream(dev), _copy_stream(dev)
-    if host is None:                # a batch collated elsewhere: its tensors may still be in flight on the compute stream
-        side.wait_stream(main)
-    with torch.cuda.stream(side):
-        g = _prepare(model, data, host, dev)
-    main.wait_stream(side)
-    _keep_until_main_passes(g.tensors(), dev)
     tr_sigma, lig_pos, n_rot, r_ei, l_ei, lr, edge_index = g.tr_sigma, g.lig_pos, g.n_rot, g.r_ei, g.l_ei, g.lr, g.edge_index
     s1, s2, s3, nL = g.s1, g.s2, g.s3, g.nL
 

@@ -530,23 +530,30 @@ class Csr:
         return self._counts
 
 
-_CSR_CACHE = {}
+_CSR_CACHE = {}          # groupings of the step being enqueued (train_forward.forward installs the prepared batch's own dict)
 
 
-def csr_of(index: torch.Tensor, n_rows: int) -> Csr:
+def csr_of(index: torch.Tensor, n_rows: int, cache=None) -> Csr:
+    """`cache`: the dict to look up / fill instead of the current step's (a batch prepared ahead of its step fills its own)"""
+    cache = _CSR_CACHE if cache is None else cache
     key = (index.data_ptr(), int(index.shape[0]), int(index.stride(0)), str(index.dtype), int(n_rows), str(index.device), index._version)
-    c = _CSR_CACHE.get(key)
+    c = cache.get(key)
     if c is None:
-        if len(_CSR_CACHE) > 256:
-            _CSR_CACHE.clear()
+        if len(cache) > 256:
+            cache.clear()
         c = Csr(index, n_rows)
         c.keep = index             # keeps the storage alive: the data_ptr in the key cannot be recycled while the entry exists
-        _CSR_CACHE[key] = c
+        cache[key] = c
     return c
 
 
 def clear_csr_cache():
-    _CSR_CACHE.clear()
+    use_csr_cache({})
+
+
+def use_csr_cache(cache: dict):
+    global _CSR_CACHE
+    _CSR_CACHE = cache
 
 
 def _segment_sum(vals: torch.Tensor, csr: Csr, mean: bool = False) -> torch.Tensor:

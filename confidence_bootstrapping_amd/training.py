@@ -194,16 +194,19 @@ def _parameter_list(model):
     return lst
 
 
-def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=None, forward_fn=None, skip=False):
+def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=None, forward_fn=None, skip=False, prepared=None,
+               before_backward=None):
     """One optimisation step on a list of noised graphs (body of the reference loop, utils/training.py:195-211).
     Returns None when the step was skipped -- on ANY rank: the skip decision (NaN loss, `skip=True` for an unusable batch) is
-    made collectively inside the gradient all-reduce, so no rank is left waiting in a collective the others never enter."""
+    made collectively inside the gradient all-reduce, so no rank is left waiting in a collective the others never enter.
+    `prepared`: the batch after train_forward.prepare_batch (done ahead of the step); `before_backward`: called once, right before the
+    backward pass is enqueued -- the moment at which the host has idle time to fetch and prepare the NEXT batch (train_epoch)."""
     if forward_fn is None:
         from .train_forward import forward as forward_fn
     optimizer.zero_grad()
     loss_tuple = None
     if not skip:
-        tr_pred, rot_pred, tor_pred, sc = forward_fn(model, data)
+        tr_pred, rot_pred, tor_pred, sc = forward_fn(model, data if prepared is None else prepared)
         loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sc, data=data, t_to_sigma=t_to_sigma, device=device)
         loss = loss_tuple[0]
         # NaN check without a pipeline flush.  The reference tests the loss between forward and backward (utils/training.py:201); on an
@@ -212,9 +215,14 @@ def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=
         # by that time the forward pass has long finished, so the wait is over the copy alone, not over the backward pass.  A NaN
         # loss gives NaN gradients, which are discarded below exactly as if backward had not run.
         nan_flag = _async_any_nan(loss.detach())
+        if before_backward is not None:
+            before_backward()
+            before_backward = None
         loss.backward()
         if nan_flag():
             skip = True
+    if before_backward is not None:         # skipped before the backward pass: the caller's look-ahead still has to start
+        before_backward()
     if not allreduce_gradients(model, skip=skip):
         optimizer.zero_grad()
         return None
@@ -242,26 +250,72 @@ def uniform_step_count(loader):
     return int(t.item())
 
 
-def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None):
+def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None, look_ahead=False):
+    """One epoch (reference utils/training.py:184-233).  With `look_ahead=True` (HIP forward on a GPU only) the NEXT batch is fetched
+    from the loader -- which is where the reference's DataLoader workers run NoiseTransform -- collated and taken through the
+    input-only part of the forward pass (train_forward.prepare_batch: radius graphs, edge groupings, ...) on a second host thread
+    while the current step's backward pass is being enqueued; the loader is only ever advanced by one thread at a time, in order, and
+    the results are identical to the sequential loop (tests/test_gpu_finetune_loop.py).  Off by default: with batches that are already
+    noised (bench.py) the two threads compete for the interpreter lock and the step time does not change (36.0 / 39.8 vs 38.3 / 36.0 ms
+    at batch 8, round 3); it pays when the loader itself does host work per batch."""
     if torsional:
         raise NotImplementedError("torsional-only training is outside the score-model fine-tuning path")
     model.train()
     meter = AverageMeter(_METRICS)
     distributed = _dist_world() > 1
     n_steps = uniform_step_count(loader) if distributed else None
-    for i, data in enumerate(loader):
-        if n_steps is not None and i >= n_steps:
-            break
+    dev = torch.device(device)
+    ahead = look_ahead and forward_fn is None and dev.type == "cuda"
+    it = iter(loader)
+
+    def fetch():
+        data = next(it, None)
+        if data is None:
+            return None
         n = len(data) if isinstance(data, (list, tuple)) else data.num_graphs
-        if n == 1:
-            print("Skipping batch of size 1 since otherwise batchnorm would not work.")
-            if distributed:     # the other ranks are inside this step's all-reduce: take part with zero gradients
-                train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn, skip=True)
-            continue
-        out = train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn)
-        if out is None:
-            print("Nan loss, skipping batch" + (" (on some rank)" if distributed else ""))
-            continue
-        meter.add(out)
+        prepared = None
+        if ahead and n > 1:
+            from .train_forward import prepare_batch
+            prepared = prepare_batch(model, data, dev)
+        return data, prepared, n
+
+    pool = None
+    if ahead:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="cbd-look-ahead")
+    try:
+        pending = pool.submit(fetch) if pool else None
+        i = 0
+        while True:
+            item = pending.result() if pool else fetch()
+            pending = None
+            if item is None or (n_steps is not None and i >= n_steps):
+                break
+            data, prepared, n = item
+            i += 1
+            nxt = {}
+
+            def start_next():
+                if pool and "f" not in nxt:
+                    nxt["f"] = pool.submit(fetch)
+
+            if n == 1:
+                print("Skipping batch of size 1 since otherwise batchnorm would not work.")
+                if distributed:     # the other ranks are inside this step's all-reduce: take part with zero gradients
+                    train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn, skip=True)
+                start_next()
+                pending = nxt.get("f")
+                continue
+            out = train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights, forward_fn=forward_fn, prepared=prepared,
+                             before_backward=start_next if pool else None)
+            start_next()
+            pending = nxt.get("f")
+            if out is None:
+                print("Nan loss, skipping batch" + (" (on some rank)" if distributed else ""))
+                continue
+            meter.add(out)
+    finally:
+        if pool:
+            pool.shutdown(wait=True)
     sync_batchnorm_buffers(model)
     return meter.summary()

@@ -448,3 +448,32 @@ def test_train_step_skips_a_nan_loss_without_touching_the_weights():
     assert out is not None and bool(torch.isfinite(out[0]).all())
     # the same healthy step from fresh weights (BatchNorm statistics aside, which the skipped forward updated as in the reference)
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+
+
+def test_train_epoch_with_look_ahead_equals_the_sequential_loop():
+    """train_epoch(look_ahead=True) fetches, collates and prepares the next batch on a second host thread while the current backward
+    pass is enqueued (train_forward.prepare_batch); parameters, EMA and the epoch's metrics must come out bit for bit as from the
+    sequential loop -- including a batch of one complex (skipped) in the middle of the epoch."""
+    from confidence_bootstrapping_amd.utils import make_score_model, load_model_args, ExponentialMovingAverage
+    from confidence_bootstrapping_amd.training import loss_function, train_epoch
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    t2s = partial(t_to_sigma, args=margs)
+    loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
+    data = _noised_batch()
+    loader = [data, data[:2], data[:1], data[1:], data]
+    res = []
+    for ahead in (False, True):
+        model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+        ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+        torch.manual_seed(3); torch.cuda.manual_seed_all(3)
+        summary = train_epoch(model, loader, opt, dev, t2s, loss_fn, ema, look_ahead=ahead)
+        torch.cuda.synchronize()
+        res.append((summary, [p.detach().clone() for p in model.parameters()], [s.clone() for s in ema.shadow_params],
+                    {n: b.clone() for n, b in model.named_buffers()}))
+    (s0, p0, e0, b0), (s1, p1, e1, b1) = res
+    assert s0 == s1 and np.isfinite(s0["loss"])
+    assert all(torch.equal(a, b) for a, b in zip(p0, p1)) and all(torch.equal(a, b) for a, b in zip(e0, e1))
+    assert all(torch.equal(b0[n], b1[n]) for n in b0)
