@@ -465,6 +465,57 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(int64_t n_rows, int wi
   }
 }
 
+// The same for FEW, LONG rows (sums per graph: 8 rows of 9 216 edge rows each in the training step -- one wave per row left the GPU to
+// eight waves for a millisecond): one workgroup of W waves per row, wave w sums the w-th contiguous part of the row's range in index
+// order, the W partial sums are added in wave order.  Fixed association: bitwise repeatable (it differs from the one-wave kernel's).
+template <bool MEAN, int W>
+__global__ __launch_bounds__(64 * W) void segment_sum_long_kernel(int64_t n_rows, int width, const float* __restrict__ vals,
+                                                                  const int64_t* __restrict__ perm, const int64_t* __restrict__ rowptr,
+                                                                  float* __restrict__ out) {
+  __shared__ float part[W][64];
+  const int64_t row = blockIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int64_t lo = rowptr[row], hi = rowptr[row + 1], len = hi - lo;
+  const int64_t a = lo + len * w / W, b = lo + len * (w + 1) / W;
+  for (int c0 = 0; c0 < width; c0 += 64) {
+    const int c = c0 + lane;
+    float acc = 0.f;
+    if (c < width) {
+      int64_t k = a;
+      for (; k + 4 <= b; k += 4) {
+        const int64_t p0 = perm[k], p1 = perm[k + 1], p2 = perm[k + 2], p3 = perm[k + 3];
+        const float v0 = vals[p0 * width + c], v1 = vals[p1 * width + c], v2 = vals[p2 * width + c], v3 = vals[p3 * width + c];
+        acc = ((acc + v0) + v1) + v2;
+        acc += v3;
+      }
+      for (; k < b; ++k) acc += vals[perm[k] * width + c];
+    }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < width) {
+      float s = part[0][lane];
+#pragma unroll
+      for (int i = 1; i < W; ++i) s += part[i][lane];
+      if (MEAN) s = s / (float)(len > 1 ? len : 1);
+      out[row * width + c] = s;
+    }
+    __syncthreads();
+  }
+}
+
+template <bool MEAN>
+static hipError_t launch_segment_sum(int64_t n_rows, int width, const float* vals, const int64_t* perm, const int64_t* rowptr, float* out,
+                                     hipStream_t s) {
+  // few rows = long rows in this code's uses (sums per graph, per ligand atom); the row count alone decides the kernel
+  if (n_rows <= 64)
+    hipLaunchKernelGGL((segment_sum_long_kernel<MEAN, 16>), dim3((unsigned)n_rows), dim3(1024), 0, s, n_rows, width, vals, perm, rowptr, out);
+  else if (n_rows <= 1024)
+    hipLaunchKernelGGL((segment_sum_long_kernel<MEAN, 4>), dim3((unsigned)n_rows), dim3(256), 0, s, n_rows, width, vals, perm, rowptr, out);
+  else
+    hipLaunchKernelGGL(segment_sum_kernel<MEAN>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, s, n_rows, width, vals, perm, rowptr, out);
+  return hipGetLastError();
+}
+
 }  // namespace cbd
 
 extern "C" {
@@ -534,9 +585,7 @@ int cbd_segment_sum(int64_t n_rows, int32_t width, const float* vals_dev, const 
                     float* out_dev, void* stream) {
   if (n_rows < 0 || width <= 0 || !rowptr_dev || !out_dev) return fail(CBD_ERR_ARG, "bad argument");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(cbd::segment_sum_kernel<false>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev);
-  const hipError_t r = hipGetLastError();
+  const hipError_t r = cbd::launch_segment_sum<false>(n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_segment_sum: %s", hipGetErrorString(r));
   return 0;
 }
@@ -545,9 +594,7 @@ int cbd_segment_mean(int64_t n_rows, int32_t width, const float* vals_dev, const
                      float* out_dev, void* stream) {
   if (n_rows < 0 || width <= 0 || !rowptr_dev || !out_dev) return fail(CBD_ERR_ARG, "bad argument");
   if (n_rows == 0) return 0;
-  hipLaunchKernelGGL(cbd::segment_sum_kernel<true>, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                     n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev);
-  const hipError_t r = hipGetLastError();
+  const hipError_t r = cbd::launch_segment_sum<true>(n_rows, (int)width, vals_dev, perm_dev, rowptr_dev, out_dev, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_segment_mean: %s", hipGetErrorString(r));
   return 0;
 }
