@@ -5,7 +5,7 @@
 //   other fields: y = x * w / sqrt(mean_{n,k} x^2 + eps)                       (k = the 2l+1 components of the field)
 // with the running statistics updated by `momentum`.  The layer's residual  out + pad(node_attr)  (tensor_layers.py:211-213) rides
 // along.  As torch ops this was ~14 launches forward and ~25 backward per layer, and the step is host-bound at the reference's batch
-// sizes.  Latency-bound: one workgroup per field, partial sums in double in a fixed order (bitwise repeatable).
+// sizes.  Latency-bound: one workgroup of 1024 threads per field, partial sums in double in a fixed order (bitwise repeatable).
 #include <hip/hip_runtime.h>
 
 #include "host_util.h"
@@ -13,13 +13,15 @@
 
 namespace cbd {
 
-// fixed-order block sum of one double per thread (256 threads)
+constexpr int BN_THREADS = 1024;     // one workgroup per field: 1024 threads keep enough strided loads in flight for 10^4 rows
+
+// fixed-order block sum of one double per thread (BN_THREADS threads)
 __device__ inline double block_sum(double v, double* sh) {
   const int t = threadIdx.x;
   sh[t] = v;
   __syncthreads();
 #pragma unroll
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = BN_THREADS / 2; s > 0; s >>= 1) {
     if (t < s) sh[t] += sh[t + s];
     __syncthreads();
   }
@@ -29,23 +31,23 @@ __device__ inline double block_sum(double v, double* sh) {
 }
 
 // chan[3c] = first column, chan[3c+1] = components, chan[3c+2] = index among the 0e fields or -1
-__global__ __launch_bounds__(256) void irreps_bn_fwd_kernel(long long N, int D, int ldx, const int* __restrict__ chan,
+__global__ __launch_bounds__(BN_THREADS) void irreps_bn_fwd_kernel(long long N, int D, int ldx, const int* __restrict__ chan,
                                                             const float* __restrict__ x, const float* __restrict__ res, int res_dim, const float* __restrict__ weight,
                                                             const float* __restrict__ bias, float* __restrict__ running_mean,
                                                             float* __restrict__ running_var, float momentum, float eps,
                                                             float* __restrict__ out, float* __restrict__ save_mean,
                                                             float* __restrict__ save_inv) {
-  __shared__ double sh[256];
+  __shared__ double sh[BN_THREADS];
   const int c = blockIdx.x, col = chan[3 * c], d = chan[3 * c + 1], i0 = chan[3 * c + 2];
   const long long cnt = N * d;
   float mean = 0.f;
   if (i0 >= 0) {
     double s = 0.0;
-    for (long long n = threadIdx.x; n < N; n += 256) s += (double)x[n * ldx + col];
+    for (long long n = threadIdx.x; n < N; n += BN_THREADS) s += (double)x[n * ldx + col];
     mean = (float)(block_sum(s, sh) / (double)N);
   }
   double s2 = 0.0;
-  for (long long i = threadIdx.x; i < cnt; i += 256) {
+  for (long long i = threadIdx.x; i < cnt; i += BN_THREADS) {
     const float v = x[(i / d) * ldx + col + (int)(i % d)] - mean;
     s2 += (double)v * (double)v;
   }
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(256) void irreps_bn_fwd_kernel(long long N, int D, 
     if (i0 >= 0) running_mean[i0] = (1.f - momentum) * running_mean[i0] + momentum * mean;
   }
   const float w = weight[c] * inv, b = i0 >= 0 ? bias[i0] : 0.f;
-  for (long long i = threadIdx.x; i < cnt; i += 256) {
+  for (long long i = threadIdx.x; i < cnt; i += BN_THREADS) {
     const long long n = i / d;
     const int cc = col + (int)(i % d);
     float y = (x[n * ldx + cc] - mean) * w + b;
@@ -67,16 +69,16 @@ __global__ __launch_bounds__(256) void irreps_bn_fwd_kernel(long long N, int D, 
   }
 }
 
-__global__ __launch_bounds__(256) void irreps_bn_bwd_kernel(long long N, int D, int ldx, const int* __restrict__ chan,
+__global__ __launch_bounds__(BN_THREADS) void irreps_bn_bwd_kernel(long long N, int D, int ldx, const int* __restrict__ chan,
                                                             const float* __restrict__ g, const float* __restrict__ x, const float* __restrict__ weight,
                                                             const float* __restrict__ save_mean, const float* __restrict__ save_inv,
                                                             float* __restrict__ gx, float* __restrict__ gw, float* __restrict__ gb) {
-  __shared__ double sh[256];
+  __shared__ double sh[BN_THREADS];
   const int c = blockIdx.x, col = chan[3 * c], d = chan[3 * c + 1], i0 = chan[3 * c + 2];
   const long long cnt = N * d;
   const float mean = save_mean[c], inv = save_inv[c];
   double s1 = 0.0, s0 = 0.0;
-  for (long long i = threadIdx.x; i < cnt; i += 256) {
+  for (long long i = threadIdx.x; i < cnt; i += BN_THREADS) {
     const long long n = i / d;
     const int cc = col + (int)(i % d);
     const float gv = g[n * D + cc];
@@ -90,13 +92,13 @@ __global__ __launch_bounds__(256) void irreps_bn_bwd_kernel(long long N, int D, 
     if (i0 >= 0) gb[i0] = (float)S0;
   }
   const float m1 = (float)(S1 / (double)cnt), m0 = (float)(S0 / (double)N), wi = weight[c] * inv;
-  for (long long i = threadIdx.x; i < cnt; i += 256) {
+  for (long long i = threadIdx.x; i < cnt; i += BN_THREADS) {
     const long long n = i / d;
     const int cc = col + (int)(i % d);
     gx[n * ldx + cc] = wi * (g[n * D + cc] - (x[n * ldx + cc] - mean) * inv * m1 - m0);
   }
   if (c == 0 && ldx > D)      // the padding columns of x carry no gradient
-    for (long long i = threadIdx.x; i < N * (ldx - D); i += 256) gx[(i / (ldx - D)) * ldx + D + (int)(i % (ldx - D))] = 0.f;
+    for (long long i = threadIdx.x; i < N * (ldx - D); i += BN_THREADS) gx[(i / (ldx - D)) * ldx + D + (int)(i % (ldx - D))] = 0.f;
 }
 
 }  // namespace cbd
@@ -109,7 +111,7 @@ int cbd_irreps_bn_forward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields,
   if (n <= 0 || dim <= 0 || ldx < dim || n_fields <= 0 || !fields_dev || !x_dev || !weight_dev || !running_var_dev || !out_dev || !save_mean_dev ||
       !save_inv_dev || (res_dev && (res_dim <= 0 || res_dim > dim)))
     return fail(CBD_ERR_ARG, "cbd_irreps_bn_forward: bad argument");
-  hipLaunchKernelGGL(cbd::irreps_bn_fwd_kernel, dim3((unsigned)n_fields), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (long long)n,
+  hipLaunchKernelGGL(cbd::irreps_bn_fwd_kernel, dim3((unsigned)n_fields), dim3(cbd::BN_THREADS), 0, reinterpret_cast<hipStream_t>(stream), (long long)n,
                      (int)dim, (int)ldx, fields_dev, x_dev, res_dev, (int)res_dim, weight_dev, bias_dev, running_mean_dev, running_var_dev, momentum,
                      eps, out_dev, save_mean_dev, save_inv_dev);
   const hipError_t r = hipGetLastError();
@@ -123,7 +125,7 @@ int cbd_irreps_bn_backward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields
   if (n <= 0 || dim <= 0 || ldx < dim || n_fields <= 0 || !fields_dev || !g_dev || !x_dev || !weight_dev || !save_mean_dev || !save_inv_dev || !gx_dev ||
       !gw_dev)
     return fail(CBD_ERR_ARG, "cbd_irreps_bn_backward: bad argument");
-  hipLaunchKernelGGL(cbd::irreps_bn_bwd_kernel, dim3((unsigned)n_fields), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), (long long)n,
+  hipLaunchKernelGGL(cbd::irreps_bn_bwd_kernel, dim3((unsigned)n_fields), dim3(cbd::BN_THREADS), 0, reinterpret_cast<hipStream_t>(stream), (long long)n,
                      (int)dim, (int)ldx, fields_dev, g_dev, x_dev, weight_dev, save_mean_dev, save_inv_dev, gx_dev, gw_dev, gb_dev);
   const hipError_t r = hipGetLastError();
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_irreps_bn_backward: %s", hipGetErrorString(r));
