@@ -88,7 +88,10 @@ class AverageMeter:
     def add(self, vals):
         self.count += 1
         dev = next((v.device for v in vals if torch.is_tensor(v)), torch.device("cpu"))
-        row = torch.stack([torch.as_tensor(v, device=dev).detach().float().mean() for v in vals])
+        if all(torch.is_tensor(v) and v.numel() == 1 and v.dtype == torch.float32 and v.device == dev for v in vals):
+            row = torch.cat([v.detach().reshape(1) for v in vals])          # the usual case (apply_mean=True): one launch
+        else:
+            row = torch.stack([torch.as_tensor(v, device=dev).detach().float().mean() for v in vals])
         self.acc = row if self.acc is None else self.acc + row
 
     def summary(self):
