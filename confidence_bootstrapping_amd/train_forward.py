@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
                         grouped_first_linear,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
@@ -556,8 +556,10 @@ def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
             (g.edge_index[0], nJ), (g.edge_index[1], nJ), (g.ei2[0], nJ), (g.ei2[1], nJ)]
     if g.t_ei is not None:
         warm += [(g.bonds[0], nL), (g.bonds[1], nL), (g.t_ei[1], nL), (g.t_ei[0], int(g.bonds.shape[1]))]
+    cache = csr_cache if csr_cache is not None else {}
+    csr_build_many(warm, cache)                 # all of them with ONE radix sort
     for k, (idx, n) in enumerate(warm):
-        setattr(g, f"_csr{k}", csr_of(idx, n, csr_cache))
+        setattr(g, f"_csr{k}", csr_of(idx, n, cache))
     return g
 
 

@@ -523,11 +523,57 @@ class Csr:
                                  _stream_handle()))
         self._counts = None
 
+    @classmethod
+    def from_parts(cls, index, n_rows, perm, rowptr):
+        c = cls.__new__(cls)
+        c.n_rows, c.index, c.perm, c.rowptr, c._counts = int(n_rows), index, perm, rowptr, None
+        return c
+
     @property
     def counts(self):
         if self._counts is None:
             self._counts = self.rowptr[1:] - self.rowptr[:-1]
         return self._counts
+
+
+def csr_build_many(items, cache):
+    """Groupings of several (index, n_rows) pairs with ONE radix sort (cbd_csr_build_batched; 7 launches instead of 6 per tensor),
+    entered into `cache` under the keys csr_of() looks up.  Pairs already in the cache are skipped."""
+    todo, seen = [], set()
+    for index, n_rows in items:
+        key = _csr_key(index, n_rows)
+        if key not in cache and key not in seen:
+            seen.add(key)
+            todo.append((key, index, index.long().contiguous(), int(n_rows)))
+    if not todo:
+        return
+    lib = _bind(load_library())
+    dev = todo[0][2].device
+    for lo in range(0, len(todo), 32):
+        chunk = todo[lo:lo + 32]
+        ns = len(chunk)
+        ptrs = (C.c_void_p * ns)(*[t[2].data_ptr() for t in chunk])
+        seg_n = (C.c_int64 * ns)(*[int(t[2].shape[0]) for t in chunk])
+        seg_rows = (C.c_int64 * ns)(*[t[3] for t in chunk])
+        n_tot, r_tot = sum(seg_n), sum(seg_rows) + ns
+        need = C.c_size_t(0)
+        _check(lib.cbd_csr_build_batched(ns, ptrs, seg_n, seg_rows, None, None, None, 0, C.byref(need), None))
+        scratch = torch.empty(need.value, dtype=torch.uint8, device=dev)
+        perm = torch.empty(n_tot, dtype=torch.long, device=dev)
+        rowptr = torch.empty(r_tot, dtype=torch.long, device=dev)
+        _check(lib.cbd_csr_build_batched(ns, ptrs, seg_n, seg_rows, _ptr(perm), _ptr(rowptr), _ptr(scratch), need.value, None, _stream_handle()))
+        po = ro = 0
+        for key, orig, idx, n_rows in chunk:
+            n = int(idx.shape[0])
+            c = Csr.from_parts(idx, n_rows, perm[po:po + n], rowptr[ro:ro + n_rows + 1])
+            c.keep = orig
+            cache[key] = c
+            po += n
+            ro += n_rows + 1
+
+
+def _csr_key(index, n_rows):
+    return (index.data_ptr(), int(index.shape[0]), int(index.stride(0)), str(index.dtype), int(n_rows), str(index.device), index._version)
 
 
 _CSR_CACHE = {}          # groupings of the step being enqueued (train_forward.forward installs the prepared batch's own dict)
@@ -536,7 +582,7 @@ _CSR_CACHE = {}          # groupings of the step being enqueued (train_forward.f
 def csr_of(index: torch.Tensor, n_rows: int, cache=None) -> Csr:
     """`cache`: the dict to look up / fill instead of the current step's (a batch prepared ahead of its step fills its own)"""
     cache = _CSR_CACHE if cache is None else cache
-    key = (index.data_ptr(), int(index.shape[0]), int(index.stride(0)), str(index.dtype), int(n_rows), str(index.device), index._version)
+    key = _csr_key(index, n_rows)
     c = cache.get(key)
     if c is None:
         if len(cache) > 256:

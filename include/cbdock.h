@@ -349,6 +349,13 @@ int cbd_radius_fill(int64_t n_query, const float* x_dev, const float* y_dev, con
 int cbd_csr_build(int64_t n, int64_t n_rows, const int64_t* index_dev, int64_t* perm_dev, int64_t* rowptr_dev, void* scratch_dev,
                   size_t scratch_bytes, size_t* scratch_needed, void* stream);
 
+/* cbd_csr_build for up to 32 index tensors in ONE sort (the 18 groupings of a training step: 108 launches one by one, 7 this way):
+ * segment s contributes keys (s << bits) | index_s[k].  index_dev / seg_n / seg_rows are HOST arrays (device pointers, element counts,
+ * row counts); perm_dev receives the segments' permutations back to back (sum of seg_n), rowptr_dev their row pointers back to back
+ * (seg_rows[s] + 1 each).  Sizing call and scratch as in cbd_csr_build. */
+int cbd_csr_build_batched(int32_t n_seg, const int64_t* const* index_dev, const int64_t* seg_n, const int64_t* seg_rows, int64_t* perm_dev,
+                          int64_t* rowptr_dev, void* scratch_dev, size_t scratch_bytes, size_t* scratch_needed, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

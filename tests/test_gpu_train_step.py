@@ -477,3 +477,25 @@ def test_train_epoch_with_look_ahead_equals_the_sequential_loop():
     assert s0 == s1 and np.isfinite(s0["loss"])
     assert all(torch.equal(a, b) for a, b in zip(p0, p1)) and all(torch.equal(a, b) for a, b in zip(e0, e1))
     assert all(torch.equal(b0[n], b1[n]) for n in b0)
+
+
+def test_batched_csr_build_equals_the_one_by_one_builds():
+    """cbd_csr_build_batched (all index tensors of a step in ONE radix sort, keys (segment << bits) | index) against cbd_csr_build per
+    tensor: identical permutations and row pointers; empty tensors, a single row, very different row counts, more than 32 segments."""
+    from confidence_bootstrapping_amd.train_ops import Csr, csr_build_many, csr_of
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(2)
+    shapes = [(0, 5), (1, 1), (7, 1), (1000, 2), (5000, 257), (4097, 1 << 15), (176000, 3300), (70000, 70001), (300, 8), (50000, 224)]
+    shapes = shapes + [(100 + 7 * k, 3 + k) for k in range(30)]          # 40 segments: two batches
+    items = [(torch.randint(0, max(n, 1), (e,), generator=g).to(dev), n) for e, n in shapes]
+    cache = {}
+    csr_build_many(items, cache)
+    assert len(cache) == len(items)
+    for idx, n in items:
+        got, want = csr_of(idx, n, cache), Csr(idx, n)
+        assert torch.equal(got.perm, want.perm) and torch.equal(got.rowptr, want.rowptr) and got.n_rows == n
+        assert torch.equal(got.counts, want.counts)
+    # entries already present are left alone
+    first = cache[next(iter(cache))]
+    csr_build_many(items[:3], cache)
+    assert cache[next(iter(cache))] is first
