@@ -57,9 +57,50 @@ __global__ __launch_bounds__(256) void radius_batched_kernel(long long ny, const
   if (!FILL && lane == 0) counts[q] = kept;
 }
 
+// Edge geometry of the training forward in one launch: vec = pos_b[idx_b] - pos_a[idx_a] (idx == NULL: identity), its unit vector (the
+// kernels' `vec` operand, F.normalize semantics: v / max(|v|, 1e-12)) and the Gaussian distance expansion exp(coeff (|v| - mu_k)^2)
+// (models/score_model.py:667-677) -- as torch ops two gathers, a subtraction, two norms, a clamp, a division, a pad and the four ops
+// of the expansion: 13 launches per edge set, five edge sets per step.
+__global__ __launch_bounds__(256) void edge_geometry_kernel(long long E, const float* __restrict__ pos_a, const float* __restrict__ pos_b,
+                                                            const long long* __restrict__ idx_a, const long long* __restrict__ idx_b,
+                                                            int K, const float* __restrict__ mu, float coeff, float* __restrict__ raw4,
+                                                            float* __restrict__ unit4, float* __restrict__ smear) {
+  const long long e = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (e >= E) return;
+  const long long a = idx_a ? idx_a[e] : e, b = idx_b ? idx_b[e] : e;
+  const float x = pos_b[b * 3 + 0] - pos_a[a * 3 + 0], y = pos_b[b * 3 + 1] - pos_a[a * 3 + 1], z = pos_b[b * 3 + 2] - pos_a[a * 3 + 2];
+  const float d = sqrtf(x * x + y * y + z * z);
+  if (lane == 0) {
+    if (raw4) *reinterpret_cast<float4*>(raw4 + e * 4) = make_float4(x, y, z, 0.f);
+    if (unit4) {
+      const float inv = 1.0f / fmaxf(d, 1e-12f);
+      *reinterpret_cast<float4*>(unit4 + e * 4) = make_float4(x * inv, y * inv, z * inv, 0.f);
+    }
+  }
+  if (smear)
+    for (int k = lane; k < K; k += 64) {
+      const float t = d - mu[k];
+      smear[e * K + k] = expf(coeff * (t * t));
+    }
+}
+
 }  // namespace cbd
 
 extern "C" {
+
+int cbd_edge_geometry(int64_t n_edges, const float* pos_a_dev, const float* pos_b_dev, const int64_t* idx_a_dev, const int64_t* idx_b_dev,
+                      int32_t n_mu, const float* mu_dev, float coeff, float* raw4_dev, float* unit4_dev, float* smear_dev, void* stream) {
+  if (n_edges < 0 || (smear_dev && (n_mu <= 0 || !mu_dev))) return fail(CBD_ERR_ARG, "cbd_edge_geometry: bad argument");
+  if (n_edges == 0) return 0;
+  if (!pos_a_dev || !pos_b_dev) return fail(CBD_ERR_ARG, "cbd_edge_geometry: null pointer");
+  hipLaunchKernelGGL(cbd::edge_geometry_kernel, dim3((unsigned)((n_edges + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                     (long long)n_edges, pos_a_dev, pos_b_dev, reinterpret_cast<const long long*>(idx_a_dev),
+                     reinterpret_cast<const long long*>(idx_b_dev), (int)n_mu, mu_dev, coeff, raw4_dev, unit4_dev, smear_dev);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_edge_geometry: %s", hipGetErrorString(r));
+  return 0;
+}
 
 static int radius_args_ok(int64_t ny, const float* x, const float* y, const int64_t* xptr, const int64_t* ybatch, int64_t cap) {
   return ny >= 0 && cap > 0 && (ny == 0 || (x && y && xptr && ybatch));

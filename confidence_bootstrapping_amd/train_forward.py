@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
                         grouped_first_linear,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
@@ -512,23 +512,18 @@ def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
     g.nL = nL
 
     # receptor graph (score_model.py:524-546)
-    r_vec = rec_pos[r_ei[1]] - rec_pos[r_ei[0]]
-    g.r_smear = gaussian_smearing(model.rec_distance_expansion, r_vec.norm(dim=-1))
-    g.r_vec4 = unit4(r_vec)
+    # edge vectors, unit vectors and distance expansions: one launch per edge set (train_ops.edge_geometry)
+    _, g.r_vec4, g.r_smear = edge_geometry(rec_pos, rec_pos, r_ei[0], r_ei[1], model.rec_distance_expansion)
     g.rec_cat = atom_encoder_index(model.rec_node_embedding, rec.x)
     g.rec_batch_src = rec_batch[r_ei[0]]
     # ligand graph (score_model.py:492-522)
     l_ei = g.l_ei = torch.cat([bond_ei, radius_edges], 1)
     g.l_attr0 = torch.cat([data["ligand", "ligand"].edge_attr.float(),
                            torch.zeros(radius_edges.shape[1], model.in_lig_edge_features, device=dev)], 0)
-    l_vec = lig_pos[l_ei[1]] - lig_pos[l_ei[0]]
-    g.l_smear = gaussian_smearing(model.lig_distance_expansion, l_vec.norm(dim=-1))
-    g.l_vec4 = unit4(l_vec)
+    _, g.l_vec4, g.l_smear = edge_geometry(lig_pos, lig_pos, l_ei[0], l_ei[1], model.lig_distance_expansion)
     g.lig_cat = atom_encoder_index(model.lig_node_embedding, lig.x)
     # cross graph (score_model.py:564-587), joint graph (score_model.py:354-362)
-    c_vec = rec_pos[lr[1]] - lig_pos[lr[0]]
-    g.c_smear = gaussian_smearing(model.cross_distance_expansion, c_vec.norm(dim=-1))
-    lr_vec4 = unit4(c_vec)
+    _, lr_vec4, g.c_smear = edge_geometry(lig_pos, rec_pos, lr[0], lr[1], model.cross_distance_expansion)
     lr_j = torch.stack([lr[0], lr[1] + nL], 0)
     g.edge_index = torch.cat([l_ei, lr_j, r_ei + nL, torch.stack([lr_j[1], lr_j[0]], 0)], 1)
     g.vec4 = torch.cat([g.l_vec4, lr_vec4, g.r_vec4, -lr_vec4], 0)
@@ -540,14 +535,16 @@ def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
     # centre geometry (score_model.py:635-648)
     counts = (torch.tensor(host["nl"]).to(dev, non_blocking=True) if host and "nl" in host else torch.bincount(lig_batch, minlength=B)).unsqueeze(1)
     center = ScatterSumFn.apply(lig_pos, csr_of(lig_batch, B, csr_cache)) / counts    # fixed-order sum (an index_add_ would be atomic)
-    g.c_vec2 = lig_pos - center[lig_batch]
-    g.center_smear = gaussian_smearing(model.center_distance_expansion, g.c_vec2.norm(dim=-1))
+    c_raw, _, g.center_smear = edge_geometry(center, lig_pos, lig_batch, None, model.center_distance_expansion, raw=True, unit=False)
+    g.c_raw = c_raw
+    g.c_vec2 = c_raw[:, :3]
     # torsion graph (score_model.py:650-664)
     g.bonds, g.t_ei = bonds, None
     if t_edges is not None:
         t_ei = g.t_ei = t_edges
-        g.t_vec = lig_pos[t_ei[1]] - bond_pos[t_ei[0]]
-        g.t_smear = gaussian_smearing(model.lig_distance_expansion, g.t_vec.norm(dim=-1))
+        t_raw, _, g.t_smear = edge_geometry(bond_pos, lig_pos, t_ei[0], t_ei[1], model.lig_distance_expansion, raw=True, unit=False)
+        g.t_raw = t_raw
+        g.t_vec = t_raw[:, :3]
         g.bond_vec_e = (lig_pos[bonds[1]] - lig_pos[bonds[0]])[t_ei[0]]
     # edge groupings of every index tensor the step gathers / scatters through (cached per tensor: the later csr_of calls hit)
     nJ = nL + nR

@@ -829,3 +829,24 @@ def radius_queries(queries):
     """edge lists of several RadiusQuery objects with ONE device->host read-back (their edge counts)"""
     totals = torch.stack([q.total for q in queries]).tolist()
     return [q.edges(n) for q, n in zip(queries, totals)]
+
+
+def edge_geometry(pos_a, pos_b, idx_a, idx_b, expansion=None, raw=False, unit=True):
+    """(raw4 | None, unit4 | None, smear | None) of the edges (idx_a[e] -> idx_b[e]): vec = pos_b[idx_b] - pos_a[idx_a] (an index may be
+    None: identity), one launch (cbd_edge_geometry).  `expansion`: a GaussianSmearing module (offset buffer, coeff)."""
+    if not pos_a.is_cuda:
+        raise RuntimeError("edge_geometry runs on the MI355X only (HIP kernel, no CPU fallback)")
+    pos_a, pos_b = pos_a.contiguous().float(), pos_b.contiguous().float()
+    E = int((idx_a if idx_a is not None else idx_b if idx_b is not None else pos_b).shape[0])
+    dev = pos_a.device
+    raw4 = torch.empty(E, 4, device=dev, dtype=torch.float32) if raw else None
+    unit4 = torch.empty(E, 4, device=dev, dtype=torch.float32) if unit else None
+    K, mu, coeff, smear = 0, None, 0.0, None
+    if expansion is not None:
+        mu = expansion.offset.contiguous().float()
+        K, coeff = int(mu.shape[0]), float(expansion.coeff)
+        smear = torch.empty(E, K, device=dev, dtype=torch.float32)
+    p = lambda t: None if t is None else _ptr(t.contiguous())
+    _check(_bind(load_library()).cbd_edge_geometry(E, _ptr(pos_a), _ptr(pos_b), p(idx_a), p(idx_b), K, p(mu), coeff, p(raw4), p(unit4), p(smear),
+                                                   _stream_handle()))
+    return raw4, unit4, smear

@@ -342,6 +342,12 @@ int cbd_radius_fill(int64_t n_query, const float* x_dev, const float* y_dev, con
                     const int64_t* ybatch_dev, int64_t cap, int32_t drop_self, const int64_t* offsets_dev, int64_t* out_query_dev,
                     int64_t* out_point_dev, void* stream);
 
+/* Edge geometry of the training forward in one launch: vec[e] = pos_b[idx_b[e]] - pos_a[idx_a[e]] (an index pointer may be NULL:
+ * identity), raw4 = (vec, 0), unit4 = (vec / max(|vec|, 1e-12), 0) -- the `vec` operand of cbd_tp_forward --, and the Gaussian distance
+ * expansion smear[e][k] = exp(coeff (|vec| - mu[k])^2) of models/score_model.py:667-677.  Any of the three outputs may be NULL. */
+int cbd_edge_geometry(int64_t n_edges, const float* pos_a_dev, const float* pos_b_dev, const int64_t* idx_a_dev, const int64_t* idx_b_dev,
+                      int32_t n_mu, const float* mu_dev, float coeff, float* raw4_dev, float* unit4_dev, float* smear_dev, void* stream);
+
 /* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
  * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training
  * graph of utils/training.py:198-205; torch's stable sort synchronises the stream).  Everything is enqueued on `stream`; scratch is the

@@ -499,3 +499,31 @@ def test_batched_csr_build_equals_the_one_by_one_builds():
     first = cache[next(iter(cache))]
     csr_build_many(items[:3], cache)
     assert cache[next(iter(cache))] is first
+
+
+def test_edge_geometry_kernel_matches_the_torch_ops():
+    """cbd_edge_geometry (edge vector, unit vector, Gaussian distance expansion in one launch) against the torch-op formulation the
+    training forward used before (gathers, subtraction, norm, F.normalize, exp(coeff (d - mu)^2)): within two ulp-level roundings;
+    identity indices, coincident points (zero vector -> zero unit vector), an empty edge set."""
+    from confidence_bootstrapping_amd.train_ops import edge_geometry
+    from confidence_bootstrapping_amd.score_model import GaussianSmearing
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    exp = GaussianSmearing(0.0, 30.0, 32).to(dev)
+    for Na, Nb, E in ((50, 70, 3000), (8, 224, 224), (10, 10, 0)):
+        pa, pb = (torch.randn(Na, 3, generator=g) * 6).to(dev), (torch.randn(Nb, 3, generator=g) * 6).to(dev)
+        ia = torch.randint(0, Na, (E,), generator=g).to(dev)
+        ib = None if Nb == E and E > 0 else torch.randint(0, Nb, (E,), generator=g).to(dev)
+        if E:
+            pb[ib[0] if ib is not None else 0] = pa[ia[0]]              # a zero-length edge
+        raw4, unit4, smear = edge_geometry(pa, pb, ia, ib, exp, raw=True, unit=True)
+        vec = (pb[ib] if ib is not None else pb) - pa[ia]
+        d = vec.norm(dim=-1)
+        assert raw4.shape == (E, 4) and unit4.shape == (E, 4) and smear.shape == (E, 32)
+        if E == 0:
+            continue
+        assert torch.equal(raw4[:, :3], vec) and float(raw4[:, 3].abs().max()) == 0.0
+        want_u = torch.nn.functional.normalize(vec, dim=-1)
+        assert float((unit4[:, :3] - want_u).abs().max()) <= 3e-7 and float(unit4[0].abs().max()) == 0.0
+        want_s = torch.exp(exp.coeff * torch.pow(d.view(-1, 1) - exp.offset.view(1, -1), 2))
+        assert float((smear - want_s).abs().max()) <= 2e-6
