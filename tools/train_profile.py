@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--fused-adam", action="store_true")
     ap.add_argument("--blas", default=None, help="torch.backends.cuda.preferred_blas_library: cublas (= rocBLAS) | cublaslt (= hipBLASLt)")
     ap.add_argument("--regions", action="store_true", help="GPU launches per forward region and per backward node type")
+    ap.add_argument("--gc", default="default", help="default | off | freeze: Python cyclic GC during the timed steps")
     ap.add_argument("--plain", action="store_true", help="free-running steps only (for rocprofv3 --kernel-trace; see tools/gap_stats.py)")
     ap.add_argument("--cprofile", action="store_true", help="Python-level profile (cProfile) of 16 free-running steps instead of the op table")
     a = ap.parse_args()
@@ -78,6 +79,11 @@ def main():
     for k in range(12):             # the caching allocator needs a few steps of every size before it stops calling hipMalloc
         step(batches[k % 8])
     sync()
+    import gc
+    if a.gc == "off":
+        gc.collect(); gc.disable()
+    elif a.gc == "freeze":
+        gc.collect(); gc.freeze()
     reps = []
     for rep in range(10 if a.plain else 3):
         t0 = time.perf_counter()
