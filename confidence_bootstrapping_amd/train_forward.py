@@ -271,10 +271,13 @@ def atom_encoder_index(enc, x_cat):
     """flat row index into the concatenation of the encoder's embedding tables, [N * n_tables] (input-only: built in `_prepare`)"""
     tables = enc.atom_embedding_list
     nf = len(tables)
-    key = (id(enc), str(x_cat.device))
+    # keyed by the table sizes themselves: an id(enc) key can be handed to ANOTHER encoder once a model has been garbage-collected (the
+    # ligand encoder of a new model then got the receptor encoder's offsets, or the other way round: wrong rows, or indices beyond
+    # the table and a GPU memory fault -- seen as a 1-in-10 flake of the training tests in round 3)
+    sizes = tuple(int(t.weight.shape[0]) for t in tables)
+    key = (sizes, str(x_cat.device))
     offs = _TABLE_OFFSETS.get(key)
     if offs is None:
-        sizes = [t.weight.shape[0] for t in tables]
         offs = _TABLE_OFFSETS[key] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)[:-1]]), dtype=torch.long).to(x_cat.device)
     return (x_cat[:, :nf].long() + offs).reshape(-1)
 

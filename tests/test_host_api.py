@@ -136,3 +136,23 @@ def test_bench_refuses_to_report_a_smaller_run():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr and not r.stdout.strip()
+
+
+def test_embedding_table_offsets_are_keyed_by_content_not_by_object_identity():
+    """train_forward.atom_encoder_index caches the row offsets of an encoder's concatenated embedding tables.  Keyed by id(encoder)
+    (round 3, first version) a NEW encoder could inherit the offsets of a garbage-collected one of another shape: wrong embedding rows
+    or indices beyond the table (a GPU memory fault in 1 of 10 runs of the training tests).  The key is the tuple of table sizes."""
+    import gc
+    import torch
+    from confidence_bootstrapping_amd.score_model import AtomEncoder
+    from confidence_bootstrapping_amd import train_forward as tf
+    for rep in range(50):
+        dims = ([3 + rep % 4, 5, 2 + rep % 3], 0) if rep % 2 else ([7 + rep % 5], 0)
+        enc = AtomEncoder(8, dims, 0)
+        x = torch.stack([torch.randint(0, d, (11,)) for d in dims[0]], 1).float()
+        idx = tf.atom_encoder_index(enc, x)
+        offs = torch.tensor([0] + list(torch.tensor(dims[0]).cumsum(0)[:-1]))
+        assert idx.shape == (11 * len(dims[0]),) and torch.equal(idx.view(11, -1), x.long() + offs)
+        assert int(idx.max()) < sum(dims[0])
+        del enc
+        gc.collect()
