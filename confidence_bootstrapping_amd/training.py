@@ -258,7 +258,7 @@ def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weigh
     from the loader -- which is where the reference's DataLoader workers run NoiseTransform -- collated and taken through the
     input-only part of the forward pass (train_forward.prepare_batch: radius graphs, edge groupings, ...) on a second host thread
     while the current step's backward pass is being enqueued; the loader is only ever advanced by one thread at a time, in order, and
-    the results are identical to the sequential loop (tests/test_gpu_finetune_loop.py).  Off by default: with batches that are already
+    the results are identical to the sequential loop (tests/test_gpu_train_step.py::test_train_epoch_with_look_ahead_...).  Off by default: with batches that are already
     noised (bench.py) the two threads compete for the interpreter lock and the step time does not change (36.0 / 39.8 vs 38.3 / 36.0 ms
     at batch 8, round 3); it pays when the loader itself does host work per batch."""
     if torsional:
