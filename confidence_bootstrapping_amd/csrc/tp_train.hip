@@ -44,6 +44,7 @@ struct TrainTpArgs {
   const float* gmsg;     // backward in  [E][NODE_STRIDE]  d loss / d msg
   float* gx;             // backward out [E][NODE_STRIDE]  d loss / d xrow
   float* gw;             // backward out [E][Wp]           d loss / d (packed w)
+  float* gh;             // g_h pass out [E][96]           d loss / d h   (tp_train_gh_kernel; wstream = TRANSPOSED streams)
 };
 
 constexpr int GX_STRIDE = 33;
@@ -378,6 +379,156 @@ static hipError_t launch_train_any(int in_level, int out_level, bool bwd, const 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// g_h = g_w W2p on the matrix cores WITHOUT reading g_w from memory: the gradient of the hidden activations of the radial MLP,
+// d loss / d h[e][k] = sum_w g_w[e][w] W2p[w][k]  (autograd of fc[3] in models/layers.py:8-15 under utils/training.py:205).
+// One wave = 32 edges, like the other two training kernels.  Per weight tile it re-forms this wave's [32 rows x 32 edges] tile of
+// g_w = g_msg (x) mid on the VALU -- exactly the registers tp_train_bwd_kernel stores -- and feeds it as the B operand of 3 x 16
+// v_mfma_f32_32x32x2_f32 (the C/D layout of the 16 registers IS a valid k order: k-step s of lane half hf is tile row
+// (s & 3) + 8 (s >> 2) + 4 hf), A = the TRANSPOSED weight tile streamed L2 -> registers one tile ahead:
+//   fragment f = 16 kb + s of lane (i, hf') = W2p[32 T + (s & 3) + 8 (s >> 2) + 4 hf'][32 kb + i]      (train_ops.StreamHub packs it)
+// accumulating the three 32-column blocks of g_h in 48 registers for the whole tile loop.
+__device__ __forceinline__ void gemm_gh(f32x4 (&a)[OpsF32::NFRAG], GPtr<f32x4> next, int lane, const float (&gw)[16], f32x16& G0,
+                                        f32x16& G1, f32x16& G2) {
+  GPtr<f32x4> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64;
+  pin_s(p0); pin_s(p1); pin_s(p2);
+#define CBD_GH_BLOCK(G, BASE, P)                                                             \
+  _Pragma("unroll") for (int sg = 0; sg < 4; ++sg) {                                          \
+    const f32x4 w = a[BASE + sg];                                                            \
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, gw[4 * sg + 0], G, 0, 0, 0);               \
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, gw[4 * sg + 1], G, 0, 0, 0);               \
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, gw[4 * sg + 2], G, 0, 0, 0);               \
+    G = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, gw[4 * sg + 3], G, 0, 0, 0);               \
+    a[BASE + sg] = P[lane + sg * 64];                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+  }
+  CBD_GH_BLOCK(G0, 0, p0)
+  CBD_GH_BLOCK(G1, 4, p1)
+  CBD_GH_BLOCK(G2, 8, p2)
+#undef CBD_GH_BLOCK
+}
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(64, 2) void tp_train_gh_kernel(TrainTpArgs A) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xT = lds;
+  const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
+  int grp = 0, e0 = 0, e_end = 0;
+  train_locate(A, blockIdx.x, grp, e0, e_end);
+  const int e = e0 + j;
+  const bool valid = e < e_end;
+  const int ec = valid ? e : e_end - 1;
+  const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(A.wstream[grp]);   // transposed stream, tile 0 = second-Linear tile 3
+  f32x4 a[OpsF32::NFRAG];
+#pragma unroll
+  for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[sg * 64 + lane];
+  {
+    const f32x4* pr = reinterpret_cast<const f32x4*>(A.xrow + (size_t)ec * NODE_STRIDE + 40 * hf);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const f32x4 r = pr[q];
+      float* o = xT + (40 * hf + 4 * q) * 32 + j;
+      o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
+    }
+  }
+  const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
+  const float v[3] = {vv.x, vv.y, vv.z};
+  const float* gm = A.gmsg + (size_t)ec * NODE_STRIDE;
+  float g0e[16], g1o[9], g1e[9], g0o[3];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const f32x4 x = reinterpret_cast<const f32x4*>(gm + 4 * hf)[2 * q];
+    g0e[4 * q + 0] = x.x; g0e[4 * q + 1] = x.y; g0e[4 * q + 2] = x.z; g0e[4 * q + 3] = x.w;
+  }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    g1o[k] = gm[COL_1O + 9 * hf + k];
+    g1e[k] = OUT >= 2 ? gm[COL_1E + 9 * hf + k] : 0.f;
+  }
+#pragma unroll
+  for (int o = 0; o < 3; ++o) g0o[o] = OUT >= 3 ? gm[COL_0O + 3 * hf + o] : 0.f;
+  __syncthreads();
+
+  const float* xc = xT + j;
+  f32x16 G0, G1, G2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { G0[r] = 0.f; G1[r] = 0.f; G2[r] = 0.f; }
+  int T = 0;
+#define CBD_GT(GW)                                                                                   \
+  {                                                                                                  \
+    gemm_gh(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, lane, GW, G0, G1, G2);                     \
+    ++T;                                                                                             \
+  }
+#pragma unroll 1
+  for (int i = 0; i < S.t0e; ++i) {
+    const float m = mid0e<IN>(xc, i, v);
+    float gw[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw[r] = m * g0e[r];
+    CBD_GT(gw);
+  }
+  auto vec_block = [&](auto mid_fn, int ntile, const float (&gk)[9]) __attribute__((always_inline)) {
+#pragma unroll 1
+    for (int t = 0; t < ntile; ++t) {
+      float gw[16];
+      gw[15] = 0.f;
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        float m[3];
+        mid_fn(xc, VEC_TILE_I * t + q, v, m);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) gw[3 * q + o] = m[0] * gk[3 * o + 0] + m[1] * gk[3 * o + 1] + m[2] * gk[3 * o + 2];
+      }
+      CBD_GT(gw);
+    }
+  };
+  vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, u, m); }, S.t1o, g1o);
+  if constexpr (OUT >= 2)
+    vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, u, m); }, S.t1e, g1e);
+  if constexpr (OUT >= 3) {
+#pragma unroll 1
+    for (int t = 0; t < S.t0o; ++t) {
+      float gw[16];
+      gw[15] = 0.f;
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) gw[3 * q + o] = m * g0o[o];
+      }
+      CBD_GT(gw);
+    }
+  }
+#undef CBD_GT
+  if (valid) {
+    float* out = A.gh + (size_t)e * KDIM + 4 * hf;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      reinterpret_cast<f32x4*>(out)[2 * q] = f32x4{G0[4 * q], G0[4 * q + 1], G0[4 * q + 2], G0[4 * q + 3]};
+      reinterpret_cast<f32x4*>(out + 32)[2 * q] = f32x4{G1[4 * q], G1[4 * q + 1], G1[4 * q + 2], G1[4 * q + 3]};
+      reinterpret_cast<f32x4*>(out + 64)[2 * q] = f32x4{G2[4 * q], G2[4 * q + 1], G2[4 * q + 2], G2[4 * q + 3]};
+    }
+  }
+}
+
+template <int IN, int OUT>
+static hipError_t launch_train_gh(const TrainTpArgs& a, hipStream_t s) {
+  int grid = 0;
+  for (int g = 0; g < a.n_groups; ++g) grid += (a.e_begin[g + 1] - a.e_begin[g] + WAVE_EDGES - 1) / WAVE_EDGES;
+  if (grid == 0) return hipSuccess;
+  hipLaunchKernelGGL((tp_train_gh_kernel<IN, OUT>), dim3(grid), dim3(64), XT_FLOATS * 4, s, a);
+  return hipGetLastError();
+}
+
+static hipError_t launch_train_gh_any(int in_level, int out_level, const TrainTpArgs& a, hipStream_t s) {
+  if (in_level == 0 && out_level == 1) return launch_train_gh<0, 1>(a, s);
+  if (in_level == 1 && out_level == 2) return launch_train_gh<1, 2>(a, s);
+  if (in_level == 2 && out_level == 3) return launch_train_gh<2, 3>(a, s);
+  if (in_level == 3 && out_level == 3) return launch_train_gh<3, 3>(a, s);
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Weight / bias gradient of the FCBlock's FIRST Linear (96 -> 96):  dW[m][n] = sum_e G[e][m] X[e][n],  db[m] = sum_e G[e][m]
 // (G = d loss / d pre-activation, X = [edge_attr | x_src[:32] | x_dst[:32]]).  A reduction over 10^5..10^6 edges into a 96 x 96
 // output: library GEMMs run it at ~10 TFLOP/s (K huge, M = N = 96: 341 us per call in profiles/r01_h_train_b32_kernel_stats.csv),
@@ -565,6 +716,18 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
   a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.gx = gx_dev; a.gw = gw_dev;
   const hipError_t r = cbd::launch_train_any(in_level, out_level, true, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges, const float* xrow_dev,
+                       const float* vec4_dev, const float* const* wstreams_t_dev, const float* gmsg_dev, float* gh_dev, void* stream) {
+  cbd::TrainTpArgs a{};
+  CHK(fill_groups(a, n_groups, group_edges, wstreams_t_dev));
+  if (a.E == 0) return 0;
+  if (!xrow_dev || !vec4_dev || !gmsg_dev || !gh_dev) return fail(CBD_ERR_ARG, "null argument");
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.gmsg = gmsg_dev; a.gh = gh_dev;
+  const hipError_t r = cbd::launch_train_gh_any(in_level, out_level, a, reinterpret_cast<hipStream_t>(stream));
+  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward_gh: %s", hipGetErrorString(r));
   return 0;
 }
 

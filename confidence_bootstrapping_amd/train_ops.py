@@ -285,7 +285,28 @@ class StreamHub:
             assert (slot[pos] >= 0).all(), "every second-Linear parameter sits in the W2p matrix or the bias table of its stream"
             p2g.append(slot[pos])
             pscale.append(sm.scale_np[pos])
+        # transposed tile streams for the g_h pass (cbd_tp_backward_gh): slot -> position in w2p_all (the logical [wp, 96] matrices back
+        # to back), or `n_w2p` = the appended zero for the padding tile behind every block
+        tidx, self.t_off, to = [], [], 0
+        n_w2p = wo
+        f = np.arange(48)
+        lane = np.arange(64)
+        kb, st = f // 16, f % 16
+        for b, (fc, sm) in enumerate(self.blocks):
+            ntw = sm.wp // 32
+            T = np.arange(ntw)
+            w = T[:, None, None] * 32 + ((st & 3) + 8 * (st >> 2))[None, :, None] + 4 * (lane >> 5)[None, None, :]      # [ntw, 48, 64]
+            k = (kb * 32)[None, :, None] + (lane & 31)[None, None, :]
+            t_src = self.w_off[b] + w * KDIM + k
+            t_slot = T[:, None, None] * TILE_W_FLOATS + (((f >> 2)[None, :, None] * 64 + lane[None, None, :]) * 4 + (f & 3)[None, :, None])
+            t_map = np.full((ntw + 1) * TILE_W_FLOATS, n_w2p, dtype=np.int64)
+            t_map[t_slot.ravel()] = t_src.ravel()
+            tidx.append(t_map)
+            self.t_off.append(to)
+            to += t_map.size
         t = lambda a, dt: torch.from_numpy(np.concatenate(a).astype(dt)).to(device)
+        self.t_idx = t(tidx, np.int64)
+        self.big_t = None
         self.src, self.scale = t(src, np.int64), t(scale, np.float32)
         self.w2p_idx = t(w2p, np.int64)
         self.p2g, self.pscale = t(p2g, np.int64), t(pscale, np.float32)
@@ -297,7 +318,8 @@ class StreamHub:
         flat = torch.cat([p.reshape(-1) for fc, _ in self.blocks for p in (fc[3].weight, fc[3].bias)])
         self.big = _HubFn.apply(flat, self)
         with torch.no_grad():
-            self.w2p_all = self.big.index_select(0, self.w2p_idx)          # W2p matrices for the g_h GEMMs of the backward pass
+            self.w2p_all = self.big.index_select(0, self.w2p_idx)          # the logical W2p matrices [wp, 96], back to back
+            self.big_t = torch.cat([self.w2p_all, self.w2p_all.new_zeros(1)]).index_select(0, self.t_idx)     # transposed tile streams
             self.grads = torch.zeros(self.n_grad, device=flat.device, dtype=torch.float32)
         self.used = set()
         return self.big
@@ -307,6 +329,9 @@ class StreamHub:
 
     def stream_ptr(self, b):
         return self.big.data_ptr() + 4 * self.stream_off[b]
+
+    def stream_t_ptr(self, b):
+        return self.big_t.data_ptr() + 4 * self.t_off[b]
 
     def w2p(self, b):
         sm = self.blocks[b][1]
@@ -355,6 +380,9 @@ def _weight_grad(gw, h, dw):
         dw.addmm_(gw[main:].t(), h[main:])
 
 
+GH_KERNEL = True        # g_h through cbd_tp_backward_gh (False: the library GEMM on the stored g_w; kept for the equivalence test)
+
+
 class TensorProductHubFn(torch.autograd.Function):
     """TensorProductFn with the weight streams (and the way back for their gradients) in a StreamHub: `big` is an input only so that
     autograd runs the hub's backward after every tensor-product backward."""
@@ -391,12 +419,17 @@ class TensorProductHubFn(torch.autograd.Function):
         TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
             in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), _ptr(gw), _stream_handle())))
         gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
+        if gh is not None and GH_KERNEL:
+            # g_h on the matrix cores from re-formed g_w tiles (cbd_tp_backward_gh): one launch for all groups, g_w is not read
+            wt = (C.c_void_p * n)(*[hub.stream_t_ptr(b) for b in blocks])
+            TIMER.wrap("gh", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward_gh(
+                in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), wt, _ptr(gmsg), _ptr(gh), _stream_handle())))
         lo = 0
         for ne, b in zip(group_edges, blocks):
             hi = lo + ne
             if ne:
                 gwg = gw[lo:hi]
-                if gh is not None:
+                if gh is not None and not GH_KERNEL:
                     torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
                 dw, db = hub.grad_views(b)
                 _weight_grad(gwg, h[lo:hi], dw)

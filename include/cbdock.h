@@ -273,6 +273,14 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
                     const float* vec4_dev, const float* h_dev, const float* const* wstreams_dev, const float* gmsg_dev, float* gx_dev,
                     float* gw_dev, void* stream);
 
+/* g_h = g_w W2p without reading g_w from memory: the gradient of the radial MLP's hidden activations (autograd of fc[3],
+ * models/layers.py:8-15 under utils/training.py:205) as a second pass over the edges that re-forms g_w = g_msg (x) mid tile by tile in
+ * registers and multiplies it with the TRANSPOSED weight tiles on the matrix cores.  wstreams_t_dev[g]: per second-Linear tile T,
+ * fragment f = 16 kb + s, lane (i, hf'): W2p[32 T + (s & 3) + 8 (s >> 2) + 4 hf'][32 kb + i] at float ((f >> 2) * 64 + lane) * 4 + (f & 3)
+ * of the tile's 3072 floats, plus one zero tile behind the last (train_ops.StreamHub builds it).  gh_dev: [E][96]. */
+int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges_host, const float* xrow_dev,
+                       const float* vec4_dev, const float* const* wstreams_t_dev, const float* gmsg_dev, float* gh_dev, void* stream);
+
 /* Weight and bias gradient of the FCBlock's first Linear (96 -> 96) in the fine-tuning step (autograd of fc[0] in
  * models/layers.py:8-15 under utils/training.py:205): partial[p] = [ sum_e g[e][m] x[e][n] (96 x 96, row-major) | sum_e g[e][m] (96) ]
  * over the p-th of n_parts contiguous chunks of the E edges; the caller adds the n_parts blocks (cbd_outer_accum_part_floats()
