@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   float* gxc = gxT + j;                                   // gxc[col * GX_STRIDE]
   float* const gwrow = A.gw + (size_t)ec * WP + 4 * hf;   // + (tile - 3) * 32 + 8q: the 4 rows (r&3) of register quad q
   auto store_gw = [&](int tile, const float (&gw)[16]) __attribute__((always_inline)) {
-    if (valid) {
+    if (valid && A.gw) {         // gw == NULL: g_w is re-formed by the g_h / dW2p passes and never stored
       f32x4* o = reinterpret_cast<f32x4*>(gwrow + (size_t)(tile - 3) * 32);
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[2 * q] = f32x4{gw[4 * q], gw[4 * q + 1], gw[4 * q + 2], gw[4 * q + 3]};
@@ -529,6 +529,189 @@ static hipError_t launch_train_gh_any(int in_level, int out_level, const TrainTp
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// dW2p = g_w^T h and db2p = column sums of g_w WITHOUT g_w in memory: the weight / bias gradient of the FCBlock's second Linear
+// (autograd of fc[3], models/layers.py:8-15, under utils/training.py:205) with the EDGES as the MFMA k dimension.
+// A workgroup of four waves owns four consecutive weight tiles (one per wave) and one chunk of the group's edges.  Per 32-edge block
+// the four waves stage h, g_msg, the gathered rows (transposed) and the edge vectors in LDS once; every wave then re-forms ITS tile of
+// g_w on the VALU -- lane (rho, hf) needs g_w[edge 2s + hf][row rho] for k-step s: mid(edge) x g_msg(edge), the same products
+// tp_train_bwd_kernel forms, here with the roles of lanes and registers exchanged -- as the A operand, takes h[edge][32 kb + n] as the
+// B operand, and accumulates its [32 rows x 96] block of dW2p in 48 registers over the whole chunk; db2p is the running sum of the A
+// operand.  One partial block per (chunk, tile); the caller adds the chunks (fixed order: bitwise repeatable).
+struct TrainDwArgs {
+  const float* xrow;     // [E][NODE_STRIDE]
+  const float* vec;      // [E][4]
+  const float* h;        // [E][96]
+  const float* gmsg;     // [E][NODE_STRIDE]
+  int e_lo, e_hi;        // the group's edge range
+  int blocks_per_chunk;  // 32-edge blocks per chunk
+  float* partial;        // [n_chunks][wp * 96 + wp]
+};
+constexpr int DW_GS = 96;                         // row stride of the staged g_msg rows: the two lane halves (edges e, e + 1) hit disjoint banks
+constexpr int DW_TILES_PER_WG = 8;                // 4 waves x 2 tiles: the staged block and the B operand reads serve two tiles per wave
+constexpr int DW_MT = 16 * 32;                    // mid table of one tile slot: [15 (+1)][32 edges]
+constexpr int DW_LDS_FLOATS = 32 * KDIM + 32 * DW_GS + NODE_STRIDE * 32 + 32 * 4 + DW_TILES_PER_WG * DW_MT;
+
+// the (up to) 15 mid components a tile needs for edge column xc: a scalar-block tile has ONE scalar mid (rows 1, 2 stay zero), a
+// vector-block tile five 3-vectors (0e / 0o block mids are scalars: component 0)
+template <int IN, int OUT>
+__device__ __forceinline__ void dw_tile_mid(int T, int q, const float* xc, const float (&v)[3], float (&m)[3]) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  m[0] = m[1] = m[2] = 0.f;
+  if (T < S.t0e) {
+    if (q == 0) m[0] = mid0e<IN>(xc, T, v);
+  } else if (T < S.t0e + S.t1o) {
+    mid1o<IN>(xc, VEC_TILE_I * (T - S.t0e) + q, v, m);
+  } else if (OUT >= 2 && T < S.t0e + S.t1o + S.t1e) {
+    mid1e<IN>(xc, VEC_TILE_I * (T - S.t0e - S.t1o) + q, v, m);
+  } else {
+    m[0] = mid0o<IN>(xc, VEC_TILE_I * (T - S.t0e - S.t1o - S.t1e) + q, v);
+  }
+}
+
+// per-lane recipe of the A operand for tile T: a = sum_c M[mrow + c][e] * g[e][gcol + c]   (c < 3; unused terms meet zeros)
+template <int IN, int OUT>
+__device__ __forceinline__ void dw_recipe(int T, int rho, int& mrow, int& gcol, float& live) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  const int vr = 4 * (rho >> 3) + (rho & 3), vh = (rho >> 2) & 1, vq = vr / 3, vo = vr % 3;     // vector rows: r = 3 q + o of half vh
+  live = 1.f;
+  if (T < S.t0e) { mrow = 0; gcol = rho; return; }                                              // row rho = output channel rho
+  live = vr < 15 ? 1.f : 0.f;
+  mrow = 3 * vq;
+  if (T < S.t0e + S.t1o) gcol = COL_1O + 9 * vh + 3 * vo;
+  else if (OUT >= 2 && T < S.t0e + S.t1o + S.t1e) gcol = COL_1E + 9 * vh + 3 * vo;
+  else { gcol = COL_0O + 3 * vh + vo; }                                                          // scalar x scalar: component 0 only
+  if (vr >= 15) { mrow = 0; gcol = 0; }
+}
+
+template <int IN, int OUT>
+__global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
+  constexpr ConvShape S = conv_shape(IN, OUT);
+  constexpr int NTW = S.ntiles - 3, WP = NTW * 32;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hS = lds;                              // [32][96]
+  float* gS = hS + 32 * KDIM;                   // [32][DW_GS]  rows of invalid edges are zero => their g_w is zero
+  float* xT = gS + 32 * DW_GS;                  // [80][32]
+  float* vS = xT + NODE_STRIDE * 32;            // [32][4]
+  float* mT = vS + 32 * 4;                      // [8 tile slots][16][32]  mids of the block's edges
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rho = lane & 31, hf = lane >> 5;
+  const int Tb = blockIdx.x * DW_TILES_PER_WG;  // first tile of this workgroup
+  const int T0 = __builtin_amdgcn_readfirstlane(Tb + wave), T1 = T0 + 4;     // this wave's two second-Linear tiles (wave-uniform)
+  const bool live0 = T0 < NTW, live1 = T1 < NTW;
+  int mrow0, gcol0, mrow1, gcol1;
+  float lv0, lv1;
+  dw_recipe<IN, OUT>(live0 ? T0 : NTW - 1, rho, mrow0, gcol0, lv0);
+  dw_recipe<IN, OUT>(live1 ? T1 : NTW - 1, rho, mrow1, gcol1, lv1);
+  if (!live0) lv0 = 0.f;
+  if (!live1) lv1 = 0.f;
+  // scalar-block tiles (0e, 0o) multiply a scalar mid with a scalar gradient: only component 0 of the generic three-term form
+  const bool three0 = T0 >= S.t0e && T0 < S.t0e + S.t1o + S.t1e, three1 = T1 >= S.t0e && T1 < S.t0e + S.t1o + S.t1e;   // vector-block tiles
+  const float* m0p = mT + wave * DW_MT + mrow0 * 32;
+  const float* m1p = mT + (wave + 4) * DW_MT + mrow1 * 32;
+  f32x16 a00, a01, a02, a10, a11, a12;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a02[r] = 0.f; a10[r] = 0.f; a11[r] = 0.f; a12[r] = 0.f; }
+  float db0 = 0.f, db1 = 0.f;
+  const int b_lo = blockIdx.y * A.blocks_per_chunk;
+  const int n_blk = min(A.blocks_per_chunk, (A.e_hi - A.e_lo + 31) / 32 - b_lo);
+  // staging through registers: block b + 1 is in flight from global memory while block b is multiplied
+  f32x4 hr[3], gr[3], xr[3], vr4;
+  auto fetch = [&](int e0) {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int k = tid + 256 * it;                                   // h: 768 float4, coalesced rows
+      const int e = min(e0 + k / (KDIM / 4), A.e_hi - 1);
+      hr[it] = reinterpret_cast<const f32x4*>(A.h + (size_t)e * KDIM)[k % (KDIM / 4)];
+      if (k < 32 * NODE_STRIDE / 4) {                                 // g_msg: 640 float4, coalesced rows
+        const int row = k / (NODE_STRIDE / 4);
+        const bool ok = e0 + row < A.e_hi;
+        const f32x4 g = reinterpret_cast<const f32x4*>(A.gmsg + (size_t)(ok ? e0 + row : A.e_hi - 1) * NODE_STRIDE)[k % (NODE_STRIDE / 4)];
+        gr[it] = ok ? g : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int xrow_i = k & 31, xc4 = k >> 5;                      // gathered rows: edge index fastest => conflict-free transposed stores
+        xr[it] = reinterpret_cast<const f32x4*>(A.xrow + (size_t)min(e0 + xrow_i, A.e_hi - 1) * NODE_STRIDE)[xc4];
+      }
+    }
+    if (tid < 32) vr4 = reinterpret_cast<const f32x4*>(A.vec)[min(e0 + tid, A.e_hi - 1)];
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int k = tid + 256 * it;
+      reinterpret_cast<f32x4*>(hS)[k] = hr[it];
+      if (k < 32 * NODE_STRIDE / 4) {
+        *reinterpret_cast<f32x4*>(gS + (k / (NODE_STRIDE / 4)) * DW_GS + 4 * (k % (NODE_STRIDE / 4))) = gr[it];
+        float* o = xT + (4 * (k >> 5)) * 32 + (k & 31);
+        o[0] = xr[it].x; o[32] = xr[it].y; o[64] = xr[it].z; o[96] = xr[it].w;
+      }
+    }
+    if (tid < 32) reinterpret_cast<f32x4*>(vS)[tid] = vr4;
+  };
+  for (int k = tid; k < DW_TILES_PER_WG * DW_MT; k += 256) mT[k] = 0.f;      // rows a scalar-block tile never writes stay zero
+  if (n_blk > 0) fetch(A.e_lo + b_lo * 32);
+  for (int bk = 0; bk < n_blk; ++bk) {
+    __syncthreads();                            // the previous block's readers are done
+    stage();
+    __syncthreads();
+    if (bk + 1 < n_blk) fetch(A.e_lo + (b_lo + bk + 1) * 32);
+    // mids of this block for the workgroup's 8 tile slots: (slot, q, edge) -> 3 components; 8 x 5 x 32 items over 256 threads
+#pragma unroll 1
+    for (int it = tid; it < DW_TILES_PER_WG * VEC_TILE_I * 32; it += 256) {
+      const int e = it & 31, q = (it >> 5) % VEC_TILE_I, slot = it / (VEC_TILE_I * 32);
+      const int T = min(Tb + slot, NTW - 1);
+      if (T < S.t0e && q > 0) continue;         // a 0e tile has one scalar mid
+      const float v[3] = {vS[4 * e], vS[4 * e + 1], vS[4 * e + 2]};
+      float m[3];
+      dw_tile_mid<IN, OUT>(T, q, xT + e, v, m);
+      float* o = mT + slot * DW_MT + (3 * q) * 32 + e;
+      o[0] = m[0]; o[32] = m[1]; o[64] = m[2];
+    }
+    __syncthreads();
+    // branch-free k-steps: a = sum_c M[mrow + c][e] g[e][gcol + c]; lanes of dead rows / dead tile slots multiply by zero
+#pragma unroll 8
+    for (int s = 0; s < 16; ++s) {
+      const int e = 2 * s + hf;                 // this lane's edge of k-step s
+      const float* ge = gS + e * DW_GS;
+      const float* hb = hS + e * KDIM + rho;    // B operand: lane (n = rho, hf) supplies h[edge 2s + hf][32 kb + n]
+      const float b0 = hb[0], b1 = hb[32], b2 = hb[64];
+      float x0 = m0p[e] * ge[gcol0], x1 = m1p[e] * ge[gcol1];
+      if (three0) x0 += m0p[32 + e] * ge[gcol0 + 1] + m0p[64 + e] * ge[gcol0 + 2];
+      if (three1) x1 += m1p[32 + e] * ge[gcol1 + 1] + m1p[64 + e] * ge[gcol1 + 2];
+      x0 *= lv0;
+      x1 *= lv1;
+      a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b0, a00, 0, 0, 0);
+      a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b1, a01, 0, 0, 0);
+      a02 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b2, a02, 0, 0, 0);
+      a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b0, a10, 0, 0, 0);
+      a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b1, a11, 0, 0, 0);
+      a12 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b2, a12, 0, 0, 0);
+      db0 += x0;
+      db1 += x1;
+    }
+  }
+  float* out = A.partial + (size_t)blockIdx.y * (WP * KDIM + WP);
+  // D layout: lane (n, hf) holds rows (r & 3) + 8 (r >> 2) + 4 hf of column n
+  auto store = [&](int T, const f32x16& c0, const f32x16& c1, const f32x16& c2, float db) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = T * 32 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      out[(size_t)row * KDIM + rho] = c0[r];
+      out[(size_t)row * KDIM + 32 + rho] = c1[r];
+      out[(size_t)row * KDIM + 64 + rho] = c2[r];
+    }
+    const float other = __shfl_xor(db, 32);
+    if (hf == 0) out[(size_t)WP * KDIM + T * 32 + rho] = db + other;
+  };
+  if (live0) store(T0, a00, a01, a02, db0);
+  if (live1) store(T1, a10, a11, a12, db1);
+}
+
+template <int IN, int OUT>
+static hipError_t launch_train_dw(const TrainDwArgs& a, int n_chunks, hipStream_t s) {
+  constexpr int NTW = conv_shape(IN, OUT).ntiles - 3;
+  hipLaunchKernelGGL((tp_train_dw_kernel<IN, OUT>), dim3((NTW + DW_TILES_PER_WG - 1) / DW_TILES_PER_WG, n_chunks), dim3(256), DW_LDS_FLOATS * 4, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Weight / bias gradient of the FCBlock's FIRST Linear (96 -> 96):  dW[m][n] = sum_e G[e][m] X[e][n],  db[m] = sum_e G[e][m]
 // (G = d loss / d pre-activation, X = [edge_attr | x_src[:32] | x_dst[:32]]).  A reduction over 10^5..10^6 edges into a 96 x 96
 // output: library GEMMs run it at ~10 TFLOP/s (K huge, M = N = 96: 341 us per call in profiles/r01_h_train_b32_kernel_stats.csv),
@@ -712,8 +895,8 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
   cbd::TrainTpArgs a{};
   CHK(fill_groups(a, n_groups, group_edges, wstreams_dev));
   if (a.E == 0) return 0;
-  if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !gx_dev || !gw_dev) return fail(CBD_ERR_ARG, "null argument");
-  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.gx = gx_dev; a.gw = gw_dev;
+  if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !gx_dev) return fail(CBD_ERR_ARG, "null argument");
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.gx = gx_dev; a.gw = gw_dev;      /* gw_dev may be NULL */
   const hipError_t r = cbd::launch_train_any(in_level, out_level, true, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward: %s", hipGetErrorString(r));
   return 0;
@@ -728,6 +911,25 @@ int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, co
   a.xrow = xrow_dev; a.vec = vec4_dev; a.gmsg = gmsg_dev; a.gh = gh_dev;
   const hipError_t r = cbd::launch_train_gh_any(in_level, out_level, a, reinterpret_cast<hipStream_t>(stream));
   if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward_gh: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_tp_backward_dw(int32_t in_level, int32_t out_level, int64_t e_lo, int64_t e_hi, const float* xrow_dev, const float* vec4_dev,
+                       const float* h_dev, const float* gmsg_dev, int32_t n_chunks, float* partial_dev, void* stream) {
+  if (e_lo < 0 || e_hi < e_lo || e_hi > ((int64_t)1 << 30) || n_chunks <= 0) return fail(CBD_ERR_ARG, "cbd_tp_backward_dw: bad argument");
+  if (e_hi == e_lo) return 0;
+  if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !partial_dev) return fail(CBD_ERR_ARG, "null argument");
+  cbd::TrainDwArgs a{};
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.e_lo = (int)e_lo; a.e_hi = (int)e_hi; a.partial = partial_dev;
+  const int64_t blocks = (e_hi - e_lo + 31) / 32;
+  a.blocks_per_chunk = (int)((blocks + n_chunks - 1) / n_chunks);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t r = hipErrorInvalidValue;
+  if (in_level == 0 && out_level == 1) r = cbd::launch_train_dw<0, 1>(a, n_chunks, st);
+  else if (in_level == 1 && out_level == 2) r = cbd::launch_train_dw<1, 2>(a, n_chunks, st);
+  else if (in_level == 2 && out_level == 3) r = cbd::launch_train_dw<2, 3>(a, n_chunks, st);
+  else if (in_level == 3 && out_level == 3) r = cbd::launch_train_dw<3, 3>(a, n_chunks, st);
+  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward_dw: %s", hipGetErrorString(r));
   return 0;
 }
 

@@ -82,6 +82,7 @@ SYMBOLS = {
     "cbd_tp_packed_width": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_tp_forward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_tp_backward": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_tp_backward_dw": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_int64, _P, _P, _P, _P, C.c_int32, _P, _P]),
     "cbd_tp_backward_gh": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_outer_accum_part_floats": (C.c_int64, []),
     "cbd_outer_accum": (C.c_int, [C.c_int64, _P, _P, C.c_int32, _P, _P]),

@@ -381,6 +381,7 @@ def _weight_grad(gw, h, dw):
 
 
 GH_KERNEL = True        # g_h through cbd_tp_backward_gh (False: the library GEMM on the stored g_w; kept for the equivalence test)
+DW_KERNEL = True        # dW2p / db2p through cbd_tp_backward_dw (with GH_KERNEL: g_w is never stored); False: split-K library GEMM on g_w
 
 
 class TensorProductHubFn(torch.autograd.Function):
@@ -413,11 +414,13 @@ class TensorProductHubFn(torch.autograd.Function):
         E, n = xrow.shape[0], len(blocks)
         gmsg = gmsg.contiguous().float()
         gx = torch.empty_like(xrow)
-        gw = torch.empty(E, sm.wp, device=xrow.device, dtype=torch.float32)
+        fused = GH_KERNEL and DW_KERNEL           # g_w never stored: re-formed by the g_h and dW2p passes
+        gw = None if fused else torch.empty(E, sm.wp, device=xrow.device, dtype=torch.float32)
         ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
         ws = (C.c_void_p * n)(*[hub.stream_ptr(b) for b in blocks])
         TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
-            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), _ptr(gw), _stream_handle())))
+            in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), None if gw is None else _ptr(gw),
+            _stream_handle())))
         gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
         if gh is not None and GH_KERNEL:
             # g_h on the matrix cores from re-formed g_w tiles (cbd_tp_backward_gh): one launch for all groups, g_w is not read
@@ -428,12 +431,22 @@ class TensorProductHubFn(torch.autograd.Function):
         for ne, b in zip(group_edges, blocks):
             hi = lo + ne
             if ne:
-                gwg = gw[lo:hi]
-                if gh is not None and not GH_KERNEL:
-                    torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
                 dw, db = hub.grad_views(b)
-                _weight_grad(gwg, h[lo:hi], dw)
-                torch.sum(gwg, 0, out=db)        # (as a matrix-vector product these column sums are 10x slower: measured)
+                if fused:
+                    # dW2p / db2p with the edges as the MFMA k dimension (cbd_tp_backward_dw), partial sums per edge chunk
+                    wp = sm.wp
+                    n_chunks = max(1, min(160, ((ne + 31) // 32) // 6))
+                    part = torch.empty(n_chunks, wp * KDIM + wp, device=xrow.device, dtype=torch.float32)
+                    TIMER.wrap("dw", in_level, out_level, ne, lambda: _check(lib.cbd_tp_backward_dw(
+                        in_level, out_level, lo, hi, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), n_chunks, _ptr(part), _stream_handle())))
+                    torch.sum(part[:, :wp * KDIM].view(n_chunks, wp, KDIM), 0, out=dw)
+                    torch.sum(part[:, wp * KDIM:], 0, out=db)
+                else:
+                    gwg = gw[lo:hi]
+                    if gh is not None and not GH_KERNEL:
+                        torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
+                    _weight_grad(gwg, h[lo:hi], dw)
+                    torch.sum(gwg, 0, out=db)        # (as a matrix-vector product these column sums are 10x slower: measured)
             lo = hi
         return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
 

@@ -281,6 +281,14 @@ int cbd_tp_backward(int32_t in_level, int32_t out_level, int32_t n_groups, const
 int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges_host, const float* xrow_dev,
                        const float* vec4_dev, const float* const* wstreams_t_dev, const float* gmsg_dev, float* gh_dev, void* stream);
 
+/* dW2p = g_w^T h and db2p = column sums of g_w for the edges [e_lo, e_hi) of one edge group, without g_w in memory (edges as the MFMA
+ * k dimension, g_w re-formed per tile from g_msg and the mids; see csrc/tp_train.hip).  partial_dev: [n_chunks][wp * 96 + wp] fp32 with
+ * wp = cbd_tp_packed_width(): chunk c holds the contribution of its share of the edges, dW2p rows first ([wp][96], the row order of
+ * cbd_tp_backward's g_w columns), then db2p [wp]; the caller adds the chunks.  With this and cbd_tp_backward_gh, cbd_tp_backward may be
+ * called with gw_dev = NULL. */
+int cbd_tp_backward_dw(int32_t in_level, int32_t out_level, int64_t e_lo, int64_t e_hi, const float* xrow_dev, const float* vec4_dev,
+                       const float* h_dev, const float* gmsg_dev, int32_t n_chunks, float* partial_dev, void* stream);
+
 /* Weight and bias gradient of the FCBlock's first Linear (96 -> 96) in the fine-tuning step (autograd of fc[0] in
  * models/layers.py:8-15 under utils/training.py:205): partial[p] = [ sum_e g[e][m] x[e][n] (96 x 96, row-major) | sum_e g[e][m] (96) ]
  * over the p-th of n_parts contiguous chunks of the E edges; the caller adds the n_parts blocks (cbd_outer_accum_part_floats()
