@@ -380,6 +380,20 @@ def _weight_grad(gw, h, dw):
         dw.addmm_(gw[main:].t(), h[main:])
 
 
+_DW_SCRATCH = {}
+
+
+def _dw_scratch(n_floats, device):
+    """One persistent buffer per device for the partial blocks of cbd_tp_backward_dw (up to 113 MB per edge group, 22 groups per
+    step, sizes changing with the edge counts: as fresh allocations they churn the caching allocator -- the fine-tuning leg of
+    bench.py, which runs after the other legs have filled the cache, went from 36 to 48 ms per step).  The groups of a step use it one
+    after the other on the same stream."""
+    buf = _DW_SCRATCH.get(str(device))
+    if buf is None or buf.numel() < n_floats:
+        buf = _DW_SCRATCH[str(device)] = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
+    return buf[:n_floats]
+
+
 GH_KERNEL = True        # g_h through cbd_tp_backward_gh (False: the library GEMM on the stored g_w; kept for the equivalence test)
 DW_KERNEL = True        # dW2p / db2p through cbd_tp_backward_dw (with GH_KERNEL: g_w is never stored); False: split-K library GEMM on g_w
 
@@ -436,7 +450,7 @@ class TensorProductHubFn(torch.autograd.Function):
                     # dW2p / db2p with the edges as the MFMA k dimension (cbd_tp_backward_dw), partial sums per edge chunk
                     wp = sm.wp
                     n_chunks = max(1, min(160, ((ne + 31) // 32) // 6))
-                    part = torch.empty(n_chunks, wp * KDIM + wp, device=xrow.device, dtype=torch.float32)
+                    part = _dw_scratch(n_chunks * (wp * KDIM + wp), xrow.device).view(n_chunks, wp * KDIM + wp)
                     TIMER.wrap("dw", in_level, out_level, ne, lambda: _check(lib.cbd_tp_backward_dw(
                         in_level, out_level, lo, hi, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), n_chunks, _ptr(part), _stream_handle())))
                     torch.sum(part[:, :wp * KDIM].view(n_chunks, wp, KDIM), 0, out=dw)
