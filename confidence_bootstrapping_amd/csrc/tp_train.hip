@@ -531,7 +531,8 @@ static hipError_t launch_train_gh_any(int in_level, int out_level, const TrainTp
 // ------------------------------------------------------------------------------------------------------------
 // dW2p = g_w^T h and db2p = column sums of g_w WITHOUT g_w in memory: the weight / bias gradient of the FCBlock's second Linear
 // (autograd of fc[3], models/layers.py:8-15, under utils/training.py:205) with the EDGES as the MFMA k dimension.
-// A workgroup of four waves owns four consecutive weight tiles (one per wave) and one chunk of the group's edges.  Per 32-edge block
+// A workgroup of four waves owns four consecutive weight tiles (one per wave: 150 registers, three residents per SIMD; two tiles per
+// wave share the B operand reads but leave two residents: 0.45 against 0.50 of peak) and one chunk of the group's edges.  Per 32-edge block
 // the four waves stage h, g_msg, the gathered rows (transposed) and the edge vectors in LDS once; every wave then re-forms ITS tile of
 // g_w on the VALU -- lane (rho, hf) needs g_w[edge 2s + hf][row rho] for k-step s: mid(edge) x g_msg(edge), the same products
 // tp_train_bwd_kernel forms, here with the roles of lanes and registers exchanged -- as the A operand, takes h[edge][32 kb + n] as the
@@ -547,7 +548,7 @@ struct TrainDwArgs {
   float* partial;        // [n_chunks][wp * 96 + wp]
 };
 constexpr int DW_GS = 96;                         // row stride of the staged g_msg rows: the two lane halves (edges e, e + 1) hit disjoint banks
-constexpr int DW_TILES_PER_WG = 8;                // 4 waves x 2 tiles: the staged block and the B operand reads serve two tiles per wave
+constexpr int DW_TILES_PER_WG = 4;                // 4 waves x 1 tile (two tiles per wave: 218 registers, two residents per SIMD, 0.45 of peak)
 constexpr int DW_MT = 16 * 32;                    // mid table of one tile slot: [15 (+1)][32 edges]
 constexpr int DW_LDS_FLOATS = 32 * KDIM + 32 * DW_GS + NODE_STRIDE * 32 + 32 * 4 + DW_TILES_PER_WG * DW_MT;
 
@@ -592,25 +593,22 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
   float* gS = hS + 32 * KDIM;                   // [32][DW_GS]  rows of invalid edges are zero => their g_w is zero
   float* xT = gS + 32 * DW_GS;                  // [80][32]
   float* vS = xT + NODE_STRIDE * 32;            // [32][4]
-  float* mT = vS + 32 * 4;                      // [8 tile slots][16][32]  mids of the block's edges
+  float* mT = vS + 32 * 4;                      // [tile slots][16][32]  mids of the block's edges
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rho = lane & 31, hf = lane >> 5;
   const int Tb = blockIdx.x * DW_TILES_PER_WG;  // first tile of this workgroup
-  const int T0 = __builtin_amdgcn_readfirstlane(Tb + wave), T1 = T0 + 4;     // this wave's two second-Linear tiles (wave-uniform)
-  const bool live0 = T0 < NTW, live1 = T1 < NTW;
-  int mrow0, gcol0, mrow1, gcol1;
-  float lv0, lv1;
+  const int T0 = __builtin_amdgcn_readfirstlane(Tb + wave);                  // this wave's second-Linear tile (wave-uniform)
+  const bool live0 = T0 < NTW;
+  int mrow0, gcol0;
+  float lv0;
   dw_recipe<IN, OUT>(live0 ? T0 : NTW - 1, rho, mrow0, gcol0, lv0);
-  dw_recipe<IN, OUT>(live1 ? T1 : NTW - 1, rho, mrow1, gcol1, lv1);
   if (!live0) lv0 = 0.f;
-  if (!live1) lv1 = 0.f;
   // scalar-block tiles (0e, 0o) multiply a scalar mid with a scalar gradient: only component 0 of the generic three-term form
-  const bool three0 = T0 >= S.t0e && T0 < S.t0e + S.t1o + S.t1e, three1 = T1 >= S.t0e && T1 < S.t0e + S.t1o + S.t1e;   // vector-block tiles
+  const bool three0 = T0 >= S.t0e && T0 < S.t0e + S.t1o + S.t1e;   // vector-block tile
   const float* m0p = mT + wave * DW_MT + mrow0 * 32;
-  const float* m1p = mT + (wave + 4) * DW_MT + mrow1 * 32;
-  f32x16 a00, a01, a02, a10, a11, a12;
+  f32x16 a00, a01, a02;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a02[r] = 0.f; a10[r] = 0.f; a11[r] = 0.f; a12[r] = 0.f; }
-  float db0 = 0.f, db1 = 0.f;
+  for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a02[r] = 0.f; }
+  float db0 = 0.f;
   const int b_lo = blockIdx.y * A.blocks_per_chunk;
   const int n_blk = min(A.blocks_per_chunk, (A.e_hi - A.e_lo + 31) / 32 - b_lo);
   // staging through registers: block b + 1 is in flight from global memory while block b is multiplied
@@ -652,7 +650,7 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
     stage();
     __syncthreads();
     if (bk + 1 < n_blk) fetch(A.e_lo + (b_lo + bk + 1) * 32);
-    // mids of this block for the workgroup's 8 tile slots: (slot, q, edge) -> 3 components; 8 x 5 x 32 items over 256 threads
+    // mids of this block for the workgroup's tile slots: (slot, q, edge) -> 3 components; 4 x 5 x 32 items over 256 threads
 #pragma unroll 1
     for (int it = tid; it < DW_TILES_PER_WG * VEC_TILE_I * 32; it += 256) {
       const int e = it & 31, q = (it >> 5) % VEC_TILE_I, slot = it / (VEC_TILE_I * 32);
@@ -672,19 +670,13 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
       const float* ge = gS + e * DW_GS;
       const float* hb = hS + e * KDIM + rho;    // B operand: lane (n = rho, hf) supplies h[edge 2s + hf][32 kb + n]
       const float b0 = hb[0], b1 = hb[32], b2 = hb[64];
-      float x0 = m0p[e] * ge[gcol0], x1 = m1p[e] * ge[gcol1];
+      float x0 = m0p[e] * ge[gcol0];
       if (three0) x0 += m0p[32 + e] * ge[gcol0 + 1] + m0p[64 + e] * ge[gcol0 + 2];
-      if (three1) x1 += m1p[32 + e] * ge[gcol1 + 1] + m1p[64 + e] * ge[gcol1 + 2];
       x0 *= lv0;
-      x1 *= lv1;
       a00 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b0, a00, 0, 0, 0);
       a01 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b1, a01, 0, 0, 0);
       a02 = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, b2, a02, 0, 0, 0);
-      a10 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b0, a10, 0, 0, 0);
-      a11 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b1, a11, 0, 0, 0);
-      a12 = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, b2, a12, 0, 0, 0);
       db0 += x0;
-      db1 += x1;
     }
   }
   float* out = A.partial + (size_t)blockIdx.y * (WP * KDIM + WP);
@@ -701,7 +693,6 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
     if (hf == 0) out[(size_t)WP * KDIM + T * 32 + rho] = db + other;
   };
   if (live0) store(T0, a00, a01, a02, db0);
-  if (live1) store(T1, a10, a11, a12, db1);
 }
 
 template <int IN, int OUT>

@@ -449,7 +449,7 @@ class TensorProductHubFn(torch.autograd.Function):
                 if fused:
                     # dW2p / db2p with the edges as the MFMA k dimension (cbd_tp_backward_dw), partial sums per edge chunk
                     wp = sm.wp
-                    n_chunks = max(1, min(160, ((ne + 31) // 32) // 6))
+                    n_chunks = max(1, min(256, ((ne + 31) // 32) // 4))
                     part = _dw_scratch(n_chunks * (wp * KDIM + wp), xrow.device).view(n_chunks, wp * KDIM + wp)
                     TIMER.wrap("dw", in_level, out_level, ne, lambda: _check(lib.cbd_tp_backward_dw(
                         in_level, out_level, lo, hi, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), n_chunks, _ptr(part), _stream_handle())))
