@@ -102,7 +102,11 @@ using namespace cbd;
 static int soa_of(int32_t n, const float* pos_dev, float** soa, hipStream_t s) {
   HIPCHK(hipMallocAsync(reinterpret_cast<void**>(soa), (size_t)3 * n * sizeof(float), s));
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, pos_dev, *soa);
-  HIPCHK(hipGetLastError());
+  if (hipError_t e = hipGetLastError(); e != hipSuccess) {     // no early return that leaks the buffer
+    hipFreeAsync(*soa, s);
+    *soa = nullptr;
+    HIPCHK(e);
+  }
   return 0;
 }
 
@@ -114,8 +118,10 @@ int cbd_knn_graph(int32_t n, int32_t k, const float* pos_dev, int32_t* nbr_out_d
   float* soa = nullptr;
   CHK(soa_of(n, pos_dev, &soa, s));
   hipLaunchKernelGGL(knn_kernel, dim3(n), dim3(64), 0, s, n, k, soa, soa + n, soa + 2 * (size_t)n, nbr_out_dev);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipFreeAsync(soa, s));
+  const hipError_t launched = hipGetLastError();
+  const hipError_t freed = hipFreeAsync(soa, s);              // freed on the error path as well
+  HIPCHK(launched);
+  HIPCHK(freed);
   return 0;
 }
 
@@ -130,7 +136,9 @@ int cbd_radius_neighbors(int32_t n, float cutoff, int32_t cap, const float* pos_
   CHK(soa_of(n, pos_dev, &soa, s));
   hipLaunchKernelGGL(radius_neighbors_kernel, dim3(n), dim3(64), 0, s, n, cutoff, cap, soa, soa + n, soa + 2 * (size_t)n, idx_out_dev,
                      cnt_out_dev);
-  HIPCHK(hipGetLastError());
-  HIPCHK(hipFreeAsync(soa, s));
+  const hipError_t launched = hipGetLastError();
+  const hipError_t freed = hipFreeAsync(soa, s);
+  HIPCHK(launched);
+  HIPCHK(freed);
   return 0;
 }

@@ -213,7 +213,7 @@ def read_sdf(path) -> Mol:
 def read_mol2(path) -> Mol:
     """TRIPOS MOL2: the first molecule's ATOM and BOND records.  Element = the SYBYL type in front of the dot; bond types 1 / 2 / 3 /
     ar (aromatic) / am (amide: single); `du`, `un` -> unspecified, `nc` records are skipped."""
-    section, atoms, pos, bonds, ids, name, seen_mol = None, [], [], [], {}, "", 0
+    section, atoms, pos, bonds, ids, name, seen_mol, sybyl = None, [], [], [], {}, "", 0, []
     with open(path) as f:
         for raw in f:
             line = raw.strip()
@@ -237,6 +237,7 @@ def read_mol2(path) -> Mol:
                     if z == 0:
                         z, sym = _element(t[1][:1])
                 ids[int(t[0])] = len(atoms)
+                sybyl.append(t[5])
                 atoms.append(Atom(len(atoms), z, sym, 0))
                 pos.append((float(t[2]), float(t[3]), float(t[4])))
             elif section == "BOND":
@@ -246,7 +247,18 @@ def read_mol2(path) -> Mol:
                     continue
                 code = {"1": 1, "2": 2, "3": 3, "ar": 4, "am": 1}.get(kind, 0)
                 bonds.append(Bond(ids[int(t[1])], ids[int(t[2])], code))
-    return Mol(atoms, bonds, np.asarray(pos).reshape(-1, 3), name=name or "")
+    mol = Mol(atoms, bonds, np.asarray(pos).reshape(-1, 3), name=name or "")
+    # SYBYL's delocalised acid groups (O.co2 with `ar` / mixed bonds on a carboxylate, phosphate, sulfonate centre): one double bond,
+    # the other oxygens single and -1 unless they carry a hydrogen -- rdkit's Mol2 clean-up of the same groups
+    for c in range(len(atoms)):
+        oxy = [(j, k) for j, k in mol.neighbors(c) if sybyl[j].lower() == "o.co2" and sum(1 for q, _ in mol.neighbors(j) if atoms[q].z > 1) == 1]
+        if len(oxy) < 2:
+            continue
+        for n_, (j, k) in enumerate(oxy):
+            bonds[k].type = 2 if n_ == 0 else 1
+            if n_ > 0 and not any(atoms[q].z == 1 for q, _ in mol.neighbors(j)):
+                atoms[j].charge = -1
+    return mol
 
 
 # ---- graph algorithms -----------------------------------------------------------------------------------------------------------------

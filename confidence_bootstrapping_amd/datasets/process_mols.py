@@ -13,7 +13,10 @@ meaning; what differs:
     package: without a GPU pass the edge lists in (`rec_edge_index=` / `atom_edge_index=`) or call with `device=None` to get the
     node stores only;
   * language-model embeddings are passed in as arrays (ESM weights are not in the image).
-The ligand side (`get_lig_graph_with_matching`, rdkit conformer matching, process_mols.py:567-660) needs rdkit and is NOT built.
+The ligand side (bottom of this file): `read_molecule` / `read_sdf_or_mol2` (SDF V2000 and MOL2 readers, datasets/molfile.py),
+`lig_atom_featurizer`, `get_lig_graph`, `get_lig_graph_with_matching` without the rdkit conformer matching (`matching=False`, what
+inference on given poses uses), `get_transformation_mask` (torsion.py) and `get_complex` = receptor + ligand from the three files of a
+PDBBind-style directory.  Which of the 16 atom features are exact and which are rdkit perception restated: molfile.LIG_FEATURE_SOURCES.
 
 Vocabularies and the 14-slot heavy-atom layout are the reference's data contract (process_mols.py:60-123, constants.py:78-98): a
 checkpoint's embedding tables are indexed by them.
@@ -94,7 +97,7 @@ def parse_pdb(path) -> ParsedPDB:
     """Minimal reader for what `prody.parsePDB(path)` + `pdb.ca` + parse_chi.get_coords give the reference: every residue (in file
     order) that owns an atom named CA, its one-letter code (unknown names -> 'X'), and the coordinates of its heavy atoms in the
     14-slot layout.  First model, first alternate location; hydrogens never match a slot name."""
-    residues, index = [], {}
+    residues, prev = [], None
     with open(path) as f:
         for line in f:
             rec = line[:6]
@@ -108,11 +111,11 @@ def parse_pdb(path) -> ParsedPDB:
             name, resn = line[12:16].strip(), line[17:20].strip()
             if rec == "HETATM" and resn not in _SEQ_MAP:
                 continue                                                # prody's `.ca` = C-alphas of PROTEIN residues (not a Ca2+ ion)
-            key = (line[72:76].strip(), line[21], line[22:27])          # segment, chain, residue number + insertion code
-            if key not in index:
-                index[key] = len(residues)
+            key = (line[72:76].strip(), line[21], line[22:27], resn)    # segment, chain, residue number + insertion code, name
+            if key != prev:                                             # prody's resindex: a new residue whenever the key changes,
+                prev = key                                              # also when the same key comes back later in the file
                 residues.append({"resn": resn, "key": key, "atoms": {}})
-            atoms = residues[index[key]]["atoms"]
+            atoms = residues[-1]["atoms"]
             if name not in atoms:
                 atoms[name] = (float(line[30:38]), float(line[38:46]), float(line[46:54]))
     residues = [r for r in residues if "CA" in r["atoms"]]
@@ -310,4 +313,143 @@ def get_receptor(path, name, device, receptor_radius=15.0, c_alpha_max_neighbors
     if all_atoms:
         g["atom"].pos = g["atom"].pos - center
     g.original_center = center
+    return g
+
+
+# ---- ligand side ------------------------------------------------------------------------------------------------------------------
+from .molfile import Mol, read_sdf, read_mol2, perceive, remove_hs as _remove_hs, BOND_FEATURE_INDEX, LIG_FEATURE_SOURCES  # noqa: E402
+from ..torsion import get_transformation_mask  # noqa: E402
+
+lig_feature_dims = ([119, 4, 12, 12, 8, 10, 6, 6, 2, 8, 2, 2, 2, 2, 2, 2], 0)          # process_mols.py:95-112
+_CHIRALITY = ["CHI_UNSPECIFIED", "CHI_TETRAHEDRAL_CW", "CHI_TETRAHEDRAL_CCW", "CHI_OTHER"]
+_HYBRIDIZATION = ["SP", "SP2", "SP3", "SP3D", "SP3D2", "misc"]
+_RANGE = {"degree": list(range(11)) + ["misc"], "charge": list(range(-5, 6)) + ["misc"], "implicit": list(range(7)) + ["misc"],
+          "numH": list(range(9)) + ["misc"], "radical": list(range(5)) + ["misc"], "numring": list(range(7)) + ["misc"]}
+
+
+def read_molecule(molecule_file, sanitize=False, calc_charges=False, remove_hs=False):
+    """Reference process_mols.py:923-957.  `.sdf` and `.mol2` are read by datasets/molfile.py (`.pdbqt` / `.pdb` ligands need rdkit's
+    bond perception: NotImplementedError).  `sanitize` runs the perception pass (`molfile.perceive`: aromatic bonds, hydrogen counts,
+    hybridisation, chirality); a file that cannot be parsed gives None like a failed sanitisation there."""
+    if molecule_file.endswith(".mol2"):
+        reader = read_mol2
+    elif molecule_file.endswith(".sdf"):
+        reader = read_sdf
+    elif molecule_file.endswith(".pdbqt") or molecule_file.endswith(".pdb"):
+        raise NotImplementedError("ligands from .pdb / .pdbqt need rdkit's bond perception; convert to .sdf or .mol2")
+    else:
+        return ValueError("Expect the format of the molecule_file to be one of .mol2, .sdf, .pdbqt and .pdb, got {}".format(molecule_file))
+    try:
+        mol = reader(molecule_file)
+        if sanitize or calc_charges:
+            perceive(mol)
+        if remove_hs:
+            mol = _remove_hs(mol)
+    except Exception:
+        return None
+    return mol
+
+
+def read_sdf_or_mol2(sdf_fileName, mol2_fileName):
+    """Reference process_mols.py:960-977: the SDF, else the MOL2; hydrogens removed; `problem` when neither parses."""
+    mol, problem = None, False
+    try:
+        mol = _remove_hs(perceive(read_sdf(sdf_fileName)))
+    except Exception:
+        problem = True
+    if problem:
+        try:
+            mol = _remove_hs(perceive(read_mol2(mol2_fileName)))
+            problem = False
+        except Exception:
+            problem = True
+    return mol, problem
+
+
+def lig_atom_featurizer(mol: Mol) -> torch.Tensor:
+    """[N, 16] categorical features in the reference's column order and vocabularies (process_mols.py:141-175)."""
+    if not mol.perceived:
+        perceive(mol)
+    ring = mol.GetRingInfo()
+    rows = []
+    for idx, atom in enumerate(mol.GetAtoms()):
+        rows.append([
+            safe_index(allowable_features["possible_atomic_num_list"], atom.GetAtomicNum()),
+            _CHIRALITY.index(atom.GetChiralTag()),
+            safe_index(_RANGE["degree"], atom.GetTotalDegree()),
+            safe_index(_RANGE["charge"], atom.GetFormalCharge()),
+            safe_index(_RANGE["implicit"], atom.GetImplicitValence()),
+            safe_index(_RANGE["numH"], atom.GetTotalNumHs()),
+            safe_index(_RANGE["radical"], atom.GetNumRadicalElectrons()),
+            safe_index(_HYBRIDIZATION, atom.GetHybridization()),
+            int(atom.GetIsAromatic()),
+            safe_index(_RANGE["numring"], ring.NumAtomRings(idx)),
+        ] + [int(ring.IsAtomInRingOfSize(idx, k)) for k in range(3, 9)])
+    return torch.tensor(rows, dtype=torch.long).reshape(-1, 16)
+
+
+def get_lig_graph(mol: Mol, complex_graph):
+    """Reference process_mols.py:567-589: atom features, every bond twice in a row (begin -> end, end -> begin) in the molecule's
+    bond order, bond-type one-hot (single / double / triple / aromatic; unspecified -> single), coordinates."""
+    atom_feats = lig_atom_featurizer(mol)
+    row, col, edge_type = [], [], []
+    for bond in mol.GetBonds():
+        start, end = bond.GetBeginAtomIdx(), bond.GetEndAtomIdx()
+        row += [start, end]
+        col += [end, start]
+        edge_type += 2 * [BOND_FEATURE_INDEX.get(bond.GetBondType(), 0)]
+    edge_index = torch.tensor([row, col], dtype=torch.long).reshape(2, -1)
+    edge_attr = torch.nn.functional.one_hot(torch.tensor(edge_type, dtype=torch.long), num_classes=4).to(torch.float)
+    complex_graph["ligand"].x = atom_feats
+    complex_graph["ligand", "lig_bond", "ligand"].edge_index = edge_index
+    complex_graph["ligand", "lig_bond", "ligand"].edge_attr = edge_attr
+    if mol.GetNumConformers() > 0:
+        complex_graph["ligand"].pos = torch.from_numpy(mol.GetConformer().GetPositions()).float()
+
+
+def get_lig_graph_with_matching(mol_, complex_graph, popsize=None, maxiter=None, matching=False, keep_original=False, num_conformers=1,
+                                remove_hs=False, tries=10, skip_matching=False):
+    """Reference process_mols.py:609-657, the `matching=False` branch (poses as given in the file; what inference on holo ligands
+    uses).  Conformer generation + torsion matching (`matching=True`) is rdkit's ETKDG and differential evolution: not built."""
+    if matching:
+        raise NotImplementedError("conformer matching needs rdkit (ETKDG embedding); call with matching=False")
+    complex_graph.rmsd_matching = 0
+    if remove_hs:
+        mol_ = _remove_hs(mol_ if mol_.perceived else perceive(mol_))
+    if keep_original:
+        complex_graph["ligand"].orig_pos = mol_.GetConformer().GetPositions()
+    get_lig_graph(mol_, complex_graph)
+    edge_mask, mask_rotate = get_transformation_mask(complex_graph)
+    complex_graph["ligand"].edge_mask = torch.tensor(edge_mask)
+    complex_graph["ligand"].mask_rotate = mask_rotate
+    return mol_
+
+
+def get_ligand(ligand_file, name, remove_hs=True, mol2_file=None, keep_original=True) -> HeteroData:
+    """One ligand graph from an .sdf (fallback .mol2) file: what `PDBBind.get_complex` does for the ligand (datasets/pdbbind.py:378-400,
+    `read_mol` :464-469), absolute coordinates."""
+    lig = read_molecule(ligand_file, remove_hs=False, sanitize=True)
+    if lig is None and mol2_file is not None:
+        lig = read_molecule(mol2_file, remove_hs=False, sanitize=True)
+    if lig is None or isinstance(lig, Exception):
+        raise ValueError(f"could not read the ligand {ligand_file}")
+    g = HeteroData()
+    g.name = name
+    g.mol = get_lig_graph_with_matching(lig, g, matching=False, keep_original=keep_original, remove_hs=remove_hs)
+    return g
+
+
+def get_complex(protein_pdb, ligand_file, name, device, remove_hs=True, mol2_file=None, all_atoms=True, lm_embeddings=None,
+                sequences_to_embeddings=None, **receptor_kwargs) -> HeteroData:
+    """Receptor + ligand of one complex from its files (e.g. data/1a0q/1a0q_protein_processed.pdb + 1a0q_ligand.sdf), as the
+    reference's datasets assemble them (pdbbind.py:378-432): ligand stores, receptor (and all-atom) stores, everything centred on the
+    C-alpha centroid, `original_center` kept, `orig_pos` in absolute coordinates."""
+    g = get_ligand(ligand_file, name, remove_hs=remove_hs, mol2_file=mol2_file)
+    rec = get_receptor(protein_pdb, name, device, all_atoms=all_atoms, lm_embeddings=lm_embeddings,
+                       sequences_to_embeddings=sequences_to_embeddings, **receptor_kwargs)
+    for key, st in rec._stores.items():
+        g._stores[key] = st
+    g.original_center = rec.original_center
+    g.receptor_name = rec.receptor_name
+    g["ligand"].pos = g["ligand"].pos - rec.original_center
     return g

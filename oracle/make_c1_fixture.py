@@ -3,8 +3,9 @@
 TEST INFRASTRUCTURE ONLY; needs /root/reference (this container).  rdkit / biopython / ESM are not available, so this
 is a PLUMBING fixture: real C-alpha coordinates and residue types of the 416 residues, real heavy-atom
 coordinates + bonds of the ligand from the SDF; per-atom categorical features reduced to what the files give
-(atomic number, degree, aromatic bond flag, ring flags = 0), rotatable bonds = single non-terminal bridge bonds with
->= 2 heavy atoms on both sides (the rule of utils/torsion.py:15-45), ESM block = seeded N(0, 0.5) placeholder.
+(atomic number, degree, aromatic bond flag, ring flags = 0), rotatable bonds = the reference's own get_transformation_mask
+(utils/torsion.py:15-45) run on the SDF's heavy-atom bond list, ESM block = seeded N(0, 0.5) placeholder.
+(The ligand as the PACKAGE featurises it -- datasets/process_mols.get_ligand -- is covered by tests/test_ligand_featurise.py.)
 Stored: arrays only (the graph schema of SURVEY.md 8b-4)."""
 import os
 import sys
@@ -23,7 +24,6 @@ Z = {"H": 1, "C": 6, "N": 7, "O": 8, "F": 9, "P": 15, "S": 16, "CL": 17, "BR": 3
 
 def main():
     from scipy.spatial import cKDTree
-    from confidence_bootstrapping_amd.synthetic import _components_without
     ca, rtype = [], []
     for line in open(os.path.join(D, "1a0q_protein_processed.pdb")):
         if line.startswith("ATOM") and line[12:16].strip() == "CA":
@@ -59,21 +59,15 @@ def main():
     for k, (a, b, t) in enumerate(hb):
         edge_index[:, 2 * k], edge_index[:, 2 * k + 1] = (a, b), (b, a)
         edge_attr[2 * k:2 * k + 2, {1: 0, 2: 1, 3: 2, 4: 3}.get(t, 0)] = 1
-    edge_mask = np.zeros(2 * len(hb), dtype=bool)
-    rows = []
-    for k, (a, b, t) in enumerate(hb):
-        if t != 1:
-            continue
-        comp, nc = _components_without(Nl, pairs, k)
-        if nc != 2 or np.bincount(comp).min() < 2:
-            continue
-        side = comp == int(np.argmin(np.bincount(comp)))
-        rows.append((2 * k + 1, side) if side[a] else (2 * k, side))
-    rows.sort(key=lambda r: r[0])
-    mask_rotate = np.zeros((len(rows), Nl), dtype=bool)
-    for i, (e, side) in enumerate(rows):
-        edge_mask[e] = True
-        mask_rotate[i] = side
+    # rotatable bonds: the REFERENCE's own get_transformation_mask (utils/torsion.py:15-45; no bond-order test there) run on this edge
+    # list through the loader and the to_networkx restatement of oracle/make_golden_ligand.py
+    from oracle import ref_import
+    from oracle.make_golden_ligand import LigandOnlyGraph, to_networkx
+    ref_import.install(load_tables=False)
+    import utils.torsion as rt
+    rt.to_networkx = to_networkx
+    edge_mask, mask_rotate = rt.get_transformation_mask(LigandOnlyGraph(Nl, edge_index))
+    rows = list(mask_rotate)
     Nr = len(ca)
     _, nbr = cKDTree(ca).query(ca, k=25)
     rec_edge_index = np.stack([nbr[:, 1:].reshape(-1), np.repeat(np.arange(Nr), 24)]).astype(np.int64)

@@ -88,6 +88,16 @@ def test_parse_pdb_rules(tmp_path):
     assert onehot[3, 7] == 1                                               # unknown -> GLY column (parse_chi.py:79)
     with pytest.raises(KeyError):
         pm.get_moad_atom_feats("X", pdb.coords[3])                        # the reference fails on such a residue in all-atom mode too
+    # insertion codes are residues of their own, and a residue key that comes back later in the file starts a NEW residue (prody's
+    # resindex; it is not merged into its first occurrence)
+    ins = [atom("ATOM", 1, " CA", " ", "GLY", "A", "52", 0, 0, 0, "C"), atom("ATOM", 2, " CA", " ", "SER", "A", "52A", 3.8, 0, 0, "C"),
+           atom("ATOM", 3, " CA", " ", "ALA", "A", "53", 7.6, 0, 0, "C"), atom("ATOM", 4, " CB", " ", "GLY", "A", "52", 1, 1, 1, "C"),
+           atom("ATOM", 5, " CA", " ", "GLY", "A", "52", 2, 2, 2, "C")]
+    ins = [l[:22] + f"{l[22:27].strip():>4} "[:5] + l[27:] if not l[22:27].strip()[-1].isalpha() else l[:22] + f"{l[22:27].strip():>5}" + l[27:] for l in ins]
+    q = tmp_path / "ins.pdb"
+    q.write_text("".join(ins))
+    pdb = pm.parse_pdb(str(q))
+    assert pdb.seq == "GSAG" and np.allclose(pdb.coords[3, 1], [2, 2, 2]) and np.allclose(pdb.coords[0, 1], [0, 0, 0])
 
 
 def _pairs(ei):
