@@ -103,7 +103,7 @@ static int soa_of(int32_t n, const float* pos_dev, float** soa, hipStream_t s) {
   HIPCHK(hipMallocAsync(reinterpret_cast<void**>(soa), (size_t)3 * n * sizeof(float), s));
   hipLaunchKernelGGL(aos_to_soa_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, pos_dev, *soa);
   if (hipError_t e = hipGetLastError(); e != hipSuccess) {     // no early return that leaks the buffer
-    hipFreeAsync(*soa, s);
+    (void)hipFreeAsync(*soa, s);
     *soa = nullptr;
     HIPCHK(e);
   }

@@ -221,7 +221,25 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 conf_engines_used.add(ceng)
         groups.clear()
 
-    with torch.no_grad():
+    def drop_stale_capacity_flags(exc_type):
+        """The confidence engine's capacity flag is sticky and lives on the (cached) engine: if this call ends by an exception
+        before the final check(), the flag must not survive into the next, unrelated call."""
+        if exc_type is not None:
+            for ceng in conf_engines_used:
+                try:
+                    ceng.check()
+                except RuntimeError:
+                    pass
+
+    class _Guard:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, exc_type, exc, tb):
+            drop_stale_capacity_flags(exc_type)
+            return False
+
+    with torch.no_grad(), _Guard():
         # The reference collates every chunk with torch_geometric's Batch (utils/sampling.py:78); only the ligand coordinates of
         # the poses and ONE copy of the complex are needed here, so the chunks are walked without collating (for a 40-pose
         # complex the collation of the 1281-wide receptor features alone costs more host time than the GPU work).

@@ -49,13 +49,17 @@ def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
     side = _copy_stream(device)
     keep_alive = []
 
-    def dv(parts, dim=0, static=False):
+    names = [getattr(d, "name", None) for d in data_list]
+    names = [n if isinstance(n, str) else None for n in names]
+
+    def dv(parts, dim=0, static=False, role=None):
         """per-graph host-to-device copies, concatenated on the device (a host-side cat of the 2 MB/complex language-model
         features costs more than the whole GPU step on a many-core host).  static=True: tensors that belong to the COMPLEX, not to the
         noised sample (receptor features / trace / graph, ligand atom types / bonds) -- the buffer hands out shallow copies that share
         them, so their device copies are cached across steps (_dev_cached) instead of being uploaded again for every sample."""
         with torch.cuda.stream(side):
-            up = [(_dev_cached(p, device) if static else p.to(device, non_blocking=True)) for p in parts]
+            up = [(_dev_cached(p, device, (n, role) if n is not None and role else None) if static else p.to(device, non_blocking=True))
+                  for p, n in zip(parts, names)]
             out = torch.cat(up, dim) if len(up) > 1 else (up[0].clone() if static else up[0])
         keep_alive.append(out)
         return out
@@ -89,24 +93,24 @@ def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
     (fdev, fall), (idev, _) = stage(fparts, torch.float32), stage(iparts, torch.int64)
     B = len(data_list)
 
-    def edges(parts, per_edge_offset):
+    def edges(parts, per_edge_offset, role):
         """edge_index tensors: cached raw copies concatenated on the device, per-graph node offsets added with one op"""
         with torch.cuda.stream(side):
-            up = [_dev_cached(p, device) for p in parts]
+            up = [_dev_cached(p, device, (n, role) if n is not None else None) for p, n in zip(parts, names)]
             out = (torch.cat(up, 1) if len(up) > 1 else up[0]) + per_edge_offset
         keep_alive.append(out)
         return out
 
-    b["ligand"].x = dv([d["ligand"].x for d in data_list], static=True)
+    b["ligand"].x = dv([d["ligand"].x for d in data_list], static=True, role="lig_x")
     b["ligand"].pos = fall[:3 * sum(nl)].view(-1, 3)
-    b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list], static=True)
+    b["ligand"].edge_mask = dv([d["ligand"].edge_mask for d in data_list], static=True, role="lig_edge_mask")
     b["ligand"].batch = idev[0]
-    b["ligand", "ligand"].edge_index = edges([d["ligand", "ligand"].edge_index for d in data_list], idev[3])
-    b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list], static=True)
-    b["receptor"].x = dv([d["receptor"].x for d in data_list], static=True)
-    b["receptor"].pos = dv([d["receptor"].pos for d in data_list], static=True)
+    b["ligand", "ligand"].edge_index = edges([d["ligand", "ligand"].edge_index for d in data_list], idev[3], "lig_edge_index")
+    b["ligand", "ligand"].edge_attr = dv([d["ligand", "ligand"].edge_attr for d in data_list], static=True, role="lig_edge_attr")
+    b["receptor"].x = dv([d["receptor"].x for d in data_list], static=True, role="rec_x")
+    b["receptor"].pos = dv([d["receptor"].pos for d in data_list], static=True, role="rec_pos")
     b["receptor"].batch = idev[1]
-    b["receptor", "receptor"].edge_index = edges([d["receptor", "receptor"].edge_index for d in data_list], idev[4])
+    b["receptor", "receptor"].edge_index = edges([d["receptor", "receptor"].edge_index for d in data_list], idev[4], "rec_edge_index")
     b.complex_t = {"tr": fdev[B], "rot": fdev[B + 1], "tor": fdev[B + 2]}
     # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
     b.host = {"t": t_host, "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl}
@@ -123,27 +127,73 @@ def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
 
 
 _COPY_STREAMS = {}
-_DEV_CACHE = {}          # (host storage pointer, shape, dtype, version, device) -> (host tensor kept alive, device copy)
+# Device copies of host tensors that do not change between training steps (receptor features and positions, ligand features, bonds).
+#   * keyed on the COMPLEX, not on the host tensor: (complex name, role, shape, dtype, device).  The bootstrapping buffer hands out
+#     shallow copies that share a complex's tensors, the reference's loaders deep-copy them; either way the same complex comes back
+#     under the same name, and a key that does not hold a storage address neither pins host memory nor depends on the allocator
+#     recycling addresses.  Graphs without a string `name` are uploaded every step (no entry);
+#   * every hit compares a fingerprint of the host tensor (32 strided elements + the last, ~5 us) with the one taken at upload time:
+#     two complexes that share a name, or a tensor edited in place (re-centring, a numpy view, `.data`), re-upload and replace the
+#     entry instead of training on a stale copy.  A guard, not a proof: an edit that leaves all 33 probes untouched goes unnoticed --
+#     callers that patch single elements of a cached tensor call `dev_cache_clear()`;
+#   * least-recently-used entries are evicted by bytes (default limit 4 GB of device copies), never the whole cache at once;
+#   * `CBD_TRAIN_DEV_CACHE=0` or `dev_cache_configure(enabled=False)` turns it off (every step uploads its inputs).
+_DEV_CACHE = __import__("collections").OrderedDict()      # key -> (device copy, fingerprint)
 _DEV_CACHE_BYTES = [0]
-_DEV_CACHE_LIMIT = 4 << 30
+_DEV_CACHE_CFG = {"enabled": os.environ.get("CBD_TRAIN_DEV_CACHE", "1") != "0", "limit": 4 << 30}
 
 
-def _dev_cached(t: torch.Tensor, device):
-    """Device copy of a host tensor that does not change between training steps, uploaded once.  The key holds the tensor's storage
-    address, shape, dtype and version counter; the entry keeps the host tensor alive, so the address cannot be recycled while the
-    entry exists.  Device tensors pass through.  Bounded (4 GB): when full the cache is dropped and refills."""
+def dev_cache_configure(enabled=None, limit_bytes=None):
+    if enabled is not None:
+        _DEV_CACHE_CFG["enabled"] = bool(enabled)
+        if not enabled:
+            dev_cache_clear()
+    if limit_bytes is not None:
+        _DEV_CACHE_CFG["limit"] = int(limit_bytes)
+
+
+def dev_cache_clear():
+    _DEV_CACHE.clear()
+    _DEV_CACHE_BYTES[0] = 0
+
+
+def dev_cache_stats():
+    return {"entries": len(_DEV_CACHE), "bytes": _DEV_CACHE_BYTES[0]}
+
+
+def _fingerprint(t: torch.Tensor):
+    n = t.numel()
+    if n == 0:
+        return b""
+    a = t.numpy().reshape(-1) if t.is_contiguous() else t.reshape(-1).numpy()       # a view of the host storage: ~5 us per call
+    return a[::max(1, n // 32)][:32].tobytes() + a[-1:].tobytes()
+
+
+def _dev_cached(t: torch.Tensor, device, ident=None):
+    """Device copy of a host tensor that belongs to a complex (`ident` = (complex name, role)) and does not change between training
+    steps, uploaded once (policy: comment above).  Device tensors pass through; without an identity the tensor is just uploaded."""
     if t.is_cuda:
         return t
-    key = (t.data_ptr(), tuple(t.shape), t.dtype, t._version, str(device))
+    if ident is None or not _DEV_CACHE_CFG["enabled"]:
+        return t.to(device, non_blocking=True)
+    key = (ident, tuple(t.shape), t.dtype, str(device))
+    fp = _fingerprint(t)
     hit = _DEV_CACHE.get(key)
     if hit is not None:
-        return hit[1]
-    if _DEV_CACHE_BYTES[0] > _DEV_CACHE_LIMIT:
-        _DEV_CACHE.clear()
-        _DEV_CACHE_BYTES[0] = 0
+        if hit[1] == fp:
+            _DEV_CACHE.move_to_end(key)
+            return hit[0]
+        _DEV_CACHE_BYTES[0] -= hit[0].numel() * hit[0].element_size()       # another complex under this name, or edited in place
+        del _DEV_CACHE[key]
     d = t.to(device, non_blocking=True)
-    _DEV_CACHE[key] = (t, d)
-    _DEV_CACHE_BYTES[0] += d.numel() * d.element_size()
+    nbytes = d.numel() * d.element_size()
+    if nbytes > _DEV_CACHE_CFG["limit"]:
+        return d
+    while _DEV_CACHE and _DEV_CACHE_BYTES[0] + nbytes > _DEV_CACHE_CFG["limit"]:
+        _, old = _DEV_CACHE.popitem(last=False)
+        _DEV_CACHE_BYTES[0] -= old[0].numel() * old[0].element_size()
+    _DEV_CACHE[key] = (d, fp)
+    _DEV_CACHE_BYTES[0] += nbytes
     return d
 
 

@@ -554,7 +554,7 @@ def first_linear(x, linear):
 # (models/tensor_layers.py:206) and autograd's index_add for every `node_attr[edge_index]` gather.  Atomic float adds make the step
 # differ from run to run in the last bits.  Here every scatter is a segmented sum over edges grouped by target row (`cbd_segment_sum`,
 # fixed order), so a training step is bitwise repeatable; the grouping (stable argsort + row pointers) is cached per index tensor.
-@lru_cache(maxsize=None)
+@lru_cache(maxsize=4096)
 def _csr_scratch_bytes(n: int, n_rows: int) -> int:
     need = C.c_size_t(0)
     _check(_bind(load_library()).cbd_csr_build(n, n_rows, None, None, None, None, 0, C.byref(need), None))
@@ -575,7 +575,9 @@ class Csr:
         self.n_rows = int(n_rows)
         self.index = index
         n = int(index.shape[0])
-        need = _csr_scratch_bytes(1 << max(n - 1, 0).bit_length(), self.n_rows)        # sized for the next power of two: cacheable
+        # sized for the next power of two (cacheable) AND for n itself: rocPRIM's temporary-storage size is not promised to be monotonic
+        # in n across its size-dependent algorithm switch
+        need = max(_csr_scratch_bytes(1 << max(n - 1, 0).bit_length(), self.n_rows), _csr_scratch_bytes(n, self.n_rows))
         scratch = torch.empty(need, dtype=torch.uint8, device=index.device)
         self.perm = torch.empty(n, dtype=torch.long, device=index.device)
         self.rowptr = torch.empty(self.n_rows + 1, dtype=torch.long, device=index.device)

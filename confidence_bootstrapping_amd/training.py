@@ -126,7 +126,12 @@ def allreduce_gradients(model, world_size=None, skip=False):
     dev = params[0].device
     grads = [torch.zeros_like(p).reshape(-1) if (skip or p.grad is None) else p.grad.reshape(-1) for p in params]
     flat = torch.cat(grads + [torch.full((1,), 1.0 if skip else 0.0, device=dev, dtype=grads[0].dtype)])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() != "nccl":     # a host-memory backend (gloo in the tests): reduce a host copy
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     n_skipped = float(flat[-1])
     if n_skipped > 0 or not bool(torch.isfinite(flat).all()):      # non-finite gradients anywhere count as a skipped step everywhere
         return False
@@ -151,7 +156,12 @@ def sync_batchnorm_buffers(model):
     if not bufs:
         return
     flat = torch.cat([b.reshape(-1).float() for b in bufs])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if flat.is_cuda and dist.get_backend() != "nccl":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat /= world
     off = 0
     with torch.no_grad():
@@ -171,9 +181,10 @@ def _async_any_nan(t):
     bad = torch.isnan(t).any()
     if not bad.is_cuda:
         return lambda: bool(bad)
-    buf = _NAN_FLAGS.get(str(t.device))
+    key = (str(t.device), __import__("threading").get_ident())     # one pinned flag per device AND host thread: two models trained from
+    buf = _NAN_FLAGS.get(key)                                       # two threads on one GPU do not share it
     if buf is None:
-        buf = _NAN_FLAGS[str(t.device)] = torch.zeros(1, dtype=torch.bool, pin_memory=True)
+        buf = _NAN_FLAGS[key] = torch.zeros(1, dtype=torch.bool, pin_memory=True)
     buf.copy_(bad.reshape(1), non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(t.device))
@@ -221,6 +232,9 @@ def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=
         if before_backward is not None:
             before_backward()
             before_backward = None
+        # INVARIANT the custom backward functions keep: nothing they write outlives the step unless the step is applied -- hub.grads is
+        # re-zeroed by pack(), train_ops._DW_SCRATCH is overwritten on its next use, parameter .grad is dropped by zero_grad() below --
+        # so a backward pass over a NaN loss leaves no trace (the reference skips BEFORE backward, utils/training.py:201)
         loss.backward()
         if nan_flag():
             skip = True

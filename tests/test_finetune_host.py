@@ -112,3 +112,48 @@ def test_loss_function_matches_reference_values():
     per = loss_function(torch.from_numpy(g11["tr_pred"]), torch.from_numpy(g11["rot_pred"]), torch.from_numpy(g11["tor_pred"]), None,
                         data=data, t_to_sigma=partial(t_to_sigma, args=load_model_args()), device=torch.device("cpu"), apply_mean=False)
     assert per[0].shape == (3,) and abs(float(per[1].mean()) - g11["loss_tuple"][1]) < 1e-5
+
+
+def test_static_tensor_cache_policy():
+    """train_forward._dev_cached: keyed on (complex name, role), so deep-copied batches (the reference's loaders) hit like
+    shared ones and pin nothing; two complexes under one name or an in-place edit behind the version counter re-upload; eviction is
+    least-recently-used by bytes; nameless graphs are never cached; the switch turns it off.  (device 'cpu' exercises the policy; on
+    a GPU box the same code holds device copies.)"""
+    import copy
+    import torch
+    from confidence_bootstrapping_amd import train_forward as tf
+    tf.dev_cache_clear()
+    tf.dev_cache_configure(enabled=True, limit_bytes=4 << 30)
+    base = [torch.randn(50, 8) for _ in range(4)]
+    ids = [(f"cplx{i}", "rec_x") for i in range(4)]
+    first = [tf._dev_cached(t, "cpu", i) for t, i in zip(base, ids)]
+    for _ in range(5):                                       # a loader that deep-copies: new storage every step, same complexes
+        for t, i, f in zip(copy.deepcopy(base), ids, first):
+            assert tf._dev_cached(t, "cpu", i) is f          # served from the entry made at the first sighting
+    assert tf.dev_cache_stats() == {"entries": 4, "bytes": 4 * 50 * 8 * 4}
+    for t in copy.deepcopy(base):                            # no name: uploaded, nothing kept
+        assert tf._dev_cached(t, "cpu", None) is t
+    assert tf.dev_cache_stats()["entries"] == 4
+    # content changed without a version bump (numpy view): the stale copy is not served
+    v = base[0]._version
+    edited = base[0].clone()
+    edited.numpy()[:] = 7.0
+    got = tf._dev_cached(edited, "cpu", ids[0])
+    assert got is edited and base[0]._version == v and tf.dev_cache_stats()["entries"] == 4
+    assert tf._dev_cached(copy.deepcopy(edited), "cpu", ids[0]) is edited
+    # another complex under the same name: replaced, not served
+    other = torch.randn(50, 8)
+    assert tf._dev_cached(other, "cpu", ids[1]) is other and tf.dev_cache_stats()["entries"] == 4
+    # LRU by bytes: room for two entries only -> the two most recently used survive
+    tf.dev_cache_clear()
+    tf.dev_cache_configure(limit_bytes=2 * 50 * 8 * 4)
+    for t, i in zip(base, ids):
+        tf._dev_cached(t, "cpu", i)
+    st = tf.dev_cache_stats()
+    assert st["entries"] == 2 and st["bytes"] == 2 * 50 * 8 * 4
+    assert [k[0] for k in tf._DEV_CACHE] == ids[2:]
+    tf.dev_cache_configure(enabled=False)
+    for _ in range(3):
+        tf._dev_cached(base[1], "cpu", ids[1])
+    assert tf.dev_cache_stats() == {"entries": 0, "bytes": 0}
+    tf.dev_cache_configure(enabled=True, limit_bytes=4 << 30)
