@@ -88,8 +88,8 @@ SYMBOLS = {
     "cbd_outer_accum": (C.c_int, [C.c_int64, _P, _P, C.c_int32, _P, _P]),
     "cbd_segment_sum": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_segment_mean": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
-    "cbd_irreps_bn_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P]),
-    "cbd_irreps_bn_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_irreps_bn_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
+    "cbd_irreps_bn_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_segment_mean_backward": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_segment_sum_ld": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_edge_cat": (C.c_int, [C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P]),

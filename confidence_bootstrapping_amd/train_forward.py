@@ -113,7 +113,7 @@ def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
     b["receptor", "receptor"].edge_index = edges([d["receptor", "receptor"].edge_index for d in data_list], idev[4], "rec_edge_index")
     b.complex_t = {"tr": fdev[B], "rot": fdev[B + 1], "tor": fdev[B + 2]}
     # host copies of what the forward pass would otherwise read back from the device (each read-back is a pipeline bubble)
-    b.host = {"t": t_host, "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl}
+    b.host = {"t": t_host, "n_rot": [int(d["ligand"].edge_mask.sum()) for d in data_list], "nl": nl, "nr": nr}
     # columns of the batch's bond list that are rotatable bonds (the mask is host data: no boolean indexing on the device, which would
     # read the count back)
     b.rot_bond_cols = idev[2]
@@ -385,15 +385,17 @@ def _bn_maps(irreps: str, device):
     return m
 
 
-def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1, residual=None):
+def irreps_batch_norm(bn, x, eps=1e-5, momentum=0.1, residual=None, exclude=None):
     """e3nn.nn.BatchNorm (0.5.0: affine, normalization='component', reduce='mean').  Training: per-channel batch mean of the 0e
     fields and batch mean of the squared (centred) components of every field, running averages updated with `momentum` -- one HIP
     launch forward, one backward (train_ops.IrrepsBatchNormFn; as torch ops ~14 + ~25 launches per call, and the step is host-bound
     at the reference's batch size); eval: running statistics, torch ops.  `residual` [N, <= D] is added to the leading columns of the
-    result (the layer's  out + pad(node_attr), models/tensor_layers.py:211-213)."""
+    result (the layer's  out + pad(node_attr), models/tensor_layers.py:211-213).  `exclude`: two row ranges left out of the batch
+    statistics (the filler graph of a capacity-padded step, `prepare_batch(pad=...)`); their rows get no input gradient."""
     m = _bn_maps(bn.irreps, x.device)
     if bn.training and x.shape[0] > 0:
-        return IrrepsBatchNormFn.apply(x, m["D"], bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, m["fields"], momentum, eps)
+        return IrrepsBatchNormFn.apply(x, m["D"], bn.weight, bn.bias, residual, bn.running_mean, bn.running_var, m["fields"], momentum, eps,
+                                       exclude)
     out = irreps_batch_norm_torch(bn, x[:, :m["D"]], eps, momentum)
     return out if residual is None else out + F.pad(residual, (0, out.shape[1] - residual.shape[1]))
 
@@ -422,7 +424,7 @@ def irreps_batch_norm_torch(bn, x, eps=1e-5, momentum=0.1):
 
 
 # ----------------------------------------------------------------------------- layers
-def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_level, hub=None, group_sizes=None):
+def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_level, hub=None, group_sizes=None, bn_exclude=None):
     """TensorProductConvLayer.forward (models/tensor_layers.py:195-217) with FasterTensorProduct on the HIP op."""
     n, din = node_attr.shape
     dout = LEVEL_DIMS[out_level]
@@ -448,7 +450,7 @@ def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_leve
             msg = tensor_product(xrow, vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level, [ne for _, ne in live])
         # the 80-float message rows go through the segmented mean and into the BatchNorm kernel as they are (it reads the layout's
         # `dout` columns): no slice copy of the [E, 80] tensor
-        return irreps_batch_norm(layer.batch_norm, scatter_mean(msg, src, n), residual=node_attr)
+        return irreps_batch_norm(layer.batch_norm, scatter_mean(msg, src, n), residual=node_attr, exclude=bn_exclude)
     return out + F.pad(node_attr, (0, dout - din))
 
 
@@ -516,8 +518,18 @@ class _Prepared:
         return out
 
 
-def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
-    """Everything of the forward pass that depends on the batch alone, not on the weights (called under the side stream)."""
+def _pad_edges(ei, bucket, a, b):
+    """[2, E] -> [2, ceil(E / bucket) * bucket] with copies of the edge (a, b) (device scalars: nodes of the filler graph)"""
+    n = int(ei.shape[1])
+    cap = -(-max(n, 1) // bucket) * bucket
+    if cap == n:
+        return ei
+    return torch.cat([ei, torch.stack([a, b]).view(2, 1).expand(2, cap - n)], 1)
+
+
+def _prepare(model, data, host, dev, csr_cache=None, pad=None) -> _Prepared:
+    """Everything of the forward pass that depends on the batch alone, not on the weights (called under the side stream).
+    `pad`: see prepare_batch (the last graph of the batch is the filler; `pad` is completed with the ranges the forward pass needs)."""
     g = _Prepared()
     lig, rec = data["ligand"], data["receptor"]
     B = data.num_graphs
@@ -551,7 +563,18 @@ def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
         found = radius_queries(qs)
         ei, lr = found[0], found[1]
         t_edges = found[2] if bonds is not None else None
+        if pad is not None:
+            # padding edges between nodes of the filler graph (the last graph): last ligand atom <-> the one before it, last ligand atom
+            # <-> last residue, the filler's rotatable bond (the last column of `bonds`) <-> last ligand atom
+            pad["edges_real"] = {"ll": int(ei.shape[1]), "lr": int(lr.shape[1]), "t": int(t_edges.shape[1]) if t_edges is not None else 0}
+            la, ra = lig_ptr[-1] - 1, rec_ptr[-1] - 1
+            ei = _pad_edges(ei, pad["buckets"]["ll"], la, la - 1)
+            lr = _pad_edges(lr, pad["buckets"]["lr"], la, ra)
+            if t_edges is not None:
+                t_edges = _pad_edges(t_edges, pad["buckets"]["t"], torch.full_like(la, int(bonds.shape[1]) - 1), la)
     else:                           # a batch collated elsewhere: dense masks, one read-back of their three counts
+        if pad is not None:
+            raise RuntimeError("capacity padding needs the collation of train_forward.collate (node offsets of the graphs)")
         m_ll = radius_graph_mask(lig_pos, model.lig_max_radius, lig_batch)
         m_lr = radius_mask(rec_pos / cutoff[rec_batch], lig_pos / cutoff[lig_batch], 1, rec_batch, lig_batch, max_num_neighbors=10000)
         m_t = radius_mask(lig_pos, bond_pos, model.lig_max_radius, lig_batch, lig_batch[bonds[0]]) if bonds is not None else None
@@ -606,6 +629,13 @@ def _prepare(model, data, host, dev, csr_cache=None) -> _Prepared:
             (g.edge_index[0], nJ), (g.edge_index[1], nJ), (g.ei2[0], nJ), (g.ei2[1], nJ)]
     if g.t_ei is not None:
         warm += [(g.bonds[0], nL), (g.bonds[1], nL), (g.t_ei[1], nL), (g.t_ei[0], int(g.bonds.shape[1]))]
+    if pad is not None:
+        nLr = nL - int(host["nl"][-1])
+        nRr = nR - int(host["nr"][-1])
+        nb = int(g.bonds.shape[1]) if g.bonds is not None else 0
+        pad.update(B_real=B - 1, T_real=int(sum(n_rot[:-1])),
+                   ex_lig=((nLr, nL), (0, 0)), ex_rec=((nRr, nR), (0, 0)), ex_joint=((nLr, nL), (nL + nRr, nL + nR)),
+                   ex_graph=((B - 1, B), (0, 0)), ex_bond=((nb - int(n_rot[-1]), nb), (0, 0)))
     cache = csr_cache if csr_cache is not None else {}
     csr_build_many(warm, cache)                 # all of them with ONE radix sort
     for k, (idx, n) in enumerate(warm):
@@ -617,36 +647,92 @@ class PreparedBatch:
     """A batch after `prepare_batch`: collated tensors, the input-only tensors of `_prepare`, the edge groupings, the side-stream
     tensors to keep alive, and the event the compute stream has to wait for."""
 
-    def __init__(self, batch, g, csr, keep, event, n_graphs):
-        self.batch, self.g, self.csr, self.keep, self.event, self.num_graphs = batch, g, csr, keep, event, n_graphs
+    def __init__(self, batch, g, csr, keep, event, n_graphs, pad=None):
+        self.batch, self.g, self.csr, self.keep, self.event, self.num_graphs, self.pad = batch, g, csr, keep, event, n_graphs, pad
 
 
-def prepare_batch(model, data, dev) -> PreparedBatch:
+FILLER_NAME = "__filler__"
+PAD_BUCKETS = {"ll": 512, "lr": 4096, "t": 256}
+
+
+def filler_complex(like: HeteroData) -> HeteroData:
+    """The filler graph of a capacity-padded step: four ligand atoms in a chain (one rotatable bond) and four residues, with the
+    feature widths and dtypes of `like`.  It is appended to the batch as one more graph; the padding edges of the three radius
+    graphs live inside it, so it is a connected component of its own: nothing flows between it and the real graphs, its rows are
+    excluded from every BatchNorm statistic and its predictions from the loss."""
+    f = HeteroData()
+    lig, rec = like["ligand"], like["receptor"]
+    f["ligand"].x = lig.x[:1].repeat(4, 1).clone()
+    # generic (non-colinear, non-planar) coordinates: a symmetric filler would make some equivariant outputs EXACTLY zero, and the heads
+    # divide by their norms -- a 0/0 in the filler's (discarded) row would still send NaN into the shared weights' gradients
+    f["ligand"].pos = torch.tensor([[0.0, 0, 0], [1.4, 0.3, 0.1], [2.1, 1.5, -0.4], [3.3, 1.9, 0.9]], dtype=lig.pos.dtype)
+    ei = torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 1, 3, 2]], dtype=like["ligand", "ligand"].edge_index.dtype)
+    f["ligand", "ligand"].edge_index = ei
+    ea = like["ligand", "ligand"].edge_attr
+    f["ligand", "ligand"].edge_attr = torch.zeros(6, ea.shape[1], dtype=ea.dtype)
+    f["ligand", "ligand"].edge_attr[:, 0] = 1
+    f["ligand"].edge_mask = torch.tensor([False, False, True, False, False, False])
+    f["ligand"].mask_rotate = np.array([[False, False, True, True]])
+    nr = min(4, int(rec.x.shape[0]))
+    f["receptor"].x = rec.x[:nr].clone()
+    f["receptor"].pos = torch.tensor([[0.5, 6.0, 1.0], [3.9, 5.1, -1.2], [6.2, 7.7, 0.8], [9.1, 6.4, 3.0]], dtype=rec.pos.dtype)[:nr]
+    pairs = [(a, b) for a in range(nr) for b in range(nr) if a != b]
+    f["receptor", "receptor"].edge_index = torch.tensor(pairs, dtype=like["receptor", "receptor"].edge_index.dtype).t().contiguous()
+    f.complex_t = {k: torch.full((1,), 0.5) for k in ("tr", "rot", "tor")}
+    f.name = FILLER_NAME
+    return f
+
+
+_FILLERS = {}
+
+
+def _filler_for(d0: HeteroData) -> HeteroData:
+    key = (tuple(d0["ligand"].x.shape[1:]), tuple(d0["receptor"].x.shape[1:]), d0["ligand"].x.dtype, d0["receptor"].x.dtype,
+           tuple(d0["ligand", "ligand"].edge_attr.shape[1:]))
+    f = _FILLERS.get(key)
+    if f is None:
+        f = _FILLERS[key] = filler_complex(d0)
+    return f
+
+
+def prepare_batch(model, data, dev, pad=None) -> PreparedBatch:
     """Collation + everything of the forward pass that depends on the batch alone (see `forward`).  Thread-safe with respect to a
     training step in flight on another host thread: it enqueues on the side stream only, fills its own caches, and does not touch the
-    model's parameters or the CPU random generators."""
+    model's parameters or the CPU random generators.
+    `pad` (True or a dict of bucket sizes {"ll", "lr", "t"}; `data` must be a list of graphs): capacity padding for the hipGraph-captured
+    step (train_graph.py) -- a filler graph is appended and the three radius graphs of the step (ligand-ligand, ligand-receptor,
+    torsion) are padded with edges INSIDE the filler up to the next multiple of their bucket, so that every tensor of the step has a
+    shape that depends on the batch composition and the buckets only, not on the noise."""
     dev = torch.device(dev)
     if dev.type != "cuda":
         raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
     torch.cuda.set_device(dev)
     keep, csr = [], {}
     side = _copy_stream(dev)
+    info = None
+    if pad:
+        if isinstance(data, Batch) or not isinstance(data, (list, tuple)):
+            raise TypeError("capacity padding takes the list of graphs (the filler graph is collated with them)")
+        buckets = dict(PAD_BUCKETS, **(pad if isinstance(pad, dict) else {}))
+        data = list(data) + [_filler_for(data[0])]
+        info = {"buckets": buckets}
     if isinstance(data, Batch):       # collated elsewhere: its tensors may still be in flight on the compute stream
         batch = data.to(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
     else:
         batch = collate(data, dev, keep=keep)
     with torch.cuda.stream(side):
-        g = _prepare(model, batch, getattr(batch, "host", None), dev, csr)
+        g = _prepare(model, batch, getattr(batch, "host", None), dev, csr, pad=info)
         event = torch.cuda.Event()
         event.record(side)
     keep.extend(g.tensors())
-    return PreparedBatch(batch, g, csr, keep, event, batch.num_graphs)
+    return PreparedBatch(batch, g, csr, keep, event, batch.num_graphs, pad=info)
 
 
 def forward(model, data):
     """(tr_pred [B,3], rot_pred [B,3], tor_pred [sum R], None) like the reference forward (score_model.py:333-449).  `data`: a list of
-    noised graphs (what the reference's DataListLoader yields), their collation, or a `PreparedBatch`."""
+    noised graphs (what the reference's DataListLoader yields), their collation, or a `PreparedBatch`.  For a capacity-padded batch
+    (`prepare_batch(pad=...)`) the filler graph's rows are excluded from the BatchNorm statistics and from the returned predictions."""
     dev = next(model.parameters()).device
     if dev.type != "cuda":
         raise RuntimeError("the training forward runs on the MI355X only (HIP tensor-product kernels, no CPU fallback)")
@@ -660,10 +746,13 @@ def forward(model, data):
     #      step's backward pass is being enqueued (training.train_epoch does).
     prep = data if isinstance(data, PreparedBatch) else prepare_batch(model, data, dev)
     use_csr_cache(prep.csr)     # edge groupings are per step (the graphs change with the poses)
-    _rotate_keep(dev)
-    torch.cuda.current_stream(dev).wait_event(prep.event)
-    _keep_until_main_passes(prep.keep, dev)
+    if prep.event is not None:  # (None: the static twin of a hipGraph capture, train_graph.py -- its tensors are already in place)
+        _rotate_keep(dev)
+        torch.cuda.current_stream(dev).wait_event(prep.event)
+        _keep_until_main_passes(prep.keep, dev)
     data, g = prep.batch, prep.g
+    pad = prep.pad or {}
+    ex_lig, ex_rec, ex_joint, ex_graph, ex_bond = (pad.get(k) for k in ("ex_lig", "ex_rec", "ex_joint", "ex_graph", "ex_bond"))
     ns = model.ns
     lig, rec = data["ligand"], data["receptor"]
     B = data.num_graphs
@@ -680,7 +769,7 @@ def forward(model, data):
     rec_node = atom_encoder(model.rec_node_embedding, g.rec_cat, rec.x[:, 1:].float())
     for l, layer in enumerate(model.rec_emb_layers):
         ea = edge_cat(rec_edge_attr, rec_node, r_ei[0], r_ei[1])
-        rec_node = conv_layer(layer, rec_node, r_ei, ea, g.r_vec4, min(l, 3), min(l + 1, 3), hub)
+        rec_node = conv_layer(layer, rec_node, r_ei, ea, g.r_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_rec)
     graph_sigma_emb = model.timestep_emb_func(ct["tr"])
     rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
     rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
@@ -693,7 +782,7 @@ def forward(model, data):
     lig_edge_attr = model.lig_edge_embedding(l_attr)
     for l, layer in enumerate(model.lig_emb_layers):
         ea = edge_cat(lig_edge_attr, lig_node, l_ei[0], l_ei[1])
-        lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub)
+        lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_lig)
 
     # ---- cross graph (score_model.py:345-352, 564-587)
     lr_edge_attr = model.cross_edge_embedding(torch.cat([take(node_sigma_emb, lr[0]), g.c_smear], 1))
@@ -705,17 +794,22 @@ def forward(model, data):
     for l, layer in enumerate(model.conv_layers):
         if l < nconv - 1:
             ea = edge_cat(edge_attr, node, edge_index[0], edge_index[1])
-            node = conv_layer(layer, node, edge_index, ea, g.vec4, 3, 3, hub, group_sizes=[s1, s2 - s1, s3 - s2, ea.shape[0] - s3])
+            node = conv_layer(layer, node, edge_index, ea, g.vec4, 3, 3, hub, group_sizes=[s1, s2 - s1, s3 - s2, ea.shape[0] - s3],
+                              bn_exclude=ex_joint)
         else:
             ea = edge_cat(edge_attr[:s2], node, g.ei2[0], g.ei2[1])
-            node = conv_layer(layer, node, g.ei2, ea, g.vec4_2, 3, 3, hub, group_sizes=[s1, s2 - s1])
+            node = conv_layer(layer, node, g.ei2, ea, g.vec4_2, 3, 3, hub, group_sizes=[s1, s2 - s1], bn_exclude=ex_joint)
     lig_node = node[:nL]
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
     c_attr = torch.cat([g.center_smear, node_sigma_emb], 1)
     c_attr = torch.cat([model.center_edge_embedding(c_attr), lig_node[:, :ns]], -1)
     gp = scatter_mean(center_tensor_product(lig_node, g.c_vec2, model.final_conv.fc(c_attr)), lig_batch, B)
-    gp = irreps_batch_norm(model.final_conv.batch_norm, gp)
+    gp = irreps_batch_norm(model.final_conv.batch_norm, gp, exclude=ex_graph)
+    so3_norm = g.so3_norm
+    if pad:     # the heads see the real graphs only: the filler's (zero) row would be a 0 / 0 in the normalisations below
+        nb_ = pad["B_real"]
+        gp, graph_sigma_emb, tr_sigma, so3_norm = gp[:nb_], graph_sigma_emb[:nb_], tr_sigma[:nb_], so3_norm[:nb_]
     tr_pred = gp[:, :3] + gp[:, 6:9]
     rot_pred = gp[:, 3:6] + gp[:, 9:]
     tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
@@ -723,7 +817,7 @@ def forward(model, data):
     rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
     rot_pred = rot_pred / rot_norm * model.rot_final_layer(torch.cat([rot_norm, graph_sigma_emb], dim=1))
     tr_pred = tr_pred / tr_sigma.unsqueeze(1)
-    rot_pred = rot_pred * g.so3_norm
+    rot_pred = rot_pred * so3_norm
 
     if model.no_torsion or sum(n_rot) == 0:
         return tr_pred, rot_pred, torch.empty(0, device=dev), None
@@ -735,7 +829,10 @@ def forward(model, data):
     t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
     msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, model.tor_bond_conv.fc(t_attr))
     tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
-    tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor)
+    tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor, exclude=ex_bond)
+    torus_norm = g.torus_norm
+    if pad:
+        tor, torus_norm = tor[:pad["T_real"]], torus_norm[:pad["T_real"]]
     tor_pred = model.tor_final_layer(tor).squeeze(1)
-    tor_pred = tor_pred * g.torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
+    tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
     return tr_pred, rot_pred, tor_pred, None

@@ -721,8 +721,14 @@ class IrrepsBatchNormFn(torch.autograd.Function):
     than the irreps layout (`dim` columns are read, e.g. the 80-float message rows): no slice copy before, no padding op behind."""
 
     @staticmethod
-    def forward(ctx, x, dim, weight, bias, res, running_mean, running_var, fields, momentum, eps):
+    def forward(ctx, x, dim, weight, bias, res, running_mean, running_var, fields, momentum, eps, exclude=None):
+        """`exclude`: ((lo0, hi0), (lo1, hi1)) row ranges left out of the statistics (filler rows of a capacity-padded step) or None"""
         lib = _bind(load_library())
+        ex = None
+        if exclude is not None:
+            (a0, b0), (a1, b1) = exclude
+            ex = (C.c_int64 * 4)(int(a0), int(b0), int(a1), int(b1))
+        ctx.ex = ex
         x = x.contiguous().float()
         n, ldx = x.shape
         nf = int(fields.shape[0])
@@ -732,7 +738,7 @@ class IrrepsBatchNormFn(torch.autograd.Function):
         _check(lib.cbd_irreps_bn_forward(n, dim, ldx, nf, _ptr(fields), _ptr(x), None if r is None else _ptr(r),
                                          0 if r is None else int(r.shape[1]), _ptr(weight), _ptr(bias) if bias.numel() else None,
                                          _ptr(running_mean) if running_mean.numel() else None, _ptr(running_var), float(momentum),
-                                         float(eps), _ptr(out), _ptr(stats[0]), _ptr(stats[1]), _stream_handle()))
+                                         float(eps), _ptr(out), _ptr(stats[0]), _ptr(stats[1]), ex, _stream_handle()))
         ctx.save_for_backward(x, weight, stats, fields)
         ctx.res_dim = None if r is None else int(r.shape[1])
         ctx.n_bias = int(bias.numel())
@@ -750,9 +756,9 @@ class IrrepsBatchNormFn(torch.autograd.Function):
         gw = torch.empty(nf, device=x.device, dtype=torch.float32)
         gb = torch.empty(ctx.n_bias, device=x.device, dtype=torch.float32)
         _check(lib.cbd_irreps_bn_backward(n, ctx.dim, ldx, nf, _ptr(fields), _ptr(g), _ptr(x), _ptr(weight), _ptr(stats[0]), _ptr(stats[1]),
-                                          _ptr(gx), _ptr(gw), _ptr(gb) if ctx.n_bias else None, _stream_handle()))
+                                          _ptr(gx), _ptr(gw), _ptr(gb) if ctx.n_bias else None, ctx.ex, _stream_handle()))
         gres = None if ctx.res_dim is None else g[:, :ctx.res_dim]
-        return gx, None, gw, gb, gres, None, None, None, None, None
+        return gx, None, gw, gb, gres, None, None, None, None, None, None
 
 
 class GatherFn(torch.autograd.Function):

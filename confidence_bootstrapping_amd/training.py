@@ -21,13 +21,11 @@ def _cat(data, name):
     return getattr(data, name)
 
 
-def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma, device, tr_weight=1, rot_weight=1, tor_weight=1,
-                  backbone_weight=0, sidechain_weight=0, apply_mean=True, no_torsion=False):
-    """Denoising score-matching loss (reference utils/training.py:17-126).  `data` is the list of noised graphs (or their
-    collation); returns the reference's 11-tuple (loss, tr, rot, tor, backbone, sidechain, and the five base losses)."""
-    if backbone_weight > 0 or sidechain_weight > 0:
-        raise NotImplementedError("side-chain / backbone losses are outside the score-model fine-tuning path")
-    dev = tr_pred.device
+def loss_targets(data, t_to_sigma, device, no_torsion=False):
+    """Everything of the loss that depends on the batch alone (reference utils/training.py:17-126): scores, sigmas and the score-norm
+    table look-ups (host tables), uploaded to `device` -- on a GPU through the side stream, so that the host does not stall on the
+    compute stream.  -> dict of device tensors; the hipGraph-captured step (train_graph.py) copies them into its static inputs."""
+    dev = torch.device(device)
     if dev.type == "cuda":          # host -> device copies that do not stall the host on the compute stream (train_forward.upload)
         from .train_forward import upload
         up = lambda t: upload(t, dev)
@@ -37,31 +35,38 @@ def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma,
     ct = {k: (torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data]) if lst else data.complex_t[k])
           for k in ("tr", "rot", "tor")}
     tr_sigma, rot_sigma, tor_sigma = t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
-    mean_dims = (0, 1) if apply_mean else 1
-    zeros = lambda: torch.zeros(1 if apply_mean else tr_pred.shape[0], dtype=torch.float, device=dev)
-
-    tr_score = up(_cat(data, "tr_score"))
-    tr_sigma = up(tr_sigma).unsqueeze(-1)
-    tr_loss = ((tr_pred - tr_score) ** 2 * tr_sigma ** 2).mean(dim=mean_dims)
-    tr_base_loss = (tr_score ** 2 * tr_sigma ** 2).mean(dim=mean_dims).detach()
-
-    rot_score = up(_cat(data, "rot_score"))
-    rot_score_norm = up(so3.score_norm(rot_sigma.cpu()).unsqueeze(-1))
-    rot_loss = (((rot_pred - rot_score) / rot_score_norm) ** 2).mean(dim=mean_dims)
-    rot_base_loss = ((rot_score / rot_score_norm) ** 2).mean(dim=mean_dims).detach()
-
+    tg = {"tr_score": up(_cat(data, "tr_score")), "tr_sigma": up(tr_sigma).unsqueeze(-1), "rot_score": up(_cat(data, "rot_score")),
+          "rot_score_norm": up(so3.score_norm(rot_sigma.cpu()).unsqueeze(-1))}
     if not no_torsion:
         sig = [d.tor_sigma_edge for d in data] if lst else data.tor_sigma_edge
         edge_tor_sigma = np.concatenate(sig) if isinstance(sig, (list, tuple)) else np.asarray(sig)
-        tor_score = up(_cat(data, "tor_score"))
-        tor_score_norm2 = up(torch.tensor(torus.score_norm(edge_tor_sigma)).float())
+        tg["tor_score"] = up(_cat(data, "tor_score"))
+        tg["tor_score_norm2"] = up(torch.tensor(torus.score_norm(edge_tor_sigma)).float())
+    return tg
+
+
+def loss_from_targets(tr_pred, rot_pred, tor_pred, tg, tr_weight=1, rot_weight=1, tor_weight=1, apply_mean=True, no_torsion=False,
+                      data=None):
+    """The arithmetic of the loss on device tensors (`tg` from loss_targets) -> the reference's 11-tuple."""
+    dev = tr_pred.device
+    mean_dims = (0, 1) if apply_mean else 1
+    zeros = lambda: torch.zeros(1 if apply_mean else tr_pred.shape[0], dtype=torch.float, device=dev)
+    tr_score, tr_sigma = tg["tr_score"], tg["tr_sigma"]
+    tr_loss = ((tr_pred - tr_score) ** 2 * tr_sigma ** 2).mean(dim=mean_dims)
+    tr_base_loss = (tr_score ** 2 * tr_sigma ** 2).mean(dim=mean_dims).detach()
+    rot_score, rot_score_norm = tg["rot_score"], tg["rot_score_norm"]
+    rot_loss = (((rot_pred - rot_score) / rot_score_norm) ** 2).mean(dim=mean_dims)
+    rot_base_loss = ((rot_score / rot_score_norm) ** 2).mean(dim=mean_dims).detach()
+    if not no_torsion:
+        tor_score, tor_score_norm2 = tg["tor_score"], tg["tor_score_norm2"]
         tor_loss = (tor_pred - tor_score) ** 2 / tor_score_norm2
         tor_base_loss = (tor_score ** 2 / tor_score_norm2).detach()
         if apply_mean:
             tor_loss, tor_base_loss = tor_loss.mean() * torch.ones(1, device=dev), tor_base_loss.mean() * torch.ones(1, device=dev)
         else:
+            lst = isinstance(data, (list, tuple))
             if lst:
-                index = up(torch.cat([torch.full((int(d["ligand"].edge_mask.sum()),), i, dtype=torch.long) for i, d in enumerate(data)]))
+                index = torch.cat([torch.full((int(d["ligand"].edge_mask.sum()),), i, dtype=torch.long) for i, d in enumerate(data)]).to(dev)
                 n = len(data)
             else:
                 index = data["ligand"].batch[data["ligand", "ligand"].edge_index[0][data["ligand"].edge_mask]].to(dev)
@@ -75,6 +80,16 @@ def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma,
     loss = tr_loss * tr_weight + rot_loss * rot_weight + tor_loss * tor_weight
     return (loss, tr_loss.detach(), rot_loss.detach(), tor_loss.detach(), backbone_loss, sidechain_loss,
             tr_base_loss, rot_base_loss, tor_base_loss, backbone_base_loss, sidechain_base_loss)
+
+
+def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma, device, tr_weight=1, rot_weight=1, tor_weight=1,
+                  backbone_weight=0, sidechain_weight=0, apply_mean=True, no_torsion=False):
+    """Denoising score-matching loss (reference utils/training.py:17-126).  `data` is the list of noised graphs (or their
+    collation); returns the reference's 11-tuple (loss, tr, rot, tor, backbone, sidechain, and the five base losses)."""
+    if backbone_weight > 0 or sidechain_weight > 0:
+        raise NotImplementedError("side-chain / backbone losses are outside the score-model fine-tuning path")
+    tg = loss_targets(data, t_to_sigma, tr_pred.device, no_torsion=no_torsion)
+    return loss_from_targets(tr_pred, rot_pred, tor_pred, tg, tr_weight, rot_weight, tor_weight, apply_mean, no_torsion, data=data)
 
 
 class AverageMeter:
@@ -267,8 +282,68 @@ def uniform_step_count(loader):
     return int(t.item())
 
 
-def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None, look_ahead=False):
-    """One epoch (reference utils/training.py:184-233).  With `look_ahead=True` (HIP forward on a GPU only) the NEXT batch is fetched
+_GRAPHED = __import__("weakref").WeakKeyDictionary()       # model -> GraphedStep (its captured graphs live as long as the model)
+
+
+def graphed_step_for(model, optimizer, device, t_to_sigma, loss_fn, ema_weights, **kw):
+    """The model's train_graph.GraphedStep (hipGraph-captured forward + loss + backward), built once and re-used across epochs as long
+    as optimiser, EMA and loss weights are the same objects / values.  `loss_fn` must be `loss_function` or a functools.partial of it."""
+    import functools
+    from .train_graph import GraphedStep
+    if isinstance(loss_fn, functools.partial) and loss_fn.func is loss_function and not loss_fn.args:
+        lw = dict(loss_fn.keywords)
+    elif loss_fn is loss_function:
+        lw = {}
+    else:
+        raise TypeError("the hipGraph-captured step evaluates training.loss_function on the device; pass it (or a partial of it)")
+    if not lw.get("apply_mean", True):
+        raise NotImplementedError("the captured step computes the batch-mean loss (apply_mean=True)")
+    lw.pop("apply_mean", None)
+    cur = _GRAPHED.get(model)
+    sig = (id(optimizer), id(ema_weights), str(torch.device(device)), tuple(sorted(lw.items())))
+    if cur is None or cur[0] != sig:
+        cur = _GRAPHED[model] = (sig, GraphedStep(model, optimizer, device, t_to_sigma, lw, ema_weights, **kw))
+    return cur[1]
+
+
+def _train_epoch_graphed(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, meter, n_steps, distributed):
+    """train_epoch on the hipGraph-captured step: while the graph of step k runs on the GPU the host fetches, collates and prepares
+    batch k + 1 (side stream); then it reads step k's NaN flag, steps the optimiser and launches k + 1."""
+    trainer = graphed_step_for(model, optimizer, device, t_to_sigma, loss_fn, ema_weights)
+
+    def close(item):
+        out = trainer.finish(item)
+        if out is None:
+            print("Nan loss, skipping batch" + (" (on some rank)" if distributed else ""))
+        else:
+            meter.add(out)
+    pending, i = None, 0
+    for data in loader:
+        if n_steps is not None and i >= n_steps:
+            break
+        i += 1
+        n = len(data) if isinstance(data, (list, tuple)) else data.num_graphs
+        if n == 1:
+            print("Skipping batch of size 1 since otherwise batchnorm would not work.")
+            if pending is not None:
+                close(pending)
+                pending = None
+            if distributed:     # the other ranks are inside this step's all-reduce: take part with zero gradients
+                allreduce_gradients(model, skip=True)
+                optimizer.zero_grad()
+            continue
+        item = trainer.prepare(data if isinstance(data, (list, tuple)) else data.to_data_list())
+        if pending is not None:
+            close(pending)
+        pending = trainer.launch(item)
+    if pending is not None:
+        close(pending)
+
+
+def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None, look_ahead=False,
+                hip_graph=False):
+    """One epoch (reference utils/training.py:184-233).  `hip_graph=True`: forward + loss + backward of every step as ONE hipGraph launch
+    (train_graph.py: capacity-padded batches, a graph per batch shape, captured at the shape's second sighting).  With `look_ahead=True` (HIP forward on a GPU only) the NEXT batch is fetched
     from the loader -- which is where the reference's DataLoader workers run NoiseTransform -- collated and taken through the
     input-only part of the forward pass (train_forward.prepare_batch: radius graphs, edge groupings, ...) on a second host thread
     while the current step's backward pass is being enqueued; the loader is only ever advanced by one thread at a time, in order, and
@@ -282,6 +357,12 @@ def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weigh
     distributed = _dist_world() > 1
     n_steps = uniform_step_count(loader) if distributed else None
     dev = torch.device(device)
+    if hip_graph:
+        if forward_fn is not None or dev.type != "cuda":
+            raise RuntimeError("hip_graph=True runs the package's own HIP forward on a GPU")
+        _train_epoch_graphed(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, meter, n_steps, distributed)
+        sync_batchnorm_buffers(model)
+        return meter.summary()
     ahead = look_ahead and forward_fn is None and dev.type == "cuda"
     it = iter(loader)
 

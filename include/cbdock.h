@@ -320,13 +320,16 @@ int cbd_segment_mean_backward(int64_t n_edges, int32_t width, const float* g_dev
  * NULL when there is none).  0e fields are centred and biased; every field is scaled by weight / sqrt(mean of its squared components
  * over rows and components + eps); running statistics are updated in place with `momentum`.  res_dev (or NULL): [n][res_dim], added to
  * the first res_dim output columns.  save_mean / save_inv feed the backward pass, which takes g [n][dim] and returns gx [n][ldx], gw [n_fields], gb [#0e]
- * (the residual's gradient is g[:, :res_dim] itself).  Sums in a fixed order: bitwise repeatable. */
+ * (the residual's gradient is g[:, :res_dim] itself).  Sums in a fixed order: bitwise repeatable.
+ * exclude4 (HOST pointer or NULL): {lo0, hi0, lo1, hi1}, two ascending disjoint row ranges left out of the statistics (the filler
+ * graph's nodes of a capacity-padded, hipGraph-captured training step): their output rows are zero, and so is their input gradient. */
 int cbd_irreps_bn_forward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields, const int32_t* fields_dev, const float* x_dev, const float* res_dev,
                           int32_t res_dim, const float* weight_dev, const float* bias_dev, float* running_mean_dev, float* running_var_dev,
-                          float momentum, float eps, float* out_dev, float* save_mean_dev, float* save_inv_dev, void* stream);
+                          float momentum, float eps, float* out_dev, float* save_mean_dev, float* save_inv_dev, const int64_t* exclude4,
+                          void* stream);
 int cbd_irreps_bn_backward(int64_t n, int32_t dim, int32_t ldx, int32_t n_fields, const int32_t* fields_dev, const float* g_dev, const float* x_dev,
                            const float* weight_dev, const float* save_mean_dev, const float* save_inv_dev, float* gx_dev, float* gw_dev,
-                           float* gb_dev, void* stream);
+                           float* gb_dev, const int64_t* exclude4, void* stream);
 /* cbd_segment_sum over rows of stride ld >= width (only the first `width` columns are summed): the backward of cbd_gather_pad. */
 int cbd_segment_sum_ld(int64_t n_rows, int32_t width, int32_t ld, const float* vals_dev, const int64_t* perm_dev, const int64_t* rowptr_dev,
                        float* out_dev, void* stream);
