@@ -209,19 +209,37 @@ def finetune_leg(dev, batch=8, warm=8, steps=16):
     for k in range(warm):
         train_step(model, batches[k % 8], opt, dev, t2s, loss_fn, ema)
     torch.cuda.synchronize()
-    # the product's own loop (training.train_epoch).  The step is host-bound at this batch size and the boxes' hosts are noisy: three
-    # epochs of `steps` batches, the median is reported, all three are listed.
-    blocks = []
-    for rep in range(3):
-        loader = [batches[(warm + k) % 8] for k in range(steps)]
-        t0 = time.perf_counter()
-        summary = train_epoch(model, loader, opt, dev, t2s, loss_fn, ema)
-        torch.cuda.synchronize()
-        blocks.append((time.perf_counter() - t0) / steps)
+
+    def blocks_of(**kw):
+        """the product's own loop (training.train_epoch): three epochs of `steps` batches, the median is reported, all three are listed"""
+        out = []
+        for rep in range(3):
+            loader = [batches[(warm + k) % 8] for k in range(steps)]
+            t0 = time.perf_counter()
+            summary = train_epoch(model, loader, opt, dev, t2s, loss_fn, ema, **kw)
+            torch.cuda.synchronize()
+            out.append((time.perf_counter() - t0) / steps)
+        return out, summary
+    blocks, summary = blocks_of()
     dt = sorted(blocks)[1]
-    return {"what": "fine-tuning step (train-mode forward + HIP backward kernels + Adam + EMA) in training.train_epoch, not part of `value`",
-            "batch": batch, "ms_per_step": round(dt * 1e3, 2), "ms_per_step_blocks": [round(b * 1e3, 2) for b in blocks],
-            "steps_per_block": steps, "complexes_per_s": round(batch / dt, 1), "loss": round(float(summary["loss"]), 4), "dtype": "f32"}
+    res = {"what": "fine-tuning step (train-mode forward + HIP backward kernels + Adam + EMA) in training.train_epoch, not part of `value`",
+           "batch": batch, "ms_per_step": round(dt * 1e3, 2), "ms_per_step_blocks": [round(b * 1e3, 2) for b in blocks],
+           "steps_per_block": steps, "complexes_per_s": round(batch / dt, 1), "loss": round(float(summary["loss"]), 4), "dtype": "f32",
+           "host_threads": int(os.environ.get("CBD_HOST_THREADS", "1"))}
+    # the same loop with forward + loss + backward of every step as ONE hipGraph launch (train_graph.py; capacity-padded batches): two
+    # untimed epochs capture the batch shapes, then three timed ones
+    try:
+        for _ in range(2):
+            train_epoch(model, [batches[k % 8] for k in range(12)], opt, dev, t2s, loss_fn, ema, hip_graph=True)
+        gblocks, gsummary = blocks_of(hip_graph=True)
+        from confidence_bootstrapping_amd.training import _GRAPHED
+        st = _GRAPHED[model][1].stats
+        res["hip_graph"] = {"ms_per_step": round(sorted(gblocks)[1] * 1e3, 2), "ms_per_step_blocks": [round(b * 1e3, 2) for b in gblocks],
+                            "graphs": len(_GRAPHED[model][1].graphs), "replays": st["replays"], "eager_steps": st["eager"],
+                            "loss": round(float(gsummary["loss"]), 4)}
+    except Exception as e:      # the graphed variant must never cost the eager figure
+        res["hip_graph"] = {"error": repr(e)[:200]}
+    return res
 
 
 def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry, n_complexes, engine_value):

@@ -543,9 +543,11 @@ struct TrainDwArgs {
   const float* vec;      // [E][4]
   const float* h;        // [E][96]
   const float* gmsg;     // [E][NODE_STRIDE]
-  int e_lo, e_hi;        // the group's edge range
-  int blocks_per_chunk;  // 32-edge blocks per chunk
-  float* partial;        // [n_chunks][wp * 96 + wp]
+  // edge groups of the layer: group g owns edges [g_lo[g], g_hi[g]) and the chunks [g_chunk0[g], g_chunk0[g + 1]) of the launch's
+  // second grid dimension, g_bpc[g] 32-edge blocks per chunk (one launch for all groups of a layer: cbd_tp_backward_dw_groups)
+  int n_groups;
+  int g_lo[TRAIN_MAX_GROUPS], g_hi[TRAIN_MAX_GROUPS], g_bpc[TRAIN_MAX_GROUPS], g_chunk0[TRAIN_MAX_GROUPS + 1];
+  float* partial;        // [total chunks][wp * 96 + wp]
 };
 constexpr int DW_GS = 96;                         // row stride of the staged g_msg rows: the two lane halves (edges e, e + 1) hit disjoint banks
 constexpr int DW_TILES_PER_WG = 4;                // 4 waves x 1 tile (two tiles per wave: 218 registers, two residents per SIMD, 0.45 of peak)
@@ -609,26 +611,31 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) { a00[r] = 0.f; a01[r] = 0.f; a02[r] = 0.f; }
   float db0 = 0.f;
-  const int b_lo = blockIdx.y * A.blocks_per_chunk;
-  const int n_blk = min(A.blocks_per_chunk, (A.e_hi - A.e_lo + 31) / 32 - b_lo);
+  int grp = 0;
+#pragma unroll
+  for (int g = 1; g < TRAIN_MAX_GROUPS; ++g)
+    if (g < A.n_groups && (int)blockIdx.y >= A.g_chunk0[g]) grp = g;
+  const int e_lo = A.g_lo[grp], e_hi = A.g_hi[grp], bpc = A.g_bpc[grp];
+  const int b_lo = ((int)blockIdx.y - A.g_chunk0[grp]) * bpc;
+  const int n_blk = min(bpc, (e_hi - e_lo + 31) / 32 - b_lo);
   // staging through registers: block b + 1 is in flight from global memory while block b is multiplied
   f32x4 hr[3], gr[3], xr[3], vr4;
   auto fetch = [&](int e0) {
 #pragma unroll
     for (int it = 0; it < 3; ++it) {
       const int k = tid + 256 * it;                                   // h: 768 float4, coalesced rows
-      const int e = min(e0 + k / (KDIM / 4), A.e_hi - 1);
+      const int e = min(e0 + k / (KDIM / 4), e_hi - 1);
       hr[it] = reinterpret_cast<const f32x4*>(A.h + (size_t)e * KDIM)[k % (KDIM / 4)];
       if (k < 32 * NODE_STRIDE / 4) {                                 // g_msg: 640 float4, coalesced rows
         const int row = k / (NODE_STRIDE / 4);
-        const bool ok = e0 + row < A.e_hi;
-        const f32x4 g = reinterpret_cast<const f32x4*>(A.gmsg + (size_t)(ok ? e0 + row : A.e_hi - 1) * NODE_STRIDE)[k % (NODE_STRIDE / 4)];
+        const bool ok = e0 + row < e_hi;
+        const f32x4 g = reinterpret_cast<const f32x4*>(A.gmsg + (size_t)(ok ? e0 + row : e_hi - 1) * NODE_STRIDE)[k % (NODE_STRIDE / 4)];
         gr[it] = ok ? g : f32x4{0.f, 0.f, 0.f, 0.f};
         const int xrow_i = k & 31, xc4 = k >> 5;                      // gathered rows: edge index fastest => conflict-free transposed stores
-        xr[it] = reinterpret_cast<const f32x4*>(A.xrow + (size_t)min(e0 + xrow_i, A.e_hi - 1) * NODE_STRIDE)[xc4];
+        xr[it] = reinterpret_cast<const f32x4*>(A.xrow + (size_t)min(e0 + xrow_i, e_hi - 1) * NODE_STRIDE)[xc4];
       }
     }
-    if (tid < 32) vr4 = reinterpret_cast<const f32x4*>(A.vec)[min(e0 + tid, A.e_hi - 1)];
+    if (tid < 32) vr4 = reinterpret_cast<const f32x4*>(A.vec)[min(e0 + tid, e_hi - 1)];
   };
   auto stage = [&]() {
 #pragma unroll
@@ -644,12 +651,12 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
     if (tid < 32) reinterpret_cast<f32x4*>(vS)[tid] = vr4;
   };
   for (int k = tid; k < DW_TILES_PER_WG * DW_MT; k += 256) mT[k] = 0.f;      // rows a scalar-block tile never writes stay zero
-  if (n_blk > 0) fetch(A.e_lo + b_lo * 32);
+  if (n_blk > 0) fetch(e_lo + b_lo * 32);
   for (int bk = 0; bk < n_blk; ++bk) {
     __syncthreads();                            // the previous block's readers are done
     stage();
     __syncthreads();
-    if (bk + 1 < n_blk) fetch(A.e_lo + (b_lo + bk + 1) * 32);
+    if (bk + 1 < n_blk) fetch(e_lo + (b_lo + bk + 1) * 32);
     // mids of this block for the workgroup's tile slots: (slot, q, edge) -> 3 components; 4 x 5 x 32 items over 256 threads
 #pragma unroll 1
     for (int it = tid; it < DW_TILES_PER_WG * VEC_TILE_I * 32; it += 256) {
@@ -905,23 +912,50 @@ int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, co
   return 0;
 }
 
+static int launch_dw_any(int32_t in_level, int32_t out_level, const cbd::TrainDwArgs& a, int total_chunks, void* stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hipError_t r = hipErrorInvalidValue;
+  if (in_level == 0 && out_level == 1) r = cbd::launch_train_dw<0, 1>(a, total_chunks, st);
+  else if (in_level == 1 && out_level == 2) r = cbd::launch_train_dw<1, 2>(a, total_chunks, st);
+  else if (in_level == 2 && out_level == 3) r = cbd::launch_train_dw<2, 3>(a, total_chunks, st);
+  else if (in_level == 3 && out_level == 3) r = cbd::launch_train_dw<3, 3>(a, total_chunks, st);
+  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward_dw: %s", hipGetErrorString(r));
+  return 0;
+}
+
 int cbd_tp_backward_dw(int32_t in_level, int32_t out_level, int64_t e_lo, int64_t e_hi, const float* xrow_dev, const float* vec4_dev,
                        const float* h_dev, const float* gmsg_dev, int32_t n_chunks, float* partial_dev, void* stream) {
   if (e_lo < 0 || e_hi < e_lo || e_hi > ((int64_t)1 << 30) || n_chunks <= 0) return fail(CBD_ERR_ARG, "cbd_tp_backward_dw: bad argument");
   if (e_hi == e_lo) return 0;
   if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !partial_dev) return fail(CBD_ERR_ARG, "null argument");
   cbd::TrainDwArgs a{};
-  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.e_lo = (int)e_lo; a.e_hi = (int)e_hi; a.partial = partial_dev;
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.partial = partial_dev;
+  a.n_groups = 1; a.g_lo[0] = (int)e_lo; a.g_hi[0] = (int)e_hi; a.g_chunk0[0] = 0;
+  for (int g = 1; g <= cbd::TRAIN_MAX_GROUPS; ++g) a.g_chunk0[g] = n_chunks;
   const int64_t blocks = (e_hi - e_lo + 31) / 32;
-  a.blocks_per_chunk = (int)((blocks + n_chunks - 1) / n_chunks);
-  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  hipError_t r = hipErrorInvalidValue;
-  if (in_level == 0 && out_level == 1) r = cbd::launch_train_dw<0, 1>(a, n_chunks, st);
-  else if (in_level == 1 && out_level == 2) r = cbd::launch_train_dw<1, 2>(a, n_chunks, st);
-  else if (in_level == 2 && out_level == 3) r = cbd::launch_train_dw<2, 3>(a, n_chunks, st);
-  else if (in_level == 3 && out_level == 3) r = cbd::launch_train_dw<3, 3>(a, n_chunks, st);
-  if (r != hipSuccess) return fail(r == hipErrorInvalidValue ? CBD_ERR_ARG : CBD_ERR_HIP, "cbd_tp_backward_dw: %s", hipGetErrorString(r));
-  return 0;
+  a.g_bpc[0] = (int)((blocks + n_chunks - 1) / n_chunks);
+  return launch_dw_any(in_level, out_level, a, n_chunks, stream);
+}
+
+int cbd_tp_backward_dw_groups(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges, const int32_t* n_chunks,
+                              const float* xrow_dev, const float* vec4_dev, const float* h_dev, const float* gmsg_dev, float* partial_dev,
+                              void* stream) {
+  if (n_groups < 1 || n_groups > cbd::TRAIN_MAX_GROUPS || !group_edges || !n_chunks) return fail(CBD_ERR_ARG, "cbd_tp_backward_dw_groups: 1..4 edge groups");
+  if (!xrow_dev || !vec4_dev || !h_dev || !gmsg_dev || !partial_dev) return fail(CBD_ERR_ARG, "null argument");
+  cbd::TrainDwArgs a{};
+  a.xrow = xrow_dev; a.vec = vec4_dev; a.h = h_dev; a.gmsg = gmsg_dev; a.partial = partial_dev; a.n_groups = n_groups;
+  int64_t e = 0;
+  int chunks = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    if (group_edges[g] <= 0 || n_chunks[g] <= 0) return fail(CBD_ERR_ARG, "cbd_tp_backward_dw_groups: bad group %d", g);
+    a.g_lo[g] = (int)e; e += group_edges[g]; a.g_hi[g] = (int)e;
+    if (e > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "too many edges");
+    a.g_chunk0[g] = chunks; chunks += n_chunks[g];
+    const int64_t blocks = (group_edges[g] + 31) / 32;
+    a.g_bpc[g] = (int)((blocks + n_chunks[g] - 1) / n_chunks[g]);
+  }
+  for (int g = n_groups; g <= cbd::TRAIN_MAX_GROUPS; ++g) a.g_chunk0[g] = chunks;
+  return launch_dw_any(in_level, out_level, a, chunks, stream);
 }
 
 int64_t cbd_outer_accum_part_floats(void) { return cbd::OUTER_PART_FLOATS; }

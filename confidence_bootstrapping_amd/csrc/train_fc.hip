@@ -1,0 +1,384 @@
+// First stage of the FCBlock in the fine-tuning step (reference models/layers.py:8-15: Linear(96, 96) -> ReLU -> Dropout, in front of the
+// second Linear that tp_train.hip fuses with the tensor product; applied per edge group by TensorProductConvLayer.forward,
+// models/tensor_layers.py:195-206, under model.train(), utils/training.py:186), forward and backward as ONE launch each for ALL edge
+// groups of a layer -- and the fixed-order reduction of per-chunk partial weight gradients, also one launch per layer.
+//
+// Round 3 ran this stage as library GEMMs (one per edge group, Tensile `Cijk_*`), a clamp, torch's dropout, and in the backward pass a
+// masked scale, a threshold, one GEMM + one outer_accum + one column sum per group and two `sum` reductions per group behind the dW2p
+// pass: ~170 launches and ~2 ms of kernel time per step at batch 8, in a step that is launch-bound.
+//
+//   cbd_fc1_forward   hid = dropout(relu(x W_g^T + b_g))        x [E, 96] rows of edge group g = rows [e_g, e_{g+1})
+//   cbd_fc1_backward  g_pre = g_hid * scale * [hid > 0],  g_x = g_pre W_g      (hid > 0  <=>  the unit was active AND kept)
+//   cbd_outer_accum_groups   per-chunk partials of dW_g = g_pre^T x, db_g = sum_e g_pre   (edges as the MFMA k dimension)
+//   cbd_partial_reduce       out[s] = sum of the partial rows of segment s, in row order (bitwise repeatable; no atomics)
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout: the reference's arithmetic.  One wave owns 32 rows at a time; the group's 96 x 96 weight
+// matrix sits in LDS once per workgroup (row stride 97: conflict-free for both the row-wise and the column-wise operand reads); the
+// row operand is read from global memory by the lane that owns the row, 32 columns (8 dwordx4 loads) at a time.
+//
+// Dropout: keep = hash(seed, call, element index) >= p * 2^32 with a counter-based integer hash (not torch's Philox stream: the
+// reference's masks are not reproduced by any other RNG either; what matters is Bernoulli(1 - p) per element, independent across
+// elements, layers and steps).  `seed` is read from DEVICE memory, so that a hipGraph-captured step (train_graph.py) gets fresh masks
+// at every replay from its static input buffer.
+#include <hip/hip_runtime.h>
+
+#include "host_util.h"
+#include "../../include/cbdock.h"
+
+namespace cbd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int FC_K = 96;
+constexpr int FC_LD = 97;                 // LDS row stride of the weight matrix
+constexpr int FC_MAX_GROUPS = 4;
+constexpr int FC_WAVES = 4;               // waves per workgroup
+constexpr int FC_TILES_PER_WAVE = 4;      // 32-row tiles a wave handles one after the other
+
+struct Fc1Args {
+  int n_groups;
+  int e_begin[FC_MAX_GROUPS + 1];
+  int wg_begin[FC_MAX_GROUPS + 1];        // first workgroup of every group
+  const float* W[FC_MAX_GROUPS];          // [96 out][96 in] row-major (nn.Linear.weight)
+  const float* b[FC_MAX_GROUPS];
+  const float* x;                         // forward: [E][96] input rows;   backward: g_hid [E][96]
+  const float* hid_in;                    // backward: hid [E][96]
+  float* out0;                            // forward: hid;                   backward: g_pre
+  float* out1;                            // backward: g_x (may be null)
+  const long long* seed;                  // device scalar (may be null when p == 0)
+  unsigned long long call;                // distinguishes the layers of a step
+  unsigned int drop_threshold;            // p * 2^32 (0: no dropout)
+  float scale;                            // 1 / (1 - p)
+};
+
+__device__ __forceinline__ unsigned int fc_hash(unsigned long long seed, unsigned long long call, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (call + 1) + idx * 0xD1B54A32D192ED03ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned int)(z >> 32);
+}
+
+__device__ __forceinline__ void fc_locate(const Fc1Args& A, int wg, int& grp, int& tile0, int& e_end) {
+  grp = 0;
+#pragma unroll
+  for (int g = 1; g < FC_MAX_GROUPS; ++g)
+    if (g < A.n_groups && wg >= A.wg_begin[g]) grp = g;
+  tile0 = (wg - A.wg_begin[grp]) * FC_WAVES * FC_TILES_PER_WAVE;
+  e_end = A.e_begin[grp + 1];
+}
+
+// acc[t] (t = 0..2: output columns 32 t .. 32 t + 31) = rows [e0, e0 + 32) of `src` (row operand; lane (m = lane & 31, hf) owns row m)
+// times the LDS matrix:  TRANSPOSED = false: out[m][n] = sum_k src[m][k] * Wl[n][k]   (x W^T)
+//                        TRANSPOSED = true:  out[m][n] = sum_k src[m][k] * Wl[k][n]   (g W)
+// `rowv` may post-process the 32 loaded values of a row chunk (backward: the dropout / ReLU mask) -- it gets the chunk index.
+template <bool TRANSPOSED, class RowFn>
+__device__ __forceinline__ void fc_rows_times_matrix(const float* __restrict__ src, int e0, int e_end, const float* Wl, int lane, f32x16 (&acc)[3],
+                                                     RowFn rowv) {
+  const int m = lane & 31, hf = lane >> 5;
+  const int row = min(e0 + m, e_end - 1);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+  for (int kc = 0; kc < 3; ++kc) {                       // 32 columns of the row operand at a time
+    float v[32];
+    const f32x4* p = reinterpret_cast<const f32x4*>(src + (size_t)row * FC_K + 32 * kc);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 x = p[q];
+      v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+    rowv(kc, row, v);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {                    // k-step: columns 32 kc + 2 ks + hf
+      const int k = 32 * kc + 2 * ks + hf;
+      const float a = hf ? v[2 * ks + 1] : v[2 * ks];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const float b = TRANSPOSED ? Wl[k * FC_LD + 32 * t + m] : Wl[(32 * t + m) * FC_LD + k];
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void fc_load_matrix(const float* __restrict__ W, float* Wl) {
+  for (int i = threadIdx.x; i < FC_K * FC_K / 4; i += FC_WAVES * 64) {
+    const f32x4 w = reinterpret_cast<const f32x4*>(W)[i];
+    float* o = Wl + (i / (FC_K / 4)) * FC_LD + 4 * (i % (FC_K / 4));
+    o[0] = w.x; o[1] = w.y; o[2] = w.z; o[3] = w.w;
+  }
+}
+
+__global__ __launch_bounds__(FC_WAVES * 64) void fc1_fwd_kernel(Fc1Args A) {
+  __shared__ float Wl[FC_K * FC_LD];
+  int grp, tile0, e_end;
+  fc_locate(A, blockIdx.x, grp, tile0, e_end);
+  fc_load_matrix(A.W[grp], Wl);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, hf = lane >> 5;
+  const unsigned long long seed = A.drop_threshold ? (unsigned long long)A.seed[0] : 0ull;
+  float bias[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) bias[t] = A.b[grp][32 * t + n];
+#pragma unroll 1
+  for (int it = 0; it < FC_TILES_PER_WAVE; ++it) {
+    const int e0 = A.e_begin[grp] + (tile0 + wave * FC_TILES_PER_WAVE + it) * 32;
+    if (e0 >= e_end) break;
+    f32x16 acc[3];
+    fc_rows_times_matrix<false>(A.x, e0, e_end, Wl, lane, acc, [](int, int, float (&)[32]) {});
+    // D layout: register r of lane (n, hf) = row (r & 3) + 8 (r >> 2) + 4 hf, column 32 t + n
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int e = e0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+      if (e >= e_end) continue;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        float y = fmaxf(acc[t][r] + bias[t], 0.f);
+        if (A.drop_threshold) {
+          const unsigned int h = fc_hash(seed, A.call, (unsigned long long)e * FC_K + 32 * t + n);
+          y = h >= A.drop_threshold ? y * A.scale : 0.f;
+        }
+        A.out0[(size_t)e * FC_K + 32 * t + n] = y;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(FC_WAVES * 64) void fc1_bwd_kernel(Fc1Args A) {
+  __shared__ float Wl[FC_K * FC_LD];
+  int grp, tile0, e_end;
+  fc_locate(A, blockIdx.x, grp, tile0, e_end);
+  fc_load_matrix(A.W[grp], Wl);
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, hf = lane >> 5;
+#pragma unroll 1
+  for (int it = 0; it < FC_TILES_PER_WAVE; ++it) {
+    const int e0 = A.e_begin[grp] + (tile0 + wave * FC_TILES_PER_WAVE + it) * 32;
+    if (e0 >= e_end) break;
+    f32x16 acc[3];
+    const bool own = e0 + (lane & 31) < e_end;
+    fc_rows_times_matrix<true>(A.x, e0, e_end, Wl, lane, acc, [&](int kc, int row, float (&v)[32]) {
+      // g_pre = g_hid * scale * [hid > 0]; the lower lane half writes the row's chunk (both halves hold the same row)
+      const f32x4* ph = reinterpret_cast<const f32x4*>(A.hid_in + (size_t)row * FC_K + 32 * kc);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 h = ph[q];
+        v[4 * q] = h.x > 0.f ? v[4 * q] * A.scale : 0.f;
+        v[4 * q + 1] = h.y > 0.f ? v[4 * q + 1] * A.scale : 0.f;
+        v[4 * q + 2] = h.z > 0.f ? v[4 * q + 2] * A.scale : 0.f;
+        v[4 * q + 3] = h.w > 0.f ? v[4 * q + 3] * A.scale : 0.f;
+      }
+      if (hf == 0 && own) {
+        f32x4* po = reinterpret_cast<f32x4*>(A.out0 + (size_t)row * FC_K + 32 * kc);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) po[q] = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      }
+    });
+    if (A.out1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int e = e0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        if (e >= e_end) continue;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) A.out1[(size_t)e * FC_K + 32 * t + n] = acc[t][r];
+      }
+    }
+  }
+}
+
+// ---- dW = g^T x, db = sum g per edge chunk, all groups of a layer in one launch (the kernel of tp_train.hip::outer_accum_kernel with a
+//      group table: every wave owns one contiguous chunk of ONE group's edges as the MFMA k dimension, nine 32 x 32 accumulators)
+constexpr int OUTER_PART = FC_K * FC_K + FC_K;
+struct OuterArgs {
+  int n_groups;
+  int e_begin[FC_MAX_GROUPS + 1];
+  int part_begin[FC_MAX_GROUPS + 1];
+  int chunk[FC_MAX_GROUPS];
+  const float* G;
+  const float* X;
+  float* partial;
+};
+
+__global__ __launch_bounds__(64, 2) void outer_accum_groups_kernel(OuterArgs A) {
+  const int lane = threadIdx.x, c = lane & 31, hf = lane >> 5;
+  int grp = 0;
+#pragma unroll
+  for (int g = 1; g < FC_MAX_GROUPS; ++g)
+    if (g < A.n_groups && (int)blockIdx.x >= A.part_begin[g]) grp = g;
+  const int E1 = A.e_begin[grp + 1];
+  const int e_lo = A.e_begin[grp] + ((int)blockIdx.x - A.part_begin[grp]) * A.chunk[grp], e_hi = min(E1, e_lo + A.chunk[grp]);
+  f32x16 acc[3][3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float colsum[3] = {0.f, 0.f, 0.f};
+  for (int e = e_lo; e < e_hi; e += 2) {
+    const int row = e + hf;
+    const bool ok = row < e_hi;
+    const size_t off = (size_t)(ok ? row : e) * FC_K + c;
+    float g[3], x[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float gv = A.G[off + 32 * i], xv = A.X[off + 32 * i];
+      g[i] = ok ? gv : 0.f;
+      x[i] = ok ? xv : 0.f;
+      colsum[i] += g[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[i], x[j], acc[i][j], 0, 0, 0);
+  }
+  float* out = A.partial + (size_t)blockIdx.x * OUTER_PART;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf;
+        out[(size_t)m * FC_K + 32 * j + c] = acc[i][j][r];
+      }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float t = colsum[i] + __shfl_xor(colsum[i], 32, 64);
+    if (hf == 0) out[FC_K * FC_K + 32 * i + c] = t;
+  }
+}
+
+// ---- out[s][c] = sum_{r in [row_begin[s], row_begin[s + 1])} partial[r][c], rows added in order; columns [0, split) go to out_a[s],
+//      the rest to out_b[s] (dW | db slots of a gradient buffer)
+constexpr int RED_MAX_SEG = 4;
+struct ReduceArgs {
+  int n_seg;
+  int row_begin[RED_MAX_SEG + 1];
+  float* out_a[RED_MAX_SEG];
+  float* out_b[RED_MAX_SEG];
+  const float* partial;
+  int width, split;
+};
+
+__global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceArgs A) {
+  const int s = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= A.width) return;
+  const float* p = A.partial + (size_t)A.row_begin[s] * A.width + c;
+  const int n = A.row_begin[s + 1] - A.row_begin[s];
+  float acc = 0.f;
+  int r = 0;
+  for (; r + 4 <= n; r += 4) {
+    const float v0 = p[(size_t)r * A.width], v1 = p[(size_t)(r + 1) * A.width], v2 = p[(size_t)(r + 2) * A.width], v3 = p[(size_t)(r + 3) * A.width];
+    acc = (((acc + v0) + v1) + v2) + v3;
+  }
+  for (; r < n; ++r) acc += p[(size_t)r * A.width];
+  if (c < A.split) A.out_a[s][c] = acc;
+  else A.out_b[s][c - A.split] = acc;
+}
+
+static int fill_fc1(Fc1Args& a, int32_t n_groups, const int64_t* group_edges, const float* const* W, const float* const* b, int* n_wg) {
+  if (n_groups < 1 || n_groups > FC_MAX_GROUPS || !group_edges || !W) return fail(CBD_ERR_ARG, "1..4 edge groups");
+  a.n_groups = n_groups;
+  int64_t e = 0;
+  int wg = 0;
+  for (int g = 0; g <= FC_MAX_GROUPS; ++g) { a.e_begin[g] = 0; a.wg_begin[g] = 0; }
+  for (int g = 0; g < n_groups; ++g) {
+    if (group_edges[g] <= 0 || !W[g] || (b && !b[g])) return fail(CBD_ERR_ARG, "bad edge group %d", g);
+    a.e_begin[g] = (int)e;
+    a.wg_begin[g] = wg;
+    a.W[g] = W[g];
+    a.b[g] = b ? b[g] : nullptr;
+    e += group_edges[g];
+    if (e > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "too many rows");
+    const int64_t tiles = (group_edges[g] + 31) / 32;
+    wg += (int)((tiles + FC_WAVES * FC_TILES_PER_WAVE - 1) / (FC_WAVES * FC_TILES_PER_WAVE));
+  }
+  for (int g = n_groups; g <= FC_MAX_GROUPS; ++g) { a.e_begin[g] = (int)e; a.wg_begin[g] = wg; }
+  *n_wg = wg;
+  return 0;
+}
+
+}  // namespace cbd
+
+extern "C" {
+
+int cbd_fc1_forward(int32_t n_groups, const int64_t* group_edges, const float* x_dev, const float* const* weight_dev, const float* const* bias_dev,
+                    float p_drop, const int64_t* seed_dev, int64_t call, float* hid_dev, void* stream) {
+  cbd::Fc1Args a{};
+  int n_wg = 0;
+  if (!bias_dev) return fail(CBD_ERR_ARG, "cbd_fc1_forward: null bias table");
+  CHK(cbd::fill_fc1(a, n_groups, group_edges, weight_dev, bias_dev, &n_wg));
+  if (!x_dev || !hid_dev || p_drop < 0.f || p_drop >= 1.f || (p_drop > 0.f && !seed_dev)) return fail(CBD_ERR_ARG, "cbd_fc1_forward: bad argument");
+  a.x = x_dev; a.out0 = hid_dev; a.seed = reinterpret_cast<const long long*>(seed_dev); a.call = (unsigned long long)call;
+  a.drop_threshold = p_drop > 0.f ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  a.scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipLaunchKernelGGL(cbd::fc1_fwd_kernel, dim3(n_wg), dim3(cbd::FC_WAVES * 64), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_fc1_forward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_fc1_backward(int32_t n_groups, const int64_t* group_edges, const float* ghid_dev, const float* hid_dev, const float* const* weight_dev,
+                     float p_drop, float* gpre_dev, float* gx_dev, void* stream) {
+  cbd::Fc1Args a{};
+  int n_wg = 0;
+  CHK(cbd::fill_fc1(a, n_groups, group_edges, weight_dev, nullptr, &n_wg));
+  if (!ghid_dev || !hid_dev || !gpre_dev || p_drop < 0.f || p_drop >= 1.f) return fail(CBD_ERR_ARG, "cbd_fc1_backward: bad argument");
+  a.x = ghid_dev; a.hid_in = hid_dev; a.out0 = gpre_dev; a.out1 = gx_dev;
+  a.scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+  hipLaunchKernelGGL(cbd::fc1_bwd_kernel, dim3(n_wg), dim3(cbd::FC_WAVES * 64), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_fc1_backward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_outer_accum_groups(int32_t n_groups, const int64_t* group_edges, const int32_t* n_parts, const float* g_dev, const float* x_dev,
+                           float* partial_dev, void* stream) {
+  if (n_groups < 1 || n_groups > cbd::FC_MAX_GROUPS || !group_edges || !n_parts || !g_dev || !x_dev || !partial_dev)
+    return fail(CBD_ERR_ARG, "cbd_outer_accum_groups: bad argument");
+  cbd::OuterArgs a{};
+  a.n_groups = n_groups; a.G = g_dev; a.X = x_dev; a.partial = partial_dev;
+  int64_t e = 0;
+  int parts = 0;
+  for (int g = 0; g < n_groups; ++g) {
+    if (group_edges[g] <= 0 || n_parts[g] <= 0) return fail(CBD_ERR_ARG, "cbd_outer_accum_groups: bad group %d", g);
+    a.e_begin[g] = (int)e; a.part_begin[g] = parts;
+    int chunk = (int)((group_edges[g] + n_parts[g] - 1) / n_parts[g]);
+    chunk += chunk & 1;                    // even: a k-step's two edges belong to one chunk
+    a.chunk[g] = chunk;
+    e += group_edges[g]; parts += n_parts[g];
+    if (e > (int64_t)1 << 30) return fail(CBD_ERR_ARG, "too many rows");
+  }
+  for (int g = n_groups; g <= cbd::FC_MAX_GROUPS; ++g) { a.e_begin[g] = (int)e; a.part_begin[g] = parts; }
+  hipLaunchKernelGGL(cbd::outer_accum_groups_kernel, dim3(parts), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_outer_accum_groups: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int cbd_partial_reduce(int32_t n_seg, const int32_t* seg_rows, int32_t width, int32_t split, const float* partial_dev, float* const* out_a_dev,
+                       float* const* out_b_dev, void* stream) {
+  if (n_seg < 1 || n_seg > cbd::RED_MAX_SEG || !seg_rows || width <= 0 || split < 0 || split > width || !partial_dev || !out_a_dev ||
+      (split < width && !out_b_dev))
+    return fail(CBD_ERR_ARG, "cbd_partial_reduce: bad argument");
+  cbd::ReduceArgs a{};
+  a.n_seg = n_seg; a.partial = partial_dev; a.width = width; a.split = split;
+  int row = 0;
+  for (int s = 0; s < n_seg; ++s) {
+    if (seg_rows[s] < 0 || !out_a_dev[s] || (split < width && !out_b_dev[s])) return fail(CBD_ERR_ARG, "cbd_partial_reduce: bad segment %d", s);
+    a.row_begin[s] = row; row += seg_rows[s];
+    a.out_a[s] = out_a_dev[s]; a.out_b[s] = split < width ? out_b_dev[s] : nullptr;
+  }
+  for (int s = n_seg; s <= cbd::RED_MAX_SEG; ++s) a.row_begin[s] = row;
+  hipLaunchKernelGGL(cbd::partial_reduce_kernel, dim3((width + 255) / 256, n_seg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_partial_reduce: %s", hipGetErrorString(r));
+  return 0;
+}
+
+}  // extern "C"

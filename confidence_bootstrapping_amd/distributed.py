@@ -18,6 +18,7 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+from .hostcfg import with_glue_threads
 
 
 def world_rank(world: Optional[int] = None, rank: Optional[int] = None):
@@ -96,6 +97,7 @@ def gather_ranked(pos: torch.Tensor, confidence: torch.Tensor, world: int, rank:
     return res + (gid[order].cpu(),) if ids is not None else res
 
 
+@with_glue_threads
 def sampling_distributed(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
                          confidence_model=None, filtering_data_list=None, filtering_model_args=None, batch_size=32,
                          no_random=False, ode=False, no_final_step_noise=False, noise=None, world=None, rank=None, dst=0,
@@ -158,6 +160,7 @@ def sampling_distributed(data_list, model, inference_steps, tr_schedule, rot_sch
     return {"pos": rpos, "confidence": rconf if has_conf else None, "index": rid}
 
 
+@with_glue_threads
 def run_complex_set(complexes: Sequence, sample_group: Callable, world=None, rank=None, dst=0, group: int = 4,
                     cost: Optional[Callable] = None):
     """A set of complexes over all ranks (BASELINE.json configs[2]): LPT partition by `cost(complex)` (default Nl * Nr), every rank

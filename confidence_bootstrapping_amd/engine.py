@@ -88,6 +88,11 @@ SYMBOLS = {
     "cbd_outer_accum": (C.c_int, [C.c_int64, _P, _P, C.c_int32, _P, _P]),
     "cbd_segment_sum": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_segment_mean": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_tp_backward_dw_groups": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "cbd_fc1_forward": (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_float, _P, C.c_int64, _P, _P]),
+    "cbd_fc1_backward": (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
+    "cbd_outer_accum_groups": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cbd_partial_reduce": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     "cbd_irreps_bn_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "cbd_irreps_bn_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_segment_mean_backward": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),

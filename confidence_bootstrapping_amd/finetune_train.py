@@ -21,6 +21,7 @@ from .hetero import Batch
 from .molecules_utils import get_symmetry_rmsd
 from .sampling import randomize_position, sampling
 from .training import loss_function, train_epoch
+from .hostcfg import with_glue_threads
 
 
 def _copy(g):
@@ -33,6 +34,7 @@ def _as_batch1(g):
     return g if isinstance(g, Batch) else Batch.from_data_list([g])
 
 
+@with_glue_threads
 def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_dict, device, t_to_sigma, args, filtering_args,
                     confidence_cutoff):
     """Sample + score every complex; returns (metrics, [(graph, confidence), ...] above the cutoff, top-confidence RMSDs)

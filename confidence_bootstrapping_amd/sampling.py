@@ -29,6 +29,7 @@ import torch
 from scipy.spatial.transform import Rotation as R
 
 from .engine import DockEngine, make_steps, complex_fingerprint, _single_complex, _single_all_atom_complex
+from .hostcfg import with_glue_threads
 
 
 
@@ -104,6 +105,7 @@ def draw_noise_like_reference(N, R_, S, batch_size, no_final_step_noise=False):
             "tor": torch.cat([p[2] for p in parts], 1) if R_ > 0 else None}
 
 
+@with_glue_threads
 def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
              no_random=False, ode=False, visualization_list=None, confidence_model=None, filtering_data_list=None,
              filtering_model_args=None, asyncronous_noise_schedule=False, t_schedule=None, batch_size=32,

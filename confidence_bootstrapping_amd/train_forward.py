@@ -24,7 +24,7 @@ from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
 from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
-                        grouped_first_linear,
+                        grouped_first_linear, fc_first_stage,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
 
@@ -197,12 +197,21 @@ def _dev_cached(t: torch.Tensor, device, ident=None):
     return d
 
 
+_SIDE_PRIORITY = [-1 if os.environ.get("CBD_TRAIN_SIDE_PRIO", "1") == "1" else 0]
+
+
+def side_priority(high: bool):
+    """Priority of the side stream that carries a step's input-only work.  Eager steps: HIGH -- its small kernels and copies (and the host
+    read-backs that wait for them) must not queue behind the compute stream's millisecond kernels of the previous step.  hipGraph-captured
+    steps (train_graph.py): NORMAL -- a high-priority queue dribbling ~350 tiny launches starves the graph running on the compute stream
+    (a replay with two prepare() calls behind it took 96.7 ms instead of 23.5; tools/train_graph_check.py)."""
+    _SIDE_PRIORITY[0] = -1 if high else 0
+
+
 def _copy_stream(device):
-    key = str(device)
+    key = (str(device), _SIDE_PRIORITY[0])
     if key not in _COPY_STREAMS:
-        # high priority: its small kernels and copies (and the host read-backs that wait for them) must not queue behind the compute
-        # stream's millisecond kernels of the previous step
-        _COPY_STREAMS[key] = torch.cuda.Stream(device=device, priority=-1 if os.environ.get("CBD_TRAIN_SIDE_PRIO", "1") == "1" else 0)
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY[0])
     return _COPY_STREAMS[key]
 
 
@@ -440,9 +449,10 @@ def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_leve
         # a layer share the dropout rate)
         sizes = list(group_sizes) if group_sizes is not None else [edge_attr.shape[0]]
         live = [(fc, ne) for fc, ne in zip(fcs, sizes) if ne > 0]
-        pre = grouped_first_linear(edge_attr, [ne for _, ne in live], [fc[0] for fc, _ in live])
-        drop = live[0][0][2]
-        hid = F.dropout(F.relu(pre), p=drop.p, training=drop.training)
+        call = 0
+        if hub is not None:
+            hub.fc_calls = call = getattr(hub, "fc_calls", 0) + 1
+        hid = fc_first_stage(edge_attr, [ne for _, ne in live], [fc for fc, _ in live], seed=getattr(hub, "drop_seed", None), call=call)
         if hub is not None:     # the model's streams packed once per step (train_ops.StreamHub)
             msg = TensorProductHubFn.apply(xrow, vec4, hid, hub.big, hub, in_level, out_level, tuple(ne for _, ne in live),
                                            tuple(hub.block(fc) for fc, _ in live))
@@ -518,13 +528,30 @@ class _Prepared:
         return out
 
 
-def _pad_edges(ei, bucket, a, b):
-    """[2, E] -> [2, ceil(E / bucket) * bucket] with copies of the edge (a, b) (device scalars: nodes of the filler graph)"""
+def _pad_edges(ei, bucket, a_lo, a_n, b_lo, b_n, distinct=False):
+    """[2, E] -> [2, ceil(E / bucket) * bucket] with padding edges (a_lo + i % a_n, b_lo + i % b_n) -- nodes of the filler graph (a_lo, b_lo:
+    device scalars).  `distinct`: both ends index the same node set; the second is shifted so that no edge is a self loop."""
     n = int(ei.shape[1])
     cap = -(-max(n, 1) // bucket) * bucket
     if cap == n:
         return ei
-    return torch.cat([ei, torch.stack([a, b]).view(2, 1).expand(2, cap - n)], 1)
+    i = torch.arange(cap - n, device=ei.device)
+    a = i % a_n
+    b = (a + 1 + (i // a_n) % (b_n - 1)) % b_n if distinct else i % b_n
+    return torch.cat([ei, torch.stack([a_lo + a, b_lo + b])], 1)
+
+
+_DROPOUT_ACTIVE = weakref.WeakKeyDictionary()
+
+
+def _dropout_active(model) -> bool:
+    """does any FCBlock of the tensor-product layers drop units right now?  (cached per model and training flag)"""
+    hit = _DROPOUT_ACTIVE.get(model)
+    if hit is None or hit[0] != model.training:
+        layers = list(model.rec_emb_layers) + list(model.lig_emb_layers) + list(model.conv_layers)
+        on = any(isinstance(m, torch.nn.Dropout) and m.p > 0 and m.training for layer in layers for m in layer.modules())
+        hit = _DROPOUT_ACTIVE[model] = (model.training, on)
+    return hit[1]
 
 
 def _prepare(model, data, host, dev, csr_cache=None, pad=None) -> _Prepared:
@@ -536,6 +563,10 @@ def _prepare(model, data, host, dev, csr_cache=None, pad=None) -> _Prepared:
     ct = data.complex_t
     lig_batch, rec_batch = lig.batch, rec.batch
     g.tr_sigma, _, _ = model.t_to_sigma(ct["tr"], ct["rot"], ct["tor"])
+    if _dropout_active(model):
+        # seed of this step's dropout masks in the fused FCBlock stage (csrc/train_fc.hip), drawn from torch's CPU generator (so that
+        # torch.manual_seed reproduces a step) and kept in device memory (so that a hipGraph replay reads a fresh one from its inputs)
+        g.drop_seed = torch.randint(0, 2 ** 62, (1,), dtype=torch.long).to(dev, non_blocking=True)
     lig_pos, rec_pos = lig.pos.float(), rec.pos.float()
     g.lig_pos = lig_pos
     t_host = host["t"] if host else {k: v.detach().cpu() for k, v in ct.items()}
@@ -564,14 +595,16 @@ def _prepare(model, data, host, dev, csr_cache=None, pad=None) -> _Prepared:
         ei, lr = found[0], found[1]
         t_edges = found[2] if bonds is not None else None
         if pad is not None:
-            # padding edges between nodes of the filler graph (the last graph): last ligand atom <-> the one before it, last ligand atom
-            # <-> last residue, the filler's rotatable bond (the last column of `bonds`) <-> last ligand atom
+            # padding edges between nodes of the filler graph (the last graph), spread over its atoms / residues / rotatable bonds (the
+            # last columns of `bonds`)
             pad["edges_real"] = {"ll": int(ei.shape[1]), "lr": int(lr.shape[1]), "t": int(t_edges.shape[1]) if t_edges is not None else 0}
-            la, ra = lig_ptr[-1] - 1, rec_ptr[-1] - 1
-            ei = _pad_edges(ei, pad["buckets"]["ll"], la, la - 1)
-            lr = _pad_edges(lr, pad["buckets"]["lr"], la, ra)
+            nfl, nfr, nfb = int(host["nl"][-1]), int(host["nr"][-1]), int(n_rot[-1])
+            l0, r0 = lig_ptr[-2], rec_ptr[-2]
+            ei = _pad_edges(ei, pad["buckets"]["ll"], l0, nfl, l0, nfl, distinct=True)
+            lr = _pad_edges(lr, pad["buckets"]["lr"], l0, nfl, r0, nfr)
             if t_edges is not None:
-                t_edges = _pad_edges(t_edges, pad["buckets"]["t"], torch.full_like(la, int(bonds.shape[1]) - 1), la)
+                b0 = torch.full_like(l0, int(bonds.shape[1]) - nfb)
+                t_edges = _pad_edges(t_edges, pad["buckets"]["t"], b0, nfb, l0, nfl)
     else:                           # a batch collated elsewhere: dense masks, one read-back of their three counts
         if pad is not None:
             raise RuntimeError("capacity padding needs the collation of train_forward.collate (node offsets of the graphs)")
@@ -652,32 +685,46 @@ class PreparedBatch:
 
 
 FILLER_NAME = "__filler__"
-PAD_BUCKETS = {"ll": 512, "lr": 4096, "t": 256}
+PAD_BUCKETS = {"ll": 1024, "lr": 8192, "t": 512}      # coarse: few distinct shapes = few graphs (the filler edges cost ~5 % of the step)
+
+
+FILLER_LIG, FILLER_REC = 32, 31      # coprime: padding edge i joins atom i % 32 and residue i % 31 -- 992 distinct pairs, degrees stay small
 
 
 def filler_complex(like: HeteroData) -> HeteroData:
-    """The filler graph of a capacity-padded step: four ligand atoms in a chain (one rotatable bond) and four residues, with the
-    feature widths and dtypes of `like`.  It is appended to the batch as one more graph; the padding edges of the three radius
-    graphs live inside it, so it is a connected component of its own: nothing flows between it and the real graphs, its rows are
-    excluded from every BatchNorm statistic and its predictions from the loss."""
+    """The filler graph of a capacity-padded step: a chain of 32 ligand atoms (its inner bonds rotatable) and 31 residues, with the
+    feature widths and dtypes of `like`.  It is appended to the batch as one more graph; the padding edges of the three radius graphs
+    live inside it, SPREAD over its nodes (thousands of copies of one edge would make one node's segmented sums -- one wave per row --
+    the long tail of every layer: 375 us instead of 45 per call in the first profile), so it is a connected component of its own:
+    nothing flows between it and the real graphs, its rows are excluded from every BatchNorm statistic and its predictions from the
+    loss."""
     f = HeteroData()
     lig, rec = like["ligand"], like["receptor"]
-    f["ligand"].x = lig.x[:1].repeat(4, 1).clone()
+    rng = np.random.default_rng(7)
+    nl, nr = FILLER_LIG, min(FILLER_REC, int(rec.x.shape[0]))
+    f["ligand"].x = lig.x[:1].repeat(nl, 1).clone()
     # generic (non-colinear, non-planar) coordinates: a symmetric filler would make some equivariant outputs EXACTLY zero, and the heads
     # divide by their norms -- a 0/0 in the filler's (discarded) row would still send NaN into the shared weights' gradients
-    f["ligand"].pos = torch.tensor([[0.0, 0, 0], [1.4, 0.3, 0.1], [2.1, 1.5, -0.4], [3.3, 1.9, 0.9]], dtype=lig.pos.dtype)
-    ei = torch.tensor([[0, 1, 1, 2, 2, 3], [1, 0, 2, 1, 3, 2]], dtype=like["ligand", "ligand"].edge_index.dtype)
-    f["ligand", "ligand"].edge_index = ei
+    step = rng.normal(size=(nl, 3))
+    step = 1.5 * step / np.linalg.norm(step, axis=1, keepdims=True)
+    f["ligand"].pos = torch.tensor(np.cumsum(step, axis=0), dtype=lig.pos.dtype)
+    a = np.arange(nl - 1)
+    ei = np.stack([np.stack([a, a + 1], 1).reshape(-1), np.stack([a + 1, a], 1).reshape(-1)])          # (0,1),(1,0),(1,2),(2,1),...
+    f["ligand", "ligand"].edge_index = torch.tensor(ei, dtype=like["ligand", "ligand"].edge_index.dtype)
     ea = like["ligand", "ligand"].edge_attr
-    f["ligand", "ligand"].edge_attr = torch.zeros(6, ea.shape[1], dtype=ea.dtype)
+    f["ligand", "ligand"].edge_attr = torch.zeros(ei.shape[1], ea.shape[1], dtype=ea.dtype)
     f["ligand", "ligand"].edge_attr[:, 0] = 1
-    f["ligand"].edge_mask = torch.tensor([False, False, True, False, False, False])
-    f["ligand"].mask_rotate = np.array([[False, False, True, True]])
-    nr = min(4, int(rec.x.shape[0]))
-    f["receptor"].x = rec.x[:nr].clone()
-    f["receptor"].pos = torch.tensor([[0.5, 6.0, 1.0], [3.9, 5.1, -1.2], [6.2, 7.7, 0.8], [9.1, 6.4, 3.0]], dtype=rec.pos.dtype)[:nr]
-    pairs = [(a, b) for a in range(nr) for b in range(nr) if a != b]
-    f["receptor", "receptor"].edge_index = torch.tensor(pairs, dtype=like["receptor", "receptor"].edge_index.dtype).t().contiguous()
+    mask = np.zeros(ei.shape[1], dtype=bool)
+    mask[2 * np.arange(1, nl - 2)] = True                   # inner bonds, one direction each: 29 rotatable bonds
+    f["ligand"].edge_mask = torch.from_numpy(mask)
+    f["ligand"].mask_rotate = np.stack([np.arange(nl) > k for k in range(1, nl - 2)])
+    f["receptor"].x = rec.x[:1].repeat(nr, 1).clone()
+    rstep = rng.normal(size=(nr, 3))
+    rstep = 3.8 * rstep / np.linalg.norm(rstep, axis=1, keepdims=True)
+    f["receptor"].pos = torch.tensor(np.cumsum(rstep, axis=0) + np.array([0.0, 8.0, 0.0]), dtype=rec.pos.dtype)
+    r = np.arange(nr)
+    pairs = np.concatenate([np.stack([r, (r + 1) % nr]), np.stack([r, (r + 2) % nr])], axis=1)
+    f["receptor", "receptor"].edge_index = torch.tensor(pairs, dtype=like["receptor", "receptor"].edge_index.dtype)
     f.complex_t = {k: torch.full((1,), 0.5) for k in ("tr", "rot", "tor")}
     f.name = FILLER_NAME
     return f
@@ -763,6 +810,7 @@ def forward(model, data):
 
     hub = _stream_hub(model, dev)
     hub.pack()
+    hub.drop_seed, hub.fc_calls = getattr(g, "drop_seed", None), 0       # the step's dropout stream (train_ops.fc_first_stage)
 
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
     rec_edge_attr = model.rec_edge_embedding(g.r_smear)

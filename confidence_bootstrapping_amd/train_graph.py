@@ -174,7 +174,7 @@ class _Captured:
 class GraphedStep:
     """forward + loss + backward of the fine-tuning step as one hipGraph launch per step (module docstring)."""
 
-    def __init__(self, model, optimizer, device, t_to_sigma, loss_kwargs=None, ema_weights=None, pad=True, max_graphs=6, capture_after=1):
+    def __init__(self, model, optimizer, device, t_to_sigma, loss_kwargs=None, ema_weights=None, pad=True, max_graphs=12, capture_after=1):
         self.model, self.opt, self.dev, self.t2s = model, optimizer, torch.device(device), t_to_sigma
         self.lw = dict(loss_kwargs or {})
         for k in ("backbone_weight", "sidechain_weight"):
@@ -190,8 +190,13 @@ class GraphedStep:
 
     # ---- stage 1: host + side stream
     def prepare(self, data: List[HeteroData]):
-        prep = tf.prepare_batch(self.model, data, self.dev, pad=self.pad)
-        targets = loss_targets(data, self.t2s, self.dev, no_torsion=self.no_torsion)
+        was = tf._SIDE_PRIORITY[0]
+        tf.side_priority(False)         # normal priority next to a running graph (train_forward.side_priority)
+        try:
+            prep = tf.prepare_batch(self.model, data, self.dev, pad=self.pad)
+            targets = loss_targets(data, self.t2s, self.dev, no_torsion=self.no_torsion)
+        finally:
+            tf._SIDE_PRIORITY[0] = was
         return {"data": data, "prep": prep, "targets": targets, "key": _signature(_structure(prep, targets))}
 
     # ---- stage 2: copy-in + graph launch (or the eager step for a shape not captured yet)
@@ -259,6 +264,7 @@ class GraphedStep:
         from .training import _async_any_nan
         item["loss_tuple"] = lt
         item["nan"] = _async_any_nan(lt[0].detach())
+        torch.cuda.current_stream(dev).query()      # push the enqueued work to the GPU now: the host goes on to prepare the next batch
         return item
 
     # ---- stage 3: the host decision and the optimiser

@@ -441,27 +441,36 @@ class TensorProductHubFn(torch.autograd.Function):
             wt = (C.c_void_p * n)(*[hub.stream_t_ptr(b) for b in blocks])
             TIMER.wrap("gh", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward_gh(
                 in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), wt, _ptr(gmsg), _ptr(gh), _stream_handle())))
-        lo = 0
-        for ne, b in zip(group_edges, blocks):
-            hi = lo + ne
-            if ne:
-                dw, db = hub.grad_views(b)
-                if fused:
-                    # dW2p / db2p with the edges as the MFMA k dimension (cbd_tp_backward_dw), partial sums per edge chunk
-                    wp = sm.wp
-                    n_chunks = max(1, min(256, ((ne + 31) // 32) // 4))
-                    part = _dw_scratch(n_chunks * (wp * KDIM + wp), xrow.device).view(n_chunks, wp * KDIM + wp)
-                    TIMER.wrap("dw", in_level, out_level, ne, lambda: _check(lib.cbd_tp_backward_dw(
-                        in_level, out_level, lo, hi, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), n_chunks, _ptr(part), _stream_handle())))
-                    torch.sum(part[:, :wp * KDIM].view(n_chunks, wp, KDIM), 0, out=dw)
-                    torch.sum(part[:, wp * KDIM:], 0, out=db)
-                else:
+        if fused:
+            # dW2p / db2p with the edges as the MFMA k dimension, ALL groups of the layer in one launch (cbd_tp_backward_dw_groups), the
+            # per-chunk partial blocks added in a fixed order by one more (cbd_partial_reduce) -- round 3: one launch + two torch.sum per group
+            wp = sm.wp
+            live = [(int(ne), b) for ne, b in zip(group_edges, blocks) if ne]
+            ng = len(live)
+            chunks = [max(1, min(256, ((ne + 31) // 32) // 4)) for ne, _ in live]
+            width = wp * KDIM + wp
+            part = _dw_scratch(sum(chunks) * width, xrow.device)
+            assert sum(ne for ne, _ in live) == E
+            ge_l = (C.c_int64 * ng)(*[ne for ne, _ in live])
+            nc = (C.c_int32 * ng)(*chunks)
+            TIMER.wrap("dw", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward_dw_groups(
+                in_level, out_level, ng, ge_l, nc, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), _ptr(part), _stream_handle())))
+            views = [hub.grad_views(b) for _, b in live]
+            oa = (C.c_void_p * ng)(*[v[0].data_ptr() for v in views])
+            ob = (C.c_void_p * ng)(*[v[1].data_ptr() for v in views])
+            _check(lib.cbd_partial_reduce(ng, nc, width, wp * KDIM, _ptr(part), oa, ob, _stream_handle()))
+        else:
+            lo = 0
+            for ne, b in zip(group_edges, blocks):
+                hi = lo + ne
+                if ne:
+                    dw, db = hub.grad_views(b)
                     gwg = gw[lo:hi]
                     if gh is not None and not GH_KERNEL:
                         torch.mm(gwg, hub.w2p(b), out=gh[lo:hi])
                     _weight_grad(gwg, h[lo:hi], dw)
                     torch.sum(gwg, 0, out=db)        # (as a matrix-vector product these column sums are 10x slower: measured)
-            lo = hi
+                lo = hi
         return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
 
 
@@ -529,6 +538,73 @@ class GroupedFirstLinearFn(torch.autograd.Function):
             grads += [tot[:KDIM * KDIM].view(KDIM, KDIM), tot[KDIM * KDIM:]]
             lo += ne
         return (gx, None, *grads)
+
+
+class FcFirstStageFn(torch.autograd.Function):
+    """hid = Dropout_p(ReLU(Linear_g(x)))  for every edge group g of a layer over ONE [E, 96] tensor of edge rows -- the first stage of the
+    FCBlocks (reference models/layers.py:8-15) as one launch forward (cbd_fc1_forward) and three backward (cbd_fc1_backward: mask + input
+    gradient; cbd_outer_accum_groups + cbd_partial_reduce: weight / bias gradients of all groups).  Round 3: one library GEMM per group, a
+    clamp, torch's dropout; backward a masked scale, a threshold and GEMM + outer_accum + sum per group (csrc/train_fc.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, seed, call, p, sizes, *wb):
+        lib = _bind(load_library())
+        x = x.contiguous().float()
+        E, n = x.shape[0], len(sizes)
+        assert x.shape[1] == KDIM and sum(sizes) == E and len(wb) == 2 * n
+        ws = [w.contiguous().float() for w in wb[0::2]]
+        bs = [b.contiguous().float() for b in wb[1::2]]
+        hid = torch.empty(E, KDIM, device=x.device, dtype=torch.float32)
+        ge = (C.c_int64 * n)(*[int(v) for v in sizes])
+        wp_, bp_ = (C.c_void_p * n)(*[w.data_ptr() for w in ws]), (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+        _check(lib.cbd_fc1_forward(n, ge, _ptr(x), wp_, bp_, float(p), None if seed is None else _ptr(seed), int(call), _ptr(hid), _stream_handle()))
+        ctx.save_for_backward(x, hid, *ws)
+        ctx.meta = (tuple(int(v) for v in sizes), float(p))
+        return hid
+
+    @staticmethod
+    def backward(ctx, ghid):
+        x, hid, *ws = ctx.saved_tensors
+        sizes, p = ctx.meta
+        lib = _bind(load_library())
+        n, E = len(sizes), x.shape[0]
+        ghid = ghid.contiguous().float()
+        gpre = torch.empty_like(x)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        ge = (C.c_int64 * n)(*sizes)
+        wp_ = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+        _check(lib.cbd_fc1_backward(n, ge, _ptr(ghid), _ptr(hid), wp_, p, _ptr(gpre), None if gx is None else _ptr(gx), _stream_handle()))
+        pf = int(lib.cbd_outer_accum_part_floats())
+        parts = [max(1, min(1024, (ne + 63) // 64)) for ne in sizes]
+        partial = torch.empty(sum(parts), pf, device=x.device, dtype=torch.float32)
+        npart = (C.c_int32 * n)(*parts)
+        _check(lib.cbd_outer_accum_groups(n, ge, npart, _ptr(gpre), _ptr(x), _ptr(partial), _stream_handle()))
+        gwb = torch.empty(n, pf, device=x.device, dtype=torch.float32)
+        oa = (C.c_void_p * n)(*[gwb[k].data_ptr() for k in range(n)])
+        ob = (C.c_void_p * n)(*[gwb[k].data_ptr() + 4 * KDIM * KDIM for k in range(n)])
+        _check(lib.cbd_partial_reduce(n, npart, pf, KDIM * KDIM, _ptr(partial), oa, ob, _stream_handle()))
+        grads = []
+        for k in range(n):
+            grads += [gwb[k, :KDIM * KDIM].view(KDIM, KDIM), gwb[k, KDIM * KDIM:]]
+        return (gx, None, None, None, None, *grads)
+
+
+FUSED_FIRST_STAGE = True      # False: the round-3 form (library GEMM per group + torch ReLU / Dropout), kept for the equivalence test
+
+
+def fc_first_stage(x, sizes, fcs, seed=None, call=0):
+    """Dropout(ReLU(fc[0](x))) of every edge group's FCBlock `fc` = nn.Sequential(Linear, ReLU, Dropout, Linear) over the rows of x; the
+    groups share the dropout rate (they are built with the layer's).  `seed`: device int64 scalar of the step's dropout stream."""
+    if not x.is_cuda:
+        raise RuntimeError("fc_first_stage runs on the MI355X only (HIP kernels, no CPU fallback)")
+    assert sum(sizes) == x.shape[0] and all(n > 0 for n in sizes) and len(sizes) == len(fcs)
+    drop = fcs[0][2]
+    p = float(drop.p) if drop.training else 0.0
+    if not FUSED_FIRST_STAGE or (p > 0 and seed is None):
+        pre = grouped_first_linear(x, sizes, [fc[0] for fc in fcs])
+        return torch.nn.functional.dropout(torch.relu(pre), p=drop.p, training=drop.training)
+    wb = [q for fc in fcs for q in (fc[0].weight, fc[0].bias)]
+    return FcFirstStageFn.apply(x, seed if p > 0 else None, int(call), p, tuple(int(n) for n in sizes), *wb)
 
 
 def grouped_first_linear(x, sizes, linears):

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from . import so3, torus
+from .hostcfg import with_glue_threads
 
 
 def _cat(data, name):
@@ -223,6 +224,7 @@ def _parameter_list(model):
     return lst
 
 
+@with_glue_threads
 def train_step(model, data, optimizer, device, t_to_sigma, loss_fn, ema_weights=None, forward_fn=None, skip=False, prepared=None,
                before_backward=None):
     """One optimisation step on a list of noised graphs (body of the reference loop, utils/training.py:195-211).
@@ -318,6 +320,9 @@ def _train_epoch_graphed(model, loader, optimizer, device, t_to_sigma, loss_fn, 
         else:
             meter.add(out)
     pending, i = None, 0
+    import os
+    import time
+    prof = trainer.stats.setdefault("host_s", {"prepare": 0.0, "finish": 0.0, "launch": 0.0, "steps": 0}) if os.environ.get("CBD_TRAIN_PROF") else None
     for data in loader:
         if n_steps is not None and i >= n_steps:
             break
@@ -332,14 +337,25 @@ def _train_epoch_graphed(model, loader, optimizer, device, t_to_sigma, loss_fn, 
                 allreduce_gradients(model, skip=True)
                 optimizer.zero_grad()
             continue
+        t0 = time.perf_counter()
         item = trainer.prepare(data if isinstance(data, (list, tuple)) else data.to_data_list())
+        t1 = time.perf_counter()
         if pending is not None:
             close(pending)
+        t2 = time.perf_counter()
         pending = trainer.launch(item)
+        if prof is not None:
+            t3 = time.perf_counter()
+            prof["prepare"] += t1 - t0
+            prof["finish"] += t2 - t1
+            prof["launch"] += t3 - t2
+            prof["steps"] += 1
+            prof.setdefault("trace", []).append((round((t1 - t0) * 1e3, 1), round((t2 - t1) * 1e3, 1), round((t3 - t2) * 1e3, 1)))
     if pending is not None:
         close(pending)
 
 
+@with_glue_threads
 def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weights, torsional=False, forward_fn=None, look_ahead=False,
                 hip_graph=False):
     """One epoch (reference utils/training.py:184-233).  `hip_graph=True`: forward + loss + backward of every step as ONE hipGraph launch

@@ -288,6 +288,30 @@ int cbd_tp_backward_gh(int32_t in_level, int32_t out_level, int32_t n_groups, co
  * called with gw_dev = NULL. */
 int cbd_tp_backward_dw(int32_t in_level, int32_t out_level, int64_t e_lo, int64_t e_hi, const float* xrow_dev, const float* vec4_dev,
                        const float* h_dev, const float* gmsg_dev, int32_t n_chunks, float* partial_dev, void* stream);
+/* cbd_tp_backward_dw for ALL edge groups of a layer in one launch: group g owns the next group_edges[g] (> 0) edge rows and n_chunks[g]
+ * consecutive partial rows of partial_dev [sum n_chunks][wp * 96 + wp]; add a group's rows in order (cbd_partial_reduce). */
+int cbd_tp_backward_dw_groups(int32_t in_level, int32_t out_level, int32_t n_groups, const int64_t* group_edges, const int32_t* n_chunks,
+                              const float* xrow_dev, const float* vec4_dev, const float* h_dev, const float* gmsg_dev, float* partial_dev,
+                              void* stream);
+/* First stage of the FCBlock in the fine-tuning step (reference models/layers.py:8-15: Linear(96, 96) -> ReLU -> Dropout; per edge group in
+ * TensorProductConvLayer.forward, models/tensor_layers.py:195-206, under model.train()), all edge groups of a layer in ONE launch each way.
+ * Group g owns the next group_edges[g] (> 0) rows of x_dev / hid_dev [E][96]; weight_dev[g] = nn.Linear.weight [96 out][96 in], bias_dev[g]
+ * [96] (host arrays of device pointers).  hid = dropout_p(relu(x W_g^T + b_g)); the dropout mask is a counter-based hash of (seed_dev[0],
+ * call, element index) -- seed_dev is DEVICE memory so that a hipGraph replay draws fresh masks from its input buffer; `call` tells the
+ * layers of a step apart.  Backward: gpre = ghid / (1 - p) where hid > 0 (active and kept), else 0;  gx (may be NULL) = gpre W_g. */
+int cbd_fc1_forward(int32_t n_groups, const int64_t* group_edges, const float* x_dev, const float* const* weight_dev, const float* const* bias_dev,
+                    float p_drop, const int64_t* seed_dev, int64_t call, float* hid_dev, void* stream);
+int cbd_fc1_backward(int32_t n_groups, const int64_t* group_edges, const float* ghid_dev, const float* hid_dev, const float* const* weight_dev,
+                     float p_drop, float* gpre_dev, float* gx_dev, void* stream);
+/* cbd_outer_accum for all edge groups of a layer in one launch: partial_dev [sum n_parts][cbd_outer_accum_part_floats()], group g's
+ * rows consecutive. */
+int cbd_outer_accum_groups(int32_t n_groups, const int64_t* group_edges, const int32_t* n_parts, const float* g_dev, const float* x_dev,
+                           float* partial_dev, void* stream);
+/* Fixed-order reduction of partial rows: segment s = the next seg_rows[s] rows of partial_dev [.][width]; the column sums of a segment
+ * go to out_a_dev[s] (columns [0, split)) and out_b_dev[s] (columns [split, width)); host arrays of device pointers, 1..4 segments.
+ * Rows are added in row order: bitwise repeatable, no atomics (stands in for the torch.sum calls behind the two weight-gradient passes). */
+int cbd_partial_reduce(int32_t n_seg, const int32_t* seg_rows, int32_t width, int32_t split, const float* partial_dev, float* const* out_a_dev,
+                       float* const* out_b_dev, void* stream);
 
 /* Weight and bias gradient of the FCBlock's first Linear (96 -> 96) in the fine-tuning step (autograd of fc[0] in
  * models/layers.py:8-15 under utils/training.py:205): partial[p] = [ sum_e g[e][m] x[e][n] (96 x 96, row-major) | sum_e g[e][m] (96) ]

@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--skip-timing", action="store_true")
+    ap.add_argument("--skip-checks", action="store_true")
+    ap.add_argument("--modes", default="eager,hip_graph")
+    ap.add_argument("--no-gc", action="store_true")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     from confidence_bootstrapping_amd.synthetic import make_complex, WORKLOADS
@@ -47,6 +50,18 @@ def main():
     torch.manual_seed(0)
     batches = [[nt(c.shallow_copy()) for c in base] for _ in range(8)]
 
+    if not a.skip_checks:
+        checks(a, dev, batches, margs, t2s, lw, out)
+    if a.skip_timing:
+        return
+    timing(a, dev, batches, margs, t2s, lw)
+
+
+def checks(a, dev, batches, margs, t2s, lw, out):
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.training import loss_targets, loss_from_targets
+    from confidence_bootstrapping_amd import train_forward as tf
+    from confidence_bootstrapping_amd.train_graph import GraphedStep
     # ---- 1 + 2: gradients (dropout 0)
     m0 = copy.deepcopy(margs)
     m0.dropout = 0.0
@@ -107,13 +122,72 @@ def main():
     torch.cuda.synchronize()
     out["second_batch_bitwise"] = bool(torch.equal(flat_grads(model), g_pad2))
     out["second_batch_max_abs_diff"] = float((flat_grads(model) - g_pad2).abs().max())
+    # ---- where a graphed step's time goes (same batch, dropout 0): host time of prepare / launch, GPU time of one replay
+    cap = trainer.graphs[trainer.prepare(data)["key"]] if trainer.prepare(data)["key"] in trainer.graphs else None
+    if cap is not None:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            cap.graph.replay()
+        torch.cuda.synchronize()
+        out["replay_only_ms"] = round((time.perf_counter() - t0) / 10 * 1e3, 2)
+        # does a replay need the host, and what does the side-stream work of the next prepare() cost it?
+        def timed(after):
+            ts = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                cap.graph.replay()
+                torch.cuda.current_stream().query()
+                after()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            return round(float(np.median(ts)), 2)
+        out["replay_then_sleep_10ms"] = timed(lambda: time.sleep(0.010))
+        out["replay_then_prepare"] = timed(lambda: trainer.prepare(data))
+        out["replay_then_prepare_x2"] = timed(lambda: (trainer.prepare(data), trainer.prepare(data)))
+        # does switching between captured graphs cost anything?
+        k1, k2 = trainer.prepare(data)["key"], trainer.prepare(data2)["key"]
+        if k1 != k2:
+            for _ in range(2):
+                trainer.step(data2)
+            ca, cb = trainer.graphs[k1], trainer.graphs[k2]
+            seq, ts = "AAABBBABABAABB", []
+            for ch in seq:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                (ca if ch == "A" else cb).graph.replay()
+                torch.cuda.synchronize()
+                ts.append(round((time.perf_counter() - t0) * 1e3, 1))
+            out["alternating_replays"] = {"sequence": seq, "ms": ts}
+        hp, hl, hf = [], [], []
+        for _ in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            item = trainer.prepare(data)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            trainer.launch(item)
+            t3 = time.perf_counter()
+            trainer.finish(item)
+            torch.cuda.synchronize()
+            t4 = time.perf_counter()
+            hp.append(t1 - t0); hl.append(t3 - t2); hf.append(t4 - t3)
+        out["host_ms"] = {"prepare": round(np.median(hp) * 1e3, 2), "prepare_drain": round((t2 - t1) * 1e3, 2), "launch_enqueue": round(np.median(hl) * 1e3, 2),
+                          "finish_incl_gpu_wait": round(np.median(hf) * 1e3, 2)}
     print(json.dumps(out), flush=True)
-    if a.skip_timing:
-        return
+
+
+def timing(a, dev, batches, margs, t2s, lw):
+    from confidence_bootstrapping_amd.utils import make_score_model, ExponentialMovingAverage
+    from confidence_bootstrapping_amd.training import loss_function, train_epoch
     # ---- 3: timing, shipped configuration
-    del trainer
     times = {}
-    for mode in ("eager", "hip_graph"):
+    if a.no_gc:
+        import gc
+        gc.disable()
+    for mode in a.modes.split(","):
         model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
         model.train()
         opt = torch.optim.Adam(model.parameters(), lr=1e-3)
@@ -132,7 +206,10 @@ def main():
         times[mode] = {"ms_per_step_blocks": [round(b, 2) for b in blocks], "loss": s["loss"]}
         if mode == "hip_graph":
             from confidence_bootstrapping_amd.training import _GRAPHED
-            times[mode]["stats"] = dict(_GRAPHED[model][1].stats)
+            times[mode]["stats"] = {k: v for k, v in _GRAPHED[model][1].stats.items() if k != "host_s"}
+            hs = _GRAPHED[model][1].stats.get("host_s")
+            if hs:
+                times[mode]["host_trace_last_32_steps_prepare_finish_launch_ms"] = hs["trace"][-32:]
             times[mode]["graphs"] = len(_GRAPHED[model][1].graphs)
     print(json.dumps({"batch": a.batch, "workload": a.workload, "timing": times}), flush=True)
 
