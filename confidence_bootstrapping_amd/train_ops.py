@@ -11,6 +11,7 @@ There is no PyTorch fallback: without the HIP library (or on CPU tensors) the op
 from __future__ import annotations
 
 import ctypes as C
+import os
 from functools import lru_cache
 
 import numpy as np
@@ -394,6 +395,7 @@ def _dw_scratch(n_floats, device):
     return buf[:n_floats]
 
 
+DW_MAX_CHUNKS = int(os.environ.get("CBD_DW_MAX_CHUNKS", "96"))
 GH_KERNEL = True        # g_h through cbd_tp_backward_gh (False: the library GEMM on the stored g_w; kept for the equivalence test)
 DW_KERNEL = True        # dW2p / db2p through cbd_tp_backward_dw (with GH_KERNEL: g_w is never stored); False: split-K library GEMM on g_w
 
@@ -447,7 +449,9 @@ class TensorProductHubFn(torch.autograd.Function):
             wp = sm.wp
             live = [(int(ne), b) for ne, b in zip(group_edges, blocks) if ne]
             ng = len(live)
-            chunks = [max(1, min(256, ((ne + 31) // 32) // 4)) for ne, _ in live]
+            # chunks per group: enough workgroups to fill the chip (14 tile groups x chunks), few enough that the reduction of the
+            # partial blocks (167 k floats each at 74 -> 74) stays small next to the pass itself
+            chunks = [max(1, min(DW_MAX_CHUNKS, ((ne + 31) // 32) // 4)) for ne, _ in live]
             width = wp * KDIM + wp
             part = _dw_scratch(sum(chunks) * width, xrow.device)
             assert sum(ne for ne, _ in live) == E
