@@ -270,15 +270,17 @@ __global__ __launch_bounds__(256) void partial_reduce_kernel(ReduceArgs A) {
   if (c >= A.width) return;
   const float* p = A.partial + (size_t)A.row_begin[s] * A.width + c;
   const int n = A.row_begin[s + 1] - A.row_begin[s];
-  float acc = 0.f;
+  // the chunks are added in double (in row order: deterministic): a weight gradient is a sum over 10^3..10^5 edge rows of terms that
+  // largely cancel, and the reference's own yardstick for it (fp64 autograd, tests/golden/g11) leaves 2e-4 of the largest entry
+  double acc = 0.0;
   int r = 0;
   for (; r + 4 <= n; r += 4) {
     const float v0 = p[(size_t)r * A.width], v1 = p[(size_t)(r + 1) * A.width], v2 = p[(size_t)(r + 2) * A.width], v3 = p[(size_t)(r + 3) * A.width];
-    acc = (((acc + v0) + v1) + v2) + v3;
+    acc = (((acc + (double)v0) + (double)v1) + (double)v2) + (double)v3;
   }
-  for (; r < n; ++r) acc += p[(size_t)r * A.width];
-  if (c < A.split) A.out_a[s][c] = acc;
-  else A.out_b[s][c - A.split] = acc;
+  for (; r < n; ++r) acc += (double)p[(size_t)r * A.width];
+  if (c < A.split) A.out_a[s][c] = (float)acc;
+  else A.out_b[s][c - A.split] = (float)acc;
 }
 
 static int fill_fc1(Fc1Args& a, int32_t n_groups, const int64_t* group_edges, const float* const* W, const float* const* b, int* n_wg) {
@@ -378,6 +380,230 @@ int cbd_partial_reduce(int32_t n_seg, const int32_t* seg_rows, int32_t width, in
   hipLaunchKernelGGL(cbd::partial_reduce_kernel, dim3((width + 255) / 256, n_seg), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
   const hipError_t r = hipGetLastError();
   if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_partial_reduce: %s", hipGetErrorString(r));
+  return 0;
+}
+
+}  // extern "C"
+
+// =====================================================================================================================================
+// Generic Linear layers of the fine-tuning step: every nn.Linear outside the FCBlocks' first stage (edge / node / sigma embeddings, the
+// FCBlocks of the two heads, the final layers; reference models/score_model.py:186-243) -- sizes 32 x {32, 64, 68, 1312}, 64 x 64,
+// 124 x 64, 96 x 96, 384 x 96, 1 x 32 -- forward and backward without a library GEMM.  Same tiling as above (one wave = 32 rows x 32
+// output columns, fp32 MFMA, K in chunks of 32 with zero padding past K), operands straight from global memory: these layers are tiny
+// next to the tensor products (the largest reads 75 k rows x 32 floats), what they cost is launches.
+//   cbd_linear_forward    y = act(x W^T + b)         act: 0 = identity, 1 = dropout_p(relu(.))
+//   cbd_linear_backward   gpre = act'(gy; y),  gx = gpre W  (optional),  partial dW = gpre^T x and db = sum gpre per row chunk
+namespace cbd {
+
+struct LinArgs {
+  int E, K, N, ldx, ldg;
+  const float* x;        // [E][ldx]
+  const float* W;        // [N][K]
+  const float* b;        // [N] or null
+  float* y;              // forward out [E][N]
+  const float* y_in;     // backward: forward output (mask) or null
+  const float* gy;       // backward in [E][N]
+  float* gpre;           // backward out [E][N] (null: no activation, gy is used as it is)
+  float* gx;             // backward out [E][K] or null
+  float* partial;        // backward out [n_chunks][N * K + N]
+  int n_chunks, rows_per_chunk;
+  int act;
+  const long long* seed;
+  unsigned long long call;
+  unsigned int drop_threshold;
+  float scale;
+};
+
+// rows [e0, e0 + 32) of src (row stride ld, K columns; zero past K and past E) times a [32-column] slice of a matrix given by `bval(k, n)`
+template <class BFn>
+__device__ __forceinline__ void lin_tile(const float* __restrict__ src, int ld, int E, int K, int e0, int lane, BFn bval, f32x16& acc) {
+  const int m = lane & 31, hf = lane >> 5;
+  const int row = min(e0 + m, E - 1);
+  const bool live = e0 + m < E;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* p = src + (size_t)row * ld;
+  const bool vec = ((ld & 3) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    float v[32];
+    if (vec && k0 + 32 <= K) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 t = reinterpret_cast<const f32x4*>(p + k0)[q];
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 32; ++q) v[q] = k0 + q < K ? p[k0 + q] : 0.f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int k = k0 + 2 * ks + hf;
+      const float a = live ? (hf ? v[2 * ks + 1] : v[2 * ks]) : 0.f;
+      const float b = k < K ? bval(k, m) : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+}
+
+// grid: (row tiles / 4, N tiles); block: 4 waves, one 32 x 32 output tile each
+__global__ __launch_bounds__(256) void linear_fwd_kernel(LinArgs A) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, hf = lane >> 5;
+  const int e0 = (blockIdx.x * 4 + wave) * 32, n0 = blockIdx.y * 32;
+  if (e0 >= A.E) return;
+  f32x16 acc;
+  lin_tile(A.x, A.ldx, A.E, A.K, e0, lane, [&](int k, int nn) { return n0 + nn < A.N ? A.W[(size_t)(n0 + nn) * A.K + k] : 0.f; }, acc);
+  if (n0 + n >= A.N) return;
+  const float bias = A.b ? A.b[n0 + n] : 0.f;
+  const unsigned long long seed = A.drop_threshold ? (unsigned long long)A.seed[0] : 0ull;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = e0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+    if (e >= A.E) continue;
+    float y = acc[r] + bias;
+    if (A.act == 1) {
+      y = fmaxf(y, 0.f);
+      if (A.drop_threshold) y = fc_hash(seed, A.call, (unsigned long long)e * A.N + n0 + n) >= A.drop_threshold ? y * A.scale : 0.f;
+    }
+    A.y[(size_t)e * A.N + n0 + n] = y;
+  }
+}
+
+// gpre = gy * scale * [y > 0] (act 1) written once; grid: (row tiles / 4, 1 + K tiles): blockIdx.y == 0 writes gpre, y >= 1 computes the
+// (y - 1)-th 32-column tile of gx = gpre W
+__global__ __launch_bounds__(256) void linear_bwd_kernel(LinArgs A) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, n = lane & 31, hf = lane >> 5;
+  const int e0 = (blockIdx.x * 4 + wave) * 32;
+  if (e0 >= A.E) return;
+  if (blockIdx.y == 0) {
+    if (!A.gpre) return;
+    for (int i = lane; i < 32 * A.N; i += 64) {
+      const int e = e0 + i / A.N, c = i % A.N;
+      if (e >= A.E) break;
+      const size_t o = (size_t)e * A.N + c;
+      A.gpre[o] = A.y_in[o] > 0.f ? A.gy[o] * A.scale : 0.f;
+    }
+    return;
+  }
+  if (!A.gx) return;
+  const int k0 = (blockIdx.y - 1) * 32;
+  // the row operand is g (masked on the fly so that this tile does not wait for the gpre tile of another workgroup)
+  const int m = lane & 31;
+  const int row = min(e0 + m, A.E - 1);
+  const bool live = e0 + m < A.E;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c0 = 0; c0 < A.N; c0 += 32) {
+    float v[32];
+#pragma unroll
+    for (int q = 0; q < 32; ++q) {
+      const int c = c0 + q;
+      float g = 0.f;
+      if (c < A.N) {
+        const size_t o = (size_t)row * A.N + c;
+        g = A.gy[o];
+        if (A.act == 1) g = A.y_in[o] > 0.f ? g * A.scale : 0.f;
+      }
+      v[q] = g;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const int c = c0 + 2 * ks + hf;
+      const float a = live ? (hf ? v[2 * ks + 1] : v[2 * ks]) : 0.f;
+      const float b = (c < A.N && k0 + n < A.K) ? A.W[(size_t)c * A.K + k0 + n] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  if (k0 + n >= A.K) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int e = e0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+    if (e < A.E) A.gx[(size_t)e * A.K + k0 + n] = acc[r];
+  }
+}
+
+// partial dW[n][k] = sum over the chunk's rows of g[e][n] x[e][k], db[n] = sum g[e][n]; rows as the MFMA k dimension.
+// grid: (n_chunks, N tiles * K tiles); one wave per (chunk, tile pair)
+__global__ __launch_bounds__(64) void linear_dw_kernel(LinArgs A) {
+  const int lane = threadIdx.x, c = lane & 31, hf = lane >> 5;
+  const int kt = (A.K + 31) / 32;
+  const int n0 = (blockIdx.y / kt) * 32, k0 = (blockIdx.y % kt) * 32;
+  const int e_lo = blockIdx.x * A.rows_per_chunk, e_hi = min(A.E, e_lo + A.rows_per_chunk);
+  const float* G = A.gpre ? A.gpre : A.gy;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float colsum = 0.f;
+  const bool gn = n0 + c < A.N, xk = k0 + c < A.K;
+  for (int e = e_lo; e < e_hi; e += 2) {
+    const int row = e + hf;
+    const bool ok = row < e_hi;
+    const float g = (ok && gn) ? G[(size_t)row * A.N + n0 + c] : 0.f;
+    const float x = (ok && xk) ? A.x[(size_t)row * A.ldx + k0 + c] : 0.f;
+    colsum += g;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(g, x, acc, 0, 0, 0);
+  }
+  float* out = A.partial + (size_t)blockIdx.x * ((size_t)A.N * A.K + A.N);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * hf;
+    if (nn < A.N && xk) out[(size_t)nn * A.K + k0 + c] = acc[r];
+  }
+  if (k0 == 0) {
+    const float t = colsum + __shfl_xor(colsum, 32, 64);
+    if (hf == 0 && gn) out[(size_t)A.N * A.K + n0 + c] = t;
+  }
+}
+
+}  // namespace cbd
+
+extern "C" {
+
+int cbd_linear_forward(int64_t n_rows, int32_t in_dim, int32_t out_dim, const float* x_dev, int32_t ldx, const float* weight_dev,
+                       const float* bias_dev, int32_t act, float p_drop, const int64_t* seed_dev, int64_t call, float* y_dev, void* stream) {
+  if (n_rows == 0) return 0;          // an empty edge set (e.g. no cross edges): nothing to do, the pointers may be null
+  if (n_rows < 0 || n_rows > ((int64_t)1 << 30) || in_dim <= 0 || out_dim <= 0 || ldx < in_dim || !x_dev || !weight_dev || !y_dev || (act != 0 && act != 1) ||
+      p_drop < 0.f || p_drop >= 1.f || (act == 1 && p_drop > 0.f && !seed_dev))
+    return fail(CBD_ERR_ARG, "cbd_linear_forward: bad argument");
+  cbd::LinArgs a{};
+  a.E = (int)n_rows; a.K = in_dim; a.N = out_dim; a.ldx = ldx; a.x = x_dev; a.W = weight_dev; a.b = bias_dev; a.y = y_dev; a.act = act;
+  a.seed = reinterpret_cast<const long long*>(seed_dev); a.call = (unsigned long long)call;
+  a.drop_threshold = (act == 1 && p_drop > 0.f) ? (unsigned int)((double)p_drop * 4294967296.0) : 0u;
+  a.scale = (act == 1 && p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const int tiles = (a.E + 31) / 32;
+  hipLaunchKernelGGL(cbd::linear_fwd_kernel, dim3((tiles + 3) / 4, (out_dim + 31) / 32), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+  const hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_linear_forward: %s", hipGetErrorString(r));
+  return 0;
+}
+
+int64_t cbd_linear_backward_chunks(int64_t n_rows) {
+  const int64_t c = (n_rows + 63) / 64;        // short chunks: <= 32 sequential fp32 accumulation steps each, the rest of the sum in double
+  return c < 1 ? 1 : (c > 256 ? 256 : c);
+}
+
+int cbd_linear_backward(int64_t n_rows, int32_t in_dim, int32_t out_dim, const float* gy_dev, const float* y_dev, const float* x_dev, int32_t ldx,
+                        const float* weight_dev, int32_t act, float p_drop, float* gpre_dev, float* gx_dev, float* partial_dev, void* stream) {
+  if (n_rows <= 0 || n_rows > ((int64_t)1 << 30) || in_dim <= 0 || out_dim <= 0 || ldx < in_dim || !gy_dev || !x_dev || !weight_dev || !partial_dev ||
+      (act != 0 && act != 1) || (act == 1 && (!y_dev || !gpre_dev)) || p_drop < 0.f || p_drop >= 1.f)
+    return fail(CBD_ERR_ARG, "cbd_linear_backward: bad argument");
+  cbd::LinArgs a{};
+  a.E = (int)n_rows; a.K = in_dim; a.N = out_dim; a.ldx = ldx; a.x = x_dev; a.W = weight_dev; a.gy = gy_dev; a.y_in = y_dev; a.act = act;
+  a.gpre = act == 1 ? gpre_dev : nullptr; a.gx = gx_dev; a.partial = partial_dev;
+  a.scale = (act == 1 && p_drop > 0.f) ? 1.0f / (1.0f - p_drop) : 1.0f;
+  a.n_chunks = (int)cbd_linear_backward_chunks(n_rows);
+  int rpc = (a.E + a.n_chunks - 1) / a.n_chunks;
+  rpc += rpc & 1;
+  a.rows_per_chunk = rpc;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const int tiles = (a.E + 31) / 32, kt = (in_dim + 31) / 32, nt = (out_dim + 31) / 32;
+  if (a.gpre || a.gx) hipLaunchKernelGGL(cbd::linear_bwd_kernel, dim3((tiles + 3) / 4, 1 + (a.gx ? kt : 0)), dim3(256), 0, st, a);
+  hipError_t r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_linear_backward: %s", hipGetErrorString(r));
+  hipLaunchKernelGGL(cbd::linear_dw_kernel, dim3(a.n_chunks, nt * kt), dim3(64), 0, st, a);
+  r = hipGetLastError();
+  if (r != hipSuccess) return fail(CBD_ERR_HIP, "cbd_linear_backward: %s", hipGetErrorString(r));
   return 0;
 }
 

@@ -93,6 +93,9 @@ SYMBOLS = {
     "cbd_fc1_backward": (C.c_int, [C.c_int32, _P, _P, _P, _P, C.c_float, _P, _P, _P]),
     "cbd_outer_accum_groups": (C.c_int, [C.c_int32, _P, _P, _P, _P, _P, _P]),
     "cbd_partial_reduce": (C.c_int, [C.c_int32, _P, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "cbd_linear_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, C.c_int32, C.c_float, _P, C.c_int64, _P, _P]),
+    "cbd_linear_backward_chunks": (C.c_int64, [C.c_int64]),
+    "cbd_linear_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, C.c_int32, C.c_float, _P, _P, _P, _P]),
     "cbd_irreps_bn_forward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P]),
     "cbd_irreps_bn_backward": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_segment_mean_backward": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P]),

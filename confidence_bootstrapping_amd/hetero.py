@@ -176,6 +176,60 @@ class Batch(HeteroData):
         return out
 
 
+    def to_data_list(self) -> List[HeteroData]:
+        """Inverse of from_data_list (torch_geometric's Batch.to_data_list, which the reference's sampler uses to crop every graph of a
+        batch on its own, utils/sampling.py:102-106): node tensors split by `batch`, edge lists split by the graph of their first node
+        with the per-graph node offsets removed, list attributes handed back element by element."""
+        n = self._num_graphs
+        out = [HeteroData() for _ in range(n)]
+        sizes, offsets = {}, {}
+        for nt in self.node_types:
+            st = self._stores[nt]
+            cnt = torch.bincount(st.batch.cpu(), minlength=n).tolist()
+            sizes[nt] = cnt
+            offsets[nt] = np.concatenate([[0], np.cumsum(cnt)]).astype(int).tolist()
+            for k, v in st.__dict__.items():
+                if k == "batch":
+                    continue
+                for i in range(n):
+                    if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == offsets[nt][-1]:
+                        setattr(out[i][nt], k, v[offsets[nt][i]:offsets[nt][i + 1]])
+                    elif isinstance(v, list) and len(v) == n:
+                        setattr(out[i][nt], k, v[i])
+                    else:
+                        setattr(out[i][nt], k, v)
+        for et in self.edge_types:
+            st = self._stores[et]
+            ei = st.edge_index
+            src_t, dst_t = et[0], et[-1]
+            gid = torch.bucketize(ei[0].cpu(), torch.tensor(offsets[src_t][1:]), right=True)
+            for i in range(n):
+                sel = (gid == i).to(ei.device)
+                for k, v in st.__dict__.items():
+                    if k == "edge_index":
+                        off = torch.tensor([[offsets[src_t][i]], [offsets[dst_t][i]]], dtype=ei.dtype, device=ei.device)
+                        setattr(out[i][et], k, ei[:, sel] - off)
+                    elif torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == ei.shape[1]:
+                        setattr(out[i][et], k, v[sel])
+                    elif isinstance(v, list) and len(v) == n:
+                        setattr(out[i][et], k, v[i])
+                    else:
+                        setattr(out[i][et], k, v)
+        for k, v in self.__dict__.items():
+            if k.startswith("_"):
+                continue
+            for i in range(n):
+                if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == n:
+                    out[i].__dict__[k] = v[i:i + 1]
+                elif isinstance(v, list) and len(v) == n:
+                    out[i].__dict__[k] = v[i]
+                elif isinstance(v, dict):
+                    out[i].__dict__[k] = {kk: (vv[i:i + 1] if torch.is_tensor(vv) and vv.dim() > 0 and vv.shape[0] == n else vv) for kk, vv in v.items()}
+                else:
+                    out[i].__dict__[k] = v
+        return out
+
+
 class DataLoader:
     """`torch_geometric.loader.DataLoader(data_list, batch_size)` without shuffling."""
 

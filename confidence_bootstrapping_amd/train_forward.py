@@ -24,7 +24,7 @@ from . import so3, torus
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
 from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
-                        grouped_first_linear, fc_first_stage,
+                        grouped_first_linear, fc_first_stage, linear as _linear, mlp as _mlp,
                         gather_rows, scatter_mean as _scatter_mean_op,
                         scatter_sum, stream_map, tensor_product)
 
@@ -352,7 +352,7 @@ def atom_encoder(enc, idx, extra):
     if nf > 1:
         emb = emb.view(idx.shape[0] // nf, nf, -1).sum(1)
     if enc.additional_features_dim > 0:
-        emb = enc.additional_features_embedder(torch.cat([emb, extra], dim=1))
+        emb = _linear(torch.cat([emb, extra], dim=1), enc.additional_features_embedder)
     return emb
 
 
@@ -475,10 +475,13 @@ def center_tensor_product(x, vec, w):
     we, wf = w[:, 100:112].reshape(E, 6, 2), w[:, 112:124].reshape(E, 6, 2)
     vb = v[:, None, :].expand(E, 6, 3)
     s2 = 1.0 / math.sqrt(2.0)
-    out1o = (torch.einsum("euw,eu,ek->ewk", wa, x0e, v) + torch.einsum("euw,euk->ewk", wb, x1o)
-             + s2 * torch.einsum("euw,euk->ewk", we, torch.linalg.cross(x1e, vb, dim=-1))) / math.sqrt(44.0)
-    out1e = (s2 * torch.einsum("euw,euk->ewk", wc, torch.linalg.cross(x1o, vb, dim=-1)) + torch.einsum("euw,euk->ewk", wd, x1e)
-             + torch.einsum("euw,eu,ek->ewk", wf, x0o, v)) / math.sqrt(18.0)
+    # per-edge contractions over u as broadcast products + sums (an einsum with a batch index runs as a batched library GEMM: a
+    # handful of Tensile launches per head for [E, 6..32] operands)
+    con = lambda wgt, y: (wgt.unsqueeze(-1) * y.unsqueeze(2)).sum(1)            # [E,u,w] x [E,u,k] -> [E,w,k]
+    out1o = (con(wa, x0e.unsqueeze(-1) * v.unsqueeze(1)) + con(wb, x1o)
+             + s2 * con(we, torch.linalg.cross(x1e, vb, dim=-1))) / math.sqrt(44.0)
+    out1e = (s2 * con(wc, torch.linalg.cross(x1o, vb, dim=-1)) + con(wd, x1e)
+             + con(wf, x0o.unsqueeze(-1) * v.unsqueeze(1))) / math.sqrt(18.0)
     return torch.cat([out1o.reshape(E, 6), out1e.reshape(E, 6)], dim=1)
 
 
@@ -492,8 +495,8 @@ def bond_tensor_product(x, edge_vec, bond_vec, w):
     t1 = (3.0 / math.sqrt(2.0)) * (b * (b * v).sum(-1, keepdim=True) - v / 3.0)
     x1o, x1e = x[:, 32:50].reshape(E, 6, 3), x[:, 50:68].reshape(E, 6, 3)
     c = 1.0 / math.sqrt(6.0) / SQ3
-    out0e = c * torch.einsum("euw,eu->ew", w[:, :192].reshape(E, 6, 32), (x1o * t1[:, None, :]).sum(-1))
-    out0o = c * torch.einsum("euw,eu->ew", w[:, 192:].reshape(E, 6, 32), (x1e * t1[:, None, :]).sum(-1))
+    out0e = c * (w[:, :192].reshape(E, 6, 32) * (x1o * t1[:, None, :]).sum(-1).unsqueeze(-1)).sum(1)
+    out0o = c * (w[:, 192:].reshape(E, 6, 32) * (x1e * t1[:, None, :]).sum(-1).unsqueeze(-1)).sum(1)
     return torch.cat([out0o, out0e], dim=1)
 
 
@@ -811,15 +814,16 @@ def forward(model, data):
     hub = _stream_hub(model, dev)
     hub.pack()
     hub.drop_seed, hub.fc_calls = getattr(g, "drop_seed", None), 0       # the step's dropout stream (train_ops.fc_first_stage)
+    M = lambda seq, x, call: _mlp(seq, x, seed=hub.drop_seed, call=call)      # embeddings / heads: Linear (+ ReLU + Dropout) on the HIP kernels
 
     # ---- receptor embedding (score_model.py:297-326), recomputed with gradients every step
-    rec_edge_attr = model.rec_edge_embedding(g.r_smear)
+    rec_edge_attr = M(model.rec_edge_embedding, g.r_smear, 100)
     rec_node = atom_encoder(model.rec_node_embedding, g.rec_cat, rec.x[:, 1:].float())
     for l, layer in enumerate(model.rec_emb_layers):
         ea = edge_cat(rec_edge_attr, rec_node, r_ei[0], r_ei[1])
         rec_node = conv_layer(layer, rec_node, r_ei, ea, g.r_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_rec)
     graph_sigma_emb = model.timestep_emb_func(ct["tr"])
-    rec_sigma_emb = model.rec_sigma_embedding(graph_sigma_emb)
+    rec_sigma_emb = M(model.rec_sigma_embedding, graph_sigma_emb, 110)
     rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
     rec_edge_attr = rec_edge_attr + take(rec_sigma_emb, g.rec_batch_src)
 
@@ -827,13 +831,13 @@ def forward(model, data):
     node_sigma_emb = take(graph_sigma_emb, lig_batch)
     l_attr = torch.cat([g.l_attr0, take(node_sigma_emb, l_ei[0]), g.l_smear], 1)
     lig_node = atom_encoder(model.lig_node_embedding, g.lig_cat, node_sigma_emb)
-    lig_edge_attr = model.lig_edge_embedding(l_attr)
+    lig_edge_attr = M(model.lig_edge_embedding, l_attr, 120)
     for l, layer in enumerate(model.lig_emb_layers):
         ea = edge_cat(lig_edge_attr, lig_node, l_ei[0], l_ei[1])
         lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_lig)
 
     # ---- cross graph (score_model.py:345-352, 564-587)
-    lr_edge_attr = model.cross_edge_embedding(torch.cat([take(node_sigma_emb, lr[0]), g.c_smear], 1))
+    lr_edge_attr = M(model.cross_edge_embedding, torch.cat([take(node_sigma_emb, lr[0]), g.c_smear], 1), 130)
 
     # ---- joint graph, interaction layers (score_model.py:354-376)
     node = torch.cat([lig_node, rec_node], 0)
@@ -851,8 +855,8 @@ def forward(model, data):
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
     c_attr = torch.cat([g.center_smear, node_sigma_emb], 1)
-    c_attr = torch.cat([model.center_edge_embedding(c_attr), lig_node[:, :ns]], -1)
-    gp = scatter_mean(center_tensor_product(lig_node, g.c_vec2, model.final_conv.fc(c_attr)), lig_batch, B)
+    c_attr = torch.cat([M(model.center_edge_embedding, c_attr, 140), lig_node[:, :ns]], -1)
+    gp = scatter_mean(center_tensor_product(lig_node, g.c_vec2, M(model.final_conv.fc, c_attr, 150)), lig_batch, B)
     gp = irreps_batch_norm(model.final_conv.batch_norm, gp, exclude=ex_graph)
     so3_norm = g.so3_norm
     if pad:     # the heads see the real graphs only: the filler's (zero) row would be a 0 / 0 in the normalisations below
@@ -861,9 +865,9 @@ def forward(model, data):
     tr_pred = gp[:, :3] + gp[:, 6:9]
     rot_pred = gp[:, 3:6] + gp[:, 9:]
     tr_norm = torch.linalg.vector_norm(tr_pred, dim=1).unsqueeze(1)
-    tr_pred = tr_pred / tr_norm * model.tr_final_layer(torch.cat([tr_norm, graph_sigma_emb], dim=1))
+    tr_pred = tr_pred / tr_norm * M(model.tr_final_layer, torch.cat([tr_norm, graph_sigma_emb], dim=1), 160)
     rot_norm = torch.linalg.vector_norm(rot_pred, dim=1).unsqueeze(1)
-    rot_pred = rot_pred / rot_norm * model.rot_final_layer(torch.cat([rot_norm, graph_sigma_emb], dim=1))
+    rot_pred = rot_pred / rot_norm * M(model.rot_final_layer, torch.cat([rot_norm, graph_sigma_emb], dim=1), 170)
     tr_pred = tr_pred / tr_sigma.unsqueeze(1)
     rot_pred = rot_pred * so3_norm
 
@@ -872,15 +876,15 @@ def forward(model, data):
 
     # ---- torsion head (score_model.py:431-448, 650-664)
     t_ei, bonds = g.t_ei, g.bonds
-    t_attr = model.final_edge_embedding(g.t_smear)
+    t_attr = M(model.final_edge_embedding, g.t_smear, 180)
     bond_attr = take(lig_node, bonds[0]) + take(lig_node, bonds[1])
     t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
-    msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, model.tor_bond_conv.fc(t_attr))
+    msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, M(model.tor_bond_conv.fc, t_attr, 190))
     tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
     tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor, exclude=ex_bond)
     torus_norm = g.torus_norm
     if pad:
         tor, torus_norm = tor[:pad["T_real"]], torus_norm[:pad["T_real"]]
-    tor_pred = model.tor_final_layer(tor).squeeze(1)
+    tor_pred = M(model.tor_final_layer, tor, 200).squeeze(1)
     tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
     return tr_pred, rot_pred, tor_pred, None

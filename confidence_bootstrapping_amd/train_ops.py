@@ -544,6 +544,87 @@ class GroupedFirstLinearFn(torch.autograd.Function):
         return (gx, None, *grads)
 
 
+class LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b) for any nn.Linear of the step outside the FCBlocks' first stage, on cbd_linear_forward / _backward (fp32 MFMA, no
+    library GEMM; csrc/train_fc.hip).  act 0: identity; act 1: dropout_p(relu(.)) with the hash mask of the step (`seed`, `call`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, act, p, seed, call):
+        lib = _bind(load_library())
+        x2 = x.reshape(-1, x.shape[-1]).contiguous().float()
+        E, K = x2.shape
+        N = int(weight.shape[0])
+        w = weight.contiguous().float()
+        y = torch.empty(E, N, device=x.device, dtype=torch.float32)
+        _check(lib.cbd_linear_forward(E, K, N, _ptr(x2), K, _ptr(w), None if bias is None else _ptr(bias.contiguous().float()), int(act), float(p),
+                                      None if seed is None else _ptr(seed), int(call), _ptr(y), _stream_handle()))
+        ctx.save_for_backward(x2, w, y if act else None)
+        ctx.meta = (int(act), float(p), bias is not None, tuple(x.shape[:-1]))
+        return y.reshape(tuple(x.shape[:-1]) + (N,))
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, w, y = ctx.saved_tensors
+        act, p, has_bias, lead = ctx.meta
+        lib = _bind(load_library())
+        E, K = x2.shape
+        N = int(w.shape[0])
+        if E == 0:
+            return (torch.zeros(lead + (K,), device=gy.device), torch.zeros_like(w), torch.zeros(N, device=gy.device) if has_bias else None,
+                    None, None, None, None)
+        gy2 = gy.reshape(E, N).contiguous().float()
+        gpre = torch.empty_like(gy2) if act else None
+        gx = torch.empty(E, K, device=gy.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        n_chunks = int(lib.cbd_linear_backward_chunks(E))
+        width = N * K + N
+        partial = torch.empty(n_chunks, width, device=gy.device, dtype=torch.float32)
+        _check(lib.cbd_linear_backward(E, K, N, _ptr(gy2), None if y is None else _ptr(y), _ptr(x2), K, _ptr(w), act, p,
+                                       None if gpre is None else _ptr(gpre), None if gx is None else _ptr(gx), _ptr(partial), _stream_handle()))
+        out = torch.empty(width, device=gy.device, dtype=torch.float32)
+        oa, ob = (C.c_void_p * 1)(out.data_ptr()), (C.c_void_p * 1)(out.data_ptr() + 4 * N * K)
+        _check(lib.cbd_partial_reduce(1, (C.c_int32 * 1)(n_chunks), width, N * K, _ptr(partial), oa, ob, _stream_handle()))
+        return (None if gx is None else gx.reshape(lead + (K,)), out[:N * K].view(N, K), out[N * K:] if has_bias else None, None, None, None, None)
+
+
+FUSED_LINEAR = True           # False: nn.Linear / torch ops (library GEMMs), kept for the equivalence test
+
+
+def linear(x, lin, act=0, p=0.0, seed=None, call=0):
+    """lin(x) (act 0) or Dropout_p(ReLU(lin(x))) (act 1) for an nn.Linear on the HIP kernels; rows = all leading dimensions of x"""
+    if not FUSED_LINEAR or not x.is_cuda or (act and p > 0 and seed is None):
+        y = torch.nn.functional.linear(x, lin.weight, lin.bias)
+        return torch.nn.functional.dropout(torch.relu(y), p=p, training=p > 0) if act else y
+    return LinearFn.apply(x, lin.weight, lin.bias, int(act), float(p), seed if (act and p > 0) else None, int(call))
+
+
+def mlp(seq, x, seed=None, call=0):
+    """nn.Sequential of Linear / ReLU / Dropout / Tanh modules (the embeddings and heads of the score model, reference
+    models/score_model.py:186-243) with every Linear -- and a ReLU / Dropout pair behind it, in either order -- on the fused kernels.
+    `call`: base of the dropout stream indices of this module (each fused Linear takes the next one)."""
+    mods = list(seq)
+    i, k = 0, 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, torch.nn.Linear):
+            nxt = mods[i + 1:i + 3]
+            kinds = tuple(type(q) for q in nxt)
+            if kinds in ((torch.nn.ReLU, torch.nn.Dropout), (torch.nn.Dropout, torch.nn.ReLU)):
+                drop = nxt[0] if isinstance(nxt[0], torch.nn.Dropout) else nxt[1]
+                x = linear(x, m, act=1, p=float(drop.p) if drop.training else 0.0, seed=seed, call=call + k)
+                i += 3
+            elif kinds[:1] == (torch.nn.ReLU,):
+                x = linear(x, m, act=1, p=0.0)
+                i += 2
+            else:
+                x = linear(x, m)
+                i += 1
+            k += 1
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
 class FcFirstStageFn(torch.autograd.Function):
     """hid = Dropout_p(ReLU(Linear_g(x)))  for every edge group g of a layer over ONE [E, 96] tensor of edge rows -- the first stage of the
     FCBlocks (reference models/layers.py:8-15) as one launch forward (cbd_fc1_forward) and three backward (cbd_fc1_backward: mask + input

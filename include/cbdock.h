@@ -312,6 +312,17 @@ int cbd_outer_accum_groups(int32_t n_groups, const int64_t* group_edges, const i
  * Rows are added in row order: bitwise repeatable, no atomics (stands in for the torch.sum calls behind the two weight-gradient passes). */
 int cbd_partial_reduce(int32_t n_seg, const int32_t* seg_rows, int32_t width, int32_t split, const float* partial_dev, float* const* out_a_dev,
                        float* const* out_b_dev, void* stream);
+/* Generic Linear layers of the fine-tuning step (every nn.Linear outside the FCBlocks' first stage: reference models/score_model.py:186-243),
+ * forward and backward without a library GEMM.  x [n_rows][ldx >= in_dim], weight [out_dim][in_dim] (nn.Linear.weight), bias [out_dim] or NULL.
+ * act 0: y = x W^T + b;  act 1: y = dropout_p(relu(x W^T + b)) with the hash mask of cbd_fc1_forward (seed_dev: device scalar; `call`).
+ * Backward: gpre = gy (act 0) or gy / (1 - p) where y > 0 (act 1: y_dev = the forward output, gpre_dev [n_rows][out_dim] is written);
+ * gx_dev (or NULL) [n_rows][in_dim] = gpre W;  partial_dev [cbd_linear_backward_chunks(n_rows)][out_dim * in_dim + out_dim] = per-chunk
+ * dW | db -- add the chunks in order with cbd_partial_reduce (split = out_dim * in_dim). */
+int cbd_linear_forward(int64_t n_rows, int32_t in_dim, int32_t out_dim, const float* x_dev, int32_t ldx, const float* weight_dev,
+                       const float* bias_dev, int32_t act, float p_drop, const int64_t* seed_dev, int64_t call, float* y_dev, void* stream);
+int64_t cbd_linear_backward_chunks(int64_t n_rows);
+int cbd_linear_backward(int64_t n_rows, int32_t in_dim, int32_t out_dim, const float* gy_dev, const float* y_dev, const float* x_dev, int32_t ldx,
+                        const float* weight_dev, int32_t act, float p_drop, float* gpre_dev, float* gx_dev, float* partial_dev, void* stream);
 
 /* Weight and bias gradient of the FCBlock's first Linear (96 -> 96) in the fine-tuning step (autograd of fc[0] in
  * models/layers.py:8-15 under utils/training.py:205): partial[p] = [ sum_e g[e][m] x[e][n] (96 x 96, row-major) | sum_e g[e][m] (96) ]

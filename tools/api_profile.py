@@ -1,0 +1,30 @@
+"""GPU busy time of the python_api leg of bench.py (sampling() with the confidence model over 20 complexes), for rocprofv3 --kernel-trace:
+   rocprofv3 --kernel-trace --output-format csv -d out -o p -- python3 tools/api_profile.py [--no-conf]"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--complexes", type=int, default=20)
+    a = ap.parse_args()
+    import bench
+    from confidence_bootstrapping_amd.synthetic import scale_tr_head, BENCH_GEOMETRY
+    from confidence_bootstrapping_amd.utils import make_score_model
+    dev = torch.device("cuda:0")
+    model, margs = make_score_model(seed=0)
+    scale_tr_head(model)
+    t0 = time.perf_counter()
+    r = bench.python_api_leg(model, margs, dev, "c2_dockgen_median", 40, 20, dict(BENCH_GEOMETRY), a.complexes, 229.0)
+    print({k: v for k, v in r.items() if k != "what"}, round(time.perf_counter() - t0, 1), flush=True)
+
+
+if __name__ == "__main__":
+    main()
