@@ -184,16 +184,28 @@ class Batch(HeteroData):
         out = [HeteroData() for _ in range(n)]
         sizes, offsets = {}, {}
         for nt in self.node_types:
-            st = self._stores[nt]
-            cnt = torch.bincount(st.batch.cpu(), minlength=n).tolist()
+            cnt = torch.bincount(self._stores[nt].batch.cpu(), minlength=n).tolist()
             sizes[nt] = cnt
             offsets[nt] = np.concatenate([[0], np.cumsum(cnt)]).astype(int).tolist()
+        edge_off = {}           # per edge type: cumulative edge counts per graph (edges are stored graph after graph)
+        for et in self.edge_types:
+            ei = self._stores[et].edge_index
+            gid = torch.bucketize(ei[0].cpu(), torch.tensor(offsets[et[0]][1:]), right=True)
+            edge_off[et] = np.concatenate([[0], np.cumsum(torch.bincount(gid, minlength=n).tolist())]).astype(int).tolist()
+        for nt in self.node_types:
+            st = self._stores[nt]
             for k, v in st.__dict__.items():
                 if k == "batch":
                     continue
+                cuts = None
+                if torch.is_tensor(v) and v.dim() > 0:
+                    if v.shape[0] == offsets[nt][-1]:
+                        cuts = offsets[nt]
+                    else:   # a per-EDGE attribute kept on the node store (ligand.edge_mask: one flag per bond of the ligand's edge list)
+                        cuts = next((edge_off[et] for et in self.edge_types if et[0] == nt and edge_off[et][-1] == v.shape[0]), None)
                 for i in range(n):
-                    if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == offsets[nt][-1]:
-                        setattr(out[i][nt], k, v[offsets[nt][i]:offsets[nt][i + 1]])
+                    if cuts is not None:
+                        setattr(out[i][nt], k, v[cuts[i]:cuts[i + 1]])
                     elif isinstance(v, list) and len(v) == n:
                         setattr(out[i][nt], k, v[i])
                     else:

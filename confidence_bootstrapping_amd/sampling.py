@@ -15,8 +15,8 @@ Differences from the reference that are deliberate and documented (SURVEY.md 8a 
     rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
   * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
     rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
-  * SVGD, pivot, return_full_trajectory, return_features, crop_beyond (score model: not in the shipped yml) raise
-    NotImplementedError (the first three also raise in the reference).
+  * SVGD, pivot, return_full_trajectory, return_features raise NotImplementedError (the last three also raise in the reference);
+    crop_beyond of the SCORE model (not in the shipped yml) runs through _sample_cropped (a set-up per distinct crop mask and step).
 Confidence scoring (reference utils/sampling.py:240-261): with `confidence_model` set, the final poses of every batch
 are scored by the all-atom confidence engine (cbd_conf_score) -- crop_beyond per pose, t = 0 -- on the all-atom graphs
 of `filtering_data_list` (or of `data_list` itself when it carries the 'atom' stores); returns the concatenated
@@ -105,6 +105,49 @@ def draw_noise_like_reference(N, R_, S, batch_size, no_final_step_noise=False):
             "tor": torch.cat([p[2] for p in parts], 1) if R_ > 0 else None}
 
 
+def _sample_cropped(eng, cplx, key, pos, steps, noise, crop):
+    """Reverse diffusion with the score model's `crop_beyond` (reference utils/sampling.py:101-108 with utils/utils.py:395-420): before
+    every step each pose's receptor is cropped to the residues within 3 sigma_tr(t) + crop_beyond of a ligand atom, and the model sees
+    that smaller complex -- other residues, other C-alpha edges, another receptor embedding.  Not in the shipped yml; implemented on the
+    existing entry points: per step the poses are grouped by their crop mask (early steps: everything is kept, late steps: the poses
+    of a converged run share a pocket), each group's cropped complex goes through cbd_set_complex and ONE step of cbd_sample.  The
+    arithmetic is the engine's; what this path adds is host orchestration (a set-up per distinct mask and step)."""
+    from .utils import crop_beyond as crop_graph
+    z_tr, z_rot, z_tor = noise
+    B, Nl = pos.shape[0], pos.shape[1]
+    R = eng.R
+    rec_pos = cplx["receptor"].pos.float().cpu()
+    base_R = int(cplx["ligand"].edge_mask.sum())
+    eng.set_option("graph", 0)
+    try:
+        for i in range(len(steps)):
+            cutoff = steps[i].tr_sigma * 3 + crop
+            host = pos.detach().cpu()
+            d2 = torch.sum((host.unsqueeze(1) - rec_pos.view(1, -1, 1, 3)) ** 2, -1)            # [B, Nr, Nl], the reference's formula
+            keep = torch.any(d2 < cutoff ** 2, dim=2)
+            groups = {}
+            for b in range(B):
+                groups.setdefault(keep[b].numpy().tobytes(), []).append(b)
+            for mask_bytes, idx in groups.items():
+                m = keep[idx[0]]
+                if not bool(m.any()):
+                    raise RuntimeError("crop_beyond left a pose without any receptor residue (the reference's model fails on an empty "
+                                       "receptor graph as well)")
+                g = cplx.shallow_copy()
+                g["ligand"].pos = host[idx[0]]
+                crop_graph(g, cutoff, False)
+                eng.set_complex(g, (key, "crop", hash(mask_bytes)))
+                sel = torch.as_tensor(idx, device=pos.device)
+                p = pos.index_select(0, sel).contiguous()
+                cols = (sel[:, None] * base_R + torch.arange(base_R, device=pos.device)[None, :]).reshape(-1)
+                take = lambda z, c=None: None if z is None else z[i:i + 1].to(pos.device).index_select(1, sel if c is None else c).contiguous()
+                eng.sample(p, (type(steps[i]) * 1)(steps[i]), take(z_tr), take(z_rot), take(z_tor, cols) if (R > 0 and z_tor is not None) else None)
+                pos.index_copy_(0, sel, p)
+    finally:
+        eng.set_option("graph", 1)
+        eng.complex_key = None          # the engine holds a cropped complex now
+
+
 @with_glue_threads
 def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
              no_random=False, ode=False, visualization_list=None, confidence_model=None, filtering_data_list=None,
@@ -133,8 +176,9 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                        "asyncronous_noise_schedule=True, as inference.py does")
     if t_schedule is not None and len(t_schedule) != inference_steps:
         raise ValueError("t_schedule length != inference_steps")
-    if getattr(model_args, "crop_beyond", None) is not None:
-        raise NotImplementedError("crop_beyond is only used by the all-atom / confidence model (SURVEY.md 8f-1)")
+    score_crop = getattr(model_args, "crop_beyond", None)
+    if score_crop is not None and getattr(model_args, "all_atoms", False):
+        raise NotImplementedError("score-model crop_beyond is supported for the C-alpha score model (the shipped architecture)")
     conf_model = getattr(confidence_model, "module", confidence_model)
     if conf_model is not None and not hasattr(conf_model, "atom_confidence_predictor"):
         raise NotImplementedError("confidence scoring runs on the all-atom confidence engine (all_atom_score_model)")
@@ -162,6 +206,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         per = next((i for i, d in enumerate(data_list) if getattr(d, "name", None) != name0), N) if name0 is not None else int(batch_size)
         co_schedule = -(-160 // max(per, 1))
     n_co = max(1, min(int(co_schedule), 8)) if n_streams == 1 else 1
+    if score_crop is not None:
+        n_co = 1            # the cropped receptor differs from pose to pose and step to step: one complex at a time (_sample_cropped)
     offset = 0
     pending = []          # (first pose index, b, pos [b,Nl,3] CPU, z_tr, z_rot, z_tor, loader batch)
     pending_key = None
@@ -196,7 +242,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             pos = torch.cat([p[2] for p in pend], dim=0).to(device, torch.float32).contiguous()
             cat = lambda k, dim: None if pend[0][k] is None else torch.cat([p[k] for p in pend], dim=dim)
             work.append((pend, e, pos, (cat(3, 1), cat(4, 1), cat(5, 1) if R_ > 0 else None), batch0))
-        if len(work) == 1:
+        if score_crop is not None:
+            for (pend, key), (_, e, pos, nz, batch0) in zip(groups, work):
+                _sample_cropped(e, _single_complex(batch0)[0], key, pos, steps, nz, float(score_crop))
+        elif len(work) == 1:
             work[0][1].sample(work[0][2], steps, *work[0][3])
         else:
             DockEngine.sample_multi([w[1] for w in work], [w[2] for w in work], steps, [w[3] for w in work])

@@ -172,3 +172,35 @@ class ExponentialMovingAverage:
         self.decay = state_dict["decay"]
         self.num_updates = state_dict["num_updates"]
         self.shadow_params = [t.to(device) for t in state_dict["shadow_params"]]
+
+
+def subgraph_mask(keep: torch.Tensor, edge_index: torch.Tensor):
+    """torch_geometric.utils.subgraph(keep, edge_index, relabel_nodes=True)[0] for a boolean node mask: the edges whose both ends are
+    kept, in their original order, re-numbered by rank among the kept nodes."""
+    m = keep[edge_index[0]] & keep[edge_index[1]]
+    return (torch.cumsum(keep.long(), 0) - 1)[edge_index[:, m]]
+
+
+def crop_beyond(complex_graph, cutoff, all_atoms):
+    """Reference utils/utils.py:395-420, same in-place semantics: residues without a ligand atom closer than `cutoff` are dropped from
+    the receptor stores (x, pos, side_chain_vecs), the C-alpha graph keeps the edges between kept residues (re-numbered), and with
+    `all_atoms` the atoms of dropped residues go as well (atom graph restricted, atom -> residue map re-numbered)."""
+    lig_pos, rec_pos = complex_graph["ligand"].pos, complex_graph["receptor"].pos
+    keep = torch.any(torch.sum((lig_pos.unsqueeze(0) - rec_pos.unsqueeze(1)) ** 2, -1) < cutoff ** 2, dim=1)
+    rec = complex_graph["receptor"]
+    if all_atoms:
+        a2r = complex_graph["atom", "atom_rec_contact", "receptor"].edge_index[1]
+        atoms_keep = keep[a2r]
+        new_map = (torch.cumsum(keep.long(), dim=0) - 1)[a2r][atoms_keep]
+    rec.pos, rec.x = rec.pos[keep], rec.x[keep]
+    if "side_chain_vecs" in rec:
+        rec.side_chain_vecs = rec.side_chain_vecs[keep]
+    rr = complex_graph["receptor", "rec_contact", "receptor"]
+    rr.edge_index = subgraph_mask(keep, rr.edge_index)
+    if all_atoms:
+        at = complex_graph["atom"]
+        at.x, at.pos = at.x[atoms_keep], at.pos[atoms_keep]
+        aa = complex_graph["atom", "atom_contact", "atom"]
+        aa.edge_index = subgraph_mask(atoms_keep, aa.edge_index)
+        complex_graph["atom", "atom_rec_contact", "receptor"].edge_index = torch.stack([torch.arange(len(new_map), device=new_map.device), new_map])
+    return keep

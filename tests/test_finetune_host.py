@@ -157,3 +157,42 @@ def test_static_tensor_cache_policy():
         tf._dev_cached(base[1], "cpu", ids[1])
     assert tf.dev_cache_stats() == {"entries": 0, "bytes": 0}
     tf.dev_cache_configure(enabled=True, limit_bytes=4 << 30)
+
+
+def test_crop_beyond_and_to_data_list_host_logic():
+    """utils.crop_beyond (reference utils/utils.py:395-420) on a graph with all-atom stores, and Batch.to_data_list as the inverse of
+    from_data_list (what the reference's sampler leans on to crop the graphs of a batch one by one, utils/sampling.py:102-106)."""
+    import copy
+    import torch
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, make_complex
+    from confidence_bootstrapping_amd.utils import crop_beyond, subgraph_mask
+    a, b = make_workload("tiny", all_atoms=True), make_complex(seed=5, Nl=8, Nr=30, R=1, knn=8)
+    big = Batch.from_data_list([Batch.from_data_list([make_workload("tiny")]), Batch.from_data_list([b])])
+    back = big.to_data_list()
+    for x, y in zip(back, [make_workload("tiny"), b]):
+        for key in ("pos", "x", "edge_mask"):
+            assert torch.equal(getattr(x["ligand"], key), getattr(y["ligand"], key)), key
+        assert torch.equal(x["receptor", "receptor"].edge_index, y["receptor", "receptor"].edge_index)
+        assert torch.equal(x["ligand", "ligand"].edge_index, y["ligand", "ligand"].edge_index) and torch.equal(x["ligand", "ligand"].edge_attr, y["ligand", "ligand"].edge_attr)
+    again = Batch.from_data_list(back)
+    assert torch.equal(again["ligand", "ligand"].edge_index, big["ligand", "ligand"].edge_index) and torch.equal(again["receptor"].batch, big["receptor"].batch)
+    g = copy.deepcopy(a)
+    Nr, Na = g["receptor"].pos.shape[0], g["atom"].pos.shape[0]
+    d = torch.cdist(g["ligand"].pos, g["receptor"].pos)
+    cutoff = float(d.min(0).values.median())             # keeps about half of the residues
+    want = d.min(0).values < cutoff
+    a2r = g["atom", "atom_rec_contact", "receptor"].edge_index[1].clone()
+    rr = g["receptor", "receptor"].edge_index.clone()
+    keep = crop_beyond(g, cutoff, True)
+    assert torch.equal(keep, want) and 0 < int(keep.sum()) < Nr
+    assert g["receptor"].pos.shape[0] == g["receptor"].x.shape[0] == int(keep.sum())
+    assert torch.equal(g["receptor"].pos, a["receptor"].pos[keep])
+    ei = g["receptor", "receptor"].edge_index
+    old_of_new = torch.nonzero(keep).flatten()
+    kept_edges = keep[rr[0]] & keep[rr[1]]
+    assert torch.equal(old_of_new[ei], rr[:, kept_edges]) and torch.equal(ei, subgraph_mask(keep, rr))
+    assert g["atom"].pos.shape[0] == int(keep[a2r].sum()) < Na
+    m = g["atom", "atom_rec_contact", "receptor"].edge_index
+    assert torch.equal(m[0], torch.arange(m.shape[1])) and torch.equal(old_of_new[m[1]], a2r[keep[a2r]])
+    assert int(g["atom", "atom"].edge_index.max()) < g["atom"].pos.shape[0]

@@ -542,3 +542,57 @@ def test_sampling_with_asyncronous_schedule_matches_reference(dev, golden):
     assert float(rmsd(got, torch.from_numpy(g["final_pos"])).max()) < 1e-3
     with pytest.raises(KeyError):
         sampling(data_list=[copy.deepcopy(d) for d in dl], model=model, **kw)
+
+
+def test_sampling_with_score_model_crop_beyond_matches_reference(dev, golden):
+    """`crop_beyond` of the SCORE model (reference utils/sampling.py:101-108, utils/utils.py:395-420; not in the shipped yml): before every
+    step each pose's receptor is cropped to the residues within 3 sigma_tr + crop_beyond of the ligand.  Golden g18 = the reference's own
+    `sampling()` with `model_args.crop_beyond = 8` (recorded noise; translation head scaled by 0.02 so that the poses stay at the
+    receptor; late schedule t = 0.3 -> 0.05): the crop keeps 22-33 of the 40 residues, differently per pose and step.  Final poses
+    within the north-star 1e-3 A; the residue counts the model saw are reproduced exactly."""
+    import copy
+    from functools import partial
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, scale_tr_head
+    from confidence_bootstrapping_amd.utils import make_score_model, load_model_args, crop_beyond
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    from confidence_bootstrapping_amd.sampling import sampling
+    g = golden("g18_sampling_crop.npz")
+    margs = load_model_args()
+    model, args = make_score_model(device=dev, seed=0, args=margs)
+    scale_tr_head(model)
+    model.invalidate_engine() if hasattr(model, "invalidate_engine") else None
+    args = copy.deepcopy(args)
+    args.crop_beyond, args.all_atoms = float(g["crop_beyond"]), False
+    cplx = make_workload("tiny")
+    cplx["receptor"].side_chain_vecs = torch.zeros(cplx["receptor"].pos.shape[0], 4, 3)
+    B, S = g["pos0"].shape[0], len(g["schedule"])
+    dl = []
+    for b in range(B):
+        d = Batch.from_data_list([copy.deepcopy(cplx)])
+        d["ligand"].pos = torch.from_numpy(g["pos0"][b]).clone()
+        dl.append(d)
+    # the crop itself (host side) against the residue counts of the reference's first step
+    sig0 = float(args.tr_sigma_min ** (1 - g["schedule"][0]) * args.tr_sigma_max ** g["schedule"][0])
+    for b in range(B):
+        one = copy.deepcopy(cplx)
+        one["ligand"].pos = torch.from_numpy(g["pos0"][b]).clone()
+        keep = crop_beyond(one, sig0 * 3 + args.crop_beyond, False)
+        assert int(keep.sum()) == int(g["n_res"][0][b]) == one["receptor"].pos.shape[0] == one["receptor"].x.shape[0]
+        assert int(one["receptor", "receptor"].edge_index.max()) < int(keep.sum())
+    noise = {"tr": torch.from_numpy(g["noise_tr"]), "rot": torch.from_numpy(g["noise_rot"]), "tor": torch.from_numpy(g["noise_tor"])}
+    out, _ = sampling(data_list=dl, model=model, inference_steps=S, tr_schedule=g["schedule"], rot_schedule=g["schedule"], tor_schedule=g["schedule"],
+                      device=dev, t_to_sigma=partial(t_to_sigma, args=args), model_args=args, batch_size=B, noise=noise)
+    got = torch.stack([d["ligand"].pos.cpu() for d in out])
+    assert float(rmsd(got, torch.from_numpy(g["final_pos"])).max()) < 1e-3
+    # without the crop the same call ends elsewhere (the crop is not a no-op on this complex)
+    args2 = copy.deepcopy(args)
+    args2.crop_beyond = None
+    dl2 = []
+    for b in range(B):
+        d = Batch.from_data_list([copy.deepcopy(cplx)])
+        d["ligand"].pos = torch.from_numpy(g["pos0"][b]).clone()
+        dl2.append(d)
+    out2, _ = sampling(data_list=dl2, model=model, inference_steps=S, tr_schedule=g["schedule"], rot_schedule=g["schedule"], tor_schedule=g["schedule"],
+                       device=dev, t_to_sigma=partial(t_to_sigma, args=args2), model_args=args2, batch_size=B, noise=noise)
+    assert float(rmsd(torch.stack([d["ligand"].pos.cpu() for d in out2]), torch.from_numpy(g["final_pos"])).max()) > 1e-3
