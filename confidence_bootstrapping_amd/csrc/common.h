@@ -126,6 +126,7 @@ struct FinGroup {
   const float* run_acc;
   int node_mod;            // > 0: the group is shared by all samples, node k = i % node_mod (layer-0 receptor edges)
   int deg_weight;          // 1: its edges count towards the node's in-degree; 0: a further slice of an already counted group
+  int col_hi;              // > 0: this slice's pieces hold only the columns [0, col_hi) (a 0e-only slice of the bf16 role split)
 };
 struct FinArgs {
   FinGroup g[4];

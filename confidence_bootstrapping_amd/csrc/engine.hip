@@ -94,6 +94,11 @@ struct cbd_engine {
   float *fsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *lsum[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float* racc[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   float *fsum_x[2] = {nullptr, nullptr}, *lsum_x[2] = {nullptr, nullptr}, *racc_x[2] = {nullptr, nullptr};   // extra slices of ll (embedding layers)
+  // bf16 role split ("bf16_roles" option): the cross / receptor groups (1 lr, 2 rr, 3 rl) run as three virtual slices per layer --
+  // 0e tiles [0, 19), 0e tiles [19, 38), vector blocks; the second 0e slice writes piece buffers of its own, laid out exactly like
+  // the group's and `piece_b_off[g]` floats behind them (first_sum, last_sum and run_acc alike)
+  long long piece_b_off[4] = {0, 0, 0, 0};
+  bool bf16_roles = false;
   int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
   int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges
   hipStream_t own = nullptr;        // used instead of the legacy default stream for graph capture (which cannot be captured)
@@ -431,6 +436,7 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
   if (const char* p = getenv("CBD_PRECISION")) e->use_bf16 = std::max(0, std::min(2, atoi(p)));   // test hook: default operand policy
+  if (const char* p = getenv("CBD_BF16_ROLES")) e->bf16_roles = atoi(p) != 0;                     // test hook: role split of the bf16 policy
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
@@ -652,9 +658,9 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
 // The edge groups ONE pose batch contributes to a tensor-product launch.
 struct ConvJob {
   cbd_engine* e = nullptr;
-  ConvGroupH g[4];
-  int caps[4] = {0, 0, 0, 0};
-  int widx[4] = {0, 1, 2, 3};      // which FCBlock of the layer each group uses
+  ConvGroupH g[10];                // 4 edge groups, or ll + three slices of each of the other three (bf16 role split)
+  int caps[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int widx[10] = {0, 1, 2, 3, 0, 0, 0, 0, 0, 0};      // which FCBlock of the layer each group uses
   int n_groups = 0;
   const float* node_in = nullptr;
 };
@@ -673,7 +679,7 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
     cbd_engine* e = J.e;
     if (a.n_groups + J.n_groups > CONV_MAX_GROUPS) return fail(CBD_ERR_STATE, "too many edge groups in one launch");
     const int base = side ? 8 : 0;
-    int slot_of[4] = {-1, -1, -1, -1}, n_slots = 0;
+    int slot_of[4] = {-1, -1, -1, -1}, n_slots = 0;     // indexed by FCBlock (widx)
     for (int g = 0; g < J.n_groups; ++g) {
       ConvGroup& G = a.g[a.n_groups + g];
       G = J.g[g];
@@ -900,9 +906,18 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
     const size_t caps[5] = {cap_ll, cap_x, (size_t)Bm * Err, cap_x, (size_t)Err};
     for (int g = 0; g < 5; ++g) {
       const size_t tiles = (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES + 1;
-      HIPCHK(e->bpool.alloc(&e->fsum[g], tiles * NODE_STRIDE));
-      HIPCHK(e->bpool.alloc(&e->lsum[g], tiles * NODE_STRIDE));
-      HIPCHK(e->bpool.alloc(&e->racc[g], (size_t)(g == 4 ? Nr : N) * NODE_STRIDE));
+      const size_t sf = tiles * NODE_STRIDE, sr = (size_t)(g == 4 ? Nr : N) * NODE_STRIDE;
+      if (g >= 1 && g <= 3) {   // one block: [first | last | run_acc] of the group, then the same again for its second 0e slice
+        const size_t D = (2 * sf + sr + 63) / 64 * 64;
+        float* base = nullptr;
+        HIPCHK(e->bpool.alloc(&base, 2 * D));
+        e->fsum[g] = base; e->lsum[g] = base + sf; e->racc[g] = base + 2 * sf;
+        e->piece_b_off[g] = (long long)D;
+        continue;
+      }
+      HIPCHK(e->bpool.alloc(&e->fsum[g], sf));
+      HIPCHK(e->bpool.alloc(&e->lsum[g], sf));
+      HIPCHK(e->bpool.alloc(&e->racc[g], sr));
     }
     for (int k = 0; k < 2; ++k) {
       const size_t tiles = (cap_ll + CONV_WG_EDGES - 1) / CONV_WG_EDGES + 1;
@@ -1013,12 +1028,24 @@ static void fill_static_desc(cbd_engine* e) {
   D.fin_lig.n_groups = 2; D.fin_lig.g[0] = f_ll; D.fin_lig.g[1] = f_lr;
   D.fin_rec.n_groups = 2; D.fin_rec.g[0] = f_rr; D.fin_rec.g[1] = f_rl;
   D.fin_rec_shared.n_groups = 2; D.fin_rec_shared.g[0] = f_rr_shared; D.fin_rec_shared.g[1] = f_rl;
+  {   // bf16 role split: + the second 0e slice (columns [0, NS) only, not counted in the degree) of every cross / receptor group
+    auto second = [&](const FinGroup& f, int g) {
+      FinGroup b = f;
+      b.first_sum = f.first_sum + e->piece_b_off[g]; b.last_sum = f.last_sum + e->piece_b_off[g]; b.run_acc = f.run_acc + e->piece_b_off[g];
+      b.deg_weight = 0; b.col_hi = NS;
+      return b;
+    };
+    D.fin_lig_r.n_groups = 3; D.fin_lig_r.g[0] = f_ll; D.fin_lig_r.g[1] = f_lr; D.fin_lig_r.g[2] = second(f_lr, 1);
+    D.fin_rec_r.n_groups = 4; D.fin_rec_r.g[0] = f_rr; D.fin_rec_r.g[1] = f_rl; D.fin_rec_r.g[2] = second(f_rr, 2); D.fin_rec_r.g[3] = second(f_rl, 3);
+    D.fin_rec_shared_r.n_groups = 3; D.fin_rec_shared_r.g[0] = f_rr_shared; D.fin_rec_shared_r.g[1] = f_rl; D.fin_rec_shared_r.g[2] = second(f_rl, 3);
+  }
   ConvGroupH sl[EMB_SLICES];
   emb_slices(e, G.ll, 0, sl);   // the piece buffers of the slices do not depend on the layer
   D.fin_emb.n_groups = EMB_SLICES;
   for (int k = 0; k < EMB_SLICES; ++k) {
     D.fin_emb.g[k] = fin_group(sl[k], gd.start_ll, gd.cnt_ll);
     D.fin_emb.g[k].deg_weight = k == 0 ? 1 : 0;
+    D.fin_emb.g[k].col_hi = sl[k].vec_on ? 0 : NS;      // a 0e-only slice holds (the bf16 kernel: writes) the scalar columns only
   }
 }
 
@@ -1117,6 +1144,7 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
   // ---- join: X[xi] (== X1) now holds the embedded ligand rows (main stream) and the receptor rows (side stream)
   HIPCHK(hipStreamWaitEvent(s, e0->ev_join, 0));
   static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
+  const bool roles = e0->use_bf16 == 1 && e0->bf16_roles;
   for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
     const ConvLayerDev& L = e0->conv[l];
     for (int k = 0; k < n; ++k) {
@@ -1124,7 +1152,26 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
       J = ConvJob{};
       J.e = E[k]; J.node_in = E[k]->desc_h.X[xi];
       const int cap_ll = E[k]->desc_h.cap_ll, cap_x = E[k]->desc_h.cap_x, cap_rr = Bk[k] * E[k]->gs.Err;
-      if (l == 0) {          // the receptor->receptor group of layer 0 is the shared one computed on the side stream
+      if (roles) {
+        // three virtual slices per cross / receptor group: 0e tiles [0, h0), [h0, t0e) and the vector blocks; what each costs a CU is
+        // a third of the weight stream, and the persistent kernel keeps a 0e slice's tiles in LDS (tp_conv_bf16p.hip)
+        const ConvShape S3 = conv_shape(3, 3);
+        const int h0 = (S3.t0e + 1) / 2;
+        J.n_groups = 0;
+        auto add = [&](const ConvGroupH& g, int cap, int w) { J.g[J.n_groups] = g; J.caps[J.n_groups] = cap; J.widx[J.n_groups] = w; ++J.n_groups; };
+        auto add3 = [&](const ConvGroupH& g, int gi, int cap, int w) {
+          ConvGroupH a = g, b = g, c = g;
+          a.i0e_lo = 0; a.i0e_hi = h0; a.vec_on = 0;
+          b.i0e_lo = h0; b.i0e_hi = S3.t0e; b.vec_on = 0;
+          b.first_sum += E[k]->piece_b_off[gi]; b.last_sum += E[k]->piece_b_off[gi]; b.run_acc += E[k]->piece_b_off[gi];
+          c.i0e_lo = S3.t0e; c.i0e_hi = S3.t0e; c.vec_on = 1;
+          add(a, cap, w); add(b, cap, w); add(c, cap, w);
+        };
+        add(G[k].ll, cap_ll, 0);
+        add3(G[k].lr, 1, cap_x, 1);
+        if (l >= 1 && l < 4) add3(G[k].rr, 2, cap_rr, 2);
+        if (l < 4) add3(G[k].rl, 3, cap_x, 3);
+      } else if (l == 0) {          // the receptor->receptor group of layer 0 is the shared one computed on the side stream
         J.n_groups = 3;
         J.g[0] = G[k].ll; J.g[1] = G[k].lr; J.g[2] = G[k].rl;
         J.caps[0] = cap_ll; J.caps[1] = cap_x; J.caps[2] = cap_x;
@@ -1140,7 +1187,7 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
       }
     }
     CHK(run_conv(L, jobs, n, s, false));
-    const int kind = l == 0 ? FIN_FIRST : l < 4 ? FIN_MID : FIN_LAST;   // receptor rows of the last layer are never read again (quirk 3)
+    const int kind = (l == 0 ? FIN_FIRST : l < 4 ? FIN_MID : FIN_LAST) + (roles ? FIN_FIRST_R - FIN_FIRST : 0);   // receptor rows of the last layer are never read again (quirk 3)
     HIPCHK(launch_conv_finalize_multi(l < 4 ? m_all_nodes : m_lig_nodes, kind, xi, xi ^ 1, L.bn_scale, L.bn_mean, L.bn_bias,
                                       in_level_dim(L.in_level), out_level_dim(L.out_level), s));
     xi ^= 1;
@@ -1295,7 +1342,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       e->complex_gen = cbd_engine::next_gen();
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16,
+    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16 + 8 * (int)e->bf16_roles,
              (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr), (int)e->timing);
     key += buf;
   }
@@ -1372,7 +1419,7 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
       if (engines[q] == e) return fail(CBD_ERR_ARG, "distinct engines are required");
     if (!pos_dev[k]) return fail(CBD_ERR_ARG, "null pose buffer");
     if (e->cfg.device != e0->cfg.device) return fail(CBD_ERR_ARG, "co-scheduled engines must live on the same device");
-    if (e->use_bf16 != e0->use_bf16) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
+    if (e->use_bf16 != e0->use_bf16 || e->bf16_roles != e0->bf16_roles) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
     if (e->cfg.no_torsion != e0->cfg.no_torsion || e->cfg.lig_max_radius != e0->cfg.lig_max_radius ||
         e->cfg.lig_radius_cap != e0->cfg.lig_radius_cap)
       return fail(CBD_ERR_ARG, "co-scheduled engines must share one model configuration");
@@ -1407,6 +1454,11 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
   }
   if (k == "bf16") {   // captured graphs bake the kernel choice in: drop them
     if (value != 0) e->use_bf16 = 1; else if (e->use_bf16 == 1) e->use_bf16 = 0;
+    drop_graphs(e);
+    return 0;
+  }
+  if (k == "bf16_roles") {   // bf16 only: cross / receptor groups as three tile slices per layer (captured graphs bake it in)
+    e->bf16_roles = value != 0;
     drop_graphs(e);
     return 0;
   }

@@ -35,12 +35,12 @@ __device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f
 // Same additions in the same order as before: results are bitwise unchanged.
 template <int NODE_STR, int OUT_STR>
 __device__ __forceinline__ void reduce_runs(const float* __restrict__ msg, const int* __restrict__ sl, int lane, int out_dim,
-                                            float* __restrict__ fs, float* __restrict__ ls, float* __restrict__ run_acc) {
+                                            float* __restrict__ fs, float* __restrict__ ls, float* __restrict__ run_acc, int col_lo = 0) {
   const int jl = lane & 31;
   const int s_me = sl[jl], s_prev = sl[jl > 0 ? jl - 1 : 0];
   const unsigned starts = (unsigned)__ballot(lane < 32 && s_me != s_prev);   // bit jj: edge jj starts a new run (bit 0 is never set)
   const int last = __builtin_amdgcn_readlane(s_me, 31);
-  for (int col = lane; col < out_dim; col += 64) {
+  for (int col = col_lo + lane; col < out_dim; col += 64) {      // [col_lo, out_dim): the columns this wave's tile slice produces
     const float* oc = msg + col * OUT_STR;
     float v[32];
 #pragma unroll

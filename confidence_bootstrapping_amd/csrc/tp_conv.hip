@@ -352,7 +352,7 @@ __device__ __forceinline__ void finalize_one(const FinArgs& fa, const float* __r
       const int k = G.node_mod > 0 ? i % G.node_mod : i;
       const int s = G.start[k], n = G.cnt[k];
       deg += G.deg_weight ? n : 0;
-      if (n <= 0) continue;
+      if (n <= 0 || (G.col_hi > 0 && c >= G.col_hi)) continue;
       const int e = s + n, t0 = s / WAVE_EDGES, t1 = (e - 1) / WAVE_EDGES;
       const bool at_start = (s % WAVE_EDGES) == 0;
       if (t0 == t1) {
@@ -397,13 +397,16 @@ __global__ void conv_finalize_multi_kernel(Multi mm, int kind, int xi_in, int xi
   const PoseBatch& PB = fin_locate(mm, blk);
   const int idx = blk * blockDim.x + threadIdx.x;
   const int i = idx / NODE_STRIDE, c = idx % NODE_STRIDE;
-  const int n0 = PB.B * PB.gs.Nl, n1 = (kind == FIN_FIRST || kind == FIN_MID) ? PB.B * PB.gs.Nr : 0;
+  const bool roles = kind >= FIN_FIRST_R;          // bf16 role split: the cross / receptor groups come with a second 0e slice
+  const int base = roles ? kind - (FIN_FIRST_R - FIN_FIRST) : kind;
+  const int n0 = PB.B * PB.gs.Nl, n1 = (base == FIN_FIRST || base == FIN_MID) ? PB.B * PB.gs.Nr : 0;
   if (i >= n0 + n1) return;
   const float* node_in = PB.X[xi_in];
   float* node_out = PB.X[xi_out];
-  if (i < n0) finalize_one(kind == FIN_EMB ? PB.fin_emb : PB.fin_lig, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, 0);
-  else finalize_one(kind == FIN_FIRST ? PB.fin_rec_shared : PB.fin_rec, node_in, node_out, bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim,
-                    PB.gs.rec_off);
+  if (i < n0) finalize_one(base == FIN_EMB ? PB.fin_emb : roles ? PB.fin_lig_r : PB.fin_lig, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim,
+                           out_dim, 0);
+  else finalize_one(base == FIN_FIRST ? (roles ? PB.fin_rec_shared_r : PB.fin_rec_shared) : (roles ? PB.fin_rec_r : PB.fin_rec), node_in, node_out,
+                    bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim, PB.gs.rec_off);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -567,10 +567,13 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   }
   __syncthreads();
   // Run-length sums per aggregating node and 32-edge reduction tile, exactly the pieces of tp_conv_kernel (reduce_runs, tp_conv_dev.h)
+  // a virtual slice writes only the columns it produces (role split, engine.hip: a 0e-only slice the 32 scalar columns, the vector
+  // slice the rest -- the two share the group's piece buffers; a second 0e slice has buffers of its own)
+  const int col_lo = (vec_on && i_lo >= i_hi) ? NS : 0, col_hi = vec_on ? S.out_dim : NS;
 #pragma unroll 1
   for (int sub = 0; sub < 2; ++sub)
-    reduce_runs<NODE_STRIDE, OUT_STRIDE>(sub ? xT1 : xT0, srcl + 32 * sub, lane, S.out_dim, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
-                G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc);
+    reduce_runs<NODE_STRIDE, OUT_STRIDE>(sub ? xT1 : xT0, srcl + 32 * sub, lane, col_hi, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
+                G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc, col_lo);
   if constexpr (DIAG == 4) {   // same record layout as tp_conv_kernel's CBD_CONV_VARIANT=8 stamps (tools/conv_clock.py)
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {
       unsigned long long* o = args.stamps + (size_t)blockIdx.x * 8;
