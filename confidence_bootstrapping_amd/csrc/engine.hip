@@ -98,7 +98,8 @@ struct cbd_engine {
   // 0e tiles [0, 19), 0e tiles [19, 38), vector blocks; the second 0e slice writes piece buffers of its own, laid out exactly like
   // the group's and `piece_b_off[g]` floats behind them (first_sum, last_sum and run_acc alike)
   long long piece_b_off[4] = {0, 0, 0, 0};
-  bool bf16_roles = false;
+  int bf16_roles = 0;      // 1: the slices run through the streaming kernel, 2: the 0e slices through the LDS-resident kernel (tp_conv_bf16p.hip)
+  int n_cus = 256;
   int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
   int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges
   hipStream_t own = nullptr;        // used instead of the legacy default stream for graph capture (which cannot be captured)
@@ -436,7 +437,9 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
   if (const char* p = getenv("CBD_PRECISION")) e->use_bf16 = std::max(0, std::min(2, atoi(p)));   // test hook: default operand policy
-  if (const char* p = getenv("CBD_BF16_ROLES")) e->bf16_roles = atoi(p) != 0;                     // test hook: role split of the bf16 policy
+  if (const char* p = getenv("CBD_BF16_ROLES")) e->bf16_roles = std::max(0, std::min(2, atoi(p)));                     // test hook: role split of the bf16 policy
+  HIPCHK(hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
+  if (const char* p = getenv("CBD_BF16P_WGS")) e->n_cus = std::max(1, atoi(p));                   // diagnostic: workgroups of the persistent kernel
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
@@ -630,7 +633,7 @@ static int record_event(hipEvent_t ev, hipStream_t s, bool capturing) {
   return 0;
 }
 
-static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s) {
+static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArgs& a, int grid, hipStream_t s, const ConvArgs* resident = nullptr) {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool cap = false;
   if (e->timing) {
@@ -651,6 +654,7 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
   if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
+  if (resident) HIPCHK(launch_tp_conv_bf16p(*resident, e->n_cus, s));
   if (e->timing) CHK(record_event(e1, s, cap));
   return 0;
 }
@@ -710,6 +714,19 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
   }
   if (pa.n_jobs) HIPCHK(launch_node_proj(pa, s));
   a.stamps = e0->stamps_dev;
+  if (e0->use_bf16 == 1 && e0->bf16_roles == 2 && L.in_level == 3 && L.out_level == 3) {
+    // role split with resident weights: the 0e-only slices go to the persistent kernel, everything else stays with the streaming one
+    ConvArgs as{}, ap{};
+    as.stamps = a.stamps;
+    int grid_s = 0, gi = 0;
+    for (int q = 0; q < n_jobs; ++q)
+      for (int g = 0; g < jobs[q].n_groups; ++g, ++gi) {
+        const ConvGroup& G = a.g[gi];
+        if (G.vec_on == 0 && G.i0e_hi > G.i0e_lo) ap.g[ap.n_groups++] = G;
+        else { as.g[as.n_groups++] = G; grid_s += (jobs[q].caps[g] + 63) / 64; }
+      }
+    if (ap.n_groups) return launch_conv_timed(e0, L, as, grid_s, s, &ap);
+  }
   return launch_conv_timed(e0, L, a, grid, s);
 }
 
@@ -1144,7 +1161,7 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
   // ---- join: X[xi] (== X1) now holds the embedded ligand rows (main stream) and the receptor rows (side stream)
   HIPCHK(hipStreamWaitEvent(s, e0->ev_join, 0));
   static const char* conv_names[5] = {"conv_0", "conv_1", "conv_2", "conv_3", "conv_4"};
-  const bool roles = e0->use_bf16 == 1 && e0->bf16_roles;
+  const bool roles = e0->use_bf16 == 1 && e0->bf16_roles != 0;
   for (int l = 0; l < 5; ++l) {   // interaction layers on the joint graph (score_model.py:365-374)
     const ConvLayerDev& L = e0->conv[l];
     for (int k = 0; k < n; ++k) {
@@ -1342,7 +1359,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       e->complex_gen = cbd_engine::next_gen();
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16 + 8 * (int)e->bf16_roles,
+    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16 + 8 * e->bf16_roles,
              (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr), (int)e->timing);
     key += buf;
   }
@@ -1458,7 +1475,7 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
     return 0;
   }
   if (k == "bf16_roles") {   // bf16 only: cross / receptor groups as three tile slices per layer (captured graphs bake it in)
-    e->bf16_roles = value != 0;
+    e->bf16_roles = (int)std::max<long long>(0, std::min<long long>(2, value));
     drop_graphs(e);
     return 0;
   }

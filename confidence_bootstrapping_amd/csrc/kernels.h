@@ -139,6 +139,8 @@ hipError_t launch_bond_conv(const BondHead& h, const Multi& m, int xi, const flo
 constexpr int BOND_CONV_TILES = 15;
 hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);
 hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);
+// the 0e-only slices of the bf16 role split (74 -> 74 layers) with LDS-resident weight tiles: persistent workgroups, one per CU
+hipError_t launch_tp_conv_bf16p(const ConvArgs& a, int n_wg, hipStream_t s);
 hipError_t launch_tp_conv_x3(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);     // bf16x3 weight streams
 // segmented sum -> mean -> BatchNorm -> residual of one layer for every batch.  kind: which node types / group sets take part
 enum FinKind { FIN_EMB = 0, FIN_FIRST = 1, FIN_MID = 2, FIN_LAST = 3,     // ligand embedding layer; interaction layer 0; 1..3; 4

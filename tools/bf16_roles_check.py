@@ -24,7 +24,7 @@ def main():
     for t in (0.9, 0.3):
         step = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
         res = {}
-        for name, opts in (("f32", {}), ("bf16", {"bf16": 1}), ("bf16_roles", {"bf16": 1, "bf16_roles": 1})):
+        for name, opts in (("f32", {}), ("bf16", {"bf16": 1}), ("bf16_roles", {"bf16": 1, "bf16_roles": 1}), ("bf16_res", {"bf16": 1, "bf16_roles": 2})):
             eng.set_option("bf16", 0); eng.set_option("bf16_roles", 0)
             for k, v in opts.items():
                 eng.set_option(k, v)
@@ -34,7 +34,10 @@ def main():
         rel = lambda x, y: max(float((p - q).abs().max() / q.abs().max()) for p, q in zip(x, y))
         out[str(t)] = {"bf16_vs_f32": rel(res["bf16"], res["f32"]), "roles_vs_f32": rel(res["bf16_roles"], res["f32"]),
                        "roles_vs_bf16": rel(res["bf16_roles"], res["bf16"]),
-                       "roles_repeatable": all(torch.equal(p, q) for p, q in zip(res["bf16_roles"], res["bf16_roles_again"]))}
+                       "roles_repeatable": all(torch.equal(p, q) for p, q in zip(res["bf16_roles"], res["bf16_roles_again"])),
+                       "resident_vs_roles": rel(res["bf16_res"], res["bf16_roles"]), "resident_vs_f32": rel(res["bf16_res"], res["f32"]),
+                       "resident_bitwise_roles": all(torch.equal(p, q) for p, q in zip(res["bf16_res"], res["bf16_roles"])),
+                       "resident_repeatable": all(torch.equal(p, q) for p, q in zip(res["bf16_res"], res["bf16_res_again"]))}
     print(json.dumps(out))
 
 
