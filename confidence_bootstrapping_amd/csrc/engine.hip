@@ -674,18 +674,21 @@ struct ConvJob {
 // per-launch drain of the long-lived waves is amortised).  Timed by jobs[0].e.
 static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipStream_t s, bool side) {
   cbd_engine* e0 = jobs[0].e;
-  ConvArgs a{};
+  constexpr int MAX_ALL = 8 * 10;      // up to eight co-scheduled batches of ten slices
+  static thread_local ConvGroup all[MAX_ALL];
+  int caps[MAX_ALL];
+  int n_all = 0;
   ProjArgs pa{};
-  int grid = 0;
   const ConvShape S = conv_shape(L.in_level, L.out_level);
   for (int q = 0; q < n_jobs; ++q) {
     const ConvJob& J = jobs[q];
     cbd_engine* e = J.e;
-    if (a.n_groups + J.n_groups > CONV_MAX_GROUPS) return fail(CBD_ERR_STATE, "too many edge groups in one launch");
+    if (n_all + J.n_groups > MAX_ALL) return fail(CBD_ERR_STATE, "too many edge groups in one launch");
     const int base = side ? 8 : 0;
     int slot_of[4] = {-1, -1, -1, -1}, n_slots = 0;     // indexed by FCBlock (widx)
     for (int g = 0; g < J.n_groups; ++g) {
-      ConvGroup& G = a.g[a.n_groups + g];
+      ConvGroup& G = all[n_all];
+      caps[n_all++] = J.caps[g];
       G = J.g[g];
       const int w = J.widx[g];
       G.wstream = (e0->use_bf16 == 1 ? L.wstream_bf16 : e0->use_bf16 == 2 ? L.wstream_x3 : L.wstream)[w];
@@ -693,7 +696,6 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
       if (G.i0e_hi == 0 && G.vec_on == 0) {   // not a virtual slice: the whole weight-tile chain
         G.i0e_lo = 0; G.i0e_hi = S.t0e; G.vec_on = 1;
       }
-      grid += e0->use_bf16 == 1 ? (J.caps[g] + 63) / 64 : (J.caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES;   // bf16: one wave per 64 edges
       if (e0->use_bf16 != 1) {
         // per-node projections of the first Linear's node parts, one job per distinct (FCBlock, role); virtual slices share them.
         // (The plain-bf16 policy keeps the whole first Linear in the edge kernel.)
@@ -710,24 +712,25 @@ static int run_conv(const ConvLayerDev& L, const ConvJob* jobs, int n_jobs, hipS
         G.pdst = e->proj[base + 2 * slot_of[w] + 1];
       }
     }
-    a.n_groups += J.n_groups;
   }
   if (pa.n_jobs) HIPCHK(launch_node_proj(pa, s));
+  // role split with resident weights (bf16_roles == 2): the 0e-only slices go to the persistent kernel (tp_conv_bf16p.hip), everything
+  // else stays with the streaming one
+  const bool resident = e0->use_bf16 == 1 && e0->bf16_roles == 2 && L.in_level == 3 && L.out_level == 3;
+  const int edges_per_wg = e0->use_bf16 == 1 ? 64 : CONV_WG_EDGES;                    // bf16: one wave per 64 edges
+  ConvArgs a{}, ap{};
   a.stamps = e0->stamps_dev;
-  if (e0->use_bf16 == 1 && e0->bf16_roles == 2 && L.in_level == 3 && L.out_level == 3) {
-    // role split with resident weights: the 0e-only slices go to the persistent kernel, everything else stays with the streaming one
-    ConvArgs as{}, ap{};
-    as.stamps = a.stamps;
-    int grid_s = 0, gi = 0;
-    for (int q = 0; q < n_jobs; ++q)
-      for (int g = 0; g < jobs[q].n_groups; ++g, ++gi) {
-        const ConvGroup& G = a.g[gi];
-        if (G.vec_on == 0 && G.i0e_hi > G.i0e_lo) ap.g[ap.n_groups++] = G;
-        else { as.g[as.n_groups++] = G; grid_s += (jobs[q].caps[g] + 63) / 64; }
-      }
-    if (ap.n_groups) return launch_conv_timed(e0, L, as, grid_s, s, &ap);
+  int grid = 0;
+  for (int i = 0; i < n_all; ++i) {
+    const ConvGroup& G = all[i];
+    const bool to_resident = resident && G.vec_on == 0 && G.i0e_hi > G.i0e_lo;
+    ConvArgs& t = to_resident ? ap : a;
+    if (t.n_groups == CONV_MAX_GROUPS) return fail(CBD_ERR_STATE, "too many edge groups in one launch");
+    t.g[t.n_groups++] = G;
+    if (!to_resident) grid += (caps[i] + edges_per_wg - 1) / edges_per_wg;
   }
-  return launch_conv_timed(e0, L, a, grid, s);
+  if (ap.n_groups) { ap.stamps = a.stamps; a.stamps = nullptr; }      // diagnostic stamps: the persistent kernel's
+  return launch_conv_timed(e0, L, a, grid, s, ap.n_groups ? &ap : nullptr);
 }
 
 static FinGroup fin_group(const ConvGroup& g, const int* start, const int* cnt, int node_mod = 0) {

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
     wg_lo = wg_hi;
   }
   if (role < 0) return;
+  // DIAG 4: per-wave phase clocks summed over the wave's units (same record layout as the streaming kernel; tools/conv_clock.py)
+  unsigned long long st_t0 = 0, st_r0 = 0, c_gather = 0, c_lin = 0, c_0e = 0, c_units = 0;
+  if constexpr (DIAG == 4) { st_t0 = stamp(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
   const int i_lo = rt.lo[role], i_hi = rt.hi[role];
   const int n_res = i_hi - i_lo;
 
@@ -113,6 +116,8 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
     const ConvGroup G = args.g[grp];
     const int cnt = *G.count;
     const int e0 = unit_in_group * 64;
+    unsigned long long u0 = 0, u1 = 0, u2 = 0;
+    if constexpr (DIAG == 4) u0 = stamp();
     const int tile_local = 2 * unit_in_group;
 
     // ---- weight stream of the first Linear (tiles 0..2 from global memory, as in the streaming kernel) and its bias rows
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
       }
     }
     wave_lds_fence();
+    if constexpr (DIAG == 4) u1 = stamp();
 
     // ---- first Linear (3 streamed tiles): h = ReLU(W1 x + b1) in the C/D layout = B operand of the second Linear
     f32x16 acc0, acc1;
@@ -217,6 +223,7 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
     v2_set_hidden(h1, 2, acc1);
     bias_ready(cb);
 
+    if constexpr (DIAG == 4) u2 = stamp();
     // ---- the slice's 0e tiles from LDS
     const bf16x8* wq = reinterpret_cast<const bf16x8*>(wl) + lane;      // fragment q of resident tile t: wq[(t * 6 + q) * 64]
 #pragma unroll
@@ -263,6 +270,7 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, bm1, o1, 0, 0, 0);
       }
     }
+    if constexpr (DIAG == 4) { const unsigned long long u3 = stamp(); c_gather += u1 - u0; c_lin += u2 - u1; c_0e += u3 - u2; ++c_units; }
     // ---- messages -> LDS tile [NS][33] (over the mid table), run-length sums per aggregating node; one sub-tile after the other
 #pragma unroll 1
     for (int sub = 0; sub < 2; ++sub) {
@@ -275,6 +283,14 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
                                            G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc);
     }
     wave_lds_fence();
+  }
+  if constexpr (DIAG == 4) {
+    const int rec = blockIdx.x * P_WAVES + wave;
+    if (lane == 0 && args.stamps && rec < 8192 && c_units) {
+      unsigned long long* o = args.stamps + (size_t)rec * 8;
+      o[0] = st_t0; o[1] = st_r0; o[2] = stamp(); o[3] = __builtin_amdgcn_s_memrealtime();
+      o[4] = st_t0 + c_gather; o[5] = o[4] + c_lin; o[6] = o[5] + c_0e; o[7] = o[4] + c_units;
+    }
   }
 }
 
@@ -299,9 +315,13 @@ hipError_t launch_tp_conv_bf16p(const ConvArgs& a, int n_wg, hipStream_t s) {
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64p_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64p_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, P_LDS_BYTES);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((tp_conv64p_kernel<0>), dim3(n_wg), dim3(P_WAVES * 64), P_LDS_BYTES, s, a, rt);
+  static const int diag = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
+  if (diag == 4) hipLaunchKernelGGL((tp_conv64p_kernel<4>), dim3(n_wg), dim3(P_WAVES * 64), P_LDS_BYTES, s, a, rt);
+  else hipLaunchKernelGGL((tp_conv64p_kernel<0>), dim3(n_wg), dim3(P_WAVES * 64), P_LDS_BYTES, s, a, rt);
   return hipGetLastError();
 }
 
