@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--fused-adam", action="store_true")
     ap.add_argument("--blas", default=None, help="torch.backends.cuda.preferred_blas_library: cublas (= rocBLAS) | cublaslt (= hipBLASLt)")
     ap.add_argument("--regions", action="store_true", help="GPU launches per forward region and per backward node type")
+    ap.add_argument("--sites", action="store_true", help="non-cbd GPU kernels (ATen, rocPRIM ...) of one step by calling source line / backward node")
     ap.add_argument("--gc", default="default", help="default | off | freeze: Python cyclic GC during the timed steps")
     ap.add_argument("--plain", action="store_true", help="free-running steps only (for rocprofv3 --kernel-trace; see tools/gap_stats.py)")
     ap.add_argument("--cprofile", action="store_true", help="Python-level profile (cProfile) of 16 free-running steps instead of the op table")
@@ -32,6 +33,7 @@ def main():
     from confidence_bootstrapping_amd.datasets.pdbbind import NoiseTransform
     from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
     dev = torch.device("cuda:0")
+    torch.set_num_threads(max(1, int(os.environ.get("CBD_HOST_THREADS", "1"))))     # what training.train_epoch runs under (hostcfg.py)
     margs = load_model_args()
     model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
     model.train()
@@ -159,6 +161,40 @@ def main():
         for name, n in count.most_common(60):
             print(f"  {n:6d}  calls {ncall[name]:5d}  {name}")
         print("  total", sum(count.values()))
+        return
+    if a.sites:
+        import collections
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+            step(batches[7])
+            sync()
+        evs = list(prof.events())
+        nodes = [e for e in evs if e.name.startswith("autograd::engine::evaluate_function")]
+        cnt, tim = collections.Counter(), collections.Counter()
+        tot_n = tot_t = cbd_t = 0.0
+        for e in evs:
+            for k in (e.kernels or []):
+                if "cbd::" in k.name:
+                    cbd_t += k.duration
+                    continue
+                site = None
+                for fr in (e.stack or []):
+                    if "confidence_bootstrapping_amd" in fr or "tools/train_profile" in fr:
+                        site = fr.split("confidence_bootstrapping_amd/")[-1]
+                        if "tools/train_profile" not in fr:
+                            break
+                if site is None or "train_profile" in site:
+                    own = None
+                    for n in nodes:
+                        if n.thread == e.thread and n.time_range.start <= e.time_range.start <= n.time_range.end:
+                            own = n
+                    site = (own.name.replace("autograd::engine::evaluate_function: ", "bwd:") if own else (site or "(no python frame)")) + " <- " + e.name
+                else:
+                    site += " <- " + e.name
+                cnt[site] += 1; tim[site] += k.duration
+                tot_n += 1; tot_t += k.duration
+        print(f"non-cbd GPU kernels in one step: {int(tot_n)} launches, {tot_t / 1e3:.2f} ms; cbd kernels {cbd_t / 1e3:.2f} ms")
+        for site, n in cnt.most_common(a.rows * 2):
+            print(f"  {n:4d}  {tim[site] / 1e3:7.3f} ms  {site[:170]}")
         return
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
         step(batches[7])
