@@ -15,7 +15,8 @@ Differences from the reference that are deliberate and documented (SURVEY.md 8a 
     rows and fails on the shape mismatch, relying on the caller's halve-and-retry);
   * the noise is drawn on the CPU generator (torch.normal, same call order and sizes as the reference: tr (b,3),
     rot (b,3), tor (b*R) per step), so a seed reproduces the reference's CPU path draw for draw;
-  * SVGD, pivot, return_full_trajectory, return_features raise NotImplementedError (the last three also raise in the reference);
+  * pivot, return_full_trajectory, return_features raise (they also raise in the reference); SVGD (experimental in the reference, off in
+    the shipped configuration) runs step by step through _sample_svgd: engine scores + batched pairwise kernel terms on the device;
     crop_beyond of the SCORE model (not in the shipped yml) runs through _sample_cropped (a set-up per distinct crop mask and step).
 Confidence scoring (reference utils/sampling.py:240-261): with `confidence_model` set, the final poses of every batch
 are scored by the all-atom confidence engine (cbd_conf_score) -- crop_beyond per pose, t = 0 -- on the all-atom graphs
@@ -148,6 +149,141 @@ def _sample_cropped(eng, cplx, key, pos, steps, noise, crop):
         eng.complex_key = None          # the engine holds a cropped complex now
 
 
+def get_dihedrals(data_list):
+    """(c, a, b, d) atom quadruples of the rotatable bonds (reference utils/torsion.py:121-139): c / d = the first listed neighbour of
+    a / b that is not the bond partner."""
+    g = data_list[0]
+    edge_index = torch.as_tensor(g["ligand", "ligand"].edge_index).cpu()
+    edge_mask = torch.as_tensor(g["ligand"].edge_mask).cpu().bool()
+    nbrs = [[] for _ in range(int(edge_index.max()) + 1)] if edge_index.numel() else []
+    for u, v in edge_index.T.tolist():
+        nbrs[u].append(v)
+    quads = []
+    for k, (a, b) in enumerate(edge_index.T.tolist()):
+        if bool(edge_mask[k]):
+            c = nbrs[a][0] if nbrs[a][0] != b else nbrs[a][1]
+            d = nbrs[b][0] if nbrs[b][0] != a else nbrs[b][1]
+            quads.append((c, a, b, d))
+    return torch.tensor(quads, dtype=torch.long).reshape(-1, 4)
+
+
+def _matrix_to_axis_angle(Rm):
+    """Rotation matrices [..., 3, 3] -> rotation vectors (reference utils/geometry.py:100-205: through the best-conditioned quaternion
+    candidate, small-angle branch sin(x/2)/x ~ 1/2 - x^2/48)."""
+    m = Rm.reshape(Rm.shape[:-2] + (9,))
+    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(m, -1)
+    q_abs = torch.sqrt(torch.clamp(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
+                                                1.0 - m00 - m11 + m22], -1), min=0.0))
+    cand = torch.stack([torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], -1),
+                        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], -1),
+                        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], -1),
+                        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], -1)], -2)
+    cand = cand / (2.0 * q_abs[..., None].clamp(min=0.1))
+    best = q_abs.argmax(-1)
+    q = torch.gather(cand, -2, best[..., None, None].expand(best.shape + (1, 4))).squeeze(-2)
+    norms = torch.linalg.vector_norm(q[..., 1:], dim=-1, keepdim=True)
+    half = torch.atan2(norms, q[..., :1])
+    ang = 2 * half
+    small = ang.abs() < 1e-6
+    k = torch.where(small, 0.5 - ang * ang / 48, torch.sin(half) / torch.where(small, torch.ones_like(ang), ang))
+    return q[..., 1:] / k
+
+
+def _rigid_svgd_terms(P):
+    """Pairwise rigid differences of the poses P [N, Nl, 3] (reference utils/torsion.py:171-185 over
+    utils/geometry.py:279-314): translation between the centroids and the Kabsch rotation vector of every pair i < j, antisymmetric;
+    all pairs as one batched 3 x 3 SVD instead of the reference's N (N - 1) / 2 sequential ones."""
+    N = P.shape[0]
+    c = P.mean(1)                                         # [N, 3]
+    Pm = P - c[:, None, :]
+    H = torch.einsum("ina,jnb->ijab", Pm, Pm)             # H[i, j] = Am_i Bm_j^T
+    U, _, Vt = torch.linalg.svd(H)
+    Rm = Vt.transpose(-1, -2) @ U.transpose(-1, -2)
+    flip = torch.linalg.det(Rm) < 0
+    D = torch.ones(N, N, 3, dtype=P.dtype, device=P.device)
+    D[..., 2] = torch.where(flip, -1.0, 1.0)
+    Rm = (Vt.transpose(-1, -2) * D[..., None, :]) @ U.transpose(-1, -2)
+    rv = _matrix_to_axis_angle(Rm)                        # [N, N, 3]
+    t = c[None, :, :] - c[:, None, :]                     # t[i, j] = -c_i + c_j
+    upper = torch.triu(torch.ones(N, N, dtype=torch.bool, device=P.device), 1)[..., None]
+    rot_diff = torch.where(upper, rv, torch.zeros_like(rv))
+    rot_diff = rot_diff - rot_diff.transpose(0, 1)
+    tr_diff = torch.where(upper, t, torch.zeros_like(t))
+    tr_diff = tr_diff - tr_diff.transpose(0, 1)
+    return (tr_diff ** 2).sum(-1, keepdim=True), (rot_diff ** 2).sum(-1, keepdim=True), tr_diff, rot_diff
+
+
+def _torsion_svgd_terms(dihedral, P):
+    """Torsion angles of the poses and their wrapped pairwise differences (reference utils/torsion.py:146-168)."""
+    c, a, b, d = (dihedral[:, k] for k in range(4))
+    bdot = lambda x, y: torch.sum(x * y, dim=-1, keepdim=True)
+    ab = P[:, b] - P[:, a]
+    c_proj = P[:, a] + bdot(P[:, c] - P[:, a], ab) / bdot(ab, ab) * ab
+    d_proj = P[:, a] + bdot(P[:, d] - P[:, a], ab) / bdot(ab, ab) * ab
+    dsh = P[:, d] - d_proj + c_proj
+    u, v = dsh - c_proj, P[:, c] - c_proj
+    cos = bdot(u, v) / (torch.linalg.vector_norm(u, dim=-1, keepdim=True) * torch.linalg.vector_norm(v, dim=-1, keepdim=True))
+    cos = torch.clamp(cos, -1 + 1e-5, 1 - 1e-5)
+    tau = (torch.acos(cos) * torch.sign(bdot(torch.linalg.cross(u, v), ab))).squeeze(-1)          # [N, R]
+    diff = tau.unsqueeze(1) - tau.unsqueeze(0)
+    diff = torch.fmod(diff + 3 * np.pi, 2 * np.pi) - np.pi
+    return (diff ** 2).sum(-1, keepdim=True), diff
+
+
+def _sample_svgd(eng, cplx, pos, steps, noise, sched, cfg, n_total):
+    """Reverse diffusion with the reference's SVGD-style repulsion between the samples of a complex (utils/sampling.py:169-218,
+    utils/torsion.py:121-185; experimental in the reference, off in the shipped configuration).  Per step: the engine's score
+    (cbd_score), the pairwise kernel terms of all samples -- centroid translations, Kabsch rotation vectors, wrapped torsion differences
+    -- as batched device tensors (the reference loops over the pairs on the host), the combined update, cbd_modify_conformer."""
+    z_tr, z_rot, z_tor = noise
+    N, dev = pos.shape[0], pos.device
+    if N != n_total:
+        raise ValueError("SVGD needs all samples of the complex in one batch (the reference reshapes the torsion scores to [1, N, R])")
+    if z_tr is None:
+        raise ValueError("SVGD sampling needs the stochastic sampler (not ode / no_random), as in the reference")
+    S, Rn = len(steps), eng.R
+    tr_s, rot_s, tor_s = sched
+    dihedral = get_dihedrals([cplx]).to(dev) if Rn > 0 else None
+    lin = lambda lo, hi, t, default: default if lo is None or hi is None else 10 ** (lo * t + hi * (1 - t))
+    rot_w, tor_w = 10 ** cfg["rot_log_rel_weight"], 10 ** cfg["tor_log_rel_weight"]
+    dt_of = lambda s, i: float(s[i] - s[i + 1]) if i < S - 1 else float(s[i])
+    for i in range(S):
+        t = i / S
+        w = lin(cfg["weight_log_0"], cfg["weight_log_1"], t, 0.0)
+        rep_w = lin(cfg["repulsive_weight_log_0"], cfg["repulsive_weight_log_1"], t, 1.0)
+        st = steps[i]
+        tr_score, rot_score, tor_score = eng.score(pos, st)
+        zt, zr = z_tr[i].to(dev), z_rot[i].to(dev)
+        zq = z_tor[i].to(dev) if (Rn > 0 and z_tor is not None) else None
+        if not w > 0:
+            tr_p = st.tr_score_coef * tr_score + st.tr_noise_coef * zt
+            rot_p = st.rot_score_coef * rot_score + st.rot_noise_coef * zr
+            tor_p = st.tor_score_coef * tor_score + st.tor_noise_coef * zq if Rn > 0 else None
+        else:
+            P = pos
+            if cfg["use_x0"]:        # kernel terms on the one-step denoised poses (coefficient g^2 t instead of g^2 dt)
+                adj = lambda coef, s, score: coef / dt_of(s, i) * float(s[i]) * score
+                P = eng.modify_conformer(pos, adj(st.tr_score_coef, tr_s, tr_score), adj(st.rot_score_coef, rot_s, rot_score),
+                                         adj(st.tor_score_coef, tor_s, tor_score) if Rn > 0 else None)
+            tr_m, rot_m, tr_d, rot_d = _rigid_svgd_terms(P)
+            tor_m, tor_d = _torsion_svgd_terms(dihedral, P) if Rn > 0 else (0.0, None)
+            total = tr_m + rot_w * rot_m + tor_w * tor_m
+            ks = lin(cfg["kernel_size_log_0"], cfg["kernel_size_log_1"], t, 1.0)
+            lw = lin(cfg["langevin_weight_log_0"], cfg["langevin_weight_log_1"], t, 1.0)
+            h = ks * torch.median(total, dim=1, keepdim=True)[0] / max(np.log(N), 1)
+            k = torch.exp(-1 / h * total)
+            tr_rep = torch.sum(2 / h * tr_d * k, dim=1)
+            rot_rep = torch.sum(2 / h * rot_w * rot_d * k, dim=1)
+            mix = lambda cs, cn, score, z, rep: 0.5 * cs * score + lw * (0.5 * cs * score + cn * z) + w * (cs * (score + rep_w * rep / N))
+            tr_p = mix(st.tr_score_coef, st.tr_noise_coef, tr_score, zt, tr_rep)
+            rot_p = mix(st.rot_score_coef, st.rot_noise_coef, rot_score, zr, rot_rep)
+            tor_p = None
+            if Rn > 0:
+                tor_rep = torch.sum(2 / h * tor_w * tor_d * k, dim=1)                     # [N, R]
+                tor_p = mix(st.tor_score_coef, st.tor_noise_coef, tor_score.reshape(N, Rn), zq.reshape(N, Rn), tor_rep).reshape(-1)
+        pos.copy_(eng.modify_conformer(pos, tr_p, rot_p, tor_p))
+
+
 @with_glue_threads
 def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_schedule, device, t_to_sigma, model_args,
              no_random=False, ode=False, visualization_list=None, confidence_model=None, filtering_data_list=None,
@@ -165,8 +301,17 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     as bring a launch to ~160 poses)."""
     N = len(data_list)
     assert not (return_full_trajectory or return_features or pivot), "Not implemented yet in new inference version"
+    svgd = None
     if svgd_weight_log_0 is not None and svgd_weight_log_1 is not None:
-        raise NotImplementedError("SVGD sampling (O(B^2) host loop in the reference) is outside the MI355X hot path")
+        if ode or no_random:
+            raise ValueError("SVGD sampling needs the stochastic sampler (the reference's SVGD branch reads the drawn noise)")
+        if not all(float(x) == 1.0 for x in (temp_sampling if np.iterable(temp_sampling) else [temp_sampling])):
+            raise NotImplementedError("SVGD together with low-temperature sampling: the reference's SVGD branch overwrites the temperature terms")
+        svgd = dict(weight_log_0=svgd_weight_log_0, weight_log_1=svgd_weight_log_1, repulsive_weight_log_0=svgd_repulsive_weight_log_0,
+                    repulsive_weight_log_1=svgd_repulsive_weight_log_1, kernel_size_log_0=svgd_kernel_size_log_0,
+                    kernel_size_log_1=svgd_kernel_size_log_1, langevin_weight_log_0=svgd_langevin_weight_log_0,
+                    langevin_weight_log_1=svgd_langevin_weight_log_1, rot_log_rel_weight=svgd_rot_log_rel_weight,
+                    tor_log_rel_weight=svgd_tor_log_rel_weight, use_x0=bool(svgd_use_x0))
     # asyncronous_noise_schedule (inference.py:384-388, utils/diffusion_utils.py:172-175): the caller passes the common time grid as
     # `t_schedule`, the three component schedules are its beta-quantile images; what the flag changes is which time the MODEL embeds,
     # and that is a property of the model (score_model.py:85) -- a model built without it ignores complex_t['t'] in the reference too
@@ -208,6 +353,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     n_co = max(1, min(int(co_schedule), 8)) if n_streams == 1 else 1
     if score_crop is not None:
         n_co = 1            # the cropped receptor differs from pose to pose and step to step: one complex at a time (_sample_cropped)
+    if svgd is not None:
+        if score_crop is not None:
+            raise NotImplementedError("SVGD together with the score model's crop_beyond")
+        n_co = 1            # the samples of ONE complex interact: step by step on the host (_sample_svgd)
     offset = 0
     pending = []          # (first pose index, b, pos [b,Nl,3] CPU, z_tr, z_rot, z_tor, loader batch)
     pending_key = None
@@ -242,7 +391,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             pos = torch.cat([p[2] for p in pend], dim=0).to(device, torch.float32).contiguous()
             cat = lambda k, dim: None if pend[0][k] is None else torch.cat([p[k] for p in pend], dim=dim)
             work.append((pend, e, pos, (cat(3, 1), cat(4, 1), cat(5, 1) if R_ > 0 else None), batch0))
-        if score_crop is not None:
+        if svgd is not None:
+            for _, e, pos, nz, batch0 in work:
+                _sample_svgd(e, _single_complex(batch0)[0], pos, steps, nz, (tr_schedule, rot_schedule, tor_schedule), svgd, N)
+        elif score_crop is not None:
             for (pend, key), (_, e, pos, nz, batch0) in zip(groups, work):
                 _sample_cropped(e, _single_complex(batch0)[0], key, pos, steps, nz, float(score_crop))
         elif len(work) == 1:
