@@ -48,9 +48,14 @@ struct TrainTpArgs {
 };
 
 constexpr int GX_STRIDE = 33;
+// forward: bias table + transposed row tile.  Backward: NO bias table (the tile's bias rows come from global memory into registers, one tile
+// ahead) and the g_x tile starts on the row tile's padding rows 76..79, which are written by the prologue and never read: 19.5 KB per wave
+// = 8 waves per CU.  (With the bias table and an 80-column g_x tile it was 27.5 KB = 5 waves per CU against the 8 the registers allow.)
+constexpr int XT_LIVE_ROWS = 76;
 __host__ __device__ constexpr int train_lds_floats(int ntiles, bool bwd) {
-  return ntiles * 32 + XT_FLOATS + (bwd ? NODE_STRIDE * GX_STRIDE : 0);
+  return bwd ? XT_LIVE_ROWS * 32 + NODE_DIM * GX_STRIDE : ntiles * 32 + XT_FLOATS;
 }
+static_assert(XT_LIVE_ROWS * 32 + NODE_DIM * GX_STRIDE >= XT_FLOATS, "the prologue writes all 80 rows of the row tile");
 
 // which group / 32-edge tile does workgroup `block` own?
 __device__ __forceinline__ void train_locate(const TrainTpArgs& A, int block, int& grp, int& e0, int& e_end) {
@@ -74,7 +79,7 @@ __device__ __forceinline__ void train_prologue(const TrainTpArgs& A, const float
   const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
   for (int sg = 0; sg < OpsF32::NFRAG; ++sg) a[sg] = gp[(size_t)3 * OpsF32::TILE_FRAGS + sg * 64 + lane];
-  {
+  if (bias_l) {
     const f32x4* gb = reinterpret_cast<const f32x4*>(wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS;
     constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
     f32x4 bt[NBI];
@@ -207,9 +212,8 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   constexpr ConvShape S = conv_shape(IN, OUT);
   constexpr int WP = (S.ntiles - 3) * 32;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* bias_l = lds;
-  float* xT = lds + S.ntiles * 32;
-  float* gxT = xT + XT_FLOATS;   // [NODE_STRIDE][GX_STRIDE] gradient wrt the gathered row, column-major per edge
+  float* xT = lds;
+  float* gxT = xT + XT_LIVE_ROWS * 32;   // [NODE_DIM][GX_STRIDE] gradient wrt the gathered row, column-major per edge (see train_lds_floats)
   const int lane = threadIdx.x, j = lane & 31, hf = lane >> 5;
   int grp = 0, e0 = 0, e_end = 0;
   train_locate(A, blockIdx.x, grp, e0, e_end);
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(wstream);   // wave-uniform stream base (tp_conv_dev.h: gemm_u)
   f32x4 a[OpsF32::NFRAG];
   OpsF32::Act h1;
-  train_prologue<IN, OUT>(A, wstream, bias_l, xT, lane, ec, gp, a, h1);
+  train_prologue<IN, OUT>(A, wstream, nullptr, xT, lane, ec, gp, a, h1);
   const f32x4 vv = reinterpret_cast<const f32x4*>(A.vec)[ec];
   const float v[3] = {vv.x, vv.y, vv.z};
   // this lane's slice of d loss / d msg in the accumulator layout: 0e rows (r&3) + 8(r>>2) + 4hf; vector outputs 3hf..3hf+2
@@ -238,14 +242,28 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
   }
 #pragma unroll
   for (int o = 0; o < 3; ++o) g0o[o] = OUT >= 3 ? gm[COL_0O + 3 * hf + o] : 0.f;
-  for (int k = lane; k < NODE_STRIDE * GX_STRIDE; k += 64) gxT[k] = 0.f;
+  for (int k = lane; k < NODE_DIM * GX_STRIDE; k += 64) gxT[k] = 0.f;     // (after the prologue's writes to the rows it overlaps)
   __syncthreads();
 
   int T = 3;
   f32x16 acc;
+  // the tile's 32 bias floats in the accumulator layout: this lane half's float4s 2q + hf of row T of the stream's bias table, requested
+  // one tile ahead with a wave-uniform base (the whole MFMA chain of the previous tile covers the latency)
+  const GPtr<f32x4> gbias = (GPtr<f32x4>)(reinterpret_cast<const f32x4*>(wstream) + (size_t)(S.ntiles + 1) * OpsF32::TILE_FRAGS);
+  f32x4 bq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = gbias[(size_t)T * 8 + hf + 2 * q];
 #define CBD_TT()                                                                                              \
   {                                                                                                           \
-    gemm_tile_u<OpsF32>(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, lane, bias_l + T * 32, h1, acc, hf);            \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                           \
+      acc[4 * q + 0] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w; \
+    }                                                                                                         \
+    {                                                                                                         \
+      GPtr<f32x4> pb = gbias + (size_t)(T + 1) * 8;                                                           \
+      pin_s(pb);                                                                                              \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) bq[q] = pb[hf + 2 * q];                                   \
+    }                                                                                                         \
+    OpsF32::gemm_u(a, gp + (size_t)(T + 1) * OpsF32::TILE_FRAGS, lane, h1, acc);                              \
     ++T;                                                                                                      \
   }
   const float* xc = xT + j;
@@ -355,8 +373,10 @@ __global__ __launch_bounds__(64, 2) void tp_train_bwd_kernel(TrainTpArgs A) {
 #undef CBD_TT
   __syncthreads();
   const int nrow = e_end - e0 < WAVE_EDGES ? e_end - e0 : WAVE_EDGES;
-  for (int col = lane; col < NODE_STRIDE; col += 64)
-    for (int jj = 0; jj < nrow; ++jj) A.gx[(size_t)(e0 + jj) * NODE_STRIDE + col] = gxT[col * GX_STRIDE + jj];
+  for (int col = lane; col < NODE_STRIDE; col += 64) {
+    const bool live = col < NODE_DIM;
+    for (int jj = 0; jj < nrow; ++jj) A.gx[(size_t)(e0 + jj) * NODE_STRIDE + col] = live ? gxT[col * GX_STRIDE + jj] : 0.f;
+  }
 }
 
 template <int IN, int OUT>
