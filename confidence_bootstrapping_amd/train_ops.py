@@ -1079,3 +1079,39 @@ def edge_geometry(pos_a, pos_b, idx_a, idx_b, expansion=None, raw=False, unit=Tr
     _check(_bind(load_library()).cbd_edge_geometry(E, _ptr(pos_a), _ptr(pos_b), p(idx_a), p(idx_b), K, p(mu), coeff, p(raw4), p(unit4), p(smear),
                                                    _stream_handle()))
     return raw4, unit4, smear
+
+
+FUSED_LOSS = True       # False: the loss as torch ops (training.loss_from_targets; kept for the equivalence test)
+
+
+class ScoreLossFn(torch.autograd.Function):
+    """The denoising score-matching loss (apply_mean form) and its gradient with respect to the predictions on cbd_score_loss: one
+    launch forward (which also writes the gradients), one small multiply per prediction backward.  Returns the reference's 11 values
+    as one [11] tensor (reference utils/training.py:17-126)."""
+
+    @staticmethod
+    def forward(ctx, tr_pred, rot_pred, tor_pred, tr_score, tr_sigma, rot_score, rot_norm, tor_score, tor_norm2, weights, has_tor):
+        lib = _bind(load_library())
+        f = lambda t: None if t is None else t.contiguous().float()
+        tr_pred, rot_pred, tor_pred, tr_score, tr_sigma, rot_score, rot_norm, tor_score, tor_norm2 = (
+            f(t) for t in (tr_pred, rot_pred, tor_pred, tr_score, tr_sigma, rot_score, rot_norm, tor_score, tor_norm2))
+        B = tr_pred.shape[0]
+        T = int(tor_pred.numel()) if (has_tor and tor_pred is not None) else 0
+        out = torch.empty(11, device=tr_pred.device, dtype=torch.float32)
+        g_tr, g_rot = torch.empty_like(tr_pred), torch.empty_like(rot_pred)
+        g_tor = torch.empty(T, device=tr_pred.device, dtype=torch.float32)
+        p = lambda t: None if (t is None or t.numel() == 0) else _ptr(t)
+        _check(lib.cbd_score_loss(B, T, int(bool(has_tor)), _ptr(tr_pred), _ptr(tr_score), _ptr(tr_sigma), _ptr(rot_pred), _ptr(rot_score),
+                                  _ptr(rot_norm), p(tor_pred), p(tor_score), p(tor_norm2), float(weights[0]), float(weights[1]),
+                                  float(weights[2]), _ptr(out), _ptr(g_tr), _ptr(g_rot), p(g_tor), _stream_handle()))
+        ctx.save_for_backward(g_tr, g_rot, g_tor)
+        ctx.tor_shape = None if tor_pred is None else tor_pred.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        g_tr, g_rot, g_tor = ctx.saved_tensors
+        k = gout[0]
+        return (g_tr * k if ctx.needs_input_grad[0] else None, g_rot * k if ctx.needs_input_grad[1] else None,
+                (g_tor * k).reshape(ctx.tor_shape) if (ctx.needs_input_grad[2] and ctx.tor_shape is not None) else None,
+                None, None, None, None, None, None, None, None)

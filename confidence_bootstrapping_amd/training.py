@@ -50,6 +50,15 @@ def loss_from_targets(tr_pred, rot_pred, tor_pred, tg, tr_weight=1, rot_weight=1
                       data=None):
     """The arithmetic of the loss on device tensors (`tg` from loss_targets) -> the reference's 11-tuple."""
     dev = tr_pred.device
+    if apply_mean and dev.type == "cuda":
+        from . import train_ops
+        if train_ops.FUSED_LOSS and tr_pred.dtype == torch.float32 and (no_torsion or tor_pred is not None):
+            # one launch for the 11 values and the gradients of the three predictions (csrc/train_loss.hip)
+            o = train_ops.ScoreLossFn.apply(tr_pred, rot_pred, None if no_torsion else tor_pred, tg["tr_score"], tg["tr_sigma"].reshape(-1),
+                                            tg["rot_score"], tg["rot_score_norm"].reshape(-1), None if no_torsion else tg["tor_score"],
+                                            None if no_torsion else tg["tor_score_norm2"], (tr_weight, rot_weight, tor_weight), not no_torsion)
+            d = o.detach()
+            return (o[0:1],) + tuple(d[k:k + 1] for k in range(1, 11))
     mean_dims = (0, 1) if apply_mean else 1
     zeros = lambda: torch.zeros(1 if apply_mean else tr_pred.shape[0], dtype=torch.float, device=dev)
     tr_score, tr_sigma = tg["tr_score"], tg["tr_sigma"]

@@ -402,6 +402,16 @@ int cbd_radius_fill(int64_t n_query, const float* x_dev, const float* y_dev, con
 int cbd_edge_geometry(int64_t n_edges, const float* pos_a_dev, const float* pos_b_dev, const int64_t* idx_a_dev, const int64_t* idx_b_dev,
                       int32_t n_mu, const float* mu_dev, float coeff, float* raw4_dev, float* unit4_dev, float* smear_dev, void* stream);
 
+/* Denoising score-matching loss of the fine-tuning step and its gradient with respect to the predictions in one launch
+ * (reference utils/training.py:17-126 `loss_function` with apply_mean=True, differentiated by `loss.backward()` at utils/training.py:205).
+ * tr / rot tensors [n_graphs][3], tr_sigma / rot_norm [n_graphs], torsion tensors [n_tor]; has_tor = 0 for no_torsion models.
+ * out11 = the reference's 11-tuple (loss, tr, rot, tor, 0, 0, tr_base, rot_base, tor_base, 0, 0); g_* = d loss / d prediction.
+ * Sums in double in a fixed order.  A batch without rotatable bonds gives NaN torsion terms, like the mean of an empty tensor. */
+int cbd_score_loss(int32_t n_graphs, int32_t n_tor, int32_t has_tor, const float* tr_pred_dev, const float* tr_score_dev,
+                   const float* tr_sigma_dev, const float* rot_pred_dev, const float* rot_score_dev, const float* rot_norm_dev,
+                   const float* tor_pred_dev, const float* tor_score_dev, const float* tor_norm2_dev, float tr_weight, float rot_weight,
+                   float tor_weight, float* out11_dev, float* g_tr_dev, float* g_rot_dev, float* g_tor_dev, void* stream);
+
 /* Edge grouping for cbd_segment_sum without a host synchronisation: perm[n] = STABLE argsort of index[n] (values in [0, n_rows)),
  * rowptr[r] = number of indices < r for r in [0, n_rows] (what `torch.argsort(index, stable=True)` + a bincount/cumsum give the training
  * graph of utils/training.py:198-205; torch's stable sort synchronises the stream).  Everything is enqueued on `stream`; scratch is the

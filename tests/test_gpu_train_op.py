@@ -187,3 +187,43 @@ def test_stream_hub_path_equals_the_per_block_streams():
             assert float(wa.abs().max()) == 0.0 and float(ba.abs().max()) == 0.0 and wb is None
             continue
         assert float((wa - wb).abs().max()) <= 2e-6 * float(wb.abs().max()) and float((ba - bb).abs().max()) <= 2e-6 * float(bb.abs().max()), blk
+
+
+def test_fused_score_loss_equals_the_torch_form():
+    """cbd_score_loss (training.loss_from_targets with train_ops.FUSED_LOSS) against the torch-op form of the same function (reference
+    utils/training.py:17-126, apply_mean=True): the 11 values to 1e-6 relative, the gradients of the three predictions to 1e-6 of their
+    largest entry; a batch without rotatable bonds gives a NaN loss in both; no_torsion models get a zero torsion term."""
+    import confidence_bootstrapping_amd.train_ops as to
+    from confidence_bootstrapping_amd.training import loss_from_targets
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    B, T = 7, 43
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+    tg = {"tr_score": r(B, 3), "tr_sigma": (r(B, 1).abs() + 0.3), "rot_score": r(B, 3), "rot_score_norm": (r(B, 1).abs() + 0.5),
+          "tor_score": r(T), "tor_score_norm2": (r(T).abs() + 0.2)}
+
+    def run(fused, T_, no_torsion=False):
+        preds = [r(B, 3).requires_grad_(), r(B, 3).requires_grad_(), r(T_).requires_grad_()]
+        t2 = dict(tg, tor_score=tg["tor_score"][:T_], tor_score_norm2=tg["tor_score_norm2"][:T_])
+        to.FUSED_LOSS = fused
+        try:
+            out = loss_from_targets(preds[0], preds[1], None if no_torsion else preds[2], t2, 0.4, 0.35, 0.25, True, no_torsion)
+        finally:
+            to.FUSED_LOSS = True
+        (out[0] * 1.7).sum().backward()
+        return [float(o.detach()) for o in out], [p.grad for p in preds]
+    for T_, no_tor in ((T, False), (T, True), (0, False)):
+        g.manual_seed(11)
+        va, ga = run(True, T_, no_tor)
+        g.manual_seed(11)
+        vb, gb = run(False, T_, no_tor)
+        for x, y in zip(va, vb):
+            assert (np.isnan(x) and np.isnan(y)) or abs(x - y) <= 1e-6 * max(abs(y), 1e-3), (T_, no_tor, va, vb)
+        if T_ > 0:
+            for k, (x, y) in enumerate(zip(ga, gb)):
+                if k == 2 and no_tor:
+                    assert x is None and y is None
+                    continue
+                assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()), (T_, no_tor, k)
+        else:
+            assert np.isnan(va[0]) and np.isnan(vb[0])
