@@ -103,6 +103,10 @@ SYMBOLS = {
     "cbd_edge_cat": (C.c_int, [C.c_int64, _P, _P, C.c_int32, _P, _P, _P, _P]),
     "cbd_edge_cat_backward": (C.c_int, [C.c_int64, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_gather_pad": (C.c_int, [C.c_int64, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    "cbd_center_tp_forward": (C.c_int, [C.c_int64, _P, C.c_int32, _P, _P, _P, _P]),
+    "cbd_center_tp_backward": (C.c_int, [C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P]),
+    "cbd_bond_tp_forward": (C.c_int, [C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_bond_tp_backward": (C.c_int, [C.c_int64, _P, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_score_loss": (C.c_int, [C.c_int32, C.c_int32, C.c_int32] + [_P] * 9 + [C.c_float] * 3 + [_P] * 5),
     "cbd_edge_geometry": (C.c_int, [C.c_int64, _P, _P, _P, _P, C.c_int32, _P, C.c_float, _P, _P, _P, _P]),
     "cbd_radius_count": (C.c_int, [C.c_int64, _P, _P, _P, C.c_float, _P, _P, C.c_int64, C.c_int32, _P, _P]),

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import so3, torus
+from . import so3, torus, train_ops
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
 from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
@@ -467,6 +467,8 @@ def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_leve
 def center_tensor_product(x, vec, w):
     """o3.FullyConnectedTensorProduct(74-irreps, '1x0e+1x1o', '2x1o+2x1e') with per-edge weights (final_conv.tp,
     models/tensor_layers.py:185): instruction-major weights [0e*1o->1o | 1o*0e->1o | 1o*1o->1e | 1e*0e->1e | 1e*1o->1o | 0o*1o->1e]."""
+    if train_ops.FUSED_HEADS and x.is_cuda and x.shape[0] > 0:
+        return train_ops.CenterTpFn.apply(x, vec, w)
     E = x.shape[0]
     v = SQ3 * F.normalize(vec, dim=-1)
     x0e, x1o, x1e, x0o = x[:, :32], x[:, 32:50].reshape(E, 6, 3), x[:, 50:68].reshape(E, 6, 3), x[:, 68:74]
@@ -489,6 +491,8 @@ def bond_tensor_product(x, edge_vec, bond_vec, w):
     """final_tp_tor (o3.FullTensorProduct('1x0e+1x1o', '2e')) followed by tor_bond_conv.tp (FCTP with two live paths):
     1o x T1 -> 32x0e (weights [0:192]) and 1e x T1 -> 32x0o ([192:384]); output order [0o | 0e].  T1 is the 1o block of the
     full product: (3/sqrt2)(b b^T - I/3)(sqrt3 v) for unit bond direction b and unit edge direction v (score_model.py:431-441)."""
+    if train_ops.FUSED_HEADS and x.is_cuda and x.shape[0] > 0:
+        return train_ops.BondTpFn.apply(x, edge_vec, bond_vec, w)
     E = x.shape[0]
     v = SQ3 * F.normalize(edge_vec, dim=-1)
     b = F.normalize(bond_vec, dim=-1)

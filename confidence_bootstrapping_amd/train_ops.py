@@ -1115,3 +1115,52 @@ class ScoreLossFn(torch.autograd.Function):
         return (g_tr * k if ctx.needs_input_grad[0] else None, g_rot * k if ctx.needs_input_grad[1] else None,
                 (g_tor * k).reshape(ctx.tor_shape) if (ctx.needs_input_grad[2] and ctx.tor_shape is not None) else None,
                 None, None, None, None, None, None, None, None)
+
+
+FUSED_HEADS = True      # False: the heads' tensor products as torch ops (train_forward.center_tensor_product / bond_tensor_product)
+
+
+class CenterTpFn(torch.autograd.Function):
+    """final_conv.tp with per-edge weights (reference models/score_model.py:245-255) on cbd_center_tp_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, x, vec, w):
+        lib = _bind(load_library())
+        x, vec, w = x.contiguous().float(), vec.contiguous().float(), w.contiguous().float()
+        n = x.shape[0]
+        out = torch.empty(n, 12, device=x.device, dtype=torch.float32)
+        _check(lib.cbd_center_tp_forward(n, _ptr(x), x.shape[1], _ptr(vec), _ptr(w), _ptr(out), _stream_handle()))
+        ctx.save_for_backward(x, vec, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, vec, w = ctx.saved_tensors
+        lib = _bind(load_library())
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        _check(lib.cbd_center_tp_backward(x.shape[0], _ptr(x), x.shape[1], _ptr(vec), _ptr(w), _ptr(g.contiguous().float()), _ptr(gx), _ptr(gw),
+                                          _stream_handle()))
+        return gx, None, gw
+
+
+class BondTpFn(torch.autograd.Function):
+    """final_tp_tor + tor_bond_conv.tp (reference models/score_model.py:257-274, 431-441) on cbd_bond_tp_forward / _backward."""
+
+    @staticmethod
+    def forward(ctx, x, edge_vec, bond_vec, w):
+        lib = _bind(load_library())
+        x, edge_vec, bond_vec, w = (t.contiguous().float() for t in (x, edge_vec, bond_vec, w))
+        n = x.shape[0]
+        out = torch.empty(n, 64, device=x.device, dtype=torch.float32)
+        _check(lib.cbd_bond_tp_forward(n, _ptr(x), x.shape[1], _ptr(edge_vec), _ptr(bond_vec), _ptr(w), _ptr(out), _stream_handle()))
+        ctx.save_for_backward(x, edge_vec, bond_vec, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, edge_vec, bond_vec, w = ctx.saved_tensors
+        lib = _bind(load_library())
+        gx, gw = torch.empty_like(x), torch.empty_like(w)
+        _check(lib.cbd_bond_tp_backward(x.shape[0], _ptr(x), x.shape[1], _ptr(edge_vec), _ptr(bond_vec), _ptr(w), _ptr(g.contiguous().float()),
+                                        _ptr(gx), _ptr(gw), _stream_handle()))
+        return gx, None, None, gw

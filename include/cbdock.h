@@ -402,6 +402,20 @@ int cbd_radius_fill(int64_t n_query, const float* x_dev, const float* y_dev, con
 int cbd_edge_geometry(int64_t n_edges, const float* pos_a_dev, const float* pos_b_dev, const int64_t* idx_a_dev, const int64_t* idx_b_dev,
                       int32_t n_mu, const float* mu_dev, float coeff, float* raw4_dev, float* unit4_dev, float* smear_dev, void* stream);
 
+/* The two e3nn heads of the score model in the fine-tuning step, one launch each way (csrc/train_heads.hip).
+ * Centre convolution: final_conv.tp = o3.FullyConnectedTensorProduct(74-irreps, '1x0e+1x1o', '2x1o+2x1e') with per-edge weights
+ * (reference models/score_model.py:245-255, 393-404 under utils/training.py:203-205): x [n][ldx] (74 columns read), vec [n][3] (not
+ * normalised; no gradient), w [n][124] instruction-major, out [n][12] = [2x1o | 2x1e]; backward writes gx [n][ldx] and gw [n][124].
+ * Torsion head: final_tp_tor (o3.FullTensorProduct('1x0e+1x1o', '2e')) + tor_bond_conv.tp (models/score_model.py:257-274, 431-441):
+ * x [n][ldx], edge_vec / bond_vec [n][3], w [n][384], out [n][64] = [32x0o | 32x0e]. */
+int cbd_center_tp_forward(int64_t n, const float* x_dev, int32_t ldx, const float* vec_dev, const float* w_dev, float* out_dev, void* stream);
+int cbd_center_tp_backward(int64_t n, const float* x_dev, int32_t ldx, const float* vec_dev, const float* w_dev, const float* gout_dev,
+                           float* gx_dev, float* gw_dev, void* stream);
+int cbd_bond_tp_forward(int64_t n, const float* x_dev, int32_t ldx, const float* edge_vec_dev, const float* bond_vec_dev, const float* w_dev,
+                        float* out_dev, void* stream);
+int cbd_bond_tp_backward(int64_t n, const float* x_dev, int32_t ldx, const float* edge_vec_dev, const float* bond_vec_dev, const float* w_dev,
+                         const float* gout_dev, float* gx_dev, float* gw_dev, void* stream);
+
 /* Denoising score-matching loss of the fine-tuning step and its gradient with respect to the predictions in one launch
  * (reference utils/training.py:17-126 `loss_function` with apply_mean=True, differentiated by `loss.backward()` at utils/training.py:205).
  * tr / rot tensors [n_graphs][3], tr_sigma / rot_norm [n_graphs], torsion tensors [n_tor]; has_tor = 0 for no_torsion models.

@@ -227,3 +227,51 @@ def test_fused_score_loss_equals_the_torch_form():
                 assert float((x - y).abs().max()) <= 1e-6 * float(y.abs().max()), (T_, no_tor, k)
         else:
             assert np.isnan(va[0]) and np.isnan(vb[0])
+
+
+def test_fused_heads_equal_the_torch_forms():
+    """cbd_center_tp_* / cbd_bond_tp_* (train_ops.CenterTpFn / BondTpFn) against the torch-op forms of the two e3nn heads
+    (train_forward.center_tensor_product / bond_tensor_product, which the reference's training step g11 pins): outputs and the gradients
+    with respect to the node rows and the per-edge weights to 2e-6 of their largest entry; the padding columns of wider rows get zero
+    gradient; a zero direction vector is handled like F.normalize does (no NaN)."""
+    import confidence_bootstrapping_amd.train_ops as to
+    import confidence_bootstrapping_amd.train_forward as tf
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: torch.randn(*s, generator=g).to(dev)
+
+    def both(fn, make):
+        res = []
+        for fused in (True, False):
+            args = make()
+            to.FUSED_HEADS = fused
+            try:
+                out = fn(*args)
+            finally:
+                to.FUSED_HEADS = True
+            gout = make.gout
+            (out * gout).sum().backward()
+            res.append((out.detach(), [a.grad for a in args if a.requires_grad]))
+        (oa, ga), (ob, gb) = res
+        assert float((oa - ob).abs().max()) <= 2e-6 * float(ob.abs().max())
+        for x, y in zip(ga, gb):
+            assert torch.isfinite(x).all() and float((x - y).abs().max()) <= 2e-6 * float(y.abs().max())
+        return ga
+
+    for n, ldx in ((133, 74), (5, 80)):
+        x0, vec, w0 = r(n, ldx), r(n, 3), r(n, 124)
+        vec[0] = 0.0                                   # F.normalize: x / max(|x|, 1e-12) -> zero direction
+
+        def make():
+            return [x0.clone().requires_grad_(), vec, w0.clone().requires_grad_()]
+        make.gout = r(n, 12)
+        ga = both(tf.center_tensor_product, make)
+        if ldx > 74:
+            assert float(ga[0][:, 74:].abs().max()) == 0.0
+    for n in (257, 3):
+        x0, ev, bv, w0 = r(n, 74), r(n, 3), r(n, 3), r(n, 384)
+
+        def make():
+            return [x0.clone().requires_grad_(), ev, bv, w0.clone().requires_grad_()]
+        make.gout = r(n, 64)
+        both(tf.bond_tensor_product, make)
