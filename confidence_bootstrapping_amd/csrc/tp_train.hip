@@ -617,7 +617,14 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
   float* vS = xT + NODE_STRIDE * 32;            // [32][4]
   float* mT = vS + 32 * 4;                      // [tile slots][16][32]  mids of the block's edges
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, rho = lane & 31, hf = lane >> 5;
-  const int Tb = blockIdx.x * DW_TILES_PER_WG;  // first tile of this workgroup
+  // XCD-aware mapping: the workgroups of one edge chunk (one per tile group) all read the same h / g_msg / row blocks.  Workgroups go
+  // round-robin over the 8 XCDs by their linear id, each XCD with an L2 of its own: the tile groups of a chunk are therefore given linear
+  // ids that are congruent mod 8, so that a chunk's edge data is fetched into ONE L2 instead of eight (grid.y is padded to a multiple
+  // of 8 chunks; the padding workgroups exit).
+  const int lin = blockIdx.x + gridDim.x * blockIdx.y, xcd = lin & 7, slot = lin >> 3;
+  const int bx = slot % (int)gridDim.x, by = (slot / (int)gridDim.x) * 8 + xcd;
+  if (by >= A.g_chunk0[A.n_groups]) return;
+  const int Tb = bx * DW_TILES_PER_WG;          // first tile of this workgroup
   const int T0 = __builtin_amdgcn_readfirstlane(Tb + wave);                  // this wave's second-Linear tile (wave-uniform)
   const bool live0 = T0 < NTW;
   int mrow0, gcol0;
@@ -634,9 +641,9 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
   int grp = 0;
 #pragma unroll
   for (int g = 1; g < TRAIN_MAX_GROUPS; ++g)
-    if (g < A.n_groups && (int)blockIdx.y >= A.g_chunk0[g]) grp = g;
+    if (g < A.n_groups && by >= A.g_chunk0[g]) grp = g;
   const int e_lo = A.g_lo[grp], e_hi = A.g_hi[grp], bpc = A.g_bpc[grp];
-  const int b_lo = ((int)blockIdx.y - A.g_chunk0[grp]) * bpc;
+  const int b_lo = (by - A.g_chunk0[grp]) * bpc;
   const int n_blk = min(bpc, (e_hi - e_lo + 31) / 32 - b_lo);
   // staging through registers: block b + 1 is in flight from global memory while block b is multiplied
   f32x4 hr[3], gr[3], xr[3], vr4;
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
       db0 += x0;
     }
   }
-  float* out = A.partial + (size_t)blockIdx.y * (WP * KDIM + WP);
+  float* out = A.partial + (size_t)by * (WP * KDIM + WP);
   // D layout: lane (n, hf) holds rows (r & 3) + 8 (r >> 2) + 4 hf of column n
   auto store = [&](int T, const f32x16& c0, const f32x16& c1, const f32x16& c2, float db) {
 #pragma unroll
@@ -725,7 +732,7 @@ __global__ __launch_bounds__(256) void tp_train_dw_kernel(TrainDwArgs A) {
 template <int IN, int OUT>
 static hipError_t launch_train_dw(const TrainDwArgs& a, int n_chunks, hipStream_t s) {
   constexpr int NTW = conv_shape(IN, OUT).ntiles - 3;
-  hipLaunchKernelGGL((tp_train_dw_kernel<IN, OUT>), dim3((NTW + DW_TILES_PER_WG - 1) / DW_TILES_PER_WG, n_chunks), dim3(256), DW_LDS_FLOATS * 4, s, a);
+  hipLaunchKernelGGL((tp_train_dw_kernel<IN, OUT>), dim3((NTW + DW_TILES_PER_WG - 1) / DW_TILES_PER_WG, (n_chunks + 7) / 8 * 8), dim3(256), DW_LDS_FLOATS * 4, s, a);
   return hipGetLastError();
 }
 
