@@ -22,6 +22,8 @@
 // regrouped per output irrep block with 1/sqrt(fan_in), sqrt(3), sqrt(1.5) folded, then the bias table); g_w columns are
 // (tile - 3) * 32 + row of that stream.  The Python side maps them back to the reference parameter layout
 // (confidence_bootstrapping_amd/train_ops.py).
+#include <type_traits>
+
 #include "host_util.h"
 #include "kernels.h"
 #include "tp_conv_dev.h"
@@ -137,48 +139,90 @@ __global__ __launch_bounds__(64, 2) void tp_train_fwd_kernel(TrainTpArgs A) {
   float o0e[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) o0e[r] = 0.f;
-#pragma unroll 1
-  for (int i = 0; i < S.t0e; ++i) {
+  // (the epilogue forms of the inference kernel, tp_conv.hip: the 0e mid is read from LDS BEFORE the tile's MFMA chain -- two loops, one per
+  //  kind of mid, so that neither body branches on the mid index -- and the vector-block tile loops are fully unrolled: compile-time mid
+  //  kinds, a tile's LDS reads issued together before the chain, scalar x direction mids factored out of the sums)
+  auto tile0e = [&](float m) __attribute__((always_inline)) {
     CBD_TT();
-    const float m = mid0e<IN>(xc, i, v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0e[r] = fmaf(m, acc[r], o0e[r]);
+  };
+#pragma unroll 1
+  for (int i = 0; i < NS; ++i) tile0e(xc[i * 32]);
+  if constexpr (IN >= 1) {
+#pragma unroll 1
+    for (int i = NS; i < S.t0e; ++i) {
+      const float* p = xc + (COL_1O + 3 * (i - NS)) * 32;
+      tile0e(p[0] * v[0] + p[32] * v[1] + p[64] * v[2]);
+    }
   }
   float k1o[9], k1e[9], k0o[3];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
   k0o[0] = k0o[1] = k0o[2] = 0.f;
-  auto vec_block = [&](auto mid_fn, int ntile, float (&keep)[9]) __attribute__((always_inline)) {
-#pragma unroll 1
+  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep)[9]) __attribute__((always_inline)) {
+    constexpr int ntile = decltype(ntile_c)::value, fan = decltype(fan_c)::value;
+    float sc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
     for (int t = 0; t < ntile; ++t) {
+      float m[VEC_TILE_I][3], xs[VEC_TILE_I];
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        const int i = VEC_TILE_I * t + q;
+        if (i >= fan) continue;
+        if (is_scalar(i)) xs[q] = scalar_of(xc, i);
+        else mid_fn(xc, i, v, m[q]);
+      }
       CBD_TT();
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
-        float m[3];
-        mid_fn(xc, VEC_TILE_I * t + q, v, m);
+        const int i = VEC_TILE_I * t + q;
+        if (i >= fan) continue;
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
           const float w = acc[3 * q + o];
-          keep[3 * o + 0] = fmaf(m[0], w, keep[3 * o + 0]);
-          keep[3 * o + 1] = fmaf(m[1], w, keep[3 * o + 1]);
-          keep[3 * o + 2] = fmaf(m[2], w, keep[3 * o + 2]);
+          if (is_scalar(i)) {
+            sc[o] = fmaf(xs[q], w, sc[o]);
+          } else {
+            keep[3 * o + 0] = fmaf(m[q][0], w, keep[3 * o + 0]);
+            keep[3 * o + 1] = fmaf(m[q][1], w, keep[3 * o + 1]);
+            keep[3 * o + 2] = fmaf(m[q][2], w, keep[3 * o + 2]);
+          }
         }
       }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) pin(sc[o]);
     }
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) keep[3 * o + c] = fmaf(v[c], sc[o], keep[3 * o + c]);
   };
-  vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, u, m); }, S.t1o, k1o);
+  vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
+            [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
+            std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o);
   if constexpr (OUT >= 2)
-    vec_block([](const float* x, int i, const float (&u)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, u, m); }, S.t1e, k1e);
+    vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
+              [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
+              std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e);
   if constexpr (OUT >= 3) {
-#pragma unroll 1
+#pragma unroll
     for (int t = 0; t < S.t0o; ++t) {
+      float m[VEC_TILE_I];
+#pragma unroll
+      for (int q = 0; q < VEC_TILE_I; ++q) {
+        if (VEC_TILE_I * t + q >= S.fan0o) continue;
+        m[q] = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+      }
       CBD_TT();
 #pragma unroll
       for (int q = 0; q < VEC_TILE_I; ++q) {
-        const float m = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+        if (VEC_TILE_I * t + q >= S.fan0o) continue;
 #pragma unroll
-        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m, acc[3 * q + o], k0o[o]);
+        for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m[q], acc[3 * q + o], k0o[o]);
       }
+#pragma unroll
+      for (int o = 0; o < 3; ++o) pin(k0o[o]);
     }
   }
 #undef CBD_TT
