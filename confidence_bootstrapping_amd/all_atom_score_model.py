@@ -148,6 +148,16 @@ class TensorProductScoreModel(nn.Module):
             self._engine_key = key
         return self._engine
 
+    def co_engines(self, n: int, main):
+        """`n` further confidence engines on the device of `main` (own weights copy, own complex / workspace): the partners of `main`
+        in cbd_conf_score_multi -- sampling() scores the final poses of a co-scheduled group of complexes in one set of launches."""
+        from .engine import ConfidenceEngine
+        if getattr(self, "_co_main", None) is not main:
+            self._co, self._co_main = [], main
+        while len(self._co) < n:
+            self._co.append(ConfidenceEngine.from_model(self, main.device, max_batch=main.max_batch))
+        return self._co[:n]
+
     def forward(self, data):
         """Same contract as the reference forward in confidence mode (models/all_atom_score_model.py:363-454):
         returns (confidence [B], atom_confidence [B*Nl, 1]).  `data` is a Batch of poses of ONE complex carrying the

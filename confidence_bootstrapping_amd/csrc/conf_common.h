@@ -84,13 +84,19 @@ struct CGroup {
   float* first_sum;      // [tiles][CN_STRIDE]
   float* last_sum;       // [tiles][CN_STRIDE]
   float* run_acc;        // row = aggregating node (joint index; pointer pre-offset by the node type's base)
+  const float* node_in;  // [N][CN_STRIDE] node features of the pose batch this group belongs to
 };
 
+// One launch carries the groups of up to four pose batches (cbd_conf_score_multi: the final poses of the complexes of a co-scheduled
+// group are scored together, so that a launch covers ~60 rounds of resident waves instead of ~15 and the last, partly filled round
+// costs 1 % instead of 6 %).
+constexpr int CONF_MAX_BATCHES = 4;
+constexpr int CONF_LAUNCH_GROUPS = CONF_MAX_GROUPS * CONF_MAX_BATCHES;
 struct CArgs {
-  CGroup g[CONF_MAX_GROUPS];
+  CGroup g[CONF_LAUNCH_GROUPS];
   int n_groups;
-  const float* node_in;  // [N][CN_STRIDE]
 };
+static_assert(sizeof(CArgs) <= 4096, "CArgs is passed by value: HIP kernel arguments are limited to 4 KB");
 
 struct CFinGroup {
   const int* start;      // [nodes of the type]

@@ -623,124 +623,183 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
   return 0;
 }
 
-int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float crop_beyond, float* confidence_dev,
-                   float* atom_confidence_dev, void* stream) {
-  if (!e || !pos_dev || !confidence_dev) return fail(CBD_ERR_ARG, "null argument");
-  if (!e->complex_ready) return fail(CBD_ERR_STATE, "cbd_conf_set_complex has not been called");
-  if (B < 1 || B > e->cfg.max_batch) return fail(CBD_ERR_CAPACITY, "batch of %d poses exceeds the engine capacity %d", B, e->cfg.max_batch);
-  HIPCHK(hipSetDevice(e->cfg.device));
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+// One pose batch inside a (multi-)score call
+namespace {
+struct ConfPass {
+  cbd_conf_engine* e;
+  int B;
+  ConfDyn cd;
+  float *Xin, *Xout;
+  float* racc[CONF_MAX_GROUPS];
+  const float* attr_of[CONF_MAX_GROUPS];
+  const float* vec_of[CONF_MAX_GROUPS];
+  float* conf_out;
+  float* atom_out;
+};
+}  // namespace
+
+// CBD_CONF_TRACE=1: synchronise after every stage and name it on stderr (fault localisation)
+static int conf_stage(const char* name, hipStream_t s) {
+  static const bool trace = getenv("CBD_CONF_TRACE") != nullptr;
+  if (!trace) return 0;
+  fprintf(stderr, "[cbd_conf] %s ...", name);
+  HIPCHK(hipStreamSynchronize(s));
+  fprintf(stderr, " ok\n");
+  return 0;
+}
+
+// crop + graphs + pose-dependent edge embeddings + initial node features of one pose batch
+static int conf_prepare(ConfPass& P, const float* pos_dev, float crop_beyond, hipStream_t s) {
+  cbd_conf_engine* e = P.e;
+  const int B = P.B;
   const ConfStatic& cs = e->cs;
-  ConfDyn cd = e->cd;
-  cd.pos = pos_dev;
+  P.cd = e->cd;
+  P.cd.pos = pos_dev;
+  ConfDyn& cd = P.cd;
   const int Nl = cs.Nl, Nr = cs.Nr, Na = cs.Na;
   const int nL = B * Nl, nR = B * Nr, nA = B * Na;
   e->last_stream = s;
   e->last_B = B;
   e->dbg.clear();
-
-  // CBD_CONF_TRACE=1: synchronise after every stage and name it on stderr (fault localisation)
-  static const bool trace = getenv("CBD_CONF_TRACE") != nullptr;
-  auto stage = [&](const char* name) -> int {
-    if (!trace) return 0;
-    fprintf(stderr, "[cbd_conf] %s ...", name);
-    HIPCHK(hipStreamSynchronize(s));
-    fprintf(stderr, " ok\n");
-    return 0;
-  };
-  // ---- crop + graphs
   const float crop2 = crop_beyond > 0 ? crop_beyond * crop_beyond : std::numeric_limits<float>::infinity();
   HIPCHK(conf_launch_keep(cs, cd, B, crop2, s));
-  CHK(stage("keep"));
+  CHK(conf_stage("keep", s));
   const float r = e->cfg.lig_max_radius;
   const int n_nodes[CONF_MAX_GROUPS] = {nL, nL, nL, nR, nR, nR, nA, nA, nA};
   HIPCHK(conf_launch_graph_lig(false, cs, cd, B, r * r, e->cfg.lig_radius_cap, e->cfg.cross_cutoff, s));
-  CHK(stage("count lig"));
+  CHK(conf_stage("count lig", s));
   HIPCHK(conf_launch_scan(cd, G_LL, G_LA + 1, n_nodes, s));
-  CHK(stage("scan lig"));
+  CHK(conf_stage("scan lig", s));
   HIPCHK(conf_launch_graph_lig(true, cs, cd, B, r * r, e->cfg.lig_radius_cap, e->cfg.cross_cutoff, s));
-  CHK(stage("fill lig"));
+  CHK(conf_stage("fill lig", s));
   HIPCHK(conf_launch_graph_rec_atom(false, cs, cd, B, s));
-  CHK(stage("count rec/atom"));
+  CHK(conf_stage("count rec/atom", s));
   HIPCHK(conf_launch_scan(cd, G_RR, G_AR + 1, n_nodes, s));
-  CHK(stage("scan rec/atom"));
+  CHK(conf_stage("scan rec/atom", s));
   HIPCHK(conf_launch_graph_rec_atom(true, cs, cd, B, s));
-  CHK(stage("fill rec/atom"));
+  CHK(conf_stage("fill rec/atom", s));
   // ---- pose-dependent edge embeddings
   HIPCHK(conf_launch_edge_mlp(e->m_ll, cd.ll_dist, cd.ll_bond4, cd.total + G_LL, e->cap[G_LL], e->ll_attr, s));
   HIPCHK(conf_launch_edge_mlp(e->m_lr, cd.lr_dist, nullptr, cd.total + G_LR, e->cap[G_LR], e->lr_attr, s));
   HIPCHK(conf_launch_edge_mlp(e->m_la, cd.la_dist, nullptr, cd.total + G_LA, e->cap[G_LA], e->la_attr, s));
-  CHK(stage("edge mlps"));
+  CHK(conf_stage("edge mlps", s));
   // ---- node features
-  float *Xin = e->X0, *Xout = e->X1;
-  HIPCHK(conf_launch_node_init(e->lig_base, e->rec_base, e->atom_base, B, Nl, Nr, Na, Xin, s));
-
+  P.Xin = e->X0; P.Xout = e->X1;
+  HIPCHK(conf_launch_node_init(e->lig_base, e->rec_base, e->atom_base, B, Nl, Nr, Na, P.Xin, s));
   const float* attr_of[CONF_MAX_GROUPS] = {e->ll_attr, e->lr_attr, e->la_attr, e->rr_attr, e->lr_attr, e->ar_attr, e->aa_attr, e->la_attr, e->ar_attr};
   const float* vec_of[CONF_MAX_GROUPS] = {cd.ll_vec, cd.lr_vec, cd.la_vec, e->rr_vec, cd.lr_vec, e->ar_vec, e->aa_vec, cd.la_vec, e->ar_vec};
   // run_acc is addressed by JOINT node index: pre-offset each buffer by its node type's base for this batch size
   const size_t type_base[CONF_MAX_GROUPS] = {0, 0, 0, (size_t)nL, (size_t)nL, (size_t)nL, (size_t)nL + nR, (size_t)nL + nR, (size_t)nL + nR};
-  float* racc[CONF_MAX_GROUPS];
-  for (int g = 0; g < CONF_MAX_GROUPS; ++g) racc[g] = e->racc[g] - type_base[g] * CN_STRIDE;
-  // conv grid = tiles of the actual capacity for this B (blocks past the device-side counts exit immediately)
-  auto tiles_cap = [&](int g) {
-    const double frac = (double)B / e->cfg.max_batch;
-    return (int)((size_t)std::ceil(e->cap[g] * frac) / WAVE_EDGES + 1);
-  };
-  for (int l = 0; l < 5; ++l) {
-    const CLayerDev& L = e->conv[l];
-    const FctpShape S = fctp_shape(L.in_level, L.out_level);
-    CArgs a{};
-    a.n_groups = L.n_groups;
-    a.node_in = Xin;
-    int grid = 0;
-    for (int g = 0; g < L.n_groups; ++g) {
-      a.g[g] = CGroup{cd.src[g], cd.dst[g], cd.aidx[g], vec_of[g], attr_of[g], L.wstream[g], cd.total + g, e->fsum[g], e->lsum[g], racc[g]};
-      grid += tiles_cap(g);
-    }
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (e->timing) {
-      if (e->ev_used == e->ev_pool.size()) {
-        hipEvent_t x, y;
-        HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
-        e->ev_pool.emplace_back(x, y);
-      }
-      ev0 = e->ev_pool[e->ev_used].first; ev1 = e->ev_pool[e->ev_used].second;
-      ++e->ev_used;
-      HIPCHK(hipEventRecord(ev0, s));
-    }
-    HIPCHK(launch_fctp_conv(L.in_level, L.out_level, a, grid, s));
-    if (e->timing) HIPCHK(hipEventRecord(ev1, s));
-    CHK(stage("conv"));
-    const int n_types = l == 4 ? 1 : 3;
-    const int type_nodes[3] = {nL, nR, nA}, type_off[3] = {0, nL, nL + nR};
-    for (int t = 0; t < n_types; ++t) {
-      CFinArgs fa{};
-      fa.n_groups = 3;
-      for (int k = 0; k < 3; ++k) {
-        const int g = 3 * t + k;
-        fa.g[k] = CFinGroup{cd.start[g], cd.cnt[g], e->fsum[g], e->lsum[g], racc[g]};
-      }
-      HIPCHK(launch_fctp_finalize(fa, Xin, Xout, L.bn_scale, L.bn_mean, L.bn_bias, type_nodes[t], S.in_dim, S.out_dim, type_off[t], s));
-    }
-    CHK(stage("finalize"));
-    std::swap(Xin, Xout);
-    if (e->keep_debug) {
-      HIPCHK(hipStreamSynchronize(s));
-      std::vector<float> h((size_t)nL * CN_STRIDE);
-      HIPCHK(hipMemcpy(h.data(), Xin, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-      e->dbg["lig_layer" + std::to_string(l + 1)] = std::move(h);
-    }
-  }
-  HIPCHK(conf_launch_heads(e->atom_head, e->conf_head, Xin, B, Nl, atom_confidence_dev ? atom_confidence_dev : e->atom_conf_scratch,
-                           confidence_dev, s));
-  CHK(stage("heads"));
-  if (e->keep_debug) {
-    HIPCHK(hipStreamSynchronize(s));
-    std::vector<int> keep((size_t)nR);
-    HIPCHK(hipMemcpy(keep.data(), cd.keep_res, keep.size() * sizeof(int), hipMemcpyDeviceToHost));
-    e->dbg["keep_res"] = std::vector<float>(keep.begin(), keep.end());
+  for (int g = 0; g < CONF_MAX_GROUPS; ++g) {
+    P.attr_of[g] = attr_of[g]; P.vec_of[g] = vec_of[g];
+    P.racc[g] = e->racc[g] - type_base[g] * CN_STRIDE;
   }
   return 0;
+}
+
+// The forward pass of up to CONF_MAX_BATCHES pose batches (one engine = one complex each): everything per batch except the fused conv
+// kernel, which runs ONCE per layer for all of them.
+static int conf_score_impl(int n, cbd_conf_engine* const* engines, const int32_t* Bs, const float* const* pos_dev, float crop_beyond,
+                           float* const* confidence_dev, float* const* atom_confidence_dev, hipStream_t s) {
+  if (n < 1 || n > CONF_MAX_BATCHES) return fail(CBD_ERR_ARG, "1 .. %d pose batches per call", CONF_MAX_BATCHES);
+  ConfPass P[CONF_MAX_BATCHES];
+  for (int k = 0; k < n; ++k) {
+    cbd_conf_engine* e = engines[k];
+    if (!e || !pos_dev[k] || !confidence_dev[k]) return fail(CBD_ERR_ARG, "null argument");
+    if (!e->complex_ready) return fail(CBD_ERR_STATE, "cbd_conf_set_complex has not been called");
+    if (Bs[k] < 1 || Bs[k] > e->cfg.max_batch) return fail(CBD_ERR_CAPACITY, "batch of %d poses exceeds the engine capacity %d", Bs[k], e->cfg.max_batch);
+    if (e->cfg.device != engines[0]->cfg.device) return fail(CBD_ERR_ARG, "the engines of one call must live on one device");
+    for (int q = 0; q < k; ++q)
+      if (engines[q] == e) return fail(CBD_ERR_ARG, "an engine may appear once per call");
+    P[k].e = e; P[k].B = Bs[k]; P[k].conf_out = confidence_dev[k];
+    P[k].atom_out = atom_confidence_dev && atom_confidence_dev[k] ? atom_confidence_dev[k] : e->atom_conf_scratch;
+  }
+  cbd_conf_engine* e0 = engines[0];
+  HIPCHK(hipSetDevice(e0->cfg.device));
+  for (int k = 0; k < n; ++k) CHK(conf_prepare(P[k], pos_dev[k], crop_beyond, s));
+
+  for (int l = 0; l < 5; ++l) {
+    const CLayerDev& L0 = e0->conv[l];
+    const FctpShape S = fctp_shape(L0.in_level, L0.out_level);
+    CArgs a{};
+    int grid = 0;
+    for (int k = 0; k < n; ++k) {
+      cbd_conf_engine* e = P[k].e;
+      const CLayerDev& L = e->conv[l];
+      const ConfDyn& cd = P[k].cd;
+      // conv grid = tiles of the actual capacity for this B (blocks past the device-side counts exit immediately)
+      const double frac = (double)P[k].B / e->cfg.max_batch;
+      for (int g = 0; g < L.n_groups; ++g) {
+        a.g[a.n_groups++] = CGroup{cd.src[g], cd.dst[g], cd.aidx[g], P[k].vec_of[g], P[k].attr_of[g], L.wstream[g], cd.total + g,
+                                   e->fsum[g], e->lsum[g], P[k].racc[g], P[k].Xin};
+        grid += (int)((size_t)std::ceil(e->cap[g] * frac) / WAVE_EDGES + 1);
+      }
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e0->timing) {      // a merged launch is timed by the first engine
+      if (e0->ev_used == e0->ev_pool.size()) {
+        hipEvent_t x, y;
+        HIPCHK(hipEventCreate(&x)); HIPCHK(hipEventCreate(&y));
+        e0->ev_pool.emplace_back(x, y);
+      }
+      ev0 = e0->ev_pool[e0->ev_used].first; ev1 = e0->ev_pool[e0->ev_used].second;
+      ++e0->ev_used;
+      HIPCHK(hipEventRecord(ev0, s));
+    }
+    HIPCHK(launch_fctp_conv(L0.in_level, L0.out_level, a, grid, s));
+    if (e0->timing) HIPCHK(hipEventRecord(ev1, s));
+    CHK(conf_stage("conv", s));
+    for (int k = 0; k < n; ++k) {
+      cbd_conf_engine* e = P[k].e;
+      const CLayerDev& L = e->conv[l];
+      const ConfDyn& cd = P[k].cd;
+      const ConfStatic& cs = e->cs;
+      const int nL = P[k].B * cs.Nl, nR = P[k].B * cs.Nr, nA = P[k].B * cs.Na;
+      const int n_types = l == 4 ? 1 : 3;
+      const int type_nodes[3] = {nL, nR, nA}, type_off[3] = {0, nL, nL + nR};
+      for (int t = 0; t < n_types; ++t) {
+        CFinArgs fa{};
+        fa.n_groups = 3;
+        for (int q = 0; q < 3; ++q) {
+          const int g = 3 * t + q;
+          fa.g[q] = CFinGroup{cd.start[g], cd.cnt[g], e->fsum[g], e->lsum[g], P[k].racc[g]};
+        }
+        HIPCHK(launch_fctp_finalize(fa, P[k].Xin, P[k].Xout, L.bn_scale, L.bn_mean, L.bn_bias, type_nodes[t], S.in_dim, S.out_dim, type_off[t], s));
+      }
+      std::swap(P[k].Xin, P[k].Xout);
+      if (e->keep_debug) {
+        HIPCHK(hipStreamSynchronize(s));
+        std::vector<float> h((size_t)nL * CN_STRIDE);
+        HIPCHK(hipMemcpy(h.data(), P[k].Xin, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+        e->dbg["lig_layer" + std::to_string(l + 1)] = std::move(h);
+      }
+    }
+    CHK(conf_stage("finalize", s));
+  }
+  for (int k = 0; k < n; ++k) {
+    cbd_conf_engine* e = P[k].e;
+    HIPCHK(conf_launch_heads(e->atom_head, e->conf_head, P[k].Xin, P[k].B, e->cs.Nl, P[k].atom_out, P[k].conf_out, s));
+    if (e->keep_debug) {
+      HIPCHK(hipStreamSynchronize(s));
+      std::vector<int> keep((size_t)P[k].B * e->cs.Nr);
+      HIPCHK(hipMemcpy(keep.data(), P[k].cd.keep_res, keep.size() * sizeof(int), hipMemcpyDeviceToHost));
+      e->dbg["keep_res"] = std::vector<float>(keep.begin(), keep.end());
+    }
+  }
+  CHK(conf_stage("heads", s));
+  return 0;
+}
+
+int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float crop_beyond, float* confidence_dev,
+                   float* atom_confidence_dev, void* stream) {
+  if (!e || !pos_dev || !confidence_dev) return fail(CBD_ERR_ARG, "null argument");
+  return conf_score_impl(1, &e, &B, &pos_dev, crop_beyond, &confidence_dev, &atom_confidence_dev, reinterpret_cast<hipStream_t>(stream));
+}
+
+int cbd_conf_score_multi(int32_t n, cbd_conf_engine* const* engines, const int32_t* B, const float* const* pos_dev, float crop_beyond,
+                         float* const* confidence_dev, float* const* atom_confidence_dev, void* stream) {
+  if (!engines || !B || !pos_dev || !confidence_dev) return fail(CBD_ERR_ARG, "null argument");
+  return conf_score_impl(n, engines, B, pos_dev, crop_beyond, confidence_dev, atom_confidence_dev, reinterpret_cast<hipStream_t>(stream));
 }
 
 int cbd_conf_check(cbd_conf_engine* e) {

@@ -12,6 +12,7 @@
 // group of 4 mids; vector blocks (6 outputs) use tiles of 5 mid indices x 6 outputs.  The Clebsch-Gordan contraction
 // runs on the VALU with canonical intermediates x, x.n, x n, x cross n and (n n^T - I/3) x; the e3nn path weights,
 // sqrt(2l+1) spherical-harmonic scales and Wigner-3j constants are folded into the packed weights.
+#include <cstddef>
 #include <type_traits>
 
 #include "conf_common.h"
@@ -136,19 +137,32 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   const int lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
 
+  // which group / tile?  The edge counts live on the device: lane g reads group g's count (one vector load for all groups; a scalar
+  // loop costs two dependent scalar loads per group), a wave prefix sum turns tile counts into ranges, a ballot finds the owner.
   int grp = -1, e0 = 0, cnt = 0, tile_local = 0;
   {
-    int t = blockIdx.x;
-    for (int g = 0; g < args.n_groups; ++g) {
-      const int c = *args.g[g].count;
-      const int nt = (c + WAVE_EDGES - 1) / WAVE_EDGES;
-      if (grp < 0) {
-        if (t < nt) { grp = g; e0 = t * WAVE_EDGES; cnt = c; tile_local = t; }
-        else t -= nt;
-      }
+    static_assert(CONF_LAUNCH_GROUPS <= 64, "one lane per group");
+    int c = 0;
+    if (lane < args.n_groups) {
+      const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+      const int* cp = *reinterpret_cast<const int* const*>(ka + offsetof(CArgs, g) + (size_t)lane * sizeof(CGroup) + offsetof(CGroup, count));
+      c = *cp;
     }
+    const int nt = (c + WAVE_EDGES - 1) / WAVE_EDGES;
+    int incl = nt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    const int t = blockIdx.x;
+    const unsigned long long owner = __ballot(t >= incl - nt && t < incl);
+    if (owner == 0) return;
+    grp = __builtin_ctzll(owner);
+    cnt = __builtin_amdgcn_readlane(c, grp);
+    tile_local = t - (__builtin_amdgcn_readlane(incl, grp) - __builtin_amdgcn_readlane(nt, grp));
+    e0 = tile_local * WAVE_EDGES;
   }
-  if (grp < 0) return;
   const CGroup G = args.g[grp];
 
   const GPtr<f32x4> gp = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(G.wstream);   // uniform; tile T fragment sg of this lane: gp[T*576 + sg*64 + lane]
@@ -177,8 +191,8 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   float Bx[CKSTEPS];   // [edge_attr(24) | x_src[:24] | x_dst[:24]]; lane half hf holds columns 12hf .. 12hf+11 of each part
   {
     const f32x4* pa = reinterpret_cast<const f32x4*>(G.attr + (size_t)aidx * CNS + 12 * hf);
-    const f32x4* ps = reinterpret_cast<const f32x4*>(args.node_in + (size_t)src_r * CN_STRIDE + 12 * hf);
-    const f32x4* pd = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * CN_STRIDE + 12 * hf);
+    const f32x4* ps = reinterpret_cast<const f32x4*>(G.node_in + (size_t)src_r * CN_STRIDE + 12 * hf);
+    const f32x4* pd = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * CN_STRIDE + 12 * hf);
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const f32x4 aa = pa[q], s = ps[q], d = pd[q];
@@ -187,7 +201,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       Bx[24 + 4 * q + 0] = d.x; Bx[24 + 4 * q + 1] = d.y; Bx[24 + 4 * q + 2] = d.z; Bx[24 + 4 * q + 3] = d.w;
     }
     // full destination row (21 float4) -> transposed LDS copy; half 0 copies float4 0..10, half 1 copies 10..20
-    const f32x4* pr = reinterpret_cast<const f32x4*>(args.node_in + (size_t)dst * CN_STRIDE) + 10 * hf;
+    const f32x4* pr = reinterpret_cast<const f32x4*>(G.node_in + (size_t)dst * CN_STRIDE) + 10 * hf;
 #pragma unroll
     for (int q = 0; q < 11; ++q) {
       const f32x4 r = pr[q];

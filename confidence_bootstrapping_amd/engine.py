@@ -72,6 +72,7 @@ SYMBOLS = {
     "cbd_conf_finalize_weights": (C.c_int, [_P]),
     "cbd_conf_set_complex": (C.c_int, [_P] + [C.c_int32] * 6 + [_P] * 10),
     "cbd_conf_score": (C.c_int, [_P, C.c_int32, _P, C.c_float, _P, _P, _P]),
+    "cbd_conf_score_multi": (C.c_int, [C.c_int32, _P, C.POINTER(C.c_int32), _P, C.c_float, _P, _P, _P]),
     "cbd_conf_check": (C.c_int, [_P]),
     "cbd_conf_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "cbd_conf_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_int64]),
@@ -568,6 +569,27 @@ class ConfidenceEngine:
             if check:
                 _check(self.lib.cbd_conf_check(self.h))
         return conf, atom.unsqueeze(1)
+
+    @staticmethod
+    def score_multi(engines, poses, crop_beyond=None, check=True):
+        """The pose batches of up to four complexes (one engine each, `poses[k]` [B_k, Nl_k, 3]) in ONE set of fused-conv launches
+        (cbd_conf_score_multi; bitwise the results of separate score() calls) -> list of (confidence, atom_confidence)."""
+        e0, n = engines[0], len(engines)
+        if n == 1:
+            return [e0.score(poses[0], crop_beyond, check=check)]
+        poses = [p.to(e0.device, torch.float32).contiguous() for p in poses]
+        conf = [torch.empty(p.shape[0], device=e0.device) for p in poses]
+        atom = [torch.empty(p.shape[0] * e.Nl, device=e0.device) for p, e in zip(poses, engines)]
+        hs = (C.c_void_p * n)(*[e.h for e in engines])
+        Bs = (C.c_int32 * n)(*[int(p.shape[0]) for p in poses])
+        arr = lambda ts: (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+        with torch.cuda.device(e0.device):
+            stream = C.c_void_p(torch.cuda.current_stream(e0.device).cuda_stream)
+            _check(e0.lib.cbd_conf_score_multi(n, hs, Bs, arr(poses), float(crop_beyond or 0.0), arr(conf), arr(atom), stream))
+            if check:
+                for e in engines:
+                    _check(e.lib.cbd_conf_check(e.h))
+        return [(c, a.unsqueeze(1)) for c, a in zip(conf, atom)]
 
     def check(self):
         """cbd_conf_check: synchronises and raises if any score() since the last check exceeded a per-atom edge capacity."""

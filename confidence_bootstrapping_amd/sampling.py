@@ -401,6 +401,17 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             work[0][1].sample(work[0][2], steps, *work[0][3])
         else:
             DockEngine.sample_multi([w[1] for w in work], [w[2] for w in work], steps, [w[3] for w in work])
+        # Confidence of the group's final poses: up to four complexes per set of fused-conv launches (cbd_conf_score_multi: a launch then
+        # covers ~4x the waves and its last, partly filled round of resident waves costs ~1 % instead of ~6 %).  No host sync per
+        # complex: the capacity flag of a confidence engine is sticky and checked once at the end.
+        from .engine import ConfidenceEngine
+        scored = []          # (confidence engine, poses, crop) waiting to be scored together
+
+        def score_waiting():
+            if scored:
+                for c, _ in ConfidenceEngine.score_multi([p[0] for p in scored], [p[1] for p in scored], scored[0][2], check=False):
+                    confidence.append(c)
+                scored.clear()
         for pend, e, pos, _, batch0 in work:
             first, B, Nl = pend[0][0], pos.shape[0], pos.shape[1]
             flat = pos.reshape(B * Nl, 3)
@@ -415,13 +426,18 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 fg, _, fNl = _single_all_atom_complex(fbatch)
                 if fNl != Nl:
                     raise RuntimeError("filtering graphs hold a different ligand than the sampled ones")
-                ceng = conf_model.engine(max_batch=eng.max_batch)
+                cmain = conf_model.engine(max_batch=eng.max_batch)
+                # the k-th complex of a group gets the k-th confidence engine (cbd_conf_score_multi takes one engine per complex)
+                k = len(scored)
+                ceng = cmain if k == 0 else conf_model.co_engines(k, cmain)[k - 1]
                 ckey = complex_fingerprint(fbatch) + (fg["atom"].pos.shape[0],)
                 if ceng.complex_key != ckey:
                     ceng.set_complex(fg, ckey)
-                # no host sync per complex: the capacity flag of the confidence engine is sticky, checked once at the end
-                confidence.append(ceng.score(pos, crop, check=False)[0])
+                scored.append((ceng, pos, crop))
                 conf_engines_used.add(ceng)
+                if len(scored) == 4:
+                    score_waiting()
+        score_waiting()
         groups.clear()
 
     def drop_stale_capacity_flags(exc_type):

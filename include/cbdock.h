@@ -230,6 +230,13 @@ int cbd_conf_set_complex(cbd_conf_engine* e, int32_t Nl, int32_t Nr, int32_t Na,
  * Outputs (device fp32): confidence_dev [B], atom_confidence_dev [B*Nl] (may be NULL).  Asynchronous on `stream`. */
 int cbd_conf_score(cbd_conf_engine* e, int32_t B, const float* pos_dev, float crop_beyond, float* confidence_dev,
                    float* atom_confidence_dev, void* stream);
+/* The same for the pose batches of up to four complexes (one engine each, all on one device) in ONE set of fused-conv launches: the
+ * final poses of a co-scheduled group (cbd_sample_multi) are scored together, so a launch carries ~4x the waves and its last, partly
+ * filled round of resident waves costs ~1 % instead of ~6 % (no reference counterpart: the reference scores one batch at a time,
+ * utils/sampling.py:240-261).  Arrays of n entries; atom_confidence_dev (or any entry of it) may be NULL.  Results are bitwise those
+ * of n cbd_conf_score calls.  Kernel timing (cbd_conf_kernel_timing) of the merged launches is recorded by engines[0]. */
+int cbd_conf_score_multi(int32_t n, cbd_conf_engine* const* engines, const int32_t* B, const float* const* pos_dev, float crop_beyond,
+                         float* const* confidence_dev, float* const* atom_confidence_dev, void* stream);
 /* After the work of the last cbd_conf_score has completed: 0 if EVERY cbd_conf_score since the previous check was valid,
  * CBD_ERR_CAPACITY if a per-atom edge capacity was exceeded in any of them (their results must be discarded; the flag is sticky
  * and cleared by this call, so several batches -- also of different complexes -- can be scored back to back and checked once).

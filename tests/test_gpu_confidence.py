@@ -172,3 +172,24 @@ def test_end_to_end_demo_runs():
     from tools.dock_demo import main
     conf, rmsds = main(["--samples", "6", "--steps", "3", "--workload", "tiny", "--batch-size", "4"])
     assert conf.shape == (6,) and torch.isfinite(conf).all() and torch.isfinite(rmsds).all()
+
+
+def test_confidence_score_multi_equals_separate_calls(conf_model):
+    """cbd_conf_score_multi: the pose batches of several complexes (different sizes, different batch sizes) in one set of fused-conv
+    launches give bitwise the confidences and atom confidences of separate cbd_conf_score calls; an engine may appear only once."""
+    from confidence_bootstrapping_amd.synthetic import make_workload
+    from confidence_bootstrapping_amd.engine import ConfidenceEngine
+    model, _ = conf_model
+    main = model.engine()
+    engines = [main] + model.co_engines(2, main)
+    cplxs = [make_workload("tiny", all_atoms=True), make_workload("c2_dockgen_median", seed=77, all_atoms=True),
+             make_workload("tiny", seed=5, all_atoms=True)]
+    poses = [_poses(c, B, 20 + k, 1.5).cuda() for k, (c, B) in enumerate(zip(cplxs, (3, 5, 2)))]
+    for e, c in zip(engines, cplxs):
+        e.set_complex(c)
+    single = [e.score(p, crop_beyond=20.0) for e, p in zip(engines, poses)]
+    multi = ConfidenceEngine.score_multi(engines, poses, crop_beyond=20.0)
+    for (c1, a1), (c2, a2) in zip(single, multi):
+        assert torch.isfinite(c1).all() and torch.equal(c1, c2) and torch.equal(a1, a2)
+    with pytest.raises(RuntimeError, match="once per call"):
+        ConfidenceEngine.score_multi([main, main], poses[:1] * 2, crop_beyond=20.0)
