@@ -26,16 +26,19 @@ __device__ __forceinline__ f32x16 cmfma32(float a, float b, f32x16 c) {
 
 // `next` is the wave-uniform base of the next tile (an SGPR pair; one pinned base per four 1-KB fragments because the immediate field
 // holds < 4 KB), the lane adds its constant offset: no vector address arithmetic per tile (see tp_conv_dev.h)
-__device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], GPtr<f32x4> next, int lane, const float* __restrict__ bias_l,
+// The tile's 32 bias floats (accumulator layout: this lane half's float4s 2q + hf of the stream's bias row) sit in `bq`, requested from
+// global memory one tile ahead -- the previous tile's MFMA chain covers the latency -- and are replaced by the next tile's here (as in
+// tp_train_bwd_kernel: no bias table in LDS, 11 KB instead of 19.8 KB per wave).
+__device__ __forceinline__ void cgemm_tile(f32x4 (&a)[CKSTEPS / 4], GPtr<f32x4> next, int lane, f32x4 (&bq)[4], GPtr<f32x4> next_bias,
                                            const float (&B)[CKSTEPS], f32x16& acc, int hf) {
-  GPtr<f32x4> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64;
-  pin_s(p0); pin_s(p1); pin_s(p2);
-  const f32x4* bp = reinterpret_cast<const f32x4*>(bias_l);
+  GPtr<f32x4> p0 = next, p1 = next + 4 * 64, p2 = next + 8 * 64, pb = next_bias;
+  pin_s(p0); pin_s(p1); pin_s(p2); pin_s(pb);
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f32x4 b = bp[2 * q + hf];
-    acc[4 * q + 0] = b.x; acc[4 * q + 1] = b.y; acc[4 * q + 2] = b.z; acc[4 * q + 3] = b.w;
+    acc[4 * q + 0] = bq[q].x; acc[4 * q + 1] = bq[q].y; acc[4 * q + 2] = bq[q].z; acc[4 * q + 3] = bq[q].w;
   }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) bq[q] = pb[hf + 2 * q];
 #pragma unroll
   for (int sg = 0; sg < CKSTEPS / 4; ++sg) {
     const f32x4 w = a[sg];
@@ -125,14 +128,13 @@ __device__ __forceinline__ float cmid0o(const float* xc, int i, const float (&n)
 
 constexpr int C_OUT_STRIDE = 33;
 constexpr int CXT_FLOATS = CN_STRIDE * C_OUT_STRIDE;   // gathered rows [84][32], later the message tile [84][33]
-__host__ __device__ constexpr int fctp_lds_floats(int ntiles) { return ntiles * 32 + CXT_FLOATS + 32; }
+__host__ __device__ constexpr int fctp_lds_floats(int ntiles) { return CXT_FLOATS + 32; }
 
 template <int IN, int OUT>
 __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   constexpr FctpShape S = fctp_shape(IN, OUT);
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* bias_l = lds;
-  float* xT = lds + S.ntiles * 32;
+  float* xT = lds;
   int* srcl = reinterpret_cast<int*>(xT + CXT_FLOATS);
   const int lane = threadIdx.x;
   const int j = lane & 31, hf = lane >> 5;
@@ -169,15 +171,10 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   f32x4 a[CKSTEPS / 4];
 #pragma unroll
   for (int sg = 0; sg < CKSTEPS / 4; ++sg) a[sg] = gp[sg * 64 + lane];
-  {
-    const f32x4* gb = reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * CTILE_W_FLOATS);
-    constexpr int NB4 = S.ntiles * 8, NBI = (NB4 + 63) / 64;
-    f32x4 bt[NBI];
+  const GPtr<f32x4> gbias = (GPtr<f32x4>)reinterpret_cast<const f32x4*>(G.wstream + (size_t)(S.ntiles + 1) * CTILE_W_FLOATS);   // [ntiles + 1][32]
+  f32x4 bq[4];
 #pragma unroll
-    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; bt[i] = gb[k < NB4 ? k : NB4 - 1]; }
-#pragma unroll
-    for (int i = 0; i < NBI; ++i) { const int k = lane + 64 * i; reinterpret_cast<f32x4*>(bias_l)[k < NB4 ? k : NB4 - 1] = bt[i]; }
-  }
+  for (int q = 0; q < 4; ++q) bq[q] = gbias[hf + 2 * q];
 
   const int e = e0 + j;
   const bool valid = e < cnt;
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   f32x16 acc;
   float h1[CKSTEPS];
 #define CBD_CTILE(BOP)                                                                             \
-  cgemm_tile(a, gp + (size_t)(T + 1) * (CTILE_W_FLOATS / 4), lane, bias_l + T * 32, BOP, acc, hf); \
+  cgemm_tile(a, gp + (size_t)(T + 1) * (CTILE_W_FLOATS / 4), lane, bq, gbias + (size_t)(T + 1 < S.ntiles ? T + 1 : T) * 8, BOP, acc, hf); \
   ++T
 
   // ---- first Linear: 72 hidden units = two full tiles + 8 live rows (registers 0..3 of both halves) of a third
