@@ -38,6 +38,7 @@ struct FctpShape {
   int n1o, n1e, n0o;
   int fan0e, fan1o, fan1e, fan0o;
   int g0e, t1o, t1e, g0o;     // scalar blocks: groups of 4 mids (3 tiles each; 2 for a tail of <= 2 mids); vector blocks: tiles of 5 mids
+  int merged;                 // 1: the half-empty second tail tile of block 0e rides in the free rows of block 0o's (see fctp_shape)
   int ntiles;
   int weight_numel;           // 720 / 972 / 1224 / 1944
   int in_dim, out_dim;
@@ -65,7 +66,10 @@ __host__ __device__ constexpr FctpShape fctp_shape(int IN, int OUT) {
   s.t1o = (s.fan1o + C_VEC_TILE_I - 1) / C_VEC_TILE_I;
   s.t1e = (s.fan1e + C_VEC_TILE_I - 1) / C_VEC_TILE_I;
   s.g0o = (s.fan0o + C_SC_TILE_I - 1) / C_SC_TILE_I;
-  s.ntiles = 3 + sc_block_tiles(s.fan0e) + s.t1o + s.t1e + sc_block_tiles(s.fan0o);
+  // Both scalar blocks of the 2 -> 3 and 3 -> 3 layers end in a dense tail whose tile B has 16 live rows (octet 2 of two mids): block 0e's
+  // are packed into slots 2, 3 of block 0o's tile B instead of a tile of their own (-1 tile of 67 / 48).
+  s.merged = OUT >= 3 && s.g0e > 0 && s.g0o > 0 && sc_tail_dense(s.fan0e, s.g0e - 1) && sc_tail_dense(s.fan0o, s.g0o - 1) ? 1 : 0;
+  s.ntiles = 3 + sc_block_tiles(s.fan0e) + s.t1o + s.t1e + sc_block_tiles(s.fan0o) - s.merged;
   s.weight_numel = s.fan0e * CNS + s.fan1o * CNV + s.fan1e * CNV + s.fan0o * CNS;
   s.in_dim = CNS + 3 * s.n1o + 3 * s.n1e + s.n0o;
   s.out_dim = CNS + 3 * CNV + (OUT >= 2 ? 3 * CNV : 0) + (OUT >= 3 ? CNS : 0);

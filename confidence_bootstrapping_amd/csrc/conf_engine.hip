@@ -165,19 +165,30 @@ static std::vector<float> pack_fctp_stream(int IN, int OUT, const float* W1, con
   };
   int wc[32];
   float sc[32];
+  const std::vector<MidSeg> segs0e = {{0, 0, CNS, 1.f}, {1, 1, S.n1o, 1.f}};
   auto scalar_block = [&](int out_kind, const std::vector<MidSeg>& segs, int fan, int ngroups) {
     for (int g = 0; g < ngroups; ++g) {
       const bool dense = sc_tail_dense(fan, g);       // tail of <= 2 mids: two denser tiles (conf_common.h)
-      for (int q = 0; q < (dense ? 2 : 3); ++q, ++T) {
+      // merged tails (FctpShape::merged): block 0e has no tile B of its own; its rows are slots 2, 3 of block 0o's tile B
+      const int ntile_g = dense ? (S.merged && out_kind == 0 ? 1 : 2) : 3;
+      for (int q = 0; q < ntile_g; ++q, ++T) {
         for (int r = 0; r < 32; ++r) {
           const int slot = r >> 3;
           int i = C_SC_TILE_I * g + slot, w = 8 * q + (r & 7);
-          if (dense) {
-            i = C_SC_TILE_I * g + (slot & 1);
-            w = (q == 0 ? 8 * (slot >> 1) : 16) + (r & 7);
-            if (q == 1 && slot >= 2) i = fan;         // zero rows
+          bool ok;
+          if (dense && q == 1 && slot >= 2) {
+            if (S.merged && out_kind == 3) {
+              const int g0 = S.g0e - 1;
+              ok = column(0, segs0e, S.fan0e, C_SC_TILE_I * g0 + (slot & 1), 16 + (r & 7), &wc[r], &sc[r]);
+            } else ok = false;                        // zero rows
+          } else {
+            if (dense) {
+              i = C_SC_TILE_I * g + (slot & 1);
+              w = (q == 0 ? 8 * (slot >> 1) : 16) + (r & 7);
+            }
+            ok = column(out_kind, segs, fan, i, w, &wc[r], &sc[r]);
           }
-          if (!column(out_kind, segs, fan, i, w, &wc[r], &sc[r])) { wc[r] = -1; sc[r] = 0.f; }
+          if (!ok) { wc[r] = -1; sc[r] = 0.f; }
         }
         fill_tile(T, wc, sc);
       }
@@ -193,7 +204,7 @@ static std::vector<float> pack_fctp_stream(int IN, int OUT, const float* W1, con
       fill_tile(T, wc, sc);
     }
   };
-  scalar_block(0, {{0, 0, CNS, 1.f}, {1, 1, S.n1o, 1.f}}, S.fan0e, S.g0e);
+  scalar_block(0, segs0e, S.fan0e, S.g0e);
   vector_block(1, {{0, 1, CNS, s3}, {1, 0, S.n1o, 1.f}, {1, 2, S.n1o, s45}, {2, 1, S.n1e, s15}}, S.fan1o, S.t1o);
   if (OUT >= 2) vector_block(2, {{1, 1, S.n1o, s15}, {2, 0, S.n1e, 1.f}, {2, 2, S.n1e, s45}, {3, 1, S.n0o, s3}}, S.fan1e, S.t1e);
   if (OUT >= 3) scalar_block(3, {{2, 1, S.n1e, 1.f}, {3, 0, S.n0o, 1.f}}, S.fan0o, S.g0o);

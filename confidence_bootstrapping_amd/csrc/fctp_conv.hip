@@ -246,17 +246,31 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   };
   // tail group of one or two mids in two denser tiles (conf_common.h::sc_tail_dense): tile A carries output octets 0 and 1 of both
   // mids (slot i = (mid i & 1, octet i >> 1)), tile B octet 2 (slots 0, 1)
-  auto scalar_tail = [&](const float (&m)[4], float (&out)[12]) __attribute__((always_inline)) {
+  // With merged tails (FctpShape::merged) block 0e runs tile A only and keeps its two tail mids; block 0o's tile B then carries block
+  // 0e's octet 2 in slots 2, 3.
+  float m0e_tail[2] = {0.f, 0.f};
+  auto scalar_tail = [&](const float (&m)[4], float (&out)[12], auto is_0e_c) __attribute__((always_inline)) {
+    constexpr bool is_0e = decltype(is_0e_c)::value;
     CBD_CTILE(h1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int c = 0; c < 4; ++c) out[4 * (i >> 1) + c] = fmaf(m[i & 1], acc[4 * i + c], out[4 * (i >> 1) + c]);
-    CBD_CTILE(h1);
+    if constexpr (S.merged && is_0e) {
+      m0e_tail[0] = m[0]; m0e_tail[1] = m[1];
+    } else {
+      CBD_CTILE(h1);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) out[8 + c] = fmaf(m[i], acc[4 * i + c], out[8 + c]);
+        for (int c = 0; c < 4; ++c) out[8 + c] = fmaf(m[i], acc[4 * i + c], out[8 + c]);
+      if constexpr (S.merged && !is_0e) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o0e[8 + c] = fmaf(m0e_tail[i], acc[4 * (2 + i) + c], o0e[8 + c]);
+      }
+    }
   };
   constexpr int G0E_PLAIN = CNS / 4;   // groups 0 .. G0E_PLAIN-1 of block 0e read x0e[4g .. 4g+3]
 #pragma unroll 1
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
     float m[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) m[i] = cmid0e<IN>(xc, 4 * g + i, n);
-    if (sc_tail_dense(S.fan0e, g)) scalar_tail(m, o0e);
+    if (sc_tail_dense(S.fan0e, g)) scalar_tail(m, o0e, std::true_type{});
     else scalar_group(m, o0e);
 #pragma unroll
     for (int r = 0; r < 12; ++r) pin(o0e[r]);   // ties the FMAs of an unrolled group to its place (tp_conv.hip)
@@ -336,7 +350,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       float m[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
-      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o);
+      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o, std::false_type{});
       else scalar_group(m, o0o);
 #pragma unroll
       for (int r = 0; r < 12; ++r) pin(o0o[r]);
@@ -352,7 +366,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       float m[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) m[i] = cmid0o<IN>(xc, 4 * g + i, n);
-      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o);
+      if (sc_tail_dense(S.fan0o, g)) scalar_tail(m, o0o, std::false_type{});
       else scalar_group(m, o0o);
 #pragma unroll
       for (int r = 0; r < 12; ++r) pin(o0o[r]);

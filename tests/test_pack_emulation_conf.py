@@ -54,7 +54,9 @@ def emulate(stream, IN, OUT, xin, xrow, n):
     S = shape(IN, OUT)
     dense = lambda fan, g: 1 <= fan - 4 * g <= 2          # tail group of <= 2 mids: two denser tiles (conf_common.h::sc_tail_dense)
     sc_tiles = lambda fan: 0 if fan == 0 else 3 * ((fan + 3) // 4 - 1) + (2 if dense(fan, (fan + 3) // 4 - 1) else 3)
-    nt = 3 + sc_tiles(S["fan0e"]) + S["t1o"] + S["t1e"] + sc_tiles(S["fan0o"])
+    # merged tails (conf_common.h::FctpShape::merged): block 0e has no tile B of its own, its octet 2 rides in slots 2, 3 of block 0o's
+    merged = OUT >= 3 and dense(S["fan0e"], S["g0e"] - 1) and dense(S["fan0o"], S["g0o"] - 1)
+    nt = 3 + sc_tiles(S["fan0e"]) + S["t1o"] + S["t1e"] + sc_tiles(S["fan0o"]) - int(merged)
     assert stream.size == (nt + 1) * TILE_W + nt * 32
     wts, bias = stream[:nt * TILE_W].reshape(nt, TILE_W), stream[(nt + 1) * TILE_W:].reshape(nt, 32)
     tiles = [(wts[k], bias[k]) for k in range(nt)]
@@ -100,9 +102,13 @@ def emulate(stream, IN, OUT, xin, xrow, n):
 
     out = np.zeros((32, STRIDE))
 
+    keeps = {}
+    tail0e = {}
+
     def scalar_block(ngroups, mid, col0, fan):
         nonlocal T
-        keep = np.zeros((12, 64))
+        keep = keeps[col0] = np.zeros((12, 64))
+        is0e = col0 == 0
         for g in range(ngroups):
             if dense(fan, g):         # tile A: slot i = (mid i & 1, output octet i >> 1); tile B: slots 0, 1 = octet 2
                 acc = gemm_tile(tiles[T], h1); T += 1
@@ -111,13 +117,21 @@ def emulate(stream, IN, OUT, xin, xrow, n):
                         m = mid(lane & 31, 4 * g + (i & 1))
                         for c in range(4):
                             keep[4 * (i >> 1) + c, lane] += m * acc[4 * i + c, lane]
+                if merged and is0e:
+                    tail0e["g"] = g
+                    continue
                 acc = gemm_tile(tiles[T], h1); T += 1
                 for lane in range(64):
-                    assert np.all(acc[8:, lane] == 0)
+                    if not merged:
+                        assert np.all(acc[8:, lane] == 0)
                     for i in range(2):
                         m = mid(lane & 31, 4 * g + i)
                         for c in range(4):
                             keep[8 + c, lane] += m * acc[4 * i + c, lane]
+                        if merged:
+                            m0 = mid0e(lane & 31, 4 * tail0e["g"] + i)
+                            for c in range(4):
+                                keeps[0][8 + c, lane] += m0 * acc[4 * (2 + i) + c, lane]
                 continue
             for q in range(3):
                 acc = gemm_tile(tiles[T], h1); T += 1
@@ -126,6 +140,8 @@ def emulate(stream, IN, OUT, xin, xrow, n):
                         m = mid(lane & 31, 4 * g + i)
                         for c in range(4):
                             keep[4 * q + c, lane] += m * acc[4 * i + c, lane]
+    def write_scalar(col0):
+        keep = keeps[col0]
         for lane in range(64):
             for q in range(3):
                 for c in range(4):
@@ -152,6 +168,8 @@ def emulate(stream, IN, OUT, xin, xrow, n):
         vec_block(S["t1e"], mid1e, C1E)
     if OUT >= 3:
         scalar_block(S["g0o"], mid0o, C0O, S["fan0o"])
+        write_scalar(C0O)
+    write_scalar(0)
     assert T == len(tiles)
     return out
 
