@@ -39,6 +39,7 @@ struct FctpShape {
   int fan0e, fan1o, fan1e, fan0o;
   int g0e, t1o, t1e, g0o;     // scalar blocks: groups of 4 mids (3 tiles each; 2 for a tail of <= 2 mids); vector blocks: tiles of 5 mids
   int merged;                 // 1: the half-empty second tail tile of block 0e rides in the free rows of block 0o's (see fctp_shape)
+  int vmerged;                // 1: the mids of block 1o's partly filled last tile ride in the free slots of block 1e's last tile
   int ntiles;
   int weight_numel;           // 720 / 972 / 1224 / 1944
   int in_dim, out_dim;
@@ -69,7 +70,11 @@ __host__ __device__ constexpr FctpShape fctp_shape(int IN, int OUT) {
   // Both scalar blocks of the 2 -> 3 and 3 -> 3 layers end in a dense tail whose tile B has 16 live rows (octet 2 of two mids): block 0e's
   // are packed into slots 2, 3 of block 0o's tile B instead of a tile of their own (-1 tile of 67 / 48).
   s.merged = OUT >= 3 && s.g0e > 0 && s.g0o > 0 && sc_tail_dense(s.fan0e, s.g0e - 1) && sc_tail_dense(s.fan0o, s.g0o - 1) ? 1 : 0;
-  s.ntiles = 3 + sc_block_tiles(s.fan0e) + s.t1o + s.t1e + sc_block_tiles(s.fan0o) - s.merged;
+  // The vector blocks' last tiles are partly filled too (fan % 5 of 5 mid slots): when both remainders fit one tile, block 1o's tail
+  // mids take the slots behind block 1e's (block 1o then runs t1o - 1 tiles of its own).
+  s.vmerged = OUT >= 2 && s.fan1o % C_VEC_TILE_I > 0 && s.fan1e % C_VEC_TILE_I > 0 &&
+              s.fan1o % C_VEC_TILE_I + s.fan1e % C_VEC_TILE_I <= C_VEC_TILE_I ? 1 : 0;
+  s.ntiles = 3 + sc_block_tiles(s.fan0e) + s.t1o + s.t1e + sc_block_tiles(s.fan0o) - s.merged - s.vmerged;
   s.weight_numel = s.fan0e * CNS + s.fan1o * CNV + s.fan1e * CNV + s.fan0o * CNS;
   s.in_dim = CNS + 3 * s.n1o + 3 * s.n1e + s.n0o;
   s.out_dim = CNS + 3 * CNV + (OUT >= 2 ? 3 * CNV : 0) + (OUT >= 3 ? CNS : 0);

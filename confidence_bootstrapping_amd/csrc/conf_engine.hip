@@ -194,18 +194,29 @@ static std::vector<float> pack_fctp_stream(int IN, int OUT, const float* W1, con
       }
     }
   };
+  const std::vector<MidSeg> segs1o = {{0, 1, CNS, s3}, {1, 0, S.n1o, 1.f}, {1, 2, S.n1o, s45}, {2, 1, S.n1e, s15}};
   auto vector_block = [&](int out_kind, const std::vector<MidSeg>& segs, int fan, int ntile) {
-    for (int t = 0; t < ntile; ++t, ++T) {
+    // merged tails (FctpShape::vmerged): block 1o stops one tile early; its tail mids sit behind block 1e's in 1e's last tile
+    const int own = S.vmerged && out_kind == 1 ? ntile - 1 : ntile;
+    const int r1o = S.fan1o % C_VEC_TILE_I, r1e = S.fan1e % C_VEC_TILE_I;
+    for (int t = 0; t < own; ++t, ++T) {
       for (int r = 0; r < 32; ++r) {
         const int reg = (r & 3) + 4 * (r >> 3), hf = (r >> 2) & 1;
-        const int i = C_VEC_TILE_I * t + reg / 3, w = 3 * hf + reg % 3;
-        if (!(reg < 15 && column(out_kind, segs, fan, i, w, &wc[r], &sc[r]))) { wc[r] = -1; sc[r] = 0.f; }
+        const int q = reg / 3, w = 3 * hf + reg % 3;
+        bool ok = false;
+        if (reg < 15) {
+          if (S.vmerged && out_kind == 2 && t == ntile - 1 && q >= r1e)
+            ok = q - r1e < r1o && column(1, segs1o, S.fan1o, C_VEC_TILE_I * (S.t1o - 1) + (q - r1e), w, &wc[r], &sc[r]);
+          else
+            ok = column(out_kind, segs, fan, C_VEC_TILE_I * t + q, w, &wc[r], &sc[r]);
+        }
+        if (!ok) { wc[r] = -1; sc[r] = 0.f; }
       }
       fill_tile(T, wc, sc);
     }
   };
   scalar_block(0, segs0e, S.fan0e, S.g0e);
-  vector_block(1, {{0, 1, CNS, s3}, {1, 0, S.n1o, 1.f}, {1, 2, S.n1o, s45}, {2, 1, S.n1e, s15}}, S.fan1o, S.t1o);
+  vector_block(1, segs1o, S.fan1o, S.t1o);
   if (OUT >= 2) vector_block(2, {{1, 1, S.n1o, s15}, {2, 0, S.n1e, 1.f}, {2, 2, S.n1e, s45}, {3, 1, S.n0o, s3}}, S.fan1e, S.t1e);
   if (OUT >= 3) scalar_block(3, {{2, 1, S.n1e, 1.f}, {3, 0, S.n0o, 1.f}}, S.fan0o, S.g0o);
   return out;

@@ -295,18 +295,28 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
   float k1o[9], k1e[9];
 #pragma unroll
   for (int r = 0; r < 9; ++r) { k1o[r] = 0.f; k1e[r] = 0.f; }
-  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep)[9]) __attribute__((always_inline)) {
+  // `guest`: with merged vector tails (FctpShape::vmerged) block 1o runs one tile less and its `guest_n` tail mids (never of the
+  // scalar x direction kind) occupy slots guest_slot .. of block 1e's last tile, accumulating into block 1o's sums (`gkeep`).
+  auto vec_block = [&](auto mid_fn, auto is_scalar, auto scalar_of, auto ntile_c, auto fan_c, float (&keep)[9], auto guest_n_c, auto guest_base_c,
+                       auto guest_slot_c, auto guest_fn, float (&gkeep)[9]) __attribute__((always_inline)) {
     constexpr int ntile = decltype(ntile_c)::value, fan = decltype(fan_c)::value;
+    constexpr int guest_n = decltype(guest_n_c)::value, guest_base = decltype(guest_base_c)::value, guest_slot = decltype(guest_slot_c)::value;
+    static_assert(guest_n == 0 || guest_base >= CNS, "guest mids must not be of the scalar x direction kind");
     float sc[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < ntile; ++t) {
       float m[C_VEC_TILE_I][3], xs[C_VEC_TILE_I];
+      float gm[guest_n > 0 ? guest_n : 1][3];
 #pragma unroll
       for (int q = 0; q < C_VEC_TILE_I; ++q) {
         const int i = C_VEC_TILE_I * t + q;
         if (i >= fan) continue;
         if (is_scalar(i)) xs[q] = scalar_of(xc, i);
         else mid_fn(xc, i, n, m[q]);
+      }
+      if (t == ntile - 1) {
+#pragma unroll
+        for (int g = 0; g < guest_n; ++g) guest_fn(xc, guest_base + g, n, gm[g]);
       }
       CBD_CTILE(h1);
 #pragma unroll
@@ -325,6 +335,17 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
           }
         }
       }
+      if (t == ntile - 1) {
+#pragma unroll
+        for (int g = 0; g < guest_n; ++g)
+#pragma unroll
+          for (int o = 0; o < 3; ++o) {
+            const float w = acc[3 * (guest_slot + g) + o];
+            gkeep[3 * o + 0] = fmaf(gm[g][0], w, gkeep[3 * o + 0]);
+            gkeep[3 * o + 1] = fmaf(gm[g][1], w, gkeep[3 * o + 1]);
+            gkeep[3 * o + 2] = fmaf(gm[g][2], w, gkeep[3 * o + 2]);
+          }
+      }
 #pragma unroll
       for (int o = 0; o < 3; ++o) pin(sc[o]);
 #pragma unroll
@@ -335,13 +356,18 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) keep[3 * o + c] = fmaf(n[c], sc[o], keep[3 * o + c]);
   };
-  vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1o<IN>(x, i, nn, m); },
-            [](int i) { return i < CNS; }, [](const float* x, int i) { return x[i * 32]; },
-            std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o);
+  auto fn1o = [](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1o<IN>(x, i, nn, m); };
+  constexpr int R1O = S.fan1o % C_VEC_TILE_I, R1E = S.fan1e % C_VEC_TILE_I;
+  using I0 = std::integral_constant<int, 0>;
+  vec_block(fn1o, [](int i) { return i < CNS; }, [](const float* x, int i) { return x[i * 32]; },
+            std::integral_constant<int, S.t1o - S.vmerged>{}, std::integral_constant<int, S.vmerged ? C_VEC_TILE_I * (S.t1o - 1) : S.fan1o>{}, k1o,
+            I0{}, I0{}, I0{}, fn1o, k1o);
   if constexpr (OUT >= 2)
     vec_block([](const float* x, int i, const float (&nn)[3], float (&m)[3]) __attribute__((always_inline)) { cmid1e<IN>(x, i, nn, m); },
               [](int i) { return i >= S.n1o + 2 * S.n1e; }, [](const float* x, int i) { return x[(CC_0O + (i - S.n1o - 2 * S.n1e)) * 32]; },
-              std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e);
+              std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e,
+              std::integral_constant<int, S.vmerged ? R1O : 0>{}, std::integral_constant<int, C_VEC_TILE_I * (S.t1o - 1)>{},
+              std::integral_constant<int, R1E>{}, fn1o, k1o);
   if constexpr (OUT >= 3) {
     // block 0o: mids 0 .. n1e-1 are 1e . direction dot products, the rest plain 0o features: unrolled head (and padded tail), rolled middle
     constexpr int G_HEAD = (S.n1e + 3) / 4, G_FULL = S.fan0o / 4;

@@ -56,7 +56,10 @@ def emulate(stream, IN, OUT, xin, xrow, n):
     sc_tiles = lambda fan: 0 if fan == 0 else 3 * ((fan + 3) // 4 - 1) + (2 if dense(fan, (fan + 3) // 4 - 1) else 3)
     # merged tails (conf_common.h::FctpShape::merged): block 0e has no tile B of its own, its octet 2 rides in slots 2, 3 of block 0o's
     merged = OUT >= 3 and dense(S["fan0e"], S["g0e"] - 1) and dense(S["fan0o"], S["g0o"] - 1)
-    nt = 3 + sc_tiles(S["fan0e"]) + S["t1o"] + S["t1e"] + sc_tiles(S["fan0o"]) - int(merged)
+    # merged vector tails (FctpShape::vmerged): block 1o's tail mids sit behind block 1e's in 1e's last tile
+    r1o, r1e = S["fan1o"] % 5, S["fan1e"] % 5
+    vmerged = OUT >= 2 and r1o > 0 and r1e > 0 and r1o + r1e <= 5
+    nt = 3 + sc_tiles(S["fan0e"]) + S["t1o"] + S["t1e"] + sc_tiles(S["fan0o"]) - int(merged) - int(vmerged)
     assert stream.size == (nt + 1) * TILE_W + nt * 32
     wts, bias = stream[:nt * TILE_W].reshape(nt, TILE_W), stream[(nt + 1) * TILE_W:].reshape(nt, 32)
     tiles = [(wts[k], bias[k]) for k in range(nt)]
@@ -147,25 +150,40 @@ def emulate(stream, IN, OUT, xin, xrow, n):
                 for c in range(4):
                     out[lane & 31, col0 + 8 * q + c + 4 * (lane >> 5)] = keep[4 * q + c, lane]
 
-    def vec_block(ntile, mid, col0):
+    vkeeps = {}
+
+    def vec_block(ntile, mid, col0, fan, guest=None):
         nonlocal T
-        keep = np.zeros((3, 3, 64))
+        keep = vkeeps[col0] = np.zeros((3, 3, 64))
         for t in range(ntile):
             acc = gemm_tile(tiles[T], h1); T += 1
             for lane in range(64):
                 for q in range(5):
+                    if 5 * t + q >= fan:
+                        continue
                     m = mid(lane & 31, 5 * t + q)
                     for o in range(3):
                         keep[o, :, lane] += m * acc[3 * q + o, lane]
+                if guest is not None and t == ntile - 1:          # block 1o's tail mids in the slots behind this block's
+                    gn, gbase, gslot = guest
+                    for g in range(gn):
+                        m = mid1o(lane & 31, gbase + g)
+                        for o in range(3):
+                            vkeeps[C1O][o, :, lane] += m * acc[3 * (gslot + g) + o, lane]
+
+    def write_vec(col0):
+        keep = vkeeps[col0]
         for lane in range(64):
             for o in range(3):
                 oo = 3 * (lane >> 5) + o
                 out[lane & 31, col0 + 3 * oo:col0 + 3 * oo + 3] = keep[o, :, lane]
 
     scalar_block(S["g0e"], mid0e, 0, S["fan0e"])
-    vec_block(S["t1o"], mid1o, C1O)
+    vec_block(S["t1o"] - int(vmerged), mid1o, C1O, 5 * (S["t1o"] - 1) if vmerged else S["fan1o"])
     if OUT >= 2:
-        vec_block(S["t1e"], mid1e, C1E)
+        vec_block(S["t1e"], mid1e, C1E, S["fan1e"], (r1o, 5 * (S["t1o"] - 1), r1e) if vmerged else None)
+        write_vec(C1E)
+    write_vec(C1O)
     if OUT >= 3:
         scalar_block(S["g0o"], mid0o, C0O, S["fan0o"])
         write_scalar(C0O)
