@@ -209,7 +209,10 @@ def finetune_leg(dev, batch=8, warm=8, steps=16):
     margs = load_model_args()
     model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    # the loop's own optimizer construction (reference utils/utils.py:134-172): Adam, fused on a GPU
+    from confidence_bootstrapping_amd.utils import get_optimizer_and_scheduler
+    from argparse import Namespace
+    opt, _ = get_optimizer_and_scheduler(Namespace(scheduler="plateau", lr=1e-3, w_decay=0.0, scheduler_patience=30), model)
     ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
     t2s = partial(t_to_sigma, args=margs)
     loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)

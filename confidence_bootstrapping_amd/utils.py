@@ -130,6 +130,62 @@ def make_score_model(device="cpu", seed=0, args=None, eval_mode=True, confidence
     return model.to(device), args
 
 
+
+def unfreeze_layer(module):
+    """requires_grad = True for every parameter below `module` (reference utils/utils.py, used by the layer-wise warm-up)."""
+    for p in module.parameters():
+        p.requires_grad = True
+
+
+# parameter groups the layer-wise warm-up releases (reference utils/utils.py:143-153): heads first, then one interaction layer per stage
+# from the last to the first, then the embeddings
+_WARMUP_HEADS = ("center_edge_embedding", "final_conv", "tr_final_layer", "rot_final_layer", "final_edge_embedding", "final_tp_tor",
+                 "tor_bond_conv", "tor_final_layer")
+_WARMUP_EMBEDDINGS = ("lig_node_embedding", "lig_edge_embedding", "rec_node_embedding", "rec_edge_embedding", "rec_sigma_embedding",
+                      "cross_edge_embedding", "rec_emb_layers", "lig_emb_layers")
+
+
+def get_optimizer_and_scheduler(args, model, scheduler_mode="min", step=0, optimizer=None):
+    """Adam + learning-rate scheduler of the fine-tuning loop, with the reference's signature and stages (utils/utils.py:134-172;
+    called by finetune_train.py:246-263): `args.scheduler` in {'plateau', 'linear_warmup', 'layer_linear_warmup', other -> None}.
+    'layer_linear_warmup' freezes everything but the batch norms at stage 0, then releases the heads, one interaction layer per stage
+    and finally the embeddings, building a new optimizer over the trainable parameters at every stage.
+    On a GPU the optimizer is PyTorch's fused Adam (one multi-tensor kernel per step instead of ~20 foreach kernels: same update)."""
+    layerwise = args.scheduler == "layer_linear_warmup"
+    if layerwise:
+        if step == 0:
+            for name, child in model.named_children():
+                if "batch_norm" in name:
+                    continue
+                for pname, p in child.named_parameters():
+                    if "batch_norm" not in pname:
+                        p.requires_grad = False
+            for name in _WARMUP_HEADS:
+                if hasattr(model, name):          # final_tp_tor holds no parameters here (closed-form kernel)
+                    unfreeze_layer(getattr(model, name))
+        elif 0 < step <= args.num_conv_layers:
+            unfreeze_layer(model.conv_layers[-step])
+        elif step == args.num_conv_layers + 1:
+            for name in _WARMUP_EMBEDDINGS:
+                unfreeze_layer(getattr(model, name))
+    if step == 0 or layerwise:
+        params = [p for p in model.parameters() if p.requires_grad]
+        fused = bool(params) and all(p.is_cuda and torch.is_floating_point(p) for p in params)
+        optimizer = torch.optim.Adam(params, lr=args.lr, weight_decay=args.w_decay, **({"fused": True} if fused else {}))
+    plateau = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode=scheduler_mode, factor=0.7, patience=args.scheduler_patience,
+                                                         min_lr=args.lr / 100)
+    if args.scheduler == "plateau":
+        scheduler = plateau
+    elif args.scheduler in ("linear_warmup", "layer_linear_warmup"):
+        warming = step < 1 if args.scheduler == "linear_warmup" else step <= args.num_conv_layers + 1
+        scheduler = torch.optim.lr_scheduler.LinearLR(optimizer, start_factor=args.lr_start_factor, end_factor=1.0,
+                                                      total_iters=args.warmup_dur) if warming else plateau
+    else:
+        print("No scheduler")
+        scheduler = None
+    return optimizer, scheduler
+
+
 class ExponentialMovingAverage:
     """Exponential moving average of the trainable parameters with the interface finetune_train.py uses (`update`, `copy_to`,
     `store`, `restore`, `state_dict`, `load_state_dict`; reference utils/utils.py:306-392): with `use_num_updates` the decay warms

@@ -196,3 +196,32 @@ def test_crop_beyond_and_to_data_list_host_logic():
     m = g["atom", "atom_rec_contact", "receptor"].edge_index
     assert torch.equal(m[0], torch.arange(m.shape[1])) and torch.equal(old_of_new[m[1]], a2r[keep[a2r]])
     assert int(g["atom", "atom"].edge_index.max()) < g["atom"].pos.shape[0]
+
+
+def test_get_optimizer_and_scheduler_stages():
+    """reference utils/utils.py:134-172: plateau / linear warm-up schedulers; the layer-wise warm-up releases heads, then one interaction
+    layer per stage, then the embeddings, and rebuilds Adam over the trainable parameters at every stage."""
+    from argparse import Namespace
+    import torch
+    from confidence_bootstrapping_amd.utils import get_optimizer_and_scheduler, make_score_model
+    model, _ = make_score_model(seed=0)
+    total = sum(p.numel() for p in model.parameters())
+    a = Namespace(scheduler="layer_linear_warmup", lr=1e-3, w_decay=0.0, scheduler_patience=5, num_conv_layers=5, lr_start_factor=0.1, warmup_dur=3)
+    counts = []
+    for step in range(8):
+        opt, sch = get_optimizer_and_scheduler(a, model, step=step)
+        n = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        assert n == sum(p.numel() for g in opt.param_groups for p in g["params"])
+        counts.append(n)
+        assert isinstance(sch, torch.optim.lr_scheduler.LinearLR if step <= 6 else torch.optim.lr_scheduler.ReduceLROnPlateau)
+    assert counts == sorted(counts) and counts[0] < counts[1] < counts[5] < counts[6] == counts[7] == total
+    bn0 = [p for n, p in model.named_parameters() if "batch_norm" in n]
+    assert bn0 and all(p.requires_grad for p in bn0)
+    for p in model.parameters():
+        p.requires_grad = True
+    a.scheduler = "plateau"
+    opt, sch = get_optimizer_and_scheduler(a, model)
+    assert isinstance(opt, torch.optim.Adam) and isinstance(sch, torch.optim.lr_scheduler.ReduceLROnPlateau)
+    assert sum(p.numel() for g in opt.param_groups for p in g["params"]) == total
+    a.scheduler = "none"
+    assert get_optimizer_and_scheduler(a, model)[1] is None

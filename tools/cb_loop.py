@@ -67,7 +67,7 @@ def main():
     t2s = partial(t_to_sigma, args=margs)
     buf = CBBuffer(cluster_name="c", cluster_to_ligands={"c": names}, max_complexes_per_couple=20,
                    transform=NoiseTransform(t_to_sigma=t2s, no_torsion=False, all_atom=False))
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)   # as utils.get_optimizer_and_scheduler builds it on a GPU
     ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
     # time the two phases by wrapping the module-level functions the loop calls
     spent = {"inference": 0.0, "train": 0.0, "poses": 0, "train_items": 0}

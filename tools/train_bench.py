@@ -41,7 +41,7 @@ def main():
         margs.dropout = a.dropout
     model, _ = make_score_model(device=dev, seed=0, args=margs, eval_mode=False)
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # as utils.get_optimizer_and_scheduler builds it on a GPU
     ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
     t2s = partial(t_to_sigma, args=margs)
     loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
