@@ -43,12 +43,17 @@ struct ConvShape {
   int n1o, n1e, n0o;          // input multiplicities
   int fan0e, fan1o, fan1e, fan0o;
   int t0e, t1o, t1e, t0o;     // tiles per block
+  int vmerged;                // 1: block 1e's partly filled last tile is merged into block 0o's (conv_shape(.., merged = true))
   int ntiles;
   int weight_numel;           // reference weight_numel (1216/1480/1588/1660)
   int in_dim, out_dim;
 };
 
-__host__ __device__ constexpr ConvShape conv_shape(int IN, int OUT) {
+// `merged` (the inference kernels of tp_conv.hip): the vector blocks' last tiles are partly filled (fan % 5 of 5 mid slots).  Where the
+// remainders of blocks 1e and 0o fit one tile, block 1e's tail mids ride in the free slots behind block 0o's own in 0o's last tile and
+// block 1e runs one tile less: 57 -> 56 tiles for the 74 -> 74 layers.  The training kernels (tp_train.hip) and the bf16 kernel keep the
+// plain layout.
+__host__ __device__ constexpr ConvShape conv_shape(int IN, int OUT, bool merged = false) {
   ConvShape s{};
   s.n1o = IN >= 1 ? NV : 0;
   s.n1e = IN >= 2 ? NV : 0;
@@ -61,7 +66,9 @@ __host__ __device__ constexpr ConvShape conv_shape(int IN, int OUT) {
   s.t1o = (s.fan1o + VEC_TILE_I - 1) / VEC_TILE_I;
   s.t1e = (s.fan1e + VEC_TILE_I - 1) / VEC_TILE_I;
   s.t0o = (s.fan0o + VEC_TILE_I - 1) / VEC_TILE_I;
-  s.ntiles = 3 + s.t0e + s.t1o + s.t1e + s.t0o;
+  s.vmerged = merged && OUT >= 3 && s.fan1e % VEC_TILE_I > 0 && s.fan0o % VEC_TILE_I > 0 &&
+              s.fan1e % VEC_TILE_I + s.fan0o % VEC_TILE_I <= VEC_TILE_I ? 1 : 0;
+  s.ntiles = 3 + s.t0e + s.t1o + s.t1e + s.t0o - s.vmerged;
   s.weight_numel = s.fan0e * NS + s.fan1o * NV + s.fan1e * NV + s.fan0o * NV;
   s.in_dim = NS + 3 * s.n1o + 3 * s.n1e + s.n0o;
   s.out_dim = NS + 3 * NV + (OUT >= 2 ? 3 * NV : 0) + (OUT >= 3 ? NV : 0);

@@ -167,8 +167,8 @@ static int need(cbd_engine* e, const std::string& k, std::initializer_list<int64
 struct TileRow { int row; float scale; };          // row < 0: zero row
 struct TileRows { std::vector<TileRow> rows; int ntiles; };   // rows[T*32 + r]; tiles 0..2 index W1/b1, the rest W2/b2
 
-static TileRows conv_tile_rows(int IN, int OUT) {
-  const ConvShape S = conv_shape(IN, OUT);
+static TileRows conv_tile_rows(int IN, int OUT, bool merged = false) {
+  const ConvShape S = conv_shape(IN, OUT, merged);
   TileRows tr;
   tr.ntiles = S.ntiles;
   tr.rows.assign((size_t)S.ntiles * 32, TileRow{-1, 0.f});
@@ -178,29 +178,38 @@ static TileRows conv_tile_rows(int IN, int OUT) {
   const float s3 = std::sqrt(3.0f), s15 = std::sqrt(1.5f);
   for (int i = 0; i < S.fan0e; ++i, ++T)
     for (int r = 0; r < 32; ++r) tr.rows[(size_t)T * 32 + r] = TileRow{i * NS + r, 1.0f / std::sqrt((float)S.fan0e)};
-  auto vec_tiles = [&](int off, int fan, int ntile, auto mid_factor) {
+  // A block's tiles: its mids [0, n_mids) five per tile (weights at `off`, 1/sqrt(fan) folded), then -- in the free slots of its last
+  // tile -- `guest_n` mids [guest_lo, ..) of ANOTHER block (weights at guest_off, that block's fan: ConvShape::vmerged).
+  auto vec_tiles = [&](int off, int fan, int n_mids, auto mid_factor, int guest_off, int guest_fan, int guest_lo, int guest_n, auto guest_factor) {
+    const int ntile = (n_mids + VEC_TILE_I - 1) / VEC_TILE_I;
     for (int t = 0; t < ntile; ++t, ++T)
       for (int r = 0; r < 32; ++r) {
         // row r = (reg&3) + 8*(reg>>2) + 4*hf  <->  reg = (r&3) + 4*(r>>3), hf = (r>>2)&1
         const int reg = (r & 3) + 4 * (r >> 3), hf = (r >> 2) & 1;
         const int i = VEC_TILE_I * t + reg / 3, o = 3 * hf + reg % 3;
-        if (reg < 15 && i < fan) tr.rows[(size_t)T * 32 + r] = TileRow{off + i * NV + o, mid_factor(i) / std::sqrt((float)fan)};
+        if (reg >= 15) continue;
+        if (i < n_mids) tr.rows[(size_t)T * 32 + r] = TileRow{off + i * NV + o, mid_factor(i) / std::sqrt((float)fan)};
+        else if (i - n_mids < guest_n) {
+          const int gi = guest_lo + (i - n_mids);
+          tr.rows[(size_t)T * 32 + r] = TileRow{guest_off + gi * NV + o, guest_factor(gi) / std::sqrt((float)guest_fan)};
+        }
       }
   };
-  int off = S.fan0e * NS;
-  vec_tiles(off, S.fan1o, S.t1o, [&](int i) { return i < NS ? s3 : (i < NS + S.n1o ? 1.0f : s15); });
-  off += S.fan1o * NV;
-  if (OUT >= 2) {
-    vec_tiles(off, S.fan1e, S.t1e, [&](int i) { return i < S.n1o ? s15 : (i < S.n1o + S.n1e ? 1.0f : s3); });
-    off += S.fan1e * NV;
-  }
-  if (OUT >= 3) vec_tiles(off, S.fan0o, S.t0o, [&](int) { return 1.0f; });
+  auto none = [](int) { return 0.f; };
+  auto f1o = [&](int i) { return i < NS ? s3 : (i < NS + S.n1o ? 1.0f : s15); };
+  auto f1e = [&](int i) { return i < S.n1o ? s15 : (i < S.n1o + S.n1e ? 1.0f : s3); };
+  const int off1o = S.fan0e * NS, off1e = off1o + S.fan1o * NV, off0o = off1e + S.fan1e * NV;
+  const int own1e = S.vmerged ? VEC_TILE_I * (S.t1e - 1) : S.fan1e;       // merged: block 1e stops one tile early
+  vec_tiles(off1o, S.fan1o, S.fan1o, f1o, 0, 1, 0, 0, none);
+  if (OUT >= 2) vec_tiles(off1e, S.fan1e, own1e, f1e, 0, 1, 0, 0, none);
+  if (OUT >= 3) vec_tiles(off0o, S.fan0o, S.fan0o, [&](int) { return 1.0f; }, off1e, S.fan1e, own1e, S.fan1e - own1e, f1e);
   return tr;
 }
 
 static std::vector<float> pack_rows_f32(const TileRows& tr, const float* W1, const float* b1, const float* W2, const float* b2);
-static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
-  return pack_rows_f32(conv_tile_rows(IN, OUT), W1, b1, W2, b2);
+static std::vector<float> pack_conv_stream(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2,
+                                           bool merged = false) {
+  return pack_rows_f32(conv_tile_rows(IN, OUT, merged), W1, b1, W2, b2);
 }
 
 // tor_bond_conv (e3nn FCTP with two live paths): 3 tiles of W1, then one tile per mid index u of path A (1o x T1 -> 32x0e,
@@ -302,7 +311,7 @@ static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1
 // bf16x3 stream (tp_conv.hip::OpsBf16x3): every weight as the exact sum of three bf16 planes; (ntiles + 1) tiles of
 // [6 k-steps x 3 planes][64 lanes][8 bf16] (18 KB, same k order as the bf16 stream), then the fp32 bias table.
 static std::vector<float> pack_conv_stream_bf16x3(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
-  const TileRows tr = conv_tile_rows(IN, OUT);
+  const TileRows tr = conv_tile_rows(IN, OUT, true);      // the merged layout of tp_conv.hip (both operand policies of that kernel)
   constexpr int TILE_BF16 = 3 * 32 * KDIM;   // 9216 bf16 = 18 KB
   std::vector<float> out(((size_t)(tr.ntiles + 1) * TILE_BF16 * 2 + (size_t)tr.ntiles * 32 * 4) / 4, 0.f);
   uint16_t* const w = reinterpret_cast<uint16_t*>(out.data());
@@ -348,7 +357,7 @@ static int build_conv_layer(cbd_engine* e, const std::string& prefix, int IN, in
     CHK(need(e, fc + ".0.bias", {KDIM}, &b0));
     CHK(need(e, fc + ".3.weight", {S.weight_numel, KDIM}, &w1));
     CHK(need(e, fc + ".3.bias", {S.weight_numel}, &b1));
-    std::vector<float> st = pack_conv_stream(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data());
+    std::vector<float> st = pack_conv_stream(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data(), true);
     HIPCHK(e->wpool.upload(&L->wstream[g], st));
     HIPCHK(e->wpool.upload(&L->wstream_bf16[g], pack_conv_stream_bf16(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
     HIPCHK(e->wpool.upload(&L->wstream_x3[g], pack_conv_stream_bf16x3(IN, OUT, w0->data.data(), b0->data.data(), w1->data.data(), b1->data.data())));
@@ -1604,6 +1613,18 @@ int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1, c
                          float* out) {
   if (in_level < 0 || in_level > 3 || out_level < 1 || out_level > 3) return fail(CBD_ERR_ARG, "bad level");
   std::vector<float> v = pack_conv_stream(in_level, out_level, w1, b1, w2, b2);
+  std::memcpy(out, v.data(), v.size() * 4);
+  return 0;
+}
+
+// the same for the layout the INFERENCE kernel reads (ConvShape::vmerged: one tile less where the vector blocks' tails fit one tile)
+int64_t cbd_conv_stream_floats_infer(int32_t in_level, int32_t out_level) {
+  return (int64_t)conv_stream_floats(conv_shape(in_level, out_level, true).ntiles);
+}
+int cbd_pack_conv_stream_infer(int32_t in_level, int32_t out_level, const float* w1, const float* b1, const float* w2, const float* b2,
+                               float* out) {
+  if (in_level < 0 || in_level > 3 || out_level < 1 || out_level > 3) return fail(CBD_ERR_ARG, "bad level");
+  std::vector<float> v = pack_conv_stream(in_level, out_level, w1, b1, w2, b2, true);
   std::memcpy(out, v.data(), v.size() * 4);
   return 0;
 }

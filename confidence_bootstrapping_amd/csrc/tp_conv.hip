@@ -39,7 +39,7 @@ namespace cbd {
 
 template <int IN, int OUT, int VAR, class Ops>
 __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
-  constexpr ConvShape S = conv_shape(IN, OUT);
+  constexpr ConvShape S = conv_shape(IN, OUT, true);   // merged vector tails (common.h)
   constexpr bool STAMPS = VAR == 8 || VAR == 13;     // diagnostics: 13 = the stamps of 8 on the gather pattern of 12
   constexpr int GV = VAR == 13 ? 12 : VAR;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -276,18 +276,31 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
     vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
               [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
               std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o);
+    // merged tails (ConvShape::vmerged): block 1e runs its first 5 (t1e - 1) mids; the others are guests of block 0o's last tile
+    constexpr int OWN1E = S.vmerged ? VEC_TILE_I * (S.t1e - 1) : S.fan1e, GUESTS = S.fan1e - OWN1E;
     if constexpr (OUT >= 2)
       vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
                 [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
-                std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e);
+                std::integral_constant<int, S.t1e - S.vmerged>{}, std::integral_constant<int, OWN1E>{}, k1e);
     if constexpr (OUT >= 3) {
 #pragma unroll
       for (int t = 0; t < S.t0o; ++t) {
         float m[VEC_TILE_I];
+        float gm[GUESTS > 0 ? GUESTS : 1][3];     // block 1e's tail mids (vectors; a scalar x direction mid is multiplied out here)
 #pragma unroll
         for (int q = 0; q < VEC_TILE_I; ++q) {
           if (VEC_TILE_I * t + q >= S.fan0o) continue;
           m[q] = mid0o<IN>(xc, VEC_TILE_I * t + q, v);
+        }
+        if (t == S.t0o - 1) {
+#pragma unroll
+          for (int g = 0; g < GUESTS; ++g) {
+            const int i = OWN1E + g;
+            if (i >= S.n1o + S.n1e) {
+              const float x = xc[(COL_0O + (i - S.n1o - S.n1e)) * 32];
+              gm[g][0] = x * v[0]; gm[g][1] = x * v[1]; gm[g][2] = x * v[2];
+            } else mid1e<IN>(xc, i, v, gm[g]);
+          }
         }
         CBD_TILE(h1, T + 1);
 #pragma unroll
@@ -295,6 +308,18 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
           if (VEC_TILE_I * t + q >= S.fan0o) continue;
 #pragma unroll
           for (int o = 0; o < 3; ++o) k0o[o] = fmaf(m[q], acc[3 * q + o], k0o[o]);
+        }
+        if (t == S.t0o - 1) {
+          constexpr int SLOT0 = S.fan0o - VEC_TILE_I * (S.t0o - 1);     // block 0o's own mids in its last tile
+#pragma unroll
+          for (int g = 0; g < GUESTS; ++g)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+              const float w = acc[3 * (SLOT0 + g) + o];
+              k1e[3 * o + 0] = fmaf(gm[g][0], w, k1e[3 * o + 0]);
+              k1e[3 * o + 1] = fmaf(gm[g][1], w, k1e[3 * o + 1]);
+              k1e[3 * o + 2] = fmaf(gm[g][2], w, k1e[3 * o + 2]);
+            }
         }
 #pragma unroll
         for (int o = 0; o < 3; ++o) pin(k0o[o]);
@@ -571,7 +596,7 @@ hipError_t launch_bond_conv(const BondHead& h, const Multi& m, int xi, const flo
 // ---------------------------------------------------------------------------------------------- host launchers
 template <int IN, int OUT>
 static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
-  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
+  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT, true).ntiles) * 4;
   // CBD_CONV_VARIANT=8 selects the diagnostic build of the 74->74 kernel that stamps s_memtime/s_memrealtime
   static const int var = getenv("CBD_CONV_VARIANT") ? atoi(getenv("CBD_CONV_VARIANT")) : 0;
   if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
@@ -590,7 +615,7 @@ static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
 // The bf16-operand variant (cbd_set_option("bf16", 1), BASELINE.json configs[3]) lives in tp_conv_bf16.hip (64 edges per wave).
 template <int IN, int OUT>
 static hipError_t launch_one_x3(const ConvArgs& a, int grid, hipStream_t s) {
-  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT).ntiles) * 4;
+  constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT, true).ntiles) * 4;
   hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsBf16x3>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }

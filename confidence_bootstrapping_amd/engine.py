@@ -63,6 +63,8 @@ SYMBOLS = {
     "cbd_kernel_timing": (C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
     "cbd_conv_stream_floats": (C.c_int64, [C.c_int32, C.c_int32]),
     "cbd_pack_conv_stream": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
+    "cbd_conv_stream_floats_infer": (C.c_int64, [C.c_int32, C.c_int32]),
+    "cbd_pack_conv_stream_infer": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     "cbd_symm_rmsd": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, _P, _P]),
     "cbd_knn_graph": (C.c_int, [C.c_int32, C.c_int32, _P, _P, _P]),
     "cbd_radius_neighbors": (C.c_int, [C.c_int32, C.c_float, C.c_int32, _P, _P, _P, _P]),
@@ -468,13 +470,14 @@ class DockEnginePool:
         return out
 
 
-def pack_conv_stream(in_level, out_level, w1, b1, w2, b2):
-    """Host-only: the MFMA weight-tile stream of one FCBlock (for the CPU emulation tests)."""
+def pack_conv_stream(in_level, out_level, w1, b1, w2, b2, merged=False):
+    """Host-only: the MFMA weight-tile stream of one FCBlock (for the CPU emulation tests).  `merged`: the layout the inference kernel
+    reads (cbd_pack_conv_stream_infer); plain: the training kernels' (cbd_pack_conv_stream)."""
     lib = load_library()
-    n = lib.cbd_conv_stream_floats(in_level, out_level)
+    n = (lib.cbd_conv_stream_floats_infer if merged else lib.cbd_conv_stream_floats)(in_level, out_level)
     out = np.empty(n, dtype=np.float32)
     arrs = [np.ascontiguousarray(x, dtype=np.float32) for x in (w1, b1, w2, b2)]
-    _check(lib.cbd_pack_conv_stream(in_level, out_level, *[_hptr(a) for a in arrs], _hptr(out)))
+    _check((lib.cbd_pack_conv_stream_infer if merged else lib.cbd_pack_conv_stream)(in_level, out_level, *[_hptr(a) for a in arrs], _hptr(out)))
     return out
 
 

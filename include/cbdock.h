@@ -177,6 +177,12 @@ int cbd_kernel_timing(cbd_engine* e, int32_t enable, int32_t reset, double* avg_
 int64_t cbd_conv_stream_floats(int32_t in_level, int32_t out_level);
 int cbd_pack_conv_stream(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host,
                          const float* w2_host, const float* b2_host, float* out_host);
+/* The same for the layout the INFERENCE kernel (tp_conv.hip) reads: where the partly filled last tiles of the 1e and 0o blocks fit one
+ * tile they share it (one tile less for the 2 -> 3 and 3 -> 3 layers).  cbd_pack_conv_stream is the layout of the training entry points
+ * (cbd_tp_forward ...) and of the bf16 kernel. */
+int64_t cbd_conv_stream_floats_infer(int32_t in_level, int32_t out_level);
+int cbd_pack_conv_stream_infer(int32_t in_level, int32_t out_level, const float* w1_host, const float* b1_host, const float* w2_host,
+                               const float* b2_host, float* out_host);
 
 
 /* Symmetry-corrected ligand RMSD of B poses against one reference pose: replaces the loop over graph

@@ -52,10 +52,15 @@ def cross(a, v):
     return np.array([a[1] * v[2] - a[2] * v[1], a[2] * v[0] - a[0] * v[2], a[0] * v[1] - a[1] * v[0]])
 
 
-def emulate(stream, IN, OUT, xin, xrow, v):
-    """One 32-edge wave tile.  xin [32,96] = [edge_attr | x_src[:32] | x_dst[:32]], xrow [32,80], v [32,3] unit."""
+def emulate(stream, IN, OUT, xin, xrow, v, merged=False):
+    """One 32-edge wave tile.  xin [32,96] = [edge_attr | x_src[:32] | x_dst[:32]], xrow [32,80], v [32,3] unit.
+    `merged`: the inference kernel's layout (common.h::ConvShape::vmerged) -- block 1e's partly filled last tile rides in the free
+    slots of block 0o's last tile."""
     S = shape(IN, OUT)
-    nt = 3 + S["t0e"] + S["t1o"] + (S["t1e"] if OUT >= 2 else 0) + (S["t0o"] if OUT >= 3 else 0)
+    r1e, r0o = (S["fan1e"] % 5, S["fan0o"] % 5) if OUT >= 3 else (0, 0)
+    vm = bool(merged and OUT >= 3 and r1e > 0 and r0o > 0 and r1e + r0o <= 5)
+    own1e = 5 * (S["t1e"] - 1) if vm else S["fan1e"]
+    nt = 3 + S["t0e"] + S["t1o"] + (S["t1e"] if OUT >= 2 else 0) + (S["t0o"] if OUT >= 3 else 0) - int(vm)
     assert stream.size == (nt + 1) * TILE_W + nt * 32
     assert np.all(stream[nt * TILE_W:(nt + 1) * TILE_W] == 0)      # prefetch target after the last tile
     wts, bias = stream[:nt * TILE_W].reshape(nt, TILE_W), stream[(nt + 1) * TILE_W:].reshape(nt, 32)
@@ -102,40 +107,56 @@ def emulate(stream, IN, OUT, xin, xrow, v):
         for reg in range(16):
             out[lane & 31, row_of(reg, lane >> 5)] = o0e[reg, lane]
 
-    def vec_block(ntile, mid, col0):
-        keep = np.zeros((3, 3, 64))          # [o local][c][lane]; lane half hf owns outputs 3hf..3hf+2
+    keeps = {}
+
+    def vec_block(ntile, mid, col0, n_mids):
+        keep = keeps[col0] = np.zeros((3, 3, 64))          # [o local][c][lane]; lane half hf owns outputs 3hf..3hf+2
         nonlocal T
         for t in range(ntile):
             acc = gemm_tile(tiles[T], h1); T += 1
             for lane in range(64):
                 for q in range(5):
+                    if 5 * t + q >= n_mids:
+                        continue
                     m = mid(lane & 31, 5 * t + q)
                     for o in range(3):
                         keep[o, :, lane] += m * acc[3 * q + o, lane]
+
+    def write_vec(col0):
         for lane in range(64):
             for o in range(3):
                 oo = 3 * (lane >> 5) + o
-                out[lane & 31, col0 + 3 * oo:col0 + 3 * oo + 3] = keep[o, :, lane]
+                out[lane & 31, col0 + 3 * oo:col0 + 3 * oo + 3] = keeps[col0][o, :, lane]
 
-    vec_block(S["t1o"], mid1o, COL_1O)
+    vec_block(S["t1o"], mid1o, COL_1O, S["fan1o"])
+    write_vec(COL_1O)
     if OUT >= 2:
-        vec_block(S["t1e"], mid1e, COL_1E)
+        vec_block(S["t1e"] - int(vm), mid1e, COL_1E, own1e)
     if OUT >= 3:
         k0 = np.zeros((3, 64))
         for t in range(S["t0o"]):
             acc = gemm_tile(tiles[T], h1); T += 1
             for lane in range(64):
                 for q in range(5):
-                    m = mid0o(lane & 31, 5 * t + q)
-                    k0[:, lane] += m * acc[3 * q:3 * q + 3, lane]
+                    i = 5 * t + q
+                    if i < S["fan0o"]:
+                        k0[:, lane] += mid0o(lane & 31, i) * acc[3 * q:3 * q + 3, lane]
+                    elif vm and i - S["fan0o"] < S["fan1e"] - own1e:      # block 1e's tail mids behind block 0o's own
+                        m = mid1e(lane & 31, own1e + (i - S["fan0o"]))
+                        for o in range(3):
+                            keeps[COL_1E][o, :, lane] += m * acc[3 * q + o, lane]
         for lane in range(64):
             out[lane & 31, COL_0O + 3 * (lane >> 5):COL_0O + 3 * (lane >> 5) + 3] = k0[:, lane]
+    if OUT >= 2:
+        write_vec(COL_1E)
     assert T == len(tiles)
     return out
 
 
+@pytest.mark.parametrize("merged", [False, True])
 @pytest.mark.parametrize("IN,OUT", [(0, 1), (1, 2), (2, 3), (3, 3)])
-def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
+def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT, merged):
+    """`merged` = the layout the inference kernel reads (cbd_pack_conv_stream_infer); plain = the training kernels' and the bf16 kernel's"""
     from confidence_bootstrapping_amd.engine import pack_conv_stream, load_library
     lib = load_library()
     g = torch.Generator().manual_seed(10 * IN + OUT)
@@ -143,9 +164,10 @@ def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
     W = sr.faster_tp_weight_numel(in_irr, out_irr)
     w1, b1 = torch.randn(96, 96, generator=g) / 8, torch.randn(96, generator=g) / 4
     w2, b2 = torch.randn(W, 96, generator=g) / 8, torch.randn(W, generator=g) / 4
-    stream = pack_conv_stream(IN, OUT, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy())
+    stream = pack_conv_stream(IN, OUT, w1.numpy(), b1.numpy(), w2.numpy(), b2.numpy(), merged=merged)
     ntiles = {(0, 1): 3 + 32 + 7, (1, 2): 3 + 38 + 8 + 2, (2, 3): 3 + 38 + 9 + 3 + 2, (3, 3): 3 + 38 + 9 + 4 + 3}[(IN, OUT)]
-    assert stream.size == (ntiles + 1) * TILE_W + ntiles * 32 == lib.cbd_conv_stream_floats(IN, OUT)
+    ntiles -= int(merged and OUT >= 3)           # 2 -> 3 and 3 -> 3: the tails of blocks 1e and 0o share a tile
+    assert stream.size == (ntiles + 1) * TILE_W + ntiles * 32 == (lib.cbd_conv_stream_floats_infer if merged else lib.cbd_conv_stream_floats)(IN, OUT)
     E = 32
     in_dim, out_dim = sr.e3.Irreps(in_irr).dim, sr.e3.Irreps(out_irr).dim
     xin = torch.randn(E, 96, generator=g)
@@ -158,6 +180,6 @@ def test_packed_stream_reproduces_fcblock_and_tensor_product(IN, OUT):
     xrow = np.zeros((E, 80))
     xrow[:, :in_dim] = xd.double().numpy()
     v = torch.nn.functional.normalize(vec.double(), dim=-1).numpy()
-    got = emulate(stream.astype(np.float64), IN, OUT, xin.double().numpy(), xrow, v)
+    got = emulate(stream.astype(np.float64), IN, OUT, xin.double().numpy(), xrow, v, merged=merged)
     np.testing.assert_allclose(got[:, :out_dim], ref, rtol=2e-5, atol=2e-5)   # fp32-rounded folded factors in the stream
     assert np.all(got[:, out_dim:] == 0)
