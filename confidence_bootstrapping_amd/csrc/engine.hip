@@ -262,7 +262,7 @@ static uint16_t f32_to_bf16_rne(float f) {
 static std::vector<float> pack_conv_stream_bf16(int IN, int OUT, const float* W1, const float* b1, const float* W2, const float* b2) {
   // stream of tp_conv_bf16.hip: (ntiles + 1) tiles of [6 k-steps][64 lanes][8 bf16] (6 KB) carrying the 96 input columns, then the fp32
   // bias rows [ntiles + 1][32] (the kernel feeds a tile's bias as the C operand of its first MFMA pair; row ntiles is the zero tile's)
-  const TileRows tr = conv_tile_rows(IN, OUT);
+  const TileRows tr = conv_tile_rows(IN, OUT, true);      // merged vector tails, as the fp32 inference stream
   constexpr int NQ = KDIM / 16;
   constexpr int TILE_BF16 = NQ * 64 * 8;   // 3072 bf16 = 6 KB
   const size_t tile_floats = (size_t)(tr.ntiles + 1) * TILE_BF16 / 2;

@@ -38,7 +38,7 @@ namespace cbd {
 // tile: the kernel without its weight stream), 24 = 16 + 8, 32 = the bias bpermutes are not waited for
 template <int IN, int OUT, int DIAG = 0>
 __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
-  constexpr ConvShape S = conv_shape(IN, OUT);
+  constexpr ConvShape S = conv_shape(IN, OUT, true);   // merged vector tails (common.h), as in tp_conv.hip
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* const xT0 = lds;                                   // sub-tile 0: [col][32] gathered rows, later [col][33] messages
   float* const xT1 = lds + V2_SUB_FLOATS;
@@ -370,18 +370,32 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
     vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1o<IN>(x, i, vv, m); },
               [](int i) { return i < NS; }, [](const float* x, int i) { return x[i * 32]; },
               std::integral_constant<int, S.t1o>{}, std::integral_constant<int, S.fan1o>{}, k1o0, k1o1);
+    // merged tails (ConvShape::vmerged): block 1e runs its first 5 (t1e - 1) mids; the others are guests of block 0o's last tile
+    constexpr int OWN1E = S.vmerged ? VEC_TILE_I * (S.t1e - 1) : S.fan1e, GUESTS = S.fan1e - OWN1E;
     if constexpr (OUT >= 2)
       vec_block([](const float* x, int i, const float (&vv)[3], float (&m)[3]) __attribute__((always_inline)) { mid1e<IN>(x, i, vv, m); },
                 [](int i) { return i >= S.n1o + S.n1e; }, [](const float* x, int i) { return x[(COL_0O + (i - S.n1o - S.n1e)) * 32]; },
-                std::integral_constant<int, S.t1e>{}, std::integral_constant<int, S.fan1e>{}, k1e0, k1e1);
+                std::integral_constant<int, S.t1e - S.vmerged>{}, std::integral_constant<int, OWN1E>{}, k1e0, k1e1);
     if constexpr (OUT >= 3) {
 #pragma unroll
       for (int t = 0; t < S.t0o; ++t) {
         float ma[VEC_TILE_I], mb[VEC_TILE_I];
+        float ga[GUESTS > 0 ? GUESTS : 1][3], gb[GUESTS > 0 ? GUESTS : 1][3];     // block 1e's tail mids of the two sub-tiles
 #pragma unroll
         for (int q = 0; q < VEC_TILE_I; ++q) {
           if (VEC_TILE_I * t + q >= S.fan0o) continue;
           ma[q] = mid0o<IN>(xc0, VEC_TILE_I * t + q, v0); mb[q] = mid0o<IN>(xc1, VEC_TILE_I * t + q, v1);
+        }
+        if (t == S.t0o - 1) {
+#pragma unroll
+          for (int g = 0; g < GUESTS; ++g) {
+            const int i = OWN1E + g;
+            if (i >= S.n1o + S.n1e) {
+              const float xa = xc0[(COL_0O + (i - S.n1o - S.n1e)) * 32], xb = xc1[(COL_0O + (i - S.n1o - S.n1e)) * 32];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) { ga[g][c] = xa * v0[c]; gb[g][c] = xb * v1[c]; }
+            } else { mid1e<IN>(xc0, i, v0, ga[g]); mid1e<IN>(xc1, i, v1, gb[g]); }
+          }
         }
         V2_TILE(h0, h1, T + 1, T + 2 < S.ntiles ? T + 2 : S.ntiles);
         if constexpr (DIAG & 2) { k0o0[0] += acc0[0]; k0o1[0] += acc1[0]; if constexpr (!(DIAG & 40)) bias_ready(cb); continue; }
@@ -390,6 +404,20 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
           if (VEC_TILE_I * t + q >= S.fan0o) continue;
 #pragma unroll
           for (int o = 0; o < 3; ++o) { k0o0[o] = fmaf(ma[q], acc0[3 * q + o], k0o0[o]); k0o1[o] = fmaf(mb[q], acc1[3 * q + o], k0o1[o]); }
+        }
+        if (t == S.t0o - 1) {
+          constexpr int SLOT0 = S.fan0o - VEC_TILE_I * (S.t0o - 1);
+#pragma unroll
+          for (int g = 0; g < GUESTS; ++g)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) {
+              const float wa = acc0[3 * (SLOT0 + g) + o], wb = acc1[3 * (SLOT0 + g) + o];
+#pragma unroll
+              for (int c = 0; c < 3; ++c) {
+                k1e0[3 * o + c] = fmaf(ga[g][c], wa, k1e0[3 * o + c]);
+                k1e1[3 * o + c] = fmaf(gb[g][c], wb, k1e1[3 * o + c]);
+              }
+            }
         }
         if constexpr (!(DIAG & 40)) bias_ready(cb);
       }

@@ -53,7 +53,7 @@ __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmc
 
 template <int DIAG = 0>
 __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs args, RoleTable rt) {
-  constexpr ConvShape S = conv_shape(3, 3);
+  constexpr ConvShape S = conv_shape(3, 3, true);      // the bf16 stream's layout (merged vector tails)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int j = lane & 31, hf = lane >> 5;
