@@ -99,6 +99,9 @@ struct cbd_engine {
   // the group's and `piece_b_off[g]` floats behind them (first_sum, last_sum and run_acc alike)
   long long piece_b_off[4] = {0, 0, 0, 0};
   int bf16_roles = 0;      // 1: the slices run through the streaming kernel, 2: the 0e slices through the LDS-resident kernel (tp_conv_bf16p.hip)
+  // 1: the 74 -> 74 layers of the bf16 policy run through the register-stationary kernel (tp_conv_bf16s.hip; "bf16_stationary" option / CBD_BF16_STATIONARY,
+  // default off while it is being tuned); 0: through the streaming kernel.  Ignored under the role split.
+  int bf16_stat = 0;
   int n_cus = 256;
   int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
   int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges
@@ -447,6 +450,7 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   e->cfg = *cfg;
   if (const char* p = getenv("CBD_PRECISION")) e->use_bf16 = std::max(0, std::min(2, atoi(p)));   // test hook: default operand policy
   if (const char* p = getenv("CBD_BF16_ROLES")) e->bf16_roles = std::max(0, std::min(2, atoi(p)));                     // test hook: role split of the bf16 policy
+  if (const char* p = getenv("CBD_BF16_STATIONARY")) e->bf16_stat = atoi(p) != 0;                                       // test hook: register-stationary bf16 kernel
   HIPCHK(hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
   if (const char* p = getenv("CBD_BF16P_WGS")) e->n_cus = std::max(1, atoi(p));                   // diagnostic: workgroups of the persistent kernel
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
@@ -660,7 +664,8 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++used;
     CHK(record_event(e0, s, cap));
   }
-  if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
+  if (e->use_bf16 == 1 && e->bf16_stat && e->bf16_roles == 0 && L.in_level == 3 && L.out_level == 3) HIPCHK(launch_tp_conv_bf16s(a, e->n_cus, s));
+  else if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
   if (resident) HIPCHK(launch_tp_conv_bf16p(*resident, e->n_cus, s));
@@ -1371,7 +1376,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
       e->complex_gen = cbd_engine::next_gen();
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16 + 8 * e->bf16_roles,
+    snprintf(buf, sizeof buf, "|%p:%llu:%d:%d:%d:%d", (void*)e, (unsigned long long)e->complex_gen, (int)B[k], e->use_bf16 + 8 * e->bf16_roles + 32 * e->bf16_stat,
              (nz(noise_tr, k) != nullptr) + 2 * (nz(noise_rot, k) != nullptr) + 4 * (nz(noise_tor, k) != nullptr), (int)e->timing);
     key += buf;
   }
@@ -1448,7 +1453,7 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
       if (engines[q] == e) return fail(CBD_ERR_ARG, "distinct engines are required");
     if (!pos_dev[k]) return fail(CBD_ERR_ARG, "null pose buffer");
     if (e->cfg.device != e0->cfg.device) return fail(CBD_ERR_ARG, "co-scheduled engines must live on the same device");
-    if (e->use_bf16 != e0->use_bf16 || e->bf16_roles != e0->bf16_roles) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
+    if (e->use_bf16 != e0->use_bf16 || e->bf16_roles != e0->bf16_roles || e->bf16_stat != e0->bf16_stat) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
     if (e->cfg.no_torsion != e0->cfg.no_torsion || e->cfg.lig_max_radius != e0->cfg.lig_max_radius ||
         e->cfg.lig_radius_cap != e0->cfg.lig_radius_cap)
       return fail(CBD_ERR_ARG, "co-scheduled engines must share one model configuration");
@@ -1488,6 +1493,11 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
   }
   if (k == "bf16_roles") {   // bf16 only: cross / receptor groups as three tile slices per layer (captured graphs bake it in)
     e->bf16_roles = (int)std::max<long long>(0, std::min<long long>(2, value));
+    drop_graphs(e);
+    return 0;
+  }
+  if (k == "bf16_stationary") {   // bf16 only: register-stationary kernel for the 74 -> 74 layers (captured graphs bake it in)
+    e->bf16_stat = value != 0;
     drop_graphs(e);
     return 0;
   }
@@ -1568,6 +1578,26 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     std::sort(ghz.begin(), ghz.end()); std::sort(dur.begin(), dur.end());
     out[0] = (float)ghz[ghz.size() / 2]; out[1] = (float)dur[dur.size() / 2]; out[2] = (float)ghz.size();
     return capacity >= 8 ? 8 : capacity >= 7 ? 7 : 3;
+  }
+  if (k == "conv_clock_s") {   // per-wave phase clocks of the last tp_conv64s launch (CBD_BF16_DIAG=4): 4 waves x 10 floats (medians)
+    if (!e->stamps_dev || capacity < 40) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_BF16_DIAG=4) or capacity < 40");
+    std::vector<unsigned long long> h(8192 * 8);
+    if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    for (int w = 0; w < 4; ++w) {
+      std::vector<double> col[10];
+      for (int rec = w; rec < 4096; rec += 4) {
+        const unsigned long long* q = h.data() + 16 * (size_t)rec;
+        const double dt = (double)(q[2] - q[0]), dr = (double)(q[3] - q[1]);
+        if (!q[3] || dr <= 0 || q[10] == 0) continue;
+        col[0].push_back(dt); col[1].push_back(dt / dr * 0.1);
+        for (int c = 0; c < 6; ++c) col[2 + c].push_back((double)q[4 + c]);
+        col[8].push_back((double)q[10]); col[9].push_back(1.0);
+      }
+      for (int c = 0; c < 9; ++c) out[10 * w + c] = (float)med(col[c]);
+      out[10 * w + 9] = (float)col[9].size();
+    }
+    return 40;
   }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);
