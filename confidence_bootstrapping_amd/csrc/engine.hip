@@ -1580,7 +1580,7 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     return capacity >= 8 ? 8 : capacity >= 7 ? 7 : 3;
   }
   if (k == "conv_clock_s") {   // per-wave phase clocks of the last tp_conv64s launch (CBD_BF16_DIAG=4): 4 waves x 10 floats (medians)
-    if (!e->stamps_dev || capacity < 40) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_BF16_DIAG=4) or capacity < 40");
+    if (!e->stamps_dev || capacity < 48) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_BF16_DIAG=4) or capacity < 48");
     std::vector<unsigned long long> h(8192 * 8);
     if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
     auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
@@ -1597,7 +1597,25 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
       for (int c = 0; c < 9; ++c) out[10 * w + c] = (float)med(col[c]);
       out[10 * w + 9] = (float)col[9].size();
     }
-    return 40;
+    {   // the launch as a whole (100 MHz real-time counter): span from the first start to the last end, lifetimes of the workgroups (wave 0)
+      unsigned long long t0 = ~0ull, t1 = 0;
+      std::vector<double> life, units;
+      for (int rec = 0; rec < 4096; rec += 4) {
+        const unsigned long long* q = h.data() + 16 * (size_t)rec;
+        if (!q[3] || q[3] <= q[1] || q[10] == 0) continue;
+        t0 = std::min(t0, q[1]); t1 = std::max(t1, q[3]);
+        life.push_back((double)(q[3] - q[1]) * 10.0); units.push_back((double)q[10]);
+      }
+      std::sort(life.begin(), life.end());
+      out[40] = life.empty() ? 0.f : (float)((double)(t1 - t0) * 10.0);
+      out[41] = life.empty() ? 0.f : (float)life[life.size() / 2];
+      out[42] = life.empty() ? 0.f : (float)life.back();
+      out[43] = life.empty() ? 0.f : (float)life.front();
+      out[44] = units.empty() ? 0.f : (float)*std::max_element(units.begin(), units.end());
+      out[45] = units.empty() ? 0.f : (float)*std::min_element(units.begin(), units.end());
+      out[46] = (float)life.size(); out[47] = 0.f;
+    }
+    return 48;
   }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);

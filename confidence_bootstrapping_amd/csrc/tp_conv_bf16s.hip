@@ -42,19 +42,25 @@ constexpr int L_X_SLOT = 76 * 32;                        // gathered destination
 constexpr int L_X = 0;                                   // [4 slots]
 constexpr int L_FRAG_SLOT = V2_NFRAG * 64 * 4;           // one B operand: [6 k-steps][64 lanes][8 bf16] = 6 KB
 constexpr int L_BX = L_X + 4 * L_X_SLOT;                 // [2 slots] first-Linear input (edge_attr | x_src[:32] | x_dst[:32]) as bf16 B operand
-constexpr int L_H = L_BX + 2 * L_FRAG_SLOT;              // [4 slots] hidden activations h as bf16 B operand
-constexpr int L_P_WAVE = 20 * 64;                        // partial sums of one wave: 16 (0e) + 3 (1o scalar sums) registers x 64 lanes
-constexpr int L_P_SLOT = 3 * L_P_WAVE;
-constexpr int L_P = L_H + 4 * L_FRAG_SLOT;               // [2 slots][3 waves]
+constexpr int L_H = L_BX + 2 * L_FRAG_SLOT;              // [3 slots] hidden activations h as bf16 B operand (slot = unit mod 3)
+constexpr int L_P_WAVE = 16 * 64;                        // partial sums of one wave: 16 (0e) registers x 64 lanes; wave 2: + one float4 row (1o scalar sums)
+constexpr int L_P_SLOT = 3 * L_P_WAVE + 4 * 64;
+constexpr int L_P = L_H + 3 * L_FRAG_SLOT;               // [2 slots][3 waves]
 constexpr int S_OSTR = 36;                               // message tile stride: lane = column reads four edges per ds_read_b128 without bank conflicts
 constexpr int L_O_SLOT = NODE_DIM * S_OSTR;              // message tile [74][36]
 constexpr int L_O = L_P + 2 * L_P_SLOT;                  // [2 slots]
-constexpr int L_BIAS = L_O + 2 * L_O_SLOT;               // [57][32] fp32 bias rows of the stream
-constexpr int L_FLW = L_BIAS + (SS.ntiles + 1) * 32;     // the three first-Linear tiles
-constexpr int L_TOTAL = L_FLW + 3 * L_FRAG_SLOT;
+constexpr int S_BIAS_ROWS = 3 + SS.t1o + SS.t1e - 1 + SS.t0o;   // the tiles that take a bias as their C operand: first Linear, blocks 1o / 1e / 0o
+constexpr int L_BIAS = L_O + 2 * L_O_SLOT;               // [18][32] fp32 bias rows (bias_row())
+constexpr int L_FLW = L_BIAS + S_BIAS_ROWS * 32;         // the three first-Linear tiles
+constexpr int S_LDS_TILES = 4;                           // second-Linear tiles read from LDS instead of held in registers: the last 0e tile of waves 0 and 2, the last two of wave 1
+constexpr int L_WT = L_FLW + 3 * L_FRAG_SLOT;
+constexpr int L_TOTAL = L_WT + S_LDS_TILES * L_FRAG_SLOT;
+__host__ __device__ constexpr int lds_tile_stream(int k) { return k == 0 ? 16 : k == 1 ? 29 : k == 2 ? 30 : 40; }      // stream index of LDS tile k
+__host__ __device__ constexpr int bias_row(int T) { return T < 3 ? T : 3 + (T - (3 + SS.t0e)); }                        // row of stream tile T in the LDS bias table
 constexpr int S_LDS_BYTES = L_TOTAL * 4;
 static_assert(S_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-static_assert(L_BX % 4 == 0 && L_H % 4 == 0 && L_P % 4 == 0 && L_O % 4 == 0 && L_BIAS % 4 == 0 && L_FLW % 4 == 0, "16-byte alignment");
+static_assert(L_BX % 4 == 0 && L_H % 4 == 0 && L_P % 4 == 0 && L_O % 4 == 0 && L_BIAS % 4 == 0 && L_FLW % 4 == 0 && L_WT % 4 == 0, "16-byte alignment");
+__device__ __forceinline__ int h_slot(int u) { return (u + 9) % 3; }      // u >= -9
 
 struct RoleTableS {
   int n_roles;
@@ -95,6 +101,26 @@ __device__ __forceinline__ void s_chain(const bf16x8 (&w)[V2_NFRAG], const Act6&
   }
 }
 
+// One tile whose weight fragments are read from LDS (three rotating fragment registers: fragment q + 2 is requested behind MFMA q's
+// predecessor, never into the register an issued MFMA may still have to read); aw[0], aw[1] hold fragments 0 and 1 on entry.
+template <class Epi>
+__device__ __forceinline__ void s_chain_lds(const bf16x8* lw, bf16x8 (&aw)[3], const Act6& B, f32x16& acc, Epi epi) {
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 0; q < V2_NFRAG; ++q) {
+    if (q + 2 < V2_NFRAG) aw[(q + 2) % 3] = lw[(q + 2) * 64];
+    if (q == 0) {
+      const f32x16 zero = {};
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], B.v[q], zero, 0, 0, 0);
+    } else {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], B.v[q], acc, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    epi(q);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Two tiles at once: two independent chains interleaved (a dependent MFMA issues ~40 cycles after its predecessor, an independent one
 // after 32: one chain alone keeps the matrix pipe at 0.8), `epi(s)` behind MFMA s = 0 .. 11 (the previous pair's epilogue slices).
 template <class Epi>
@@ -126,7 +152,7 @@ __device__ __forceinline__ void s_chain2(const bf16x8 (&wa)[V2_NFRAG], const bf1
 
 // bias rows of tile T as the C operand (accumulator layout: register r of lane half hf = row (r & 3) + 8 (r >> 2) + 4 hf)
 __device__ __forceinline__ void s_load_bias(const float* bias_lds, int T, int hf, f32x16& cb) {
-  const f32x4* b4 = reinterpret_cast<const f32x4*>(bias_lds + T * 32);
+  const f32x4* b4 = reinterpret_cast<const f32x4*>(bias_lds + bias_row(T) * 32);
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) {
     const f32x4 b = b4[hf + 2 * qq];
@@ -277,21 +303,236 @@ __device__ __forceinline__ void v_drain(const f32x16& acc, const RawT& raw, cons
   for (int q = 0; q < VEC_TILE_I; ++q) v_epi<KIND, T>(q, acc, raw, v, o);
 }
 
-// ---- the program of wave W over the units [u0, u0 + n) of one group entry ------------------------------------------------------
-// Pipeline over tau = 0 .. n + 4 (one barrier per iteration):  unit tau: edge indices; tau-1: gathers issued at the start of the iteration,
-// written to LDS at its end (X rows, first-Linear input);  tau-2: first Linear (wave 3) -> H;  tau-3: waves 0..2 tiles -> partials P;
-// tau-4: wave 3 tiles -> message tile O;  tau-5: wave 2 reduction -> global memory.
+// ---- waves 0 .. 2: one fused, branch-free instruction stream per unit iteration ----------------------------------------------------
+// A wave that is alone on its SIMD has nobody to fill its stalls, and every instruction it issues next to an MFMA costs matrix-pipe
+// time only if it WAITS there.  So everything that is not a tile -- the first-Linear chain of this wave's hidden tile (one unit ahead),
+// the gather issue (two units ahead), the LDS writes of the gathered data, the run-length reduction (wave 0, two units behind) -- is cut
+// into slices that sit in the issue slots between the MFMAs of the 0e pairs, their LDS / memory operands requested several slots
+// earlier.  Stages whose unit is outside [0, n) run on whatever the LDS slots hold (no branches; the slots they write are not live,
+// section "fill / drain" in DESIGN.md) -- only global stores are guarded, global loads use clamped indices.
 template <int W, int NT, int DIAG>
-__device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, const int u0, const int n, float* const lds,
+__device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, const int u0, const int n, float* const lds,
+                                            const bf16x8 (&wt)[NT][V2_NFRAG], const bf16x8 (&ab0e)[3], const int lane,
+                                            unsigned long long (&clk)[6]) {
+  static_assert(W <= 2, "waves 0 .. 2");
+  constexpr int I_LO = 14 * W, N0E = W == 2 ? 10 : 14;      // this wave's 0e tiles: mids [I_LO, I_LO + N0E); the last one's weights are read from LDS
+  constexpr int NLDS = W == 1 ? 2 : 1, V0 = N0E - NLDS;     // tiles k >= V0 come from LDS; wave 2: wt[V0 + t] = block 1o tile t
+  constexpr int LDS0 = W == 0 ? 0 : W == 1 ? 1 : 3;         // this wave's first tile in the LDS tile table
+  const int j = lane & 31, hf = lane >> 5;
+  const int q4 = 2 * W + hf;                       // this lane's 16-byte granule (columns 4 q4 ..) of the 32-column segments
+  const float* const bias_lds = lds + L_BIAS;
+  const bf16x8* const lw = reinterpret_cast<const bf16x8*>(lds + L_WT) + LDS0 * V2_TILE_FRAGS + lane;
+  const GPtr<float> g_node = (GPtr<float>)G.node_in;
+  const GPtr<float> g_attr = (GPtr<float>)G.attr;
+  int i_dst = 0, i_src = 0, i_attr = 0;            // indices of edge j of the unit whose gathers are issued next
+  float vn[3] = {0.f, 0.f, 0.f};                   // edge direction of the unit this wave's tiles process next iteration (wave 2)
+  int red_src = 0;                                 // aggregating node of edge j of the unit reduced next iteration (wave 0)
+  auto edge_of = [&](int u) __attribute__((always_inline)) -> int {      // clamped edge index of lane j in unit u (any u)
+    int e = (u0 + u) * SU + j;
+    e = e < cnt ? e : cnt - 1;
+    return e > 0 ? e : 0;
+  };
+
+#pragma unroll 1
+  for (int tau = 0; tau < n + 5; ++tau) {
+    unsigned long long c0 = 0;
+    if constexpr (DIAG == 4) c0 = stamp();
+    const int ug = tau - 1, uf = tau - 2, ut = tau - 3, ur = tau - 5;
+    // ================= LDS operands of this iteration: h of the tiles' unit, k-step 0 of the first-Linear chain
+    const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
+    Act6 h;
+    s_load_act(lds + L_H + h_slot(ut) * L_FRAG_SLOT, lane, h);
+    const bf16x8* const bxp = reinterpret_cast<const bf16x8*>(lds + L_BX + (uf & 1) * L_FRAG_SLOT) + lane;
+    const bf16x8* const fwp = reinterpret_cast<const bf16x8*>(lds + L_FLW) + W * V2_TILE_FRAGS + lane;
+    bf16x8 fa[2], fb[2];
+    fa[0] = fwp[0]; fb[0] = bxp[0];
+    f32x16 fac;
+    s_load_bias(bias_lds, W, hf, fac);
+    float dots[6];
+    float v[3] = {vn[0], vn[1], vn[2]};
+    auto mid_ld = [&](int i) __attribute__((always_inline)) -> float { return i < NS ? xc[i * 32] : dots[i - NS]; };
+    if constexpr (W == 2) {   // the six 1o . direction mids (0e mids 32 .. 37): tiles of this wave and k-step 2 of the bias product
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const float* p = xc + (COL_1O + 3 * k) * 32;
+        dots[k] = p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
+      }
+    }
+    float mid2[2];
+    mid2[0] = mid_ld(I_LO);
+    __builtin_amdgcn_sched_barrier(0);      // the LDS reads above are in flight while the gather addresses below are formed
+    // ================= gathers of unit tau - 1: issue (written to LDS between the MFMAs of pair 2)
+    f32x4 gx[W == 2 ? 3 : 2], gf[2];
+    {
+      const GPtr<f32x4> rowd = (GPtr<f32x4>)(g_node + (size_t)i_dst * NODE_STRIDE);
+      gx[0] = rowd[q4];
+      gx[1] = rowd[q4 + 8];
+      if constexpr (W == 2) gx[2] = rowd[q4 + 12];      // granules 16, 17 (wave 3: 18)
+      gf[0] = ((GPtr<f32x4>)(g_attr + (size_t)i_attr * 32))[q4];
+      gf[1] = ((GPtr<f32x4>)(g_node + (size_t)i_src * NODE_STRIDE))[q4];
+    }
+    // edge indices of unit tau (used at the start of the next iteration); direction / aggregating node for the next iteration's stages
+    {
+      const int ec = edge_of(tau);
+      i_dst = G.dst[ec]; i_src = G.src[ec]; i_attr = G.attr_idx[ec];
+    }
+    if constexpr (W == 2) {
+      const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[edge_of(ut + 1)];
+      vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
+    }
+    const int s_red = red_src;
+    if constexpr (W == RED_WAVE) red_src = G.src[edge_of(ur + 1)];
+    const bool red_on = W == RED_WAVE && ur >= 0 && ur < n;
+
+    // ================= the side work of pair p, slot s (0 .. 11)
+    f32x16 o0e;
+    {
+      const f32x16 zero = {};
+      o0e = zero;
+    }
+    bf16x8 bm, aw[3];
+    float* const xw = lds + L_X + (ug & 3) * L_X_SLOT;
+    __bf16* const bxw = reinterpret_cast<__bf16*>(lds + L_BX + (ug & 1) * L_FRAG_SLOT);
+    bf16x8* const hs = reinterpret_cast<bf16x8*>(lds + L_H + h_slot(uf) * L_FRAG_SLOT) + lane;
+    auto side = [&](int k, int q) __attribute__((always_inline)) {      // behind MFMA q (0 .. 5) of this wave's tile k (0 .. 13)
+      if (k == 0) {
+        // ---- first-Linear chain of hidden tile W (unit tau - 2): its MFMA q behind the tile's MFMA q, operands of q + 1 requested there
+        if (q + 1 < V2_NFRAG) { fa[(q + 1) & 1] = fwp[(q + 1) * 64]; fb[(q + 1) & 1] = bxp[(q + 1) * 64]; }
+        fac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q & 1], fb[q & 1], fac, 0, 0, 0);
+      }
+      if (k == 1) {
+        // ---- hidden tile: ReLU, bf16, store as the B operand of the second Linear
+        if (q == 2 || q == 4) {
+          const int s2 = q == 2 ? 0 : 1;
+          bf16x8 hh;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) hh[r] = (__bf16)relu1(fac[8 * s2 + r]);
+          hs[(2 * W + s2) * 64] = hh;
+        }
+        if constexpr (W == 2) {   // bias product k-step 2: the six dot mids (lower lane half; the upper half's slice is padding)
+          if (q == 1) {
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)((jj < SS.n1o && hf == 0) ? dots[jj < 6 ? jj : 0] : 0.f);
+          }
+          if (q == 3) o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[2], bm, o0e, 0, 0, 0);
+        }
+      }
+      // first two fragments of an LDS-resident tile: behind MFMA 2 of the register tile in front of it, or -- second LDS tile in a row --
+      // behind the last MFMA of the first one (fragments 0 and 1 of that chain were read by MFMAs 3 and 4, which have completed)
+      if (k == V0 - 1 && q == 2) { aw[0] = lw[0]; aw[1] = lw[64]; }
+      if (k >= V0 && k + 1 < N0E && q == 5) { aw[0] = lw[(k + 1 - V0) * V2_TILE_FRAGS]; aw[1] = lw[(k + 1 - V0) * V2_TILE_FRAGS + 64]; }
+      if (k == 4 || k == 5) {
+        // ---- gathered rows of unit tau - 1 -> X (transposed), first-Linear input -> Bx (layout of v2_set_in, tp_conv_bf16_dev.h)
+        if (k == 4 && q >= 1 && q <= 3) {
+          const int kk = q - 1;
+          if (!(kk == 2 && W != 2)) {
+            const int gran = kk < 2 ? q4 + 8 * kk : q4 + 12;
+            const f32x4 r = gx[kk < 2 ? kk : (W == 2 ? 2 : 0)];
+            float* o = xw + (4 * gran) * 32 + j;
+            o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
+          }
+        }
+        if (k == 5 && q >= 1 && q <= 3) {
+          const int seg = q - 1;
+          const int hb = q4 >> 2, qq = q4 & 3;
+          const f32x4 x = seg == 0 ? gf[0] : seg == 1 ? gf[1] : gx[0];
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 pk;
+          pk[0] = (__bf16)x.x; pk[1] = (__bf16)x.y; pk[2] = (__bf16)x.z; pk[3] = (__bf16)x.w;
+          *reinterpret_cast<bf16x4*>(bxw + (((2 * seg + (qq >> 1)) * 64 + 32 * hb + j) * 8 + 4 * (qq & 1))) = pk;
+        }
+      }
+    };
+
+    // ================= 0e tiles: one chain each; the epilogue of tile k - 1 and the side work behind the MFMAs of tile k
+    f32x16 acc2[2];
+    s_chain<true>(wt[0], h, acc2[0], acc2[0], [&](int q) __attribute__((always_inline)) { side(0, q); });
+#pragma unroll
+    for (int k = 1; k < N0E; ++k) {
+      mid2[k & 1] = mid_ld(I_LO + k);
+      const f32x16& ya = acc2[(k - 1) & 1];
+      const float ma = mid2[(k - 1) & 1];
+      auto epi = [&](int q) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (r >= S_EPI_LO[q] && r < S_EPI_LO[q + 1]) o0e[r] = fmaf(ma, ya[r], o0e[r]);
+        side(k, q);
+      };
+      if (k < V0) s_chain<true>(wt[k < V0 ? k : 0], h, acc2[k & 1], acc2[k & 1], epi);
+      else s_chain_lds(lw + (k - V0) * V2_TILE_FRAGS, aw, h, acc2[k & 1], epi);
+    }
+    {
+      const f32x16& ya = acc2[(N0E - 1) & 1];
+      const float ma = mid2[(N0E - 1) & 1];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o0e[r] = fmaf(ma, ya[r], o0e[r]);
+    }
+    if constexpr (W == 1) {
+      // bias product, k-steps 0 and 1 (sum over the 32 scalar mids of b_i m_i): accumulated onto the finished partial sums, when the
+      // registers of the first-Linear chain and of the gathers are free again (this wave waits at the barrier anyway)
+#pragma unroll
+      for (int s3 = 0; s3 < 2; ++s3) {
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)xc[(16 * s3 + 8 * hf + jj) * 32];
+        o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[s3], bm, o0e, 0, 0, 0);
+      }
+    }
+    VOut vo;
+    vo.s1o[0] = vo.s1o[1] = vo.s1o[2] = 0.f;
+    if constexpr (W == 2) {
+      // ---- block 1o, tiles 0 .. 3: mids 0 .. 19 are (scalar feature) x (edge direction): sum_i x_i w_io, the direction is applied by wave 3
+      f32x16 cb, a2[2];
+      RawT raw2[2];
+      s_load_bias(bias_lds, S_T1O, hf, cb);
+      v_step<VK_1O, 0, 0, 0>(wt[V0 + 0], h, cb, bias_lds, S_T1O + 1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+      v_step<VK_1O, 1, VK_1O, 0>(wt[V0 + 1], h, cb, bias_lds, S_T1O + 2, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+      v_step<VK_1O, 2, VK_1O, 1>(wt[V0 + 2], h, cb, bias_lds, S_T1O + 3, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+      v_step<VK_1O, 3, VK_1O, 2>(wt[V0 + 3], h, cb, bias_lds, -1, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+      v_drain<VK_1O, 3>(a2[1], raw2[1], v, vo);
+    }
+    // ---- partial sums -> LDS (lane-linear float4 rows)
+    {
+      f32x4* const p4 = reinterpret_cast<f32x4*>(lds + L_P + (ut & 1) * L_P_SLOT + W * L_P_WAVE) + lane;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) p4[qq * 64] = f32x4{o0e[4 * qq], o0e[4 * qq + 1], o0e[4 * qq + 2], o0e[4 * qq + 3]};
+      if constexpr (W == 2) p4[4 * 64] = f32x4{vo.s1o[0], vo.s1o[1], vo.s1o[2], 0.f};
+    }
+    unsigned long long c4 = 0, c5 = 0;
+    if constexpr (DIAG == 4) c4 = stamp();
+    // ================= reduction wave: run-length sums of unit tau - 5 -> global memory
+    if constexpr (W == RED_WAVE) {
+      if (red_on) {
+        const float* const om = lds + L_O + (ur & 1) * L_O_SLOT;
+        const size_t tile = (size_t)(u0 + ur);
+        const int sm = (u0 + ur) * SU + j < cnt ? s_red : -1;      // lanes past the end of the group
+        s_reduce_runs<NODE_STRIDE>(om, sm, lane, G.first_sum + tile * NODE_STRIDE, G.last_sum + tile * NODE_STRIDE, G.run_acc);
+      }
+    }
+    if constexpr (DIAG == 4) c5 = stamp();
+    lds_barrier();
+    if constexpr (DIAG == 4) {
+      const unsigned long long c6 = stamp();
+      clk[2] += c4 - c0; clk[3] += c5 - c4; clk[5] += c6 - c5;
+    }
+  }
+}
+
+// ---- wave 3 over the units [u0, u0 + n) of one group entry ---------------------------------------------------------------------
+// Pipeline over tau = 0 .. n + 4 (one barrier per iteration):  unit tau: edge indices; tau-1: gathers (all four waves; X rows, first-Linear
+// input);  tau-2: first Linear (waves 0 .. 2, one hidden tile each) -> H;  tau-3: waves 0 .. 2 tiles -> partials P;  tau-4: wave 3 -> message
+// tile O;  tau-5: wave 0 reduction -> global memory.  Wave 3: its share of the gathers, the sum of the partials, block 1o tiles 4 .. 8,
+// blocks 1e and 0o as software-pipelined steps (v_step), the message tile.
+template <int NT, int DIAG>
+__device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, const int u0, const int n, float* const lds,
                                           const bf16x8 (&wt)[NT][V2_NFRAG], const bf16x8 (&ab0e)[3], const int lane,
                                           unsigned long long (&clk)[6]) {
+  constexpr int W = 3;
   const int j = lane & 31, hf = lane >> 5;
   const int q4 = 2 * W + hf;                       // this lane's 16-byte granule (columns 4 q4 ..) of the 32-column segments
   const float* const bias_lds = lds + L_BIAS;
   int i_dst = 0, i_src = 0, i_attr = 0;            // indices of edge j of the unit whose gathers are issued next
   f32x4 gx[3], gf[2];                              // gathers in flight: X-row granules q4, q4 + 8, q4 + 16; attr / x_src granule q4
   float vn[3] = {0.f, 0.f, 0.f};                   // edge direction of the unit this wave's tiles process next iteration
-  int red_src = -1;
 
 #pragma unroll 1
   for (int tau = 0; tau < n + 5; ++tau) {
@@ -304,7 +545,7 @@ __device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, con
       const float* rowd = G.node_in + (size_t)i_dst * NODE_STRIDE;
       gx[0] = *reinterpret_cast<const f32x4*>(rowd + 4 * q4);
       gx[1] = *reinterpret_cast<const f32x4*>(rowd + 4 * (q4 + 8));
-      if constexpr (W <= 1) gx[2] = *reinterpret_cast<const f32x4*>(rowd + 4 * (W == 0 ? q4 + 16 : 18));
+      gx[2] = *reinterpret_cast<const f32x4*>(rowd + 4 * 18);      // granule 18 (columns 72 .. 75), stored by the lower lane half
       gf[0] = *reinterpret_cast<const f32x4*>(G.attr + (size_t)i_attr * 32 + 4 * q4);
       gf[1] = *reinterpret_cast<const f32x4*>(G.node_in + (size_t)i_src * NODE_STRIDE + 4 * q4);
     }
@@ -316,141 +557,28 @@ __device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, con
     }
     // edge directions / aggregating nodes for the stages of the NEXT iteration
     float v[3] = {vn[0], vn[1], vn[2]};
-    if constexpr (W >= 2) {
-      const int un = tau + 1 - (W == 2 ? 3 : 4);
+    {
+      const int un = tau + 1 - 4;
       if (un >= 0 && un < n) {
         const int e = (u0 + un) * SU + j;
         const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[e < cnt ? e : cnt - 1];
         vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
       }
     }
-    int s_red = red_src;
-    if constexpr (W == RED_WAVE) {
-      const int un = tau + 1 - 5;
-      if (un >= 0 && un < n) {
-        const int e = (u0 + un) * SU + j;
-        red_src = G.src[e < cnt ? e : cnt - 1];        // lanes past the end of the group are masked at the use (no wait on the load here)
-      }
-    }
     if constexpr (DIAG == 4) c1 = stamp();
 
-    // ================= waves 0 .. 2: hidden tile W of the first Linear of unit tau - 2 -> H (h = ReLU(W1 x + b1) as the bf16 B operand)
-    if constexpr (W <= 2) {
-      const int uf = tau - 2;
-      if (uf >= 0 && uf < n) {
-        Act6 Bx;
-        s_load_act(lds + L_BX + (uf & 1) * L_FRAG_SLOT, lane, Bx);
-        bf16x8* const hs = reinterpret_cast<bf16x8*>(lds + L_H + (uf & 3) * L_FRAG_SLOT) + lane;
-        const bf16x8* const fw = reinterpret_cast<const bf16x8*>(lds + L_FLW) + W * V2_TILE_FRAGS + lane;
-        bf16x8 fa[V2_NFRAG];
-#pragma unroll
-        for (int q = 0; q < V2_NFRAG; ++q) fa[q] = fw[q * 64];
-        f32x16 cb, fac;
-        s_load_bias(bias_lds, W, hf, cb);
-        s_chain<false>(fa, Bx, cb, fac, [](int) {});
-        bf16x8 h0, h1;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) { h0[r] = (__bf16)relu1(fac[r]); h1[r] = (__bf16)relu1(fac[8 + r]); }
-        hs[(2 * W) * 64] = h0;
-        hs[(2 * W + 1) * 64] = h1;
-      }
-    }
     if constexpr (DIAG == 4) c2 = stamp();
 
     // ================= tiles
-    const int ut = tau - (W == 3 ? 4 : 3);
+    const int ut = tau - 4;
     if (ut >= 0 && ut < n) {
       const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
       Act6 h;
-      s_load_act(lds + L_H + (ut & 3) * L_FRAG_SLOT, lane, h);
+      s_load_act(lds + L_H + h_slot(ut) * L_FRAG_SLOT, lane, h);
       float* const pw = lds + L_P + (ut & 1) * L_P_SLOT;
       f32x16 o0e;
 
-      if constexpr (W <= 2) {
-        // ---- 0e tiles [I_LO, I_LO + N0E): tile = one mid index x 32 output scalars
-        constexpr int I_LO = 14 * W, N0E = W == 2 ? 10 : 14;
-        // The 0e tiles carry no bias: sum_i m_i (w_i + b_i) = sum_i m_i w_i + sum_i b_i m_i, and the second sum over ALL 38 mids is one
-        // [32 x 48] . [48 x 32] bf16 product (tp_conv_bf16.hip) -- k-steps 0 and 1 (the 32 scalar mids) start wave 1's partial sums,
-        // k-step 2 (the six dot mids, which need the edge direction) wave 2's
-        {
-          const f32x16 zero = {};
-          o0e = zero;
-        }
-        if constexpr (W == 1) {
-#pragma unroll
-          for (int s3 = 0; s3 < 2; ++s3) {
-            bf16x8 bm;
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)xc[(16 * s3 + 8 * hf + jj) * 32];
-            o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[s3], bm, o0e, 0, 0, 0);
-          }
-        }
-        if constexpr (W == 2) {
-          bf16x8 bm;
-#pragma unroll
-          for (int jj = 0; jj < 8; ++jj) {
-            float m = 0.f;
-            if (jj < SS.n1o) {
-              const float* p = xc + (COL_1O + 3 * jj) * 32;
-              m = p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
-            }
-            if (hf) m = 0.f;
-            bm[jj] = (__bf16)m;
-          }
-          o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[2], bm, o0e, 0, 0, 0);
-        }
-        auto mid_of = [&](int i) __attribute__((always_inline)) -> float {
-          if (i < NS) return xc[i * 32];
-          const float* p = xc + (COL_1O + 3 * (i - NS)) * 32;
-          return p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
-        };
-        // pairs of tiles as two interleaved chains; the epilogue of pair p (16 FMAs per tile) sits behind the 12 MFMAs of pair p + 1:
-        // slices 0 .. 5 the first tile of the pair, 6 .. 11 the second
-        static_assert(N0E % 2 == 0, "0e tiles are processed in pairs");
-        f32x16 acc4[4];
-        float mid4[4];
-        mid4[0] = mid_of(I_LO); mid4[1] = mid_of(I_LO + 1);
-        s_chain2(wt[0], wt[1], h, acc4[0], acc4[1], [](int) {});
-#pragma unroll
-        for (int p = 1; p < N0E / 2; ++p) {
-          const int cur = 2 * (p & 1), prv = 2 * ((p - 1) & 1);
-          mid4[cur] = mid_of(I_LO + 2 * p); mid4[cur + 1] = mid_of(I_LO + 2 * p + 1);
-          const f32x16& ya = acc4[prv];
-          const f32x16& yb = acc4[prv + 1];
-          const float ma = mid4[prv], mb = mid4[prv + 1];
-          s_chain2(wt[2 * p], wt[2 * p + 1], h, acc4[cur], acc4[cur + 1], [&](int sl) __attribute__((always_inline)) {
-            const int q = sl < 6 ? sl : sl - 6;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (r >= S_EPI_LO[q] && r < S_EPI_LO[q + 1]) { if (sl < 6) o0e[r] = fmaf(ma, ya[r], o0e[r]); else o0e[r] = fmaf(mb, yb[r], o0e[r]); }
-          });
-        }
-        {
-          constexpr int prv = 2 * ((N0E / 2 - 1) & 1);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o0e[r] = fmaf(mid4[prv], acc4[prv][r], o0e[r]);
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o0e[r] = fmaf(mid4[prv + 1], acc4[prv + 1][r], o0e[r]);
-        }
-        VOut vo;
-        vo.s1o[0] = vo.s1o[1] = vo.s1o[2] = 0.f;
-        if constexpr (W == 2) {
-          // ---- block 1o, tiles 0 .. 3: mids 0 .. 19 are (scalar feature) x (edge direction): sum_i x_i w_io, the direction is applied by wave 3
-          f32x16 cb, a2[2];
-          RawT raw2[2];
-          s_load_bias(bias_lds, S_T1O, hf, cb);
-          v_step<VK_1O, 0, 0, 0>(wt[N0E + 0], h, cb, bias_lds, S_T1O + 1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-          v_step<VK_1O, 1, VK_1O, 0>(wt[N0E + 1], h, cb, bias_lds, S_T1O + 2, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-          v_step<VK_1O, 2, VK_1O, 1>(wt[N0E + 2], h, cb, bias_lds, S_T1O + 3, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-          v_step<VK_1O, 3, VK_1O, 2>(wt[N0E + 3], h, cb, bias_lds, -1, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-          v_drain<VK_1O, 3>(a2[1], raw2[1], v, vo);
-        }
-        // ---- partial sums -> LDS (lane-linear float4 rows)
-        f32x4* const p4 = reinterpret_cast<f32x4*>(pw + W * L_P_WAVE) + lane;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) p4[qq * 64] = f32x4{o0e[4 * qq], o0e[4 * qq + 1], o0e[4 * qq + 2], o0e[4 * qq + 3]};
-        if constexpr (W == 2) p4[4 * 64] = f32x4{vo.s1o[0], vo.s1o[1], vo.s1o[2], 0.f};
-      } else {
+      {
         // ================= wave 3: sum of the partials, remaining vector tiles, message tile
         {
           const f32x4* const p4 = reinterpret_cast<const f32x4*>(pw) + lane;
@@ -511,16 +639,6 @@ __device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, con
     }
     if constexpr (DIAG == 4) c3 = stamp();
 
-    // ================= reduction wave: run-length sums of unit tau - 5 -> global memory
-    if constexpr (W == RED_WAVE) {
-      const int ur = tau - 5;
-      if (ur >= 0 && ur < n) {
-        const float* const om = lds + L_O + (ur & 1) * L_O_SLOT;
-        const size_t tile = (size_t)(u0 + ur);
-        const int sm = (u0 + ur) * SU + j < cnt ? s_red : -1;      // lanes past the end of the group
-        s_reduce_runs<NODE_STRIDE>(om, sm, lane, G.first_sum + tile * NODE_STRIDE, G.last_sum + tile * NODE_STRIDE, G.run_acc);
-      }
-    }
     if constexpr (DIAG == 4) c4 = stamp();
 
     // ================= gathers of unit tau - 1: write to LDS
@@ -528,9 +646,8 @@ __device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, con
       float* const X = lds + L_X + (ug & 3) * L_X_SLOT;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
-        if (k == 2 && W > 1) continue;
-        const int gran = k < 2 ? q4 + 8 * k : (W == 0 ? q4 + 16 : 18);
-        if (k == 2 && W == 1 && hf) continue;
+        if (k == 2 && hf) continue;
+        const int gran = k < 2 ? q4 + 8 * k : 18;
         const f32x4 r = gx[k];
         float* o = X + (4 * gran) * 32 + j;
         o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
@@ -561,19 +678,22 @@ __device__ __forceinline__ void s_segment(const ConvGroup& G, const int cnt, con
 template <int W, int DIAG>
 __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const lds, const float* const wstream, const int lane,
                                             const int u_lo, const int u_hi, const int mine, const int incl) {
-  constexpr int T0 = W == 0 ? 3 : W == 1 ? 17 : W == 2 ? 31 : 3 + SS.t0e + 4;
-  constexpr int NT = W == 3 ? 11 : 14;
+  // stationary tiles (stream indices): wave 0: 3 .. 15 (0e mids 0 .. 12; mid 13 = tile 16 is read from LDS), wave 1: 17 .. 28 (+ 29, 30 from
+  // LDS), wave 2: 31 .. 39 (0e mids 28 .. 36; 37 = tile 40 from LDS) and 41 .. 44 (block 1o tiles 0 .. 3), wave 3: 45 .. 55
+  constexpr int NT = W == 3 ? 11 : W == 1 ? 12 : 13;
   const GFrag gp = (GFrag)reinterpret_cast<const bf16x8*>(wstream);
   bf16x8 wt[NT][V2_NFRAG];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    const int T = W == 0 ? 3 + t : W == 1 ? 17 + t : W == 2 ? (t < 9 ? 31 + t : 41 + (t - 9)) : 45 + t;
 #pragma unroll
     for (int q = 0; q < V2_NFRAG; ++q) {
-      wt[t][q] = gp[(size_t)(T0 + t) * V2_TILE_FRAGS + q * 64 + lane];
+      wt[t][q] = gp[(size_t)T * V2_TILE_FRAGS + q * 64 + lane];
       // ten tiles live in the accumulation half of the register file (256 registers; the MFMA reads srcA from it directly), the rest
       // in ordinary VGPRs -- pinning more than fit makes hipcc copy the overflow in front of every MFMA that uses it
       if (t < 10) asm volatile("" : "+a"(wt[t][q])); else asm volatile("" : "+v"(wt[t][q]));
     }
+  }
   bf16x8 ab0e[3];
   if constexpr (W == 1 || W == 2) {
     const GFrag gb0e = (GFrag)reinterpret_cast<const bf16x8*>(reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(wstream) + (size_t)(SS.ntiles + 1) * V2_TILE_FRAGS) + (size_t)(SS.ntiles + 1) * 32);
@@ -592,7 +712,8 @@ __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const l
     if (a >= b) continue;
     const ConvGroup G = args.g[g];
     const int cnt = *G.count;
-    s_segment<W, NT, DIAG>(G, cnt, a - start, b - a, lds, wt, ab0e, lane, clk);
+    if constexpr (W <= 2) s_segment_a<W, NT, DIAG>(G, cnt, a - start, b - a, lds, wt, ab0e, lane, clk);
+    else s_segment_b<NT, DIAG>(G, cnt, a - start, b - a, lds, wt, ab0e, lane, clk);
   }
   if constexpr (DIAG == 4) {
     const int rec = blockIdx.x * SW_WAVES + W;
@@ -611,7 +732,11 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
 
-  // ---- roles: 32-edge units per entry (lane g <-> entry g), workgroups per role, this workgroup's role and unit range
+  // ---- work split: 32-edge units per entry (lane g <-> entry g); the units of the launch in ROLE-MAJOR order form one range that is cut
+  //      into gridDim.x equal pieces.  A workgroup whose piece straddles a role boundary finishes the first role, reloads its registers
+  //      and LDS with the next role's FCBlock and goes on (a few microseconds, at most n_roles - 1 workgroups per launch).  Dealing whole
+  //      workgroups to roles in proportion to their units looked simpler and cost up to 2x: the small ligand-ligand role deserved 1.8
+  //      workgroups, got 1, and that workgroup finished last (profiles/r05_*).
   int units = 0, my_role = -1;
   if (lane < args.n_groups) {
     const char* ka = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -622,44 +747,50 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
   const int total = s_wave_sum(units);
   if (total == 0) return;
   const int n_wg = gridDim.x;
-  int role = -1, rank = 0, n_role_wg = 1, role_units = 0, acc_units = 0, wg_lo = 0;
+  const int U_lo = (int)((long long)total * blockIdx.x / n_wg), U_hi = (int)((long long)total * (blockIdx.x + 1) / n_wg);
+  if (U_lo >= U_hi) return;
+  int acc_units = 0;
 #pragma unroll 1
-  for (int r = 0; r < rt.n_roles; ++r) {
-    const int w = s_wave_sum(my_role == r ? units : 0);
+  for (int role = 0; role < rt.n_roles; ++role) {
+    const int w = s_wave_sum(my_role == role ? units : 0);
+    const int R_lo = acc_units;
     acc_units += w;
-    int wg_hi = (int)((long long)n_wg * acc_units / total);
-    if (w > 0 && wg_hi <= wg_lo) wg_hi = wg_lo + 1;                 // every role with work gets a workgroup
-    if (r == rt.n_roles - 1 || wg_hi > n_wg) wg_hi = n_wg;
-    if (role < 0 && (int)blockIdx.x >= wg_lo && (int)blockIdx.x < wg_hi && w > 0) { role = r; rank = blockIdx.x - wg_lo; n_role_wg = wg_hi - wg_lo; role_units = w; }
-    wg_lo = wg_hi;
-  }
-  if (role < 0) return;
-  const int u_lo = (int)((long long)role_units * rank / n_role_wg), u_hi = (int)((long long)role_units * (rank + 1) / n_role_wg);
-  if (u_lo >= u_hi) return;
-  const float* const wstream = rt.wstream[role];
-
-  // ---- bias rows and the three first-Linear tiles -> LDS, once
-  {
-    const float* gb = reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(wstream) + (size_t)(SS.ntiles + 1) * V2_TILE_FRAGS);
-    for (int k = threadIdx.x; k < (SS.ntiles + 1) * 32; k += SW_WAVES * 64) lds[L_BIAS + k] = gb[k];
-    const f32x4* src = reinterpret_cast<const f32x4*>(wstream);
-    f32x4* dst = reinterpret_cast<f32x4*>(lds + L_FLW);
-    for (int k = threadIdx.x; k < 3 * V2_TILE_FRAGS; k += SW_WAVES * 64) dst[k] = src[k];
-  }
-  __syncthreads();
-
-  // units of this role per entry and their inclusive prefix (unit -> entry)
-  const int mine = my_role == role ? units : 0;
-  int incl = mine;
+    const int a = U_lo > R_lo ? U_lo : R_lo, b = U_hi < acc_units ? U_hi : acc_units;
+    if (a >= b) continue;
+    const int u_lo = a - R_lo, u_hi = b - R_lo;
+    const float* const wstream = rt.wstream[role];
+    // ---- bias rows, the three first-Linear tiles and one second-Linear tile per wave 0 .. 2 -> LDS
+    __syncthreads();
+    {
+      const float* gb = reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(wstream) + (size_t)(SS.ntiles + 1) * V2_TILE_FRAGS);
+      for (int k = threadIdx.x; k < S_BIAS_ROWS * 32; k += SW_WAVES * 64) {
+        const int row = k >> 5;
+        lds[L_BIAS + k] = gb[(row < 3 ? row : 3 + SS.t0e + (row - 3)) * 32 + (k & 31)];
+      }
+      const f32x4* src = reinterpret_cast<const f32x4*>(wstream);
+      f32x4* dst = reinterpret_cast<f32x4*>(lds + L_FLW);
+      for (int k = threadIdx.x; k < 3 * V2_TILE_FRAGS; k += SW_WAVES * 64) dst[k] = src[k];
+      // stream tiles 16 | 29, 30 | 40 = the last 0e tiles of waves 0 | 1 | 2 (mids 13 | 26, 27 | 37)
+      f32x4* dw = reinterpret_cast<f32x4*>(lds + L_WT);
+      for (int k = threadIdx.x; k < S_LDS_TILES * V2_TILE_FRAGS; k += SW_WAVES * 64) {
+        const int ww = k / V2_TILE_FRAGS, r = k - ww * V2_TILE_FRAGS;
+        dw[k] = src[(size_t)lds_tile_stream(ww) * V2_TILE_FRAGS + r];
+      }
+    }
+    __syncthreads();
+    // units of this role per entry and their inclusive prefix (unit -> entry)
+    const int mine = my_role == role ? units : 0;
+    int incl = mine;
 #pragma unroll
-  for (int d = 1; d < CONV_MAX_GROUPS; d <<= 1) {
-    const int v = __shfl_up(incl, d);
-    if (lane >= d) incl += v;
+    for (int d = 1; d < CONV_MAX_GROUPS; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      if (lane >= d) incl += v;
+    }
+    if (wave == 0) s_wave_prog<0, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
+    else if (wave == 1) s_wave_prog<1, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
+    else if (wave == 2) s_wave_prog<2, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
+    else s_wave_prog<3, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
   }
-  if (wave == 0) s_wave_prog<0, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-  else if (wave == 1) s_wave_prog<1, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-  else if (wave == 2) s_wave_prog<2, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-  else s_wave_prog<3, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
 }
 
 // a: the edge groups of a 74 -> 74 layer (whole tile chains); n_wg: workgroups (<= CUs).  Roles = distinct weight streams.

@@ -14,7 +14,7 @@ model, args = make_score_model(seed=0)
 cplx = make_workload("c4_large_pocket", seed=1234, **BENCH_GEOMETRY)
 B = 64
 eng = DockEngine(dev, max_batch=B); eng.load_state_dict(model.state_dict()); eng.set_complex(cplx)
-eng.set_option("bf16", 1)
+eng.set_option("bf16", 1); eng.set_option("bf16_stationary", 1)
 steps = make_steps(get_t_schedule("expbeta", 20), args, model.timestep_emb_func)
 g = torch.Generator().manual_seed(0)
 pos0 = (cplx["ligand"].pos[None].repeat(B, 1, 1) + 2 * torch.randn(B, 1, 3, generator=g)).to(dev)
@@ -22,7 +22,9 @@ noise = [torch.randn(20, B, 3, generator=g), torch.randn(20, B, 3, generator=g),
 t0 = time.time()
 while time.time() - t0 < 3.0:
     p = pos0.clone(); eng.sample(p, steps, *noise); torch.cuda.synchronize()
-r = eng.fetch("conv_clock_s", 64).reshape(4, 10)
+raw = eng.fetch("conv_clock_s", 64)
+r = raw[:40].reshape(4, 10)
+print(f"launch span {raw[40] / 1e3:.1f} us; workgroup lifetime median {raw[41] / 1e3:.1f} / max {raw[42] / 1e3:.1f} / min {raw[43] / 1e3:.1f} us; units per workgroup {raw[45]:.0f} .. {raw[44]:.0f}; {int(raw[46])} workgroups")
 names = ["idx+issue", "firstLin", "tiles", "reduce", "ldsWrite", "barrier"]
 for w in range(4):
     tot, ghz, units, n = r[w, 0], r[w, 1], max(r[w, 8], 1.0), r[w, 9]
