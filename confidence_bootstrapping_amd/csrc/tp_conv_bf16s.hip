@@ -35,7 +35,7 @@ constexpr ConvShape SS = conv_shape(3, 3, true);         // the bf16 stream's la
 static_assert(SS.ntiles == 56 && SS.t0e == 38 && SS.t1o == 9 && SS.t1e - SS.vmerged == 3 && SS.t0o == 3 && SS.vmerged == 1,
               "the wave programs below are written for the 74 -> 74 layer shape");
 constexpr int S_MAX_ROLES = 8;
-constexpr int RED_WAVE = 0;                              // the wave that runs the run-length reduction
+constexpr int RED_COLS = (NODE_DIM + 1) / 2;               // waves 0 and 1 reduce the message columns [0, 37) and [37, 74)
 
 // ---- LDS map (floats)
 constexpr int L_X_SLOT = 76 * 32;                        // gathered destination rows, transposed [col][32 edges]
@@ -55,7 +55,7 @@ constexpr int L_FLW = L_BIAS + S_BIAS_ROWS * 32;         // the three first-Line
 constexpr int S_LDS_TILES = 4;                           // second-Linear tiles read from LDS instead of held in registers: the last 0e tile of waves 0 and 2, the last two of wave 1
 constexpr int L_WT = L_FLW + 3 * L_FRAG_SLOT;
 constexpr int L_TOTAL = L_WT + S_LDS_TILES * L_FRAG_SLOT;
-__host__ __device__ constexpr int lds_tile_stream(int k) { return k == 0 ? 16 : k == 1 ? 29 : k == 2 ? 30 : 40; }      // stream index of LDS tile k
+__host__ __device__ constexpr int lds_tile_stream(int k) { return k == 0 ? 16 : k == 1 ? 23 : k == 2 ? 30 : 40; }      // stream index of LDS tile k
 __host__ __device__ constexpr int bias_row(int T) { return T < 3 ? T : 3 + (T - (3 + SS.t0e)); }                        // row of stream tile T in the LDS bias table
 constexpr int S_LDS_BYTES = L_TOTAL * 4;
 static_assert(S_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
@@ -168,55 +168,48 @@ __device__ __forceinline__ void s_load_act(const float* slot, int lane, Act6& h)
 
 constexpr int S_EPI_LO[V2_NFRAG + 1] = {0, 3, 6, 9, 12, 14, 16};
 
-// Run-length sums of one message tile: reduce_runs (reduce_runs.h) with the aggregating-node ids in a register instead of LDS, and ONE
-// pass over the 32 edges for all 74 columns -- lane l sums column l and, for l < 10, column 64 + l as well (the scalar run bookkeeping
-// is shared); the tile is read with ds_read_b128 (stride 36), and a group of eight edges without a run boundary -- most of them: a unit
-// holds one to three runs -- is summed without a single branch.  Same additions in the same order as reduce_runs.
-template <int NODE_STR>
+// Run-length sums of one message tile for the columns [C_LO, C_LO + C_N): reduce_runs (reduce_runs.h) with the aggregating-node ids in a
+// register instead of LDS; lane l sums column C_LO + l.  The tile is read with ds_read_b128 (stride 36), and a group of eight edges
+// without a run boundary -- most of them: a unit holds one to three runs -- is summed without a single branch.  Same additions in the
+// same order as reduce_runs.  Waves 0 and 1 each take half of the 74 columns.
+template <int NODE_STR, int C_LO, int C_N>
 __device__ __forceinline__ void s_reduce_runs(const float* __restrict__ msg, int s_me, int lane, float* __restrict__ fs,
                                               float* __restrict__ ls, float* __restrict__ run_acc) {
-  constexpr int REST = NODE_DIM - 64;
   const int s_up = __shfl_up(s_me, 1, 64);
   const int s_prev = (lane & 31) > 0 ? s_up : s_me;
   const unsigned starts = (unsigned)__ballot(lane < 32 && s_me != s_prev);
   const int last = __builtin_amdgcn_readlane(s_me, 31);
-  const bool two = lane < REST;
-  const f32x4* oc = reinterpret_cast<const f32x4*>(msg + lane * S_OSTR);
-  const f32x4* oc2 = reinterpret_cast<const f32x4*>(msg + (64 + (two ? lane : 0)) * S_OSTR);
-  float v[32], w[32];
+  const bool on = lane < C_N;
+  const int col = C_LO + (on ? lane : 0);
+  const f32x4* oc = reinterpret_cast<const f32x4*>(msg + col * S_OSTR);
+  float v[32];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const f32x4 a = oc[k], b = oc2[k];
+    const f32x4 a = oc[k];
     v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
-    w[4 * k] = b.x; w[4 * k + 1] = b.y; w[4 * k + 2] = b.z; w[4 * k + 3] = b.w;
   }
-  float sum = 0.f, sum2 = 0.f;
+  float sum = 0.f;
   int a0 = 0;
 #pragma unroll
   for (int g8 = 0; g8 < 4; ++g8) {
     if (((starts >> (8 * g8)) & 0xffu) == 0u) {
 #pragma unroll
-      for (int jj = 8 * g8; jj < 8 * g8 + 8; ++jj) { sum += v[jj]; sum2 += w[jj]; }
+      for (int jj = 8 * g8; jj < 8 * g8 + 8; ++jj) sum += v[jj];
     } else {
 #pragma unroll
       for (int jj = 8 * g8; jj < 8 * g8 + 8; ++jj) {
         if (jj > 0 && ((starts >> jj) & 1u)) {   // run [a0, jj-1] is complete
           const int node = __builtin_amdgcn_readlane(s_me, a0);
           float* dst = a0 == 0 ? fs : run_acc + (size_t)node * NODE_STR;
-          dst[lane] = sum;
-          if (two) dst[64 + lane] = sum2;
-          sum = 0.f; sum2 = 0.f;
+          if (on) dst[col] = sum;
+          sum = 0.f;
           a0 = jj;
         }
-        sum += v[jj]; sum2 += w[jj];
+        sum += v[jj];
       }
     }
   }
-  if (last >= 0) {
-    float* dst = a0 == 0 ? fs : ls;
-    dst[lane] = sum;
-    if (two) dst[64 + lane] = sum2;
-  }
+  if (last >= 0 && on) (a0 == 0 ? fs : ls)[col] = sum;
 }
 
 // ---- biased tiles (vector / pseudoscalar blocks) as software-pipelined steps: the CG epilogue of step s - 1 sits between the MFMAs of
@@ -287,21 +280,40 @@ __device__ __forceinline__ void v_epi(int qs, const f32x16& a, const RawT& r, co
 }
 
 // one step: raw operands of THIS tile from LDS, its chain, and between the MFMAs the previous step's epilogue + the next step's bias rows
-template <int KIND, int T, int PKIND, int PT>
+template <int KIND, int T, int PKIND, int PT, class Side>
 __device__ __forceinline__ void v_step(const bf16x8 (&w)[V2_NFRAG], const Act6& h, f32x16& cb, const float* bias_lds, const int next_bias, const int hf,
                                        const float* xc, f32x16& acc_cur, const f32x16& acc_prev, RawT& raw_cur, const RawT& raw_prev,
-                                       const float (&v)[3], VOut& o) {
+                                       const float (&v)[3], VOut& o, Side side) {
   v_raw<KIND, T>(xc, raw_cur);
   s_chain<false>(w, h, cb, acc_cur, [&](int q) __attribute__((always_inline)) {
     if (q == 1 && next_bias >= 0) s_load_bias(bias_lds, next_bias, hf, cb);
     if constexpr (PKIND != 0) { if (q < VEC_TILE_I) v_epi<PKIND, PT>(q, acc_prev, raw_prev, v, o); }
+    side(q);
   });
+}
+template <int KIND, int T, int PKIND, int PT>
+__device__ __forceinline__ void v_step(const bf16x8 (&w)[V2_NFRAG], const Act6& h, f32x16& cb, const float* bias_lds, const int next_bias, const int hf,
+                                       const float* xc, f32x16& acc_cur, const f32x16& acc_prev, RawT& raw_cur, const RawT& raw_prev,
+                                       const float (&v)[3], VOut& o) {
+  v_step<KIND, T, PKIND, PT>(w, h, cb, bias_lds, next_bias, hf, xc, acc_cur, acc_prev, raw_cur, raw_prev, v, o, [](int) {});
 }
 template <int KIND, int T>
 __device__ __forceinline__ void v_drain(const f32x16& acc, const RawT& raw, const float (&v)[3], VOut& o) {
 #pragma unroll
   for (int q = 0; q < VEC_TILE_I; ++q) v_epi<KIND, T>(q, acc, raw, v, o);
 }
+
+// Which of a wave's 0e tiles (position k = mid index - I_LO) are read from LDS, and where the others sit in its register array.
+// Wave 1 has two LDS tiles; they are kept apart (positions 6 and 13) so that only one LDS tile is in flight in the staggered chains.
+template <int W>
+struct WMap {
+  static constexpr int N0E = W == 2 ? 10 : 14;
+  static constexpr int I_LO = 14 * W;
+  static constexpr bool is_lds(int k) { return W == 0 ? k == 13 : W == 1 ? (k == 6 || k == 13) : k == 9; }
+  static constexpr int ridx(int k) { return W == 1 ? (k < 6 ? k : k - 1) : k; }
+  static constexpr int lidx(int k) { return W == 0 ? 0 : W == 1 ? (k == 6 ? 1 : 2) : 3; }
+  static constexpr int NREG0E = W == 0 ? 13 : W == 1 ? 12 : 9;      // register-resident 0e tiles; wave 2: wt[NREG0E + t] = block 1o tile t
+};
 
 // ---- waves 0 .. 2: one fused, branch-free instruction stream per unit iteration ----------------------------------------------------
 // A wave that is alone on its SIMD has nobody to fill its stalls, and every instruction it issues next to an MFMA costs matrix-pipe
@@ -315,13 +327,13 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
                                             const bf16x8 (&wt)[NT][V2_NFRAG], const bf16x8 (&ab0e)[3], const int lane,
                                             unsigned long long (&clk)[6]) {
   static_assert(W <= 2, "waves 0 .. 2");
-  constexpr int I_LO = 14 * W, N0E = W == 2 ? 10 : 14;      // this wave's 0e tiles: mids [I_LO, I_LO + N0E); the last one's weights are read from LDS
-  constexpr int NLDS = W == 1 ? 2 : 1, V0 = N0E - NLDS;     // tiles k >= V0 come from LDS; wave 2: wt[V0 + t] = block 1o tile t
-  constexpr int LDS0 = W == 0 ? 0 : W == 1 ? 1 : 3;         // this wave's first tile in the LDS tile table
+  constexpr int I_LO = 14 * W;                              // this wave's 0e tiles: mids [I_LO, I_LO + WMap<W>::N0E)
+  using M = WMap<W>;
+  constexpr int V0 = M::NREG0E;                             // wave 2: wt[V0 + t] = block 1o tile t
   const int j = lane & 31, hf = lane >> 5;
   const int q4 = 2 * W + hf;                       // this lane's 16-byte granule (columns 4 q4 ..) of the 32-column segments
   const float* const bias_lds = lds + L_BIAS;
-  const bf16x8* const lw = reinterpret_cast<const bf16x8*>(lds + L_WT) + LDS0 * V2_TILE_FRAGS + lane;
+  const bf16x8* const lw = reinterpret_cast<const bf16x8*>(lds + L_WT) + lane;      // LDS tile t: lw + t * V2_TILE_FRAGS
   const GPtr<float> g_node = (GPtr<float>)G.node_in;
   const GPtr<float> g_attr = (GPtr<float>)G.attr;
   int i_dst = 0, i_src = 0, i_attr = 0;            // indices of edge j of the unit whose gathers are issued next
@@ -358,8 +370,6 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
         dots[k] = p[0] * v[0] + p[32] * v[1] + p[64] * v[2];
       }
     }
-    float mid2[2];
-    mid2[0] = mid_ld(I_LO);
     __builtin_amdgcn_sched_barrier(0);      // the LDS reads above are in flight while the gather addresses below are formed
     // ================= gathers of unit tau - 1: issue (written to LDS between the MFMAs of pair 2)
     f32x4 gx[W == 2 ? 3 : 2], gf[2];
@@ -381,8 +391,8 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
     }
     const int s_red = red_src;
-    if constexpr (W == RED_WAVE) red_src = G.src[edge_of(ur + 1)];
-    const bool red_on = W == RED_WAVE && ur >= 0 && ur < n;
+    if constexpr (W <= 1) red_src = G.src[edge_of(ur + 1)];
+    const bool red_on = W <= 1 && ur >= 0 && ur < n;
 
     // ================= the side work of pair p, slot s (0 .. 11)
     f32x16 o0e;
@@ -394,37 +404,32 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
     float* const xw = lds + L_X + (ug & 3) * L_X_SLOT;
     __bf16* const bxw = reinterpret_cast<__bf16*>(lds + L_BX + (ug & 1) * L_FRAG_SLOT);
     bf16x8* const hs = reinterpret_cast<bf16x8*>(lds + L_H + h_slot(uf) * L_FRAG_SLOT) + lane;
-    auto side = [&](int k, int q) __attribute__((always_inline)) {      // behind MFMA q (0 .. 5) of this wave's tile k (0 .. 13)
-      if (k == 0) {
-        // ---- first-Linear chain of hidden tile W (unit tau - 2): its MFMA q behind the tile's MFMA q, operands of q + 1 requested there
-        if (q + 1 < V2_NFRAG) { fa[(q + 1) & 1] = fwp[(q + 1) * 64]; fb[(q + 1) & 1] = bxp[(q + 1) * 64]; }
-        fac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[q & 1], fb[q & 1], fac, 0, 0, 0);
+    // Side work of half-step hs_ (0 .. N0E), slot sl (0 .. 5).  Half-step s issues MFMAs 3, 4, 5 of tile s - 1 and MFMAs 0, 1, 2 of tile s,
+    // alternating (slot 2 i follows MFMA 3 + i of tile s - 1, slot 2 i + 1 MFMA i of tile s): two chains in flight, staggered by half a
+    // tile, so no MFMA waits for its predecessor; the epilogue of tile s - 2 -- finished one half-step ago -- fills the same slots.
+    auto side = [&](int hs_, int sl) __attribute__((always_inline)) {
+      if (hs_ <= 1 && (sl & 1)) {
+        // ---- first-Linear chain of hidden tile W (unit tau - 2): MFMA f = 3 hs_ + sl / 2, operands of f + 1 requested in front of it
+        const int f = 3 * hs_ + (sl >> 1);
+        if (f + 1 < V2_NFRAG) { fa[(f + 1) & 1] = fwp[(f + 1) * 64]; fb[(f + 1) & 1] = bxp[(f + 1) * 64]; }
+        fac = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[f & 1], fb[f & 1], fac, 0, 0, 0);
       }
-      if (k == 1) {
+      if (hs_ == 2) {
         // ---- hidden tile: ReLU, bf16, store as the B operand of the second Linear
-        if (q == 2 || q == 4) {
-          const int s2 = q == 2 ? 0 : 1;
+        if (sl == 1 || sl == 3) {
+          const int s2 = sl >> 1;
           bf16x8 hh;
 #pragma unroll
           for (int r = 0; r < 8; ++r) hh[r] = (__bf16)relu1(fac[8 * s2 + r]);
           hs[(2 * W + s2) * 64] = hh;
         }
-        if constexpr (W == 2) {   // bias product k-step 2: the six dot mids (lower lane half; the upper half's slice is padding)
-          if (q == 1) {
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)((jj < SS.n1o && hf == 0) ? dots[jj < 6 ? jj : 0] : 0.f);
-          }
-          if (q == 3) o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[2], bm, o0e, 0, 0, 0);
-        }
       }
-      // first two fragments of an LDS-resident tile: behind MFMA 2 of the register tile in front of it, or -- second LDS tile in a row --
-      // behind the last MFMA of the first one (fragments 0 and 1 of that chain were read by MFMAs 3 and 4, which have completed)
-      if (k == V0 - 1 && q == 2) { aw[0] = lw[0]; aw[1] = lw[64]; }
-      if (k >= V0 && k + 1 < N0E && q == 5) { aw[0] = lw[(k + 1 - V0) * V2_TILE_FRAGS]; aw[1] = lw[(k + 1 - V0) * V2_TILE_FRAGS + 64]; }
-      if (k == 4 || k == 5) {
+      // first two fragments of an LDS-resident tile, one half-step ahead of its first MFMA
+      if (hs_ + 1 < M::N0E && M::is_lds(hs_ + 1) && sl == 3) { aw[0] = lw[M::lidx(hs_ + 1) * V2_TILE_FRAGS]; aw[1] = lw[M::lidx(hs_ + 1) * V2_TILE_FRAGS + 64]; }
+      if (hs_ == 5 || hs_ == 6) {
         // ---- gathered rows of unit tau - 1 -> X (transposed), first-Linear input -> Bx (layout of v2_set_in, tp_conv_bf16_dev.h)
-        if (k == 4 && q >= 1 && q <= 3) {
-          const int kk = q - 1;
+        if (hs_ == 5 && sl >= 1 && sl <= 3) {
+          const int kk = sl - 1;
           if (!(kk == 2 && W != 2)) {
             const int gran = kk < 2 ? q4 + 8 * kk : q4 + 12;
             const f32x4 r = gx[kk < 2 ? kk : (W == 2 ? 2 : 0)];
@@ -432,8 +437,8 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
             o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
           }
         }
-        if (k == 5 && q >= 1 && q <= 3) {
-          const int seg = q - 1;
+        if (hs_ == 6 && sl >= 1 && sl <= 3) {
+          const int seg = sl - 1;
           const int hb = q4 >> 2, qq = q4 & 3;
           const f32x4 x = seg == 0 ? gf[0] : seg == 1 ? gf[1] : gx[0];
           typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -444,28 +449,65 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       }
     };
 
-    // ================= 0e tiles: one chain each; the epilogue of tile k - 1 and the side work behind the MFMAs of tile k
-    f32x16 acc2[2];
-    s_chain<true>(wt[0], h, acc2[0], acc2[0], [&](int q) __attribute__((always_inline)) { side(0, q); });
-#pragma unroll
-    for (int k = 1; k < N0E; ++k) {
-      mid2[k & 1] = mid_ld(I_LO + k);
-      const f32x16& ya = acc2[(k - 1) & 1];
-      const float ma = mid2[(k - 1) & 1];
-      auto epi = [&](int q) __attribute__((always_inline)) {
+    // ================= 0e tiles: staggered chains (three accumulators: two tiles in flight, one in its epilogue)
+    f32x16 acc3[3];
+    float mid3[3];
+    auto mf = [&](int k, int q) __attribute__((always_inline)) {      // MFMA q of this wave's tile k
+      const f32x16 zero = {};
+      f32x16& a = acc3[k % 3];
+      if (!M::is_lds(k)) {
+        if (q == 0) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[M::ridx(k)][q], h.v[q], zero, 0, 0, 0);
+        else a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[M::ridx(k)][q], h.v[q], a, 0, 0, 0);
+      } else {
+        // fragment q + 2 into the register fragment q - 1 was read from: that MFMA has completed (MFMA q depends on it and an MFMA of
+        // the other tile lies in between)
+        if (q + 2 < V2_NFRAG) aw[(q + 2) % 3] = lw[M::lidx(k) * V2_TILE_FRAGS + (q + 2) * 64];
+        if (q == 0) a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], h.v[q], zero, 0, 0, 0);
+        else a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], h.v[q], a, 0, 0, 0);
+      }
+    };
+    auto slot = [&](int hs_, int sl) __attribute__((always_inline)) {
+      if (hs_ >= 2) {      // epilogue slice of tile hs_ - 2
+        const f32x16& ya = acc3[(hs_ - 2) % 3];
+        const float ma = mid3[(hs_ - 2) % 3];
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (r >= S_EPI_LO[q] && r < S_EPI_LO[q + 1]) o0e[r] = fmaf(ma, ya[r], o0e[r]);
-        side(k, q);
-      };
-      if (k < V0) s_chain<true>(wt[k < V0 ? k : 0], h, acc2[k & 1], acc2[k & 1], epi);
-      else s_chain_lds(lw + (k - V0) * V2_TILE_FRAGS, aw, h, acc2[k & 1], epi);
+          if (r >= S_EPI_LO[sl] && r < S_EPI_LO[sl + 1]) o0e[r] = fmaf(ma, ya[r], o0e[r]);
+      }
+      side(hs_, sl);
+    };
+#pragma unroll
+    for (int hs_ = 0; hs_ <= M::N0E; ++hs_) {
+      if (hs_ >= 1) mid3[(hs_ - 1) % 3] = mid_ld(M::I_LO + hs_ - 1);      // used one half-step from now
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (hs_ >= 1) {
+          mf(hs_ - 1, 3 + i);
+          __builtin_amdgcn_sched_barrier(0);
+          slot(hs_, 2 * i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hs_ < M::N0E) {
+          mf(hs_, i);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (hs_ < M::N0E || hs_ >= 1) {      // (the last half-step has no second chain: both slices behind the one MFMA)
+          slot(hs_, 2 * i + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     {
-      const f32x16& ya = acc2[(N0E - 1) & 1];
-      const float ma = mid2[(N0E - 1) & 1];
+      const f32x16& ya = acc3[(M::N0E - 1) % 3];
+      const float ma = mid3[(M::N0E - 1) % 3];
 #pragma unroll
       for (int r = 0; r < 16; ++r) o0e[r] = fmaf(ma, ya[r], o0e[r]);
+    }
+    if constexpr (W == 2) {   // bias product k-step 2: the six dot mids (lower lane half; the upper half's slice is padding), onto the finished sums
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)((jj < SS.n1o && hf == 0) ? dots[jj < 6 ? jj : 0] : 0.f);
+      o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[2], bm, o0e, 0, 0, 0);
     }
     if constexpr (W == 1) {
       // bias product, k-steps 0 and 1 (sum over the 32 scalar mids of b_i m_i): accumulated onto the finished partial sums, when the
@@ -499,13 +541,14 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
     }
     unsigned long long c4 = 0, c5 = 0;
     if constexpr (DIAG == 4) c4 = stamp();
-    // ================= reduction wave: run-length sums of unit tau - 5 -> global memory
-    if constexpr (W == RED_WAVE) {
+    // ================= waves 0 and 1: run-length sums of unit tau - 5 -> global memory, half of the columns each
+    if constexpr (W <= 1) {
       if (red_on) {
         const float* const om = lds + L_O + (ur & 1) * L_O_SLOT;
         const size_t tile = (size_t)(u0 + ur);
         const int sm = (u0 + ur) * SU + j < cnt ? s_red : -1;      // lanes past the end of the group
-        s_reduce_runs<NODE_STRIDE>(om, sm, lane, G.first_sum + tile * NODE_STRIDE, G.last_sum + tile * NODE_STRIDE, G.run_acc);
+        s_reduce_runs<NODE_STRIDE, W * RED_COLS, W == 0 ? RED_COLS : NODE_DIM - RED_COLS>(om, sm, lane, G.first_sum + tile * NODE_STRIDE,
+                                                                                          G.last_sum + tile * NODE_STRIDE, G.run_acc);
       }
     }
     if constexpr (DIAG == 4) c5 = stamp();
@@ -524,145 +567,123 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
 // blocks 1e and 0o as software-pipelined steps (v_step), the message tile.
 template <int NT, int DIAG>
 __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, const int u0, const int n, float* const lds,
-                                          const bf16x8 (&wt)[NT][V2_NFRAG], const bf16x8 (&ab0e)[3], const int lane,
-                                          unsigned long long (&clk)[6]) {
+                                            const bf16x8 (&wt)[NT][V2_NFRAG], const bf16x8 (&ab0e)[3], const int lane,
+                                            unsigned long long (&clk)[6]) {
   constexpr int W = 3;
   const int j = lane & 31, hf = lane >> 5;
   const int q4 = 2 * W + hf;                       // this lane's 16-byte granule (columns 4 q4 ..) of the 32-column segments
   const float* const bias_lds = lds + L_BIAS;
+  const GPtr<float> g_node = (GPtr<float>)G.node_in;
+  const GPtr<float> g_attr = (GPtr<float>)G.attr;
   int i_dst = 0, i_src = 0, i_attr = 0;            // indices of edge j of the unit whose gathers are issued next
-  f32x4 gx[3], gf[2];                              // gathers in flight: X-row granules q4, q4 + 8, q4 + 16; attr / x_src granule q4
   float vn[3] = {0.f, 0.f, 0.f};                   // edge direction of the unit this wave's tiles process next iteration
+  auto edge_of = [&](int u) __attribute__((always_inline)) -> int {      // clamped edge index of lane j in unit u (any u)
+    int e = (u0 + u) * SU + j;
+    e = e < cnt ? e : cnt - 1;
+    return e > 0 ? e : 0;
+  };
 
 #pragma unroll 1
   for (int tau = 0; tau < n + 5; ++tau) {
-    unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0, c4 = 0;
+    unsigned long long c0 = 0;
     if constexpr (DIAG == 4) c0 = stamp();
-    // ================= gathers of unit tau - 1: issue
-    const int ug = tau - 1;
-    const bool g_on = ug >= 0 && ug < n;
-    if (g_on) {
-      const float* rowd = G.node_in + (size_t)i_dst * NODE_STRIDE;
-      gx[0] = *reinterpret_cast<const f32x4*>(rowd + 4 * q4);
-      gx[1] = *reinterpret_cast<const f32x4*>(rowd + 4 * (q4 + 8));
-      gx[2] = *reinterpret_cast<const f32x4*>(rowd + 4 * 18);      // granule 18 (columns 72 .. 75), stored by the lower lane half
-      gf[0] = *reinterpret_cast<const f32x4*>(G.attr + (size_t)i_attr * 32 + 4 * q4);
-      gf[1] = *reinterpret_cast<const f32x4*>(G.node_in + (size_t)i_src * NODE_STRIDE + 4 * q4);
+    const int ug = tau - 1, ut = tau - 4;
+    // ================= LDS operands: h, the three partial sums of the 0e block, wave 2's scalar sums of block 1o
+    const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
+    Act6 h;
+    s_load_act(lds + L_H + h_slot(ut) * L_FRAG_SLOT, lane, h);
+    const float* const pw = lds + L_P + (ut & 1) * L_P_SLOT;
+    const f32x4 sp = (reinterpret_cast<const f32x4*>(pw) + lane)[3 * (L_P_WAVE / 4)];
+    f32x16 cb;
+    s_load_bias(bias_lds, S_T1O + 4, hf, cb);
+    __builtin_amdgcn_sched_barrier(0);      // the LDS reads above are in flight while the gather addresses below are formed
+    // ================= gathers of unit tau - 1: issue (written to LDS between the MFMAs of steps 5 and 6)
+    f32x4 gx[3], gf[2];
+    {
+      const GPtr<f32x4> rowd = (GPtr<f32x4>)(g_node + (size_t)i_dst * NODE_STRIDE);
+      gx[0] = rowd[q4];
+      gx[1] = rowd[q4 + 8];
+      gx[2] = rowd[18];                              // granule 18 (columns 72 .. 75)
+      gf[0] = ((GPtr<f32x4>)(g_attr + (size_t)i_attr * 32))[q4];
+      gf[1] = ((GPtr<f32x4>)(g_node + (size_t)i_src * NODE_STRIDE))[q4];
     }
-    // ================= edge indices of unit tau (used at the start of the next iteration)
-    if (tau < n) {
-      const int e = (u0 + tau) * SU + j;
-      const int ec = e < cnt ? e : cnt - 1;
+    {
+      const int ec = edge_of(tau);
       i_dst = G.dst[ec]; i_src = G.src[ec]; i_attr = G.attr_idx[ec];
     }
-    // edge directions / aggregating nodes for the stages of the NEXT iteration
     float v[3] = {vn[0], vn[1], vn[2]};
     {
-      const int un = tau + 1 - 4;
-      if (un >= 0 && un < n) {
-        const int e = (u0 + un) * SU + j;
-        const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[e < cnt ? e : cnt - 1];
-        vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
+      const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[edge_of(ut + 1)];
+      vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
+    }
+    f32x16 o0e;
+    {
+      const f32x4* const p4 = reinterpret_cast<const f32x4*>(pw) + lane;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const f32x4 a = p4[qq * 64], b = p4[(L_P_WAVE / 4) + qq * 64], c = p4[2 * (L_P_WAVE / 4) + qq * 64];
+        o0e[4 * qq + 0] = (a.x + b.x) + c.x; o0e[4 * qq + 1] = (a.y + b.y) + c.y;
+        o0e[4 * qq + 2] = (a.z + b.z) + c.z; o0e[4 * qq + 3] = (a.w + b.w) + c.w;
       }
     }
-    if constexpr (DIAG == 4) c1 = stamp();
-
-    if constexpr (DIAG == 4) c2 = stamp();
-
-    // ================= tiles
-    const int ut = tau - 4;
-    if (ut >= 0 && ut < n) {
-      const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
-      Act6 h;
-      s_load_act(lds + L_H + h_slot(ut) * L_FRAG_SLOT, lane, h);
-      float* const pw = lds + L_P + (ut & 1) * L_P_SLOT;
-      f32x16 o0e;
-
-      {
-        // ================= wave 3: sum of the partials, remaining vector tiles, message tile
-        {
-          const f32x4* const p4 = reinterpret_cast<const f32x4*>(pw) + lane;
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const f32x4 a = p4[qq * 64], b = p4[(L_P_WAVE / 4) + qq * 64], c = p4[2 * (L_P_WAVE / 4) + qq * 64];
-            o0e[4 * qq + 0] = (a.x + b.x) + c.x; o0e[4 * qq + 1] = (a.y + b.y) + c.y;
-            o0e[4 * qq + 2] = (a.z + b.z) + c.z; o0e[4 * qq + 3] = (a.w + b.w) + c.w;
-          }
-        }
-        const f32x4 sp = (reinterpret_cast<const f32x4*>(pw) + lane)[2 * (L_P_WAVE / 4) + 4 * 64];
-        VOut vo;
-        vo.s1o[0] = sp.x; vo.s1o[1] = sp.y; vo.s1o[2] = sp.z;
-        vo.s1e[0] = vo.s1e[1] = vo.s1e[2] = 0.f;
-        vo.k0o[0] = vo.k0o[1] = vo.k0o[2] = 0.f;
-#pragma unroll
-        for (int r = 0; r < 9; ++r) { vo.k1o[r] = 0.f; vo.k1e[r] = 0.f; }
-        f32x16 cb, a2[2];
-        RawT raw2[2];
-        s_load_bias(bias_lds, S_T1O + 4, hf, cb);
-        // block 1o tiles 4 .. 8 (mids 20 .. 43 + one padded slot), block 1e's own three tiles, block 0o's three (with 1e's tail mids as guests)
-        v_step<VK_1O, 4, 0, 0>(wt[0], h, cb, bias_lds, S_T1O + 5, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_step<VK_1O, 5, VK_1O, 4>(wt[1], h, cb, bias_lds, S_T1O + 6, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-        v_step<VK_1O, 6, VK_1O, 5>(wt[2], h, cb, bias_lds, S_T1O + 7, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_step<VK_1O, 7, VK_1O, 6>(wt[3], h, cb, bias_lds, S_T1O + 8, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-        v_step<VK_1O, 8, VK_1O, 7>(wt[4], h, cb, bias_lds, S_T1E + 0, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_step<VK_1E, 0, VK_1O, 8>(wt[5], h, cb, bias_lds, S_T1E + 1, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-        v_step<VK_1E, 1, VK_1E, 0>(wt[6], h, cb, bias_lds, S_T1E + 2, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_step<VK_1E, 2, VK_1E, 1>(wt[7], h, cb, bias_lds, S_T0O + 0, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-        v_step<VK_0O, 0, VK_1E, 2>(wt[8], h, cb, bias_lds, S_T0O + 1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_step<VK_0O, 1, VK_0O, 0>(wt[9], h, cb, bias_lds, S_T0O + 2, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
-        v_step<VK_0O, 2, VK_0O, 1>(wt[10], h, cb, bias_lds, -1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
-        v_drain<VK_0O, 2>(a2[0], raw2[0], v, vo);
-        float k1o[9], k1e[9], k0o[3];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-          k0o[o] = vo.k0o[o];
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            k1o[3 * o + c] = fmaf(v[c], vo.s1o[o], vo.k1o[3 * o + c]);
-            k1e[3 * o + c] = fmaf(v[c], vo.s1e[o], vo.k1e[3 * o + c]);
-          }
-        }
-        // ---- message tile [col][36]
-        float* const om = lds + L_O + (ut & 1) * L_O_SLOT;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) om[((r & 3) + 8 * (r >> 2) + 4 * hf) * S_OSTR + j] = o0e[r];
-#pragma unroll
-        for (int o = 0; o < 3; ++o) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) {
-            om[(COL_1O + 3 * (3 * hf + o) + c) * S_OSTR + j] = k1o[3 * o + c];
-            om[(COL_1E + 3 * (3 * hf + o) + c) * S_OSTR + j] = k1e[3 * o + c];
-          }
-          om[(COL_0O + 3 * hf + o) * S_OSTR + j] = k0o[o];
-        }
+    float* const xw = lds + L_X + (ug & 3) * L_X_SLOT;
+    __bf16* const bxw = reinterpret_cast<__bf16*>(lds + L_BX + (ug & 1) * L_FRAG_SLOT);
+    auto gather_write = [&](int part, int q) __attribute__((always_inline)) {
+      if (part == 0 && q >= 1 && q <= 3) {
+        const int kk = q - 1;
+        const int gran = kk < 2 ? q4 + 8 * kk : 18;
+        const f32x4 r = gx[kk];
+        float* o = xw + (4 * gran) * 32 + j;
+        o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;      // (granule 18: both lane halves hold and store the same values -- no predicate, no control flow inside the chain)
       }
-    }
-    if constexpr (DIAG == 4) c3 = stamp();
-
-    if constexpr (DIAG == 4) c4 = stamp();
-
-    // ================= gathers of unit tau - 1: write to LDS
-    if (g_on) {
-      float* const X = lds + L_X + (ug & 3) * L_X_SLOT;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        if (k == 2 && hf) continue;
-        const int gran = k < 2 ? q4 + 8 * k : 18;
-        const f32x4 r = gx[k];
-        float* o = X + (4 * gran) * 32 + j;
-        o[0] = r.x; o[32] = r.y; o[64] = r.z; o[96] = r.w;
-      }
-      // first-Linear input: granule q4 of part seg (0 edge_attr, 1 x_src, 2 x_dst) -> k-step 2 seg + (q >> 1), elements 4 (q & 1) .. + 3 of
-      // lane (j, hb), where q4 = 4 hb + q (the layout of v2_set_in, tp_conv_bf16_dev.h)
-      __bf16* const bx = reinterpret_cast<__bf16*>(lds + L_BX + (ug & 1) * L_FRAG_SLOT);
-      const int hb = q4 >> 2, q = q4 & 3;
-#pragma unroll
-      for (int seg = 0; seg < 3; ++seg) {
+      if (part == 1 && q >= 1 && q <= 3) {
+        const int seg = q - 1;
+        const int hb = q4 >> 2, qq = q4 & 3;
         const f32x4 x = seg == 0 ? gf[0] : seg == 1 ? gf[1] : gx[0];
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 pk;
         pk[0] = (__bf16)x.x; pk[1] = (__bf16)x.y; pk[2] = (__bf16)x.z; pk[3] = (__bf16)x.w;
-        *reinterpret_cast<bf16x4*>(bx + (((2 * seg + (q >> 1)) * 64 + 32 * hb + j) * 8 + 4 * (q & 1))) = pk;
+        *reinterpret_cast<bf16x4*>(bxw + (((2 * seg + (qq >> 1)) * 64 + 32 * hb + j) * 8 + 4 * (qq & 1))) = pk;
+      }
+    };
+
+    // ================= block 1o tiles 4 .. 8 (mids 20 .. 43 + one padded slot), block 1e's own three tiles, block 0o's three (with 1e's
+    //                   tail mids as guests) as software-pipelined steps
+    VOut vo;
+    vo.s1o[0] = sp.x; vo.s1o[1] = sp.y; vo.s1o[2] = sp.z;
+    vo.s1e[0] = vo.s1e[1] = vo.s1e[2] = 0.f;
+    vo.k0o[0] = vo.k0o[1] = vo.k0o[2] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) { vo.k1o[r] = 0.f; vo.k1e[r] = 0.f; }
+    f32x16 a2[2];
+    RawT raw2[2];
+    v_step<VK_1O, 4, 0, 0>(wt[0], h, cb, bias_lds, S_T1O + 5, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    v_step<VK_1O, 5, VK_1O, 4>(wt[1], h, cb, bias_lds, S_T1O + 6, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+    v_step<VK_1O, 6, VK_1O, 5>(wt[2], h, cb, bias_lds, S_T1O + 7, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    v_step<VK_1O, 7, VK_1O, 6>(wt[3], h, cb, bias_lds, S_T1O + 8, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+    v_step<VK_1O, 8, VK_1O, 7>(wt[4], h, cb, bias_lds, S_T1E + 0, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    v_step<VK_1E, 0, VK_1O, 8>(wt[5], h, cb, bias_lds, S_T1E + 1, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo,
+                               [&](int q) __attribute__((always_inline)) { gather_write(0, q); });
+    v_step<VK_1E, 1, VK_1E, 0>(wt[6], h, cb, bias_lds, S_T1E + 2, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo,
+                               [&](int q) __attribute__((always_inline)) { gather_write(1, q); });
+    v_step<VK_1E, 2, VK_1E, 1>(wt[7], h, cb, bias_lds, S_T0O + 0, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+    v_step<VK_0O, 0, VK_1E, 2>(wt[8], h, cb, bias_lds, S_T0O + 1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    v_step<VK_0O, 1, VK_0O, 0>(wt[9], h, cb, bias_lds, S_T0O + 2, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+    v_step<VK_0O, 2, VK_0O, 1>(wt[10], h, cb, bias_lds, -1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    v_drain<VK_0O, 2>(a2[0], raw2[0], v, vo);
+    // ---- message tile [col][36]
+    {
+      float* const om = lds + L_O + (ut & 1) * L_O_SLOT;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) om[((r & 3) + 8 * (r >> 2) + 4 * hf) * S_OSTR + j] = o0e[r];
+#pragma unroll
+      for (int o = 0; o < 3; ++o) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          om[(COL_1O + 3 * (3 * hf + o) + c) * S_OSTR + j] = fmaf(v[c], vo.s1o[o], vo.k1o[3 * o + c]);
+          om[(COL_1E + 3 * (3 * hf + o) + c) * S_OSTR + j] = fmaf(v[c], vo.s1e[o], vo.k1e[3 * o + c]);
+        }
+        om[(COL_0O + 3 * hf + o) * S_OSTR + j] = vo.k0o[o];
       }
     }
     unsigned long long c5 = 0;
@@ -670,7 +691,7 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
     lds_barrier();
     if constexpr (DIAG == 4) {
       const unsigned long long c6 = stamp();
-      clk[0] += c1 - c0; clk[1] += c2 - c1; clk[2] += c3 - c2; clk[3] += c4 - c3; clk[4] += c5 - c4; clk[5] += c6 - c5;
+      clk[2] += c5 - c0; clk[5] += c6 - c5;
     }
   }
 }
@@ -678,14 +699,14 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
 template <int W, int DIAG>
 __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const lds, const float* const wstream, const int lane,
                                             const int u_lo, const int u_hi, const int mine, const int incl) {
-  // stationary tiles (stream indices): wave 0: 3 .. 15 (0e mids 0 .. 12; mid 13 = tile 16 is read from LDS), wave 1: 17 .. 28 (+ 29, 30 from
-  // LDS), wave 2: 31 .. 39 (0e mids 28 .. 36; 37 = tile 40 from LDS) and 41 .. 44 (block 1o tiles 0 .. 3), wave 3: 45 .. 55
+  // stationary tiles (stream indices): wave 0: 3 .. 15 (0e mids 0 .. 12; mid 13 = tile 16 is read from LDS), wave 1: 17 .. 22 and 24 .. 29
+  // (23, 30 from LDS), wave 2: 31 .. 39 (0e mids 28 .. 36; 37 = tile 40 from LDS) and 41 .. 44 (block 1o tiles 0 .. 3), wave 3: 45 .. 55
   constexpr int NT = W == 3 ? 11 : W == 1 ? 12 : 13;
   const GFrag gp = (GFrag)reinterpret_cast<const bf16x8*>(wstream);
   bf16x8 wt[NT][V2_NFRAG];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int T = W == 0 ? 3 + t : W == 1 ? 17 + t : W == 2 ? (t < 9 ? 31 + t : 41 + (t - 9)) : 45 + t;
+    const int T = W == 0 ? 3 + t : W == 1 ? (t < 6 ? 17 + t : 18 + t) : W == 2 ? (t < 9 ? 31 + t : 41 + (t - 9)) : 45 + t;
 #pragma unroll
     for (int q = 0; q < V2_NFRAG; ++q) {
       wt[t][q] = gp[(size_t)T * V2_TILE_FRAGS + q * 64 + lane];
@@ -770,7 +791,7 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
       const f32x4* src = reinterpret_cast<const f32x4*>(wstream);
       f32x4* dst = reinterpret_cast<f32x4*>(lds + L_FLW);
       for (int k = threadIdx.x; k < 3 * V2_TILE_FRAGS; k += SW_WAVES * 64) dst[k] = src[k];
-      // stream tiles 16 | 29, 30 | 40 = the last 0e tiles of waves 0 | 1 | 2 (mids 13 | 26, 27 | 37)
+      // stream tiles 16 | 23, 30 | 40 = 0e tiles of waves 0 | 1 | 2 (mids 13 | 20, 27 | 37), WMap
       f32x4* dw = reinterpret_cast<f32x4*>(lds + L_WT);
       for (int k = threadIdx.x; k < S_LDS_TILES * V2_TILE_FRAGS; k += SW_WAVES * 64) {
         const int ww = k / V2_TILE_FRAGS, r = k - ww * V2_TILE_FRAGS;
