@@ -973,7 +973,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
   HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
   if ((getenv("CBD_CONV_VARIANT") && (atoi(getenv("CBD_CONV_VARIANT")) == 8 || atoi(getenv("CBD_CONV_VARIANT")) == 13)) ||
-      (getenv("CBD_BF16_DIAG") && atoi(getenv("CBD_BF16_DIAG")) == 4)) {
+      (getenv("CBD_BF16_DIAG") && (atoi(getenv("CBD_BF16_DIAG")) == 4 || atoi(getenv("CBD_BF16_DIAG")) == 5))) {
     HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 8));
     HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 8 * 8));
   } else e->stamps_dev = nullptr;
@@ -1614,8 +1614,18 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
       out[44] = units.empty() ? 0.f : (float)*std::max_element(units.begin(), units.end());
       out[45] = units.empty() ? 0.f : (float)*std::min_element(units.begin(), units.end());
       out[46] = (float)life.size(); out[47] = 0.f;
+      // per role (weight stream): median nanoseconds per unit over the workgroups whose LAST piece belongs to it and is a large one
+      for (int r = 0; r < 4; ++r) {
+        std::vector<double> per;
+        for (int rec = 0; rec < 4096; rec += 4) {
+          const unsigned long long* q = h.data() + 16 * (size_t)rec;
+          if (!q[3] || q[3] <= q[1] || q[10] < 32 || (int)q[11] != r) continue;
+          per.push_back((double)(q[3] - q[1]) * 10.0 / (double)q[10]);
+        }
+        if (capacity >= 56) { out[48 + 2 * r] = per.empty() ? 0.f : (float)med(per); out[49 + 2 * r] = (float)per.size(); }
+      }
     }
-    return 48;
+    return capacity >= 56 ? 56 : 48;
   }
   auto it = e->dbg.find(k);
   if (it == e->dbg.end()) return fail(CBD_ERR_ARG, "unknown debug tensor '%s'", name);

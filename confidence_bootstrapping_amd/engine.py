@@ -353,6 +353,11 @@ class DockEngine:
 
     def set_option(self, name: str, value: int):
         _check(self.lib.cbd_set_option(self.h, name.encode(), int(value)))
+        self.__dict__.setdefault("_options", {})[name] = int(value)
+
+    def get_option(self, name: str, default=None):
+        """the value last set through set_option (the library has no getter); `default` for an option never set"""
+        return self.__dict__.get("_options", {}).get(name, default)
 
     def stats(self, reset=False):
         out = (C.c_uint64 * 4)()
@@ -425,6 +430,9 @@ class DockEnginePool:
     def set_option(self, name, value):
         for e in self.engines:
             e.set_option(name, value)
+
+    def get_option(self, name, default=None):
+        return self.engines[0].get_option(name, default)
 
     def recompute_receptor(self):
         cur = torch.cuda.current_stream(self.device)

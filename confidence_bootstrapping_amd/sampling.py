@@ -119,6 +119,7 @@ def _sample_cropped(eng, cplx, key, pos, steps, noise, crop):
     R = eng.R
     rec_pos = cplx["receptor"].pos.float().cpu()
     base_R = int(cplx["ligand"].edge_mask.sum())
+    graph_before = eng.get_option("graph", 1)      # the caller may have switched hipGraph replay off (debugging / profiling): restored as found
     eng.set_option("graph", 0)
     try:
         for i in range(len(steps)):
@@ -145,7 +146,7 @@ def _sample_cropped(eng, cplx, key, pos, steps, noise, crop):
                 eng.sample(p, (type(steps[i]) * 1)(steps[i]), take(z_tr), take(z_rot), take(z_tor, cols) if (R > 0 and z_tor is not None) else None)
                 pos.index_copy_(0, sel, p)
     finally:
-        eng.set_option("graph", 1)
+        eng.set_option("graph", graph_before)
         eng.complex_key = None          # the engine holds a cropped complex now
 
 

@@ -18,6 +18,8 @@ from typing import List
 
 import numpy as np
 import torch
+
+from .hostcfg import canonical_device, dev_key
 import torch.nn.functional as F
 
 from . import so3, torus, train_ops
@@ -127,15 +129,20 @@ def collate(data_list: List[HeteroData], device, keep=None) -> Batch:
 
 
 _COPY_STREAMS = {}
+
 # Device copies of host tensors that do not change between training steps (receptor features and positions, ligand features, bonds).
 #   * keyed on the COMPLEX, not on the host tensor: (complex name, role, shape, dtype, device).  The bootstrapping buffer hands out
 #     shallow copies that share a complex's tensors, the reference's loaders deep-copy them; either way the same complex comes back
 #     under the same name, and a key that does not hold a storage address neither pins host memory nor depends on the allocator
 #     recycling addresses.  Graphs without a string `name` are uploaded every step (no entry);
-#   * every hit compares a fingerprint of the host tensor (32 strided elements + the last, ~5 us) with the one taken at upload time:
-#     two complexes that share a name, or a tensor edited in place (re-centring, a numpy view, `.data`), re-upload and replace the
-#     entry instead of training on a stale copy.  A guard, not a proof: an edit that leaves all 33 probes untouched goes unnoticed --
-#     callers that patch single elements of a cached tensor call `dev_cache_clear()`;
+#   * every hit compares a fingerprint of the host tensor -- storage address, torch's version counter and a contents probe (whole tensor
+#     below 4096 elements, else 32 strided elements + the last, ~5 us) -- with the one taken at upload time: two complexes that share a
+#     name, or a tensor edited in place (re-centring, a numpy view, `.data`), re-upload and replace the entry instead of training on a
+#     stale copy.  Still a guard, not a proof, for edits of large tensors behind torch's back that miss all 33 probes
+#     (`dev_cache_clear()`);
+#   * an entry remembers the stream it was uploaded on and an event behind the upload: a hit from another stream (the side stream changes
+#     priority between eager and hipGraph-captured steps) waits for that event, and an entry that is evicted or replaced is kept alive
+#     until the compute stream has passed (its last reader may still be queued);
 #   * least-recently-used entries are evicted by bytes (default limit 4 GB of device copies), never the whole cache at once;
 #   * `CBD_TRAIN_DEV_CACHE=0` or `dev_cache_configure(enabled=False)` turns it off (every step uploads its inputs).
 _DEV_CACHE = __import__("collections").OrderedDict()      # key -> (device copy, fingerprint)
@@ -161,12 +168,19 @@ def dev_cache_stats():
     return {"entries": len(_DEV_CACHE), "bytes": _DEV_CACHE_BYTES[0]}
 
 
+_FP_FULL_BELOW = 4096      # elements: index / mask tensors and small feature blocks are compared in full
+
+
 def _fingerprint(t: torch.Tensor):
+    """(storage address, version counter, contents probe): another tensor under the same complex name, an in-place edit through torch, or
+    an edit behind torch's back (numpy view) of a probed element all change it.  Tensors below _FP_FULL_BELOW elements are hashed whole;
+    the large feature matrices by 32 strided elements + the last (~5 us)."""
     n = t.numel()
     if n == 0:
-        return b""
-    a = t.numpy().reshape(-1) if t.is_contiguous() else t.reshape(-1).numpy()       # a view of the host storage: ~5 us per call
-    return a[::max(1, n // 32)][:32].tobytes() + a[-1:].tobytes()
+        return (t.data_ptr(), t._version, b"")
+    a = t.numpy().reshape(-1) if t.is_contiguous() else t.reshape(-1).numpy()       # a view of the host storage
+    probe = a.tobytes() if n <= _FP_FULL_BELOW else a[::max(1, n // 32)][:32].tobytes() + a[-1:].tobytes()
+    return (t.data_ptr(), t._version, probe)
 
 
 def _dev_cached(t: torch.Tensor, device, ident=None):
@@ -176,14 +190,18 @@ def _dev_cached(t: torch.Tensor, device, ident=None):
         return t
     if ident is None or not _DEV_CACHE_CFG["enabled"]:
         return t.to(device, non_blocking=True)
-    key = (ident, tuple(t.shape), t.dtype, str(device))
+    key = (ident, tuple(t.shape), t.dtype, dev_key(device))
     fp = _fingerprint(t)
+    cur = torch.cuda.current_stream(device)
     hit = _DEV_CACHE.get(key)
     if hit is not None:
         if hit[1] == fp:
             _DEV_CACHE.move_to_end(key)
+            if hit[3] != cur.cuda_stream:          # uploaded on another stream: order this stream behind the upload
+                cur.wait_event(hit[2])
             return hit[0]
         _DEV_CACHE_BYTES[0] -= hit[0].numel() * hit[0].element_size()       # another complex under this name, or edited in place
+        _keep_until_main_passes([hit[0]], device)
         del _DEV_CACHE[key]
     d = t.to(device, non_blocking=True)
     nbytes = d.numel() * d.element_size()
@@ -192,7 +210,10 @@ def _dev_cached(t: torch.Tensor, device, ident=None):
     while _DEV_CACHE and _DEV_CACHE_BYTES[0] + nbytes > _DEV_CACHE_CFG["limit"]:
         _, old = _DEV_CACHE.popitem(last=False)
         _DEV_CACHE_BYTES[0] -= old[0].numel() * old[0].element_size()
-    _DEV_CACHE[key] = (d, fp)
+        _keep_until_main_passes([old[0]], device)
+    ev = torch.cuda.Event()
+    ev.record(cur)
+    _DEV_CACHE[key] = (d, fp, ev, cur.cuda_stream)
     _DEV_CACHE_BYTES[0] += nbytes
     return d
 
@@ -209,7 +230,7 @@ def side_priority(high: bool):
 
 
 def _copy_stream(device):
-    key = (str(device), _SIDE_PRIORITY[0])
+    key = (dev_key(device), _SIDE_PRIORITY[0])
     if key not in _COPY_STREAMS:
         _COPY_STREAMS[key] = torch.cuda.Stream(device=device, priority=_SIDE_PRIORITY[0])
     return _COPY_STREAMS[key]
@@ -231,13 +252,13 @@ def _keep_until_main_passes(tensors, device):
         for t in tensors:
             t.record_stream(main)
         return
-    _KEEP_NOW.setdefault(str(device), []).extend(tensors)
+    _KEEP_NOW.setdefault(dev_key(device), []).extend(tensors)
 
 
 def _rotate_keep(device):
     """called at the start of every step: closes the previous step's set behind an event, frees the sets whose event has completed"""
     import collections
-    key = str(device)
+    key = dev_key(device)
     old = _KEEP_OLD.setdefault(key, collections.deque())
     cur = _KEEP_NOW.get(key)
     if cur:
@@ -363,7 +384,7 @@ _BN_MAPS = {}
 def _bn_maps(irreps: str, device):
     """Constant index tensors of an irreps layout: column -> channel, channel-averaging matrix [D, F] (1/dim entries), and the
     columns of the 0e (scalar, even) fields, which are the only ones that are centred and biased."""
-    key = (irreps, str(device))
+    key = (irreps, dev_key(device))
     m = _BN_MAPS.get(key)
     if m is None:
         col2chan, cols0e, ch = [], [], 0
@@ -511,7 +532,7 @@ _HUBS = weakref.WeakKeyDictionary()
 def _stream_hub(model, dev) -> StreamHub:
     """the model's StreamHub (every FCBlock that feeds a FasterTensorProduct, with the irreps levels of its layer), built once"""
     hub = _HUBS.get(model)          # kept beside the model, not on it: a hub holds non-leaf tensors, which copy.deepcopy(model) refuses
-    if hub is None or hub.src.device != dev:
+    if hub is None or hub.src.device != canonical_device(dev):
         blocks = []
         for layers in (model.rec_emb_layers, model.lig_emb_layers):
             for l, layer in enumerate(layers):
@@ -752,7 +773,10 @@ def _filler_for(d0: HeteroData) -> HeteroData:
 def prepare_batch(model, data, dev, pad=None) -> PreparedBatch:
     """Collation + everything of the forward pass that depends on the batch alone (see `forward`).  Thread-safe with respect to a
     training step in flight on another host thread: it enqueues on the side stream only, fills its own caches, and does not touch the
-    model's parameters or the CPU random generators.
+    model's parameters.  Random numbers: ONE int64 -- the step's dropout seed -- is drawn from torch's global CPU generator per call (when
+    the model has dropout), so that a step is reproducible under torch.manual_seed (tests/test_gpu_train_step.py); with the look-ahead
+    thread of train_epoch (off by default) that draw happens on the worker thread, i.e. its position relative to the caller's own draws
+    from the global generator is not fixed -- seed per step, or keep look_ahead off, where that matters.
     `pad` (True or a dict of bucket sizes {"ll", "lr", "t"}; `data` must be a list of graphs): capacity padding for the hipGraph-captured
     step (train_graph.py) -- a filler graph is appended and the three radius graphs of the step (ligand-ligand, ligand-receptor,
     torsion) are padded with edges INSIDE the filler up to the next multiple of their bucket, so that every tensor of the step has a

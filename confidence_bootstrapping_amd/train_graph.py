@@ -28,6 +28,8 @@ from typing import List
 import numpy as np
 import torch
 
+from .hostcfg import canonical_device, dev_key
+
 from . import train_forward as tf
 from . import train_ops as to
 from .hetero import Batch, HeteroData, Store
@@ -174,8 +176,17 @@ class _Captured:
 class GraphedStep:
     """forward + loss + backward of the fine-tuning step as one hipGraph launch per step (module docstring)."""
 
+    @property
+    def model(self):
+        m = self._model_ref()
+        if m is None:
+            raise RuntimeError("the model of this GraphedStep has been garbage-collected")
+        return m
+
     def __init__(self, model, optimizer, device, t_to_sigma, loss_kwargs=None, ema_weights=None, pad=True, max_graphs=12, capture_after=1):
-        self.model, self.opt, self.dev, self.t2s = model, optimizer, torch.device(device), t_to_sigma
+        # the model is held weakly: training._GRAPHED maps model -> this object, and a value that kept its key alive would never be collected
+        self._model_ref = __import__("weakref").ref(model)
+        self.opt, self.dev, self.t2s = optimizer, canonical_device(device), t_to_sigma
         self.lw = dict(loss_kwargs or {})
         for k in ("backbone_weight", "sidechain_weight"):
             if self.lw.pop(k, 0):
@@ -222,16 +233,16 @@ class GraphedStep:
         if hub is not None:
             hub.big = hub.w2p_all = hub.big_t = hub.grads = None
         graph = torch.cuda.CUDAGraph()
-        eager_scratch = to._DW_SCRATCH.pop(str(dev), None)       # the graph gets a scratch buffer of its own, from its private pool
+        eager_scratch = to._DW_SCRATCH.pop(dev_key(dev), None)       # the graph gets a scratch buffer of its own, from its private pool
         try:
             with torch.cuda.graph(graph):
                 tr, rot, tor, _ = tf.forward(self.model, twin.prep)
                 lt = loss_from_targets(tr, rot, tor, twin.targets, **self.lw)
                 lt[0].backward()
         finally:
-            to._DW_SCRATCH.pop(str(dev), None)
+            to._DW_SCRATCH.pop(dev_key(dev), None)
             if eager_scratch is not None:
-                to._DW_SCRATCH[str(dev)] = eager_scratch
+                to._DW_SCRATCH[dev_key(dev)] = eager_scratch
         grads = [p.grad for p in self.params]
         cap = _Captured(graph, twin, grads, tuple(t.detach() for t in lt))
         self.stats["captures"] += 1

@@ -17,6 +17,8 @@ from functools import lru_cache
 import numpy as np
 import torch
 
+from .hostcfg import dev_key
+
 from .engine import load_library, _check
 
 NODE_STRIDE = 80      # csrc/common.h
@@ -80,12 +82,12 @@ class StreamMap:
         self._dev = {}
 
     def on(self, device):
-        d = self._dev.get(str(device))
+        d = self._dev.get(dev_key(device))
         if d is None:
             d = {"src": torch.from_numpy(self.src_np).to(device), "scale": torch.from_numpy(self.scale_np).to(device),
                  "inv": torch.from_numpy(self.inv_np).to(device),
                  "w2p": torch.from_numpy(self.w2p_np.ravel()).to(device), "b2p": torch.from_numpy(self.b2p_np).to(device)}
-            self._dev[str(device)] = d
+            self._dev[dev_key(device)] = d
         return d
 
     def stream(self, fc) -> torch.Tensor:
@@ -389,9 +391,9 @@ def _dw_scratch(n_floats, device):
     step, sizes changing with the edge counts: as fresh allocations they churn the caching allocator -- the fine-tuning leg of
     bench.py, which runs after the other legs have filled the cache, went from 36 to 48 ms per step).  The groups of a step use it one
     after the other on the same stream."""
-    buf = _DW_SCRATCH.get(str(device))
+    buf = _DW_SCRATCH.get(dev_key(device))
     if buf is None or buf.numel() < n_floats:
-        buf = _DW_SCRATCH[str(device)] = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
+        buf = _DW_SCRATCH[dev_key(device)] = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
     return buf[:n_floats]
 
 

@@ -12,6 +12,8 @@ from __future__ import annotations
 import numpy as np
 import torch
 
+from .hostcfg import canonical_device, dev_key
+
 from . import so3, torus
 from .hostcfg import with_glue_threads
 
@@ -206,7 +208,7 @@ def _async_any_nan(t):
     bad = torch.isnan(t).any()
     if not bad.is_cuda:
         return lambda: bool(bad)
-    key = (str(t.device), __import__("threading").get_ident())     # one pinned flag per device AND host thread: two models trained from
+    key = (dev_key(t.device), __import__("threading").get_ident())     # one pinned flag per device AND host thread: two models trained from
     buf = _NAN_FLAGS.get(key)                                       # two threads on one GPU do not share it
     if buf is None:
         buf = _NAN_FLAGS[key] = torch.zeros(1, dtype=torch.bool, pin_memory=True)
@@ -293,7 +295,15 @@ def uniform_step_count(loader):
     return int(t.item())
 
 
-_GRAPHED = __import__("weakref").WeakKeyDictionary()       # model -> GraphedStep (its captured graphs live as long as the model)
+_GRAPHED = __import__("weakref").WeakKeyDictionary()       # model -> GraphedStep, which holds its model WEAKLY: the graphs go when the model goes
+
+
+def release_graphs(model=None):
+    """Drops the captured graphs (and their private memory pools) of `model`, or of every model."""
+    if model is None:
+        _GRAPHED.clear()
+    else:
+        _GRAPHED.pop(model, None)
 
 
 def graphed_step_for(model, optimizer, device, t_to_sigma, loss_fn, ema_weights, **kw):
@@ -311,7 +321,7 @@ def graphed_step_for(model, optimizer, device, t_to_sigma, loss_fn, ema_weights,
         raise NotImplementedError("the captured step computes the batch-mean loss (apply_mean=True)")
     lw.pop("apply_mean", None)
     cur = _GRAPHED.get(model)
-    sig = (id(optimizer), id(ema_weights), str(torch.device(device)), tuple(sorted(lw.items())))
+    sig = (id(optimizer), id(ema_weights), dev_key(device), tuple(sorted(lw.items())))
     if cur is None or cur[0] != sig:
         cur = _GRAPHED[model] = (sig, GraphedStep(model, optimizer, device, t_to_sigma, lw, ema_weights, **kw))
     return cur[1]
@@ -381,7 +391,7 @@ def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weigh
     meter = AverageMeter(_METRICS)
     distributed = _dist_world() > 1
     n_steps = uniform_step_count(loader) if distributed else None
-    dev = torch.device(device)
+    dev = device = canonical_device(device)      # one spelling for every per-device cache key downstream ('cuda' == 'cuda:0')
     if hip_graph:
         if forward_fn is not None or dev.type != "cuda":
             raise RuntimeError("hip_graph=True runs the package's own HIP forward on a GPU")

@@ -233,3 +233,83 @@ def test_bf16_role_split_options_agree(model_args):
         assert float((p - q).abs().max()) <= 1e-5 * float(q.abs().max())
     assert not all(torch.equal(p, q) for p, q in zip(res[1], res[0]))      # the slices really ran
     assert all(torch.equal(p, q) for p, q in zip(res[2], res[1]))
+
+
+def test_bf16_stationary_kernel_agrees_with_the_streaming_kernel(model_args):
+    """cbd_set_option("bf16_stationary", 1) (tp_conv_bf16s.hip): the 74 -> 74 layers of the bf16 policy through persistent
+    four-wave workgroups that keep a whole FCBlock in registers.  Same bf16 products as the streaming kernel; a message's tile
+    contributions are added per wave and then across waves, so the two kernels agree to fp32 rounding of those sums (2e-5 of the largest
+    component here; measured 5e-7 .. 3e-6), not bitwise.  Deterministic.  Covered: a tiny complex (ragged last units, roles with a handful
+    of units), a C2-sized one, three co-scheduled complexes in one launch (several entries per role; R = 0 ligand) eager and under
+    hipGraph replay, and a whole trajectory against the streaming kernel."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, make_complex
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    model, args = model_args
+    dev = torch.device("cuda:0")
+    for workload, B in (("tiny", 3), ("c2_dockgen_median", 4)):
+        cplx = make_workload(workload)
+        torch.manual_seed(6); np.random.seed(6)
+        dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        pos = torch.stack([d["ligand"].pos for d in dl]).cuda()
+        eng = model.engine()
+        eng.set_complex(cplx)
+        try:
+            eng.set_option("bf16", 1)
+            for t in (1.0, 0.4):
+                step = make_steps(np.array([t]), args, model.timestep_emb_func)[0]
+                eng.set_option("bf16_stationary", 0)
+                ref = [x.clone() for x in eng.score(pos, step)]
+                eng.set_option("bf16_stationary", 1)
+                got = [x.clone() for x in eng.score(pos, step)]
+                again = eng.score(pos, step)
+                assert all(torch.equal(p, q) for p, q in zip(got, again)), (workload, t)
+                for p, q in zip(got, ref):
+                    assert torch.isfinite(p).all()
+                    assert float((p - q).abs().max()) <= 2e-5 * float(q.abs().max()), (workload, t, float((p - q).abs().max()), float(q.abs().max()))
+                assert not all(torch.equal(p, q) for p, q in zip(got, ref))      # the other kernel really ran
+        finally:
+            eng.set_option("bf16_stationary", 0)
+            eng.set_option("bf16", 0)
+    # three different complexes in one launch, S steps: stationary eager = stationary under hipGraph replay (bitwise), close to streaming
+    cps = [make_workload("tiny"), make_complex(Nl=17, Nr=60, R=3, knn=10, seed=77), make_complex(Nl=9, Nr=33, R=0, knn=8, seed=78)]
+    Bs, S = [5, 3, 6], 4
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    engs = [DockEngine.from_model(model, dev, max_batch=8)]
+    for _ in range(2):
+        e = DockEngine(dev, max_batch=8)
+        e.share_weights_from(engs[0])
+        engs.append(e)
+    g = torch.Generator().manual_seed(4)
+    inputs = []
+    for e, c, B in zip(engs, cps, Bs):
+        e.set_complex(c)
+        torch.manual_seed(B); np.random.seed(B)
+        dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        R = int(c["ligand"].edge_mask.sum())
+        inputs.append((torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous(),
+                       [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * R, generator=g).to(dev)]))
+
+    def run(stationary, graph):
+        for e in engs:
+            e.set_option("bf16", 1); e.set_option("bf16_stationary", stationary); e.set_option("graph", graph)
+        ps = [p.clone() for p, _ in inputs]
+        for _ in range(2 if graph else 1):          # second call replays the captured graph
+            ps = [p.clone() for p, _ in inputs]
+            DockEngine.sample_multi(engs, ps, steps, [nz for _, nz in inputs])
+        torch.cuda.synchronize()
+        return ps
+    try:
+        stream = run(0, 0)
+        eager = run(1, 0)
+        replay = run(1, 1)
+    finally:
+        for e in engs:
+            e.set_option("bf16_stationary", 0); e.set_option("bf16", 0); e.set_option("graph", 1)
+    for a, b, c in zip(eager, replay, stream):
+        assert torch.equal(a, b)
+        assert torch.isfinite(a).all() and float((a - c).norm(dim=-1).max()) < 2e-3      # positions after S steps, in Angstrom

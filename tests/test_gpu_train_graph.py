@@ -228,3 +228,47 @@ def test_static_input_cache_with_deep_copied_batches():
         assert tf.dev_cache_stats()["entries"] == 0
     finally:
         tf.dev_cache_configure(enabled=True)
+
+
+def test_graphed_epoch_with_an_unindexed_device_and_eager_steps_in_between():
+    """the reference's fine-tuning code builds its device as torch.device('cuda'); every per-device cache key (dW scratch, copy
+    streams, keep-alive sets, stream hub) must then be the one of 'cuda:0'.  With mismatching keys the capture baked the EAGER scratch
+    buffer's address into the graph, and an eager step that grew the scratch afterwards left the replays writing into freed memory:
+    here a graphed epoch, eager steps on a LARGER batch, and graphed epochs again must agree with a run that never left the graph."""
+    import gc
+    from confidence_bootstrapping_amd.utils import ExponentialMovingAverage
+    from confidence_bootstrapping_amd.training import loss_function, train_epoch, train_step, _GRAPHED, release_graphs
+    from confidence_bootstrapping_amd import train_ops as to, train_forward as tf
+    from confidence_bootstrapping_amd.hostcfg import dev_key
+    loss_fn = partial(loss_function, **LW)
+
+    def run(eager_between):
+        dev, margs, t2s, batches, model = _setup(dropout=0.0)
+        opt = torch.optim.SGD(model.parameters(), lr=1e-3)
+        ema = ExponentialMovingAverage(model.parameters(), decay=0.999)
+        loader = [batches[0], batches[1], batches[0], batches[1]]
+        train_epoch(model, loader, opt, "cuda", t2s, loss_fn, ema, hip_graph=True)
+        if eager_between:       # a bigger eager batch: grows the eager dW scratch (must not be the buffer the graph writes to)
+            big = list(batches[0]) + list(batches[1])
+            saved = [p.detach().clone() for p in model.parameters()]
+            train_step(model, big, opt, "cuda", t2s, loss_fn, ema)
+            with torch.no_grad():
+                for p, q in zip(model.parameters(), saved):
+                    p.copy_(q)
+            junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]      # poison whatever the allocator got back
+            del junk
+        out = train_epoch(model, loader, opt, torch.device("cuda"), t2s, loss_fn, ema, hip_graph=True)
+        assert set(to._DW_SCRATCH) <= {dev_key("cuda")} and all(k[0] == dev_key("cuda") for k in tf._COPY_STREAMS)
+        return out["loss"], torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(), model
+
+    l0, w0, m0 = run(False)
+    l1, w1, m1 = run(True)
+    assert np.isfinite(l0) and np.isfinite(l1)
+    assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)) and float((w0 - w1).abs().max()) <= 1e-6 * float(w0.abs().max())
+    # the captured graphs do not keep their model alive (training._GRAPHED holds the model weakly through GraphedStep)
+    import weakref
+    r = weakref.ref(m1)
+    del m1, m0
+    gc.collect()
+    assert r() is None
+    release_graphs()

@@ -156,3 +156,41 @@ def test_embedding_table_offsets_are_keyed_by_content_not_by_object_identity():
         assert int(idx.max()) < sum(dims[0])
         del enc
         gc.collect()
+
+
+def test_glue_threads_is_reference_counted_and_gpu_only():
+    """hostcfg: nested / overlapping users restore the saved thread count only when the last one leaves; the decorator
+    leaves torch's threads alone when the wrapped call runs on the CPU."""
+    import threading
+    import torch
+    from confidence_bootstrapping_amd import hostcfg
+    before = torch.get_num_threads()
+    if before < 2:
+        torch.set_num_threads(2)
+    base = torch.get_num_threads()
+    try:
+        with hostcfg.glue_threads(1):
+            assert torch.get_num_threads() == 1
+            with hostcfg.glue_threads(1):
+                assert torch.get_num_threads() == 1
+            assert torch.get_num_threads() == 1          # the inner exit must not restore
+        assert torch.get_num_threads() == base
+        # two host threads entering and leaving out of order
+        inside, leave_a = threading.Event(), threading.Event()
+        def a():
+            with hostcfg.glue_threads(1):
+                inside.set(); leave_a.wait(5)
+        t = threading.Thread(target=a); t.start(); inside.wait(5)
+        with hostcfg.glue_threads(1):
+            leave_a.set(); t.join()
+            assert torch.get_num_threads() == 1          # thread a left first: still limited for this user
+        assert torch.get_num_threads() == base
+        seen = {}
+        @hostcfg.with_glue_threads
+        def step(model, device, x=0):
+            seen[str(device)] = torch.get_num_threads()
+        step(None, "cpu"); step(None, device="cuda:0")
+        assert seen["cpu"] == base and seen["cuda:0"] == 1
+        assert hostcfg.dev_key("cpu") == "cpu" and hostcfg.dev_key("cuda:1") == "cuda:1"
+    finally:
+        torch.set_num_threads(before)
