@@ -126,8 +126,8 @@ __device__ __forceinline__ float cmid0o(const float* xc, int i, const float (&n)
   return 0.f;
 }
 
-constexpr int C_OUT_STRIDE = 33;
-constexpr int CXT_FLOATS = CN_STRIDE * C_OUT_STRIDE;   // gathered rows [84][32], later the message tile [84][33]
+constexpr int C_OUT_STRIDE = 34;      // two edges per ds_read_b64 in reduce_runs (reduce_runs.h)
+constexpr int CXT_FLOATS = CN_STRIDE * C_OUT_STRIDE;   // gathered rows [84][32], later the message tile [84][34]
 __host__ __device__ constexpr int fctp_lds_floats(int ntiles) { return CXT_FLOATS + 32; }
 
 template <int IN, int OUT>

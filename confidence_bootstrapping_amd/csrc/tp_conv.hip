@@ -329,7 +329,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
 
 #undef CBD_TILE
   if constexpr (STAMPS) st_t3 = stamp();
-  // ---- messages -> LDS (re-using the gathered-row tile, stride 33 so that the column reads below are conflict free),
+  // ---- messages -> LDS (re-using the gathered-row tile, stride 34: reduce_runs.h),
   //      then run-length sum per aggregating node
   __syncthreads();   // every read of xT (mids) is complete before it is overwritten
 #pragma unroll

@@ -40,7 +40,7 @@ template <int IN, int OUT, int DIAG = 0>
 __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   constexpr ConvShape S = conv_shape(IN, OUT, true);   // merged vector tails (common.h), as in tp_conv.hip
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* const xT0 = lds;                                   // sub-tile 0: [col][32] gathered rows, later [col][33] messages
+  float* const xT0 = lds;                                   // sub-tile 0: [col][32] gathered rows, later [col][34] messages
   float* const xT1 = lds + V2_SUB_FLOATS;
   int* const srcl = reinterpret_cast<int*>(lds + 2 * V2_SUB_FLOATS);   // [2][32]
   const int lane = threadIdx.x;
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   }
 #undef V2_TILE
 
-  // ---- messages -> LDS (re-using the gathered-row tiles, stride 33), then run-length sums per aggregating node and sub-tile
+  // ---- messages -> LDS (re-using the gathered-row tiles, stride 34), then run-length sums per aggregating node and sub-tile
   if constexpr (DIAG == 4) st_t3 = stamp();
   __syncthreads();   // every read of xT (mids) is complete before it is overwritten
 #pragma unroll

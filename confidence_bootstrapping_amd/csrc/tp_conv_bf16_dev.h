@@ -11,7 +11,7 @@ namespace cbd {
 
 constexpr int V2_NFRAG = 6;                      // 6 k-steps of 16 = the 96 inputs; the bias enters as the C operand of the first pair
 constexpr int V2_TILE_FRAGS = V2_NFRAG * 64;     // 16-byte fragments per tile
-constexpr int V2_SUB_FLOATS = NODE_DIM * OUT_STRIDE;   // 74 x 33 floats per 32-edge sub-tile (>= 76 x 32 of the gather image)
+constexpr int V2_SUB_FLOATS = NODE_DIM * OUT_STRIDE;   // 74 x 34 floats per 32-edge sub-tile (>= 76 x 32 of the gather image)
 static_assert(V2_SUB_FLOATS >= 76 * 32, "gather image must fit the message tile");
 
 struct Act6 { bf16x8 v[V2_NFRAG]; };

@@ -50,7 +50,7 @@ __device__ __forceinline__ bool find_group(const ConvArgs& args, int t, int lane
   return true;
 }
 
-constexpr int OUT_STRIDE = 33;   // message tile stride (conflict-free column reads)
+constexpr int OUT_STRIDE = 34;   // message tile stride: lane = column reads two edges per ds_read_b64, 32 lanes on 64 distinct banks (reduce_runs.h)
 
 // ---- operand policies: how the two Linears of the radial MLP run on the matrix cores ------------------------------------
 // One 32x32 tile: acc = bias + A_tile * B.  The A fragments of the CURRENT tile are in registers, loaded one tile ahead
@@ -455,7 +455,8 @@ __device__ __forceinline__ float mid0o(const float* xc, int i, const float (&v)[
   return 0.f;
 }
 
-constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed copy of the gathered rows
+constexpr int XT_FLOATS = NODE_STRIDE * 32;              // per-wave transposed copy of the gathered rows, later the message tile
+static_assert(XT_FLOATS >= NODE_DIM * OUT_STRIDE, "the message tile re-uses the gathered-row tile");
 __host__ __device__ constexpr int conv_lds_floats(int ntiles) { return ntiles * 32 + XT_FLOATS + 32; }
 
 }  // namespace cbd
