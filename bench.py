@@ -262,7 +262,7 @@ def finetune_leg(dev, batch=8, warm=8, steps=16):
     return res
 
 
-def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry, n_complexes, engine_value):
+def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry, n_complexes, engine_value, conf_ms_per_40=None):
     """The headline workload through the API north_star names: `sampling(data_list, model, ..., confidence_model=...)` over the poses of
     `n_complexes` complexes.  Inside the timed region, as in the reference (inference.py:450-495 takes its run time around the
     filtering-list copies and the `sampling()` call): the per-pose copies of the all-atom graphs, drawing the N(0,1) noise in the
@@ -329,10 +329,16 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
     run(dl2, ztr2, with_conf=False)
     dt2 = time.perf_counter() - t0
     v, v2 = n_complexes * samples / dt, n_complexes * samples / dt2
+    # engine-level sampling + the confidence model's own kernels (the `confidence` leg's time for these poses): what the same WORK costs
+    # below the API -- the fraction of THAT is the API's overhead proper (noise drawing, copies, set-up, co-scheduling)
+    both = None
+    if engine_value and conf_ms_per_40:
+        both = samples / (samples / engine_value + conf_ms_per_40 * 1e-3 * samples / 40.0)
     return {"what": "the same workload through sampling(data_list, model, ..., confidence_model=...): noise drawing, co-scheduling, per-complex "
                     "set-up of both engines, step loops, confidence scoring of every pose, write-back; not part of `value`",
             "value": round(v, 2), "unit": "poses/s", "complexes": n_complexes, "s_total": round(dt, 3),
             "vs_engine_level_value": round(v / engine_value, 4) if engine_value else None,
+            "engine_plus_confidence_kernels": round(both, 2) if both else None, "vs_engine_plus_confidence": round(v / both, 4) if both else None,
             "without_confidence_model": {"value": round(v2, 2), "s_total": round(dt2, 3),
                                          "vs_engine_level_value": round(v2 / engine_value, 4) if engine_value else None},
             "confidences_finite": bool(torch.isfinite(conf).all()), "mean_final_centroid_distance_from_pocket_A": round(drift, 2)}
@@ -633,8 +639,10 @@ def final_line(out, legs):
         line["legs"][name if not sub else sub] = [r.get(vkey), frac(r) if frac else None]
     if legs:
         line["legs"] = {}
-        line["legs_fields"] = "[value, fraction]: poses/s (ms for confidence/finetune); fraction = roofline frac, or of `value` for python_api"
+        line["legs_fields"] = "[value, fraction]: poses/s (ms for confidence/finetune); fraction = roofline frac; python_api: [poses/s, of `value`, of engine + confidence kernels]"
         pair("python_api", "value", lambda r: r.get("vs_engine_level_value"))
+        if isinstance(line["legs"].get("python_api"), list):
+            line["legs"]["python_api"].append((legs.get("python_api") or {}).get("vs_engine_plus_confidence"))
         pair("c4_bf16", "value", lambda r: r["roofline"]["frac"])
         pair("confidence", "ms_per_40_poses", lambda r: r.get("frac"))
         pair("complex_set", "value")
@@ -752,7 +760,8 @@ def main():
         if extras:
             cplx, sched, geometry = ctx["cplx"], ctx["sched"], ctx["geometry"]
             ctx = engines = pos0 = run = None          # release the headline's engines before the other legs allocate theirs
-            leg("python_api", lambda: python_api_leg(model, margs, dev, a.workload, a.samples, a.denoise_steps, geometry, 20, out["value"]))
+            conf_ms = (legs.get("confidence") or {}).get("ms_per_40_poses")
+            leg("python_api", lambda: python_api_leg(model, margs, dev, a.workload, a.samples, a.denoise_steps, geometry, 20, out["value"], conf_ms))
 
             def c4():
                 r, _ = measure(model.cpu(), margs, dev, workload="c4_large_pocket", samples=64, denoise_steps=40, dtype="bf16",

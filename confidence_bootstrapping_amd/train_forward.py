@@ -135,11 +135,10 @@ _COPY_STREAMS = {}
 #     shallow copies that share a complex's tensors, the reference's loaders deep-copy them; either way the same complex comes back
 #     under the same name, and a key that does not hold a storage address neither pins host memory nor depends on the allocator
 #     recycling addresses.  Graphs without a string `name` are uploaded every step (no entry);
-#   * every hit compares a fingerprint of the host tensor -- storage address, torch's version counter and a contents probe (whole tensor
-#     below 4096 elements, else 32 strided elements + the last, ~5 us) -- with the one taken at upload time: two complexes that share a
-#     name, or a tensor edited in place (re-centring, a numpy view, `.data`), re-upload and replace the entry instead of training on a
-#     stale copy.  Still a guard, not a proof, for edits of large tensors behind torch's back that miss all 33 probes
-#     (`dev_cache_clear()`);
+#   * every hit compares a fingerprint of the host tensor's CONTENTS (whole tensor below 4096 elements -- index / mask tensors, bond
+#     lists --, else 32 strided elements + the last, ~5 us) with the one taken at upload time: two complexes that share a name, or a
+#     tensor edited in place (re-centring, a numpy view, `.data`), re-upload and replace the entry instead of training on a stale
+#     copy.  Still a guard, not a proof, for edits of the large feature matrices that miss all 33 probes (`dev_cache_clear()`);
 #   * an entry remembers the stream it was uploaded on and an event behind the upload: a hit from another stream (the side stream changes
 #     priority between eager and hipGraph-captured steps) waits for that event, and an entry that is evicted or replaced is kept alive
 #     until the compute stream has passed (its last reader may still be queued);
@@ -172,15 +171,15 @@ _FP_FULL_BELOW = 4096      # elements: index / mask tensors and small feature bl
 
 
 def _fingerprint(t: torch.Tensor):
-    """(storage address, version counter, contents probe): another tensor under the same complex name, an in-place edit through torch, or
-    an edit behind torch's back (numpy view) of a probed element all change it.  Tensors below _FP_FULL_BELOW elements are hashed whole;
-    the large feature matrices by 32 strided elements + the last (~5 us)."""
+    """Contents probe of a host tensor.  Tensors below _FP_FULL_BELOW elements (index and mask tensors, small feature blocks: where a
+    same-shape ligand or bond list under a re-used name would differ in few places) are compared WHOLE; the large feature matrices by 32
+    strided elements + the last (~5 us).  Deliberately NOT the storage address or the version counter: the reference's loaders deep-copy
+    their graphs, and a deep copy of a cached complex must hit (tests/test_finetune_host.py::test_static_tensor_cache_policy)."""
     n = t.numel()
     if n == 0:
-        return (t.data_ptr(), t._version, b"")
+        return b""
     a = t.numpy().reshape(-1) if t.is_contiguous() else t.reshape(-1).numpy()       # a view of the host storage
-    probe = a.tobytes() if n <= _FP_FULL_BELOW else a[::max(1, n // 32)][:32].tobytes() + a[-1:].tobytes()
-    return (t.data_ptr(), t._version, probe)
+    return a.tobytes() if n <= _FP_FULL_BELOW else a[::max(1, n // 32)][:32].tobytes() + a[-1:].tobytes()
 
 
 def _dev_cached(t: torch.Tensor, device, ident=None):
@@ -192,16 +191,18 @@ def _dev_cached(t: torch.Tensor, device, ident=None):
         return t.to(device, non_blocking=True)
     key = (ident, tuple(t.shape), t.dtype, dev_key(device))
     fp = _fingerprint(t)
-    cur = torch.cuda.current_stream(device)
+    gpu = torch.device(device).type == "cuda"
+    cur = torch.cuda.current_stream(device) if gpu else None
     hit = _DEV_CACHE.get(key)
     if hit is not None:
         if hit[1] == fp:
             _DEV_CACHE.move_to_end(key)
-            if hit[3] != cur.cuda_stream:          # uploaded on another stream: order this stream behind the upload
+            if gpu and hit[3] != cur.cuda_stream:          # uploaded on another stream: order this stream behind the upload
                 cur.wait_event(hit[2])
             return hit[0]
         _DEV_CACHE_BYTES[0] -= hit[0].numel() * hit[0].element_size()       # another complex under this name, or edited in place
-        _keep_until_main_passes([hit[0]], device)
+        if gpu:
+            _keep_until_main_passes([hit[0]], device)
         del _DEV_CACHE[key]
     d = t.to(device, non_blocking=True)
     nbytes = d.numel() * d.element_size()
@@ -210,10 +211,13 @@ def _dev_cached(t: torch.Tensor, device, ident=None):
     while _DEV_CACHE and _DEV_CACHE_BYTES[0] + nbytes > _DEV_CACHE_CFG["limit"]:
         _, old = _DEV_CACHE.popitem(last=False)
         _DEV_CACHE_BYTES[0] -= old[0].numel() * old[0].element_size()
-        _keep_until_main_passes([old[0]], device)
-    ev = torch.cuda.Event()
-    ev.record(cur)
-    _DEV_CACHE[key] = (d, fp, ev, cur.cuda_stream)
+        if gpu:
+            _keep_until_main_passes([old[0]], device)
+    ev = None
+    if gpu:
+        ev = torch.cuda.Event()
+        ev.record(cur)
+    _DEV_CACHE[key] = (d, fp, ev, cur.cuda_stream if gpu else 0)
     _DEV_CACHE_BYTES[0] += nbytes
     return d
 

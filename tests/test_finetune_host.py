@@ -141,6 +141,15 @@ def test_static_tensor_cache_policy():
     got = tf._dev_cached(edited, "cpu", ids[0])
     assert got is edited and base[0]._version == v and tf.dev_cache_stats()["entries"] == 4
     assert tf._dev_cached(copy.deepcopy(edited), "cpu", ids[0]) is edited
+    # a small tensor (bond list / mask) that differs from the cached one in ONE element the strided probes of a large
+    # tensor would miss (200 elements: stride 6, element 1 is not probed) -- small tensors are compared whole, so it is not served stale
+    idx = torch.arange(200).reshape(2, 100)
+    kept = tf._dev_cached(idx, "cpu", ("cplx0", "lig_bonds"))
+    idx2 = idx.clone()
+    idx2[0, 1] = 77
+    assert tf._dev_cached(idx2, "cpu", ("cplx0", "lig_bonds")) is idx2 and tf._dev_cached(idx.clone(), "cpu", ("cplx0", "lig_bonds")) is not kept
+    tf.dev_cache_clear()
+    first = [tf._dev_cached(t, "cpu", i) for t, i in zip(base, ids)]
     # another complex under the same name: replaced, not served
     other = torch.randn(50, 8)
     assert tf._dev_cached(other, "cpu", ids[1]) is other and tf.dev_cache_stats()["entries"] == 4
