@@ -708,13 +708,18 @@ __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const l
   for (int t = 0; t < NT; ++t) {
     const int T = W == 0 ? 3 + t : W == 1 ? (t < 6 ? 17 + t : 18 + t) : W == 2 ? (t < 9 ? 31 + t : 41 + (t - 9)) : 45 + t;
 #pragma unroll
+    for (int q = 0; q < V2_NFRAG; ++q) wt[t][q] = gp[(size_t)T * V2_TILE_FRAGS + q * 64 + lane];
+  }
+  // Ten tiles live in the accumulation half of the register file (256 registers; the MFMA reads srcA from it directly), the rest in
+  // ordinary VGPRs -- pinning more than fit makes hipcc copy the overflow in front of every MFMA that uses it.  The pins come AFTER all
+  // the loads have been issued: a pin right behind its load made every one of the 78 loads wait for its own data (vmcnt(0) each,
+  // tens of microseconds per workgroup and launch).
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
     for (int q = 0; q < V2_NFRAG; ++q) {
-      wt[t][q] = gp[(size_t)T * V2_TILE_FRAGS + q * 64 + lane];
-      // ten tiles live in the accumulation half of the register file (256 registers; the MFMA reads srcA from it directly), the rest
-      // in ordinary VGPRs -- pinning more than fit makes hipcc copy the overflow in front of every MFMA that uses it
       if (t < 10) asm volatile("" : "+a"(wt[t][q])); else asm volatile("" : "+v"(wt[t][q]));
     }
-  }
   bf16x8 ab0e[3];
   if constexpr (W == 1 || W == 2) {
     const GFrag gb0e = (GFrag)reinterpret_cast<const bf16x8*>(reinterpret_cast<const float*>(reinterpret_cast<const bf16x8*>(wstream) + (size_t)(SS.ntiles + 1) * V2_TILE_FRAGS) + (size_t)(SS.ntiles + 1) * 32);
