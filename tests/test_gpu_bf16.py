@@ -249,7 +249,7 @@ def test_bf16_stationary_kernel_agrees_with_the_streaming_kernel(model_args):
     from confidence_bootstrapping_amd.sampling import randomize_position
     model, args = model_args
     dev = torch.device("cuda:0")
-    for workload, B in (("tiny", 3), ("c2_dockgen_median", 4)):
+    for workload, B in (("tiny", 3), ("c2_dockgen_median", 4), ("c4_large_pocket", 8)):      # C4: hundreds of units per workgroup, several segments
         cplx = make_workload(workload)
         torch.manual_seed(6); np.random.seed(6)
         dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(B)]
