@@ -973,7 +973,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
   HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
   if ((getenv("CBD_CONV_VARIANT") && (atoi(getenv("CBD_CONV_VARIANT")) == 8 || atoi(getenv("CBD_CONV_VARIANT")) == 13)) ||
-      (getenv("CBD_BF16_DIAG") && (atoi(getenv("CBD_BF16_DIAG")) == 4 || atoi(getenv("CBD_BF16_DIAG")) == 5))) {
+      (getenv("CBD_BF16_DIAG") && (atoi(getenv("CBD_BF16_DIAG")) >= 4 && atoi(getenv("CBD_BF16_DIAG")) <= 6))) {
     HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 8));
     HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 8 * 8));
   } else e->stamps_dev = nullptr;

@@ -348,7 +348,7 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
 #pragma unroll 1
   for (int tau = 0; tau < n + 5; ++tau) {
     unsigned long long c0 = 0;
-    if constexpr (DIAG == 4) c0 = stamp();
+    if constexpr (DIAG == 4 || DIAG == 6) c0 = stamp();
     const int ug = tau - 1, uf = tau - 2, ut = tau - 3, ur = tau - 5;
     // ================= LDS operands of this iteration: h of the tiles' unit, k-step 0 of the first-Linear chain
     const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
@@ -476,8 +476,11 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       }
       side(hs_, sl);
     };
+    unsigned long long d_pre = 0, d_a = 0, d_b = 0, d_c = 0;      // DIAG 6: finer clocks of the fused iteration (prologue | half-steps 0-2 | 3-7 | 8-14 | tail | barrier)
+    if constexpr (DIAG == 6) d_pre = stamp();
 #pragma unroll
     for (int hs_ = 0; hs_ <= M::N0E; ++hs_) {
+      if constexpr (DIAG == 6) { if (hs_ == 3) d_a = stamp(); if (hs_ == 8) d_b = stamp(); }
       if (hs_ >= 1) mid3[(hs_ - 1) % 3] = mid_ld(M::I_LO + hs_ - 1);      // used one half-step from now
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -498,6 +501,7 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
         }
       }
     }
+    if constexpr (DIAG == 6) d_c = stamp();
     {
       const f32x16& ya = acc3[(M::N0E - 1) % 3];
       const float ma = mid3[(M::N0E - 1) % 3];
@@ -540,7 +544,7 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       if constexpr (W == 2) p4[4 * 64] = f32x4{vo.s1o[0], vo.s1o[1], vo.s1o[2], 0.f};
     }
     unsigned long long c4 = 0, c5 = 0;
-    if constexpr (DIAG == 4) c4 = stamp();
+    if constexpr (DIAG == 4 || DIAG == 6) c4 = stamp();
     // ================= waves 0 and 1: run-length sums of unit tau - 5 -> global memory, half of the columns each
     if constexpr (W <= 1) {
       if (red_on) {
@@ -551,11 +555,15 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
                                                                                           G.last_sum + tile * NODE_STRIDE, G.run_acc);
       }
     }
-    if constexpr (DIAG == 4) c5 = stamp();
+    if constexpr (DIAG == 4 || DIAG == 6) c5 = stamp();
     lds_barrier();
     if constexpr (DIAG == 4) {
       const unsigned long long c6 = stamp();
       clk[2] += c4 - c0; clk[3] += c5 - c4; clk[5] += c6 - c5;
+    }
+    if constexpr (DIAG == 6) {      // prologue | half-steps 0-2 | 3-7 | 8-14 | last epilogue, partial sums, reduction | barrier
+      const unsigned long long c6 = stamp();
+      clk[0] += d_pre - c0; clk[1] += d_a - d_pre; clk[2] += d_b - d_a; clk[3] += d_c - d_b; clk[4] += c5 - d_c; clk[5] += c6 - c5;
     }
   }
 }
@@ -698,7 +706,7 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
 
 template <int W, int DIAG>
 __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const lds, const float* const wstream, const int lane,
-                                            const int u_lo, const int u_hi, const int mine, const int incl) {
+                                            const int u_lo, const int u_hi, const int mine, const int incl, const int role) {
   // stationary tiles (stream indices): wave 0: 3 .. 15 (0e mids 0 .. 12; mid 13 = tile 16 is read from LDS), wave 1: 17 .. 22 and 24 .. 29
   // (23, 30 from LDS), wave 2: 31 .. 39 (0e mids 28 .. 36; 37 = tile 40 from LDS) and 41 .. 44 (block 1o tiles 0 .. 3), wave 3: 45 .. 55
   constexpr int NT = W == 3 ? 11 : W == 1 ? 12 : 13;
@@ -728,7 +736,7 @@ __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const l
   }
   unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long st0 = 0, sr0 = 0;
-  if constexpr (DIAG == 4) { st0 = stamp(); sr0 = __builtin_amdgcn_s_memrealtime(); }
+  if constexpr (DIAG >= 4 && DIAG <= 6) { st0 = stamp(); sr0 = __builtin_amdgcn_s_memrealtime(); }      // 4: phase clocks, 5: lifetimes only, 6: finer clocks of waves 0 .. 2
 #pragma unroll 1
   for (int g = 0; g < args.n_groups; ++g) {
     const int mg = __builtin_amdgcn_readlane(mine, g);
@@ -741,7 +749,7 @@ __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const l
     if constexpr (W <= 2) s_segment_a<W, NT, DIAG>(G, cnt, a - start, b - a, lds, wt, ab0e, lane, clk);
     else s_segment_b<NT, DIAG>(G, cnt, a - start, b - a, lds, wt, ab0e, lane, clk);
   }
-  if constexpr (DIAG == 4) {
+  if constexpr (DIAG >= 4 && DIAG <= 6) {
     const int rec = blockIdx.x * SW_WAVES + W;
     if (lane == 0 && args.stamps && rec < 8192 / 2) {
       unsigned long long* o = args.stamps + (size_t)rec * 16;
@@ -749,6 +757,7 @@ __device__ __forceinline__ void s_wave_prog(const ConvArgs& args, float* const l
 #pragma unroll
       for (int k = 0; k < 6; ++k) o[4 + k] = clk[k];
       o[10] = (unsigned long long)(u_hi - u_lo);
+      o[11] = (unsigned long long)role;
     }
   }
 }
@@ -812,10 +821,10 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
       const int v = __shfl_up(incl, d);
       if (lane >= d) incl += v;
     }
-    if (wave == 0) s_wave_prog<0, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-    else if (wave == 1) s_wave_prog<1, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-    else if (wave == 2) s_wave_prog<2, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
-    else s_wave_prog<3, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl);
+    if (wave == 0) s_wave_prog<0, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl, role);
+    else if (wave == 1) s_wave_prog<1, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl, role);
+    else if (wave == 2) s_wave_prog<2, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl, role);
+    else s_wave_prog<3, DIAG>(args, lds, wstream, lane, u_lo, u_hi, mine, incl, role);
   }
 }
 
@@ -842,10 +851,18 @@ hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s) {
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    if (e != hipSuccess) return e;
     attr_set = true;
   }
-  static const int diag = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
+  static const int diag_env = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
+  static const int diag_min_roles = getenv("CBD_DIAG_MIN_ROLES") ? atoi(getenv("CBD_DIAG_MIN_ROLES")) : 0;      // stamps only from launches with at least so many roles
+  const int diag = rt.n_roles >= diag_min_roles ? diag_env : 0;
   if (diag == 4) hipLaunchKernelGGL((tp_conv64s_kernel<4>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
+  else if (diag == 5) hipLaunchKernelGGL((tp_conv64s_kernel<5>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
+  else if (diag == 6) hipLaunchKernelGGL((tp_conv64s_kernel<6>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
   else hipLaunchKernelGGL((tp_conv64s_kernel<0>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
   return hipGetLastError();
 }

@@ -26,6 +26,8 @@ raw = eng.fetch("conv_clock_s", 64)
 r = raw[:40].reshape(4, 10)
 print(f"launch span {raw[40] / 1e3:.1f} us; workgroup lifetime median {raw[41] / 1e3:.1f} / max {raw[42] / 1e3:.1f} / min {raw[43] / 1e3:.1f} us; units per workgroup {raw[45]:.0f} .. {raw[44]:.0f}; {int(raw[46])} workgroups")
 names = ["idx+issue", "firstLin", "tiles", "reduce", "ldsWrite", "barrier"]
+if os.environ.get("CBD_BF16_DIAG") == "6":      # finer clocks of waves 0 .. 2 (wave 3: not instrumented)
+    names = ["prologue", "hs 0-2", "hs 3-7", "hs 8-14", "tail+red", "barrier"]
 for w in range(4):
     tot, ghz, units, n = r[w, 0], r[w, 1], max(r[w, 8], 1.0), r[w, 9]
     per = "  ".join(f"{nm} {r[w, 2 + k] / units:7.0f}" for k, nm in enumerate(names))
