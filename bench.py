@@ -676,7 +676,7 @@ def main():
     ap.add_argument("--denoise-steps", type=int, default=HEADLINE[2])
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32_split"],
                     help="bf16: FCBlock GEMMs on bf16 MFMA (configs[3]); f32_split: fp32 operands as three bf16 planes on the bf16 MFMA")
-    ap.add_argument("--pair", type=int, default=4, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
+    ap.add_argument("--pair", type=int, default=8, help="co-schedule consecutive complexes (cbd_sample_multi: one tensor-product "
                     "launch covers the 40-pose batches of several complexes): 0 = one complex at a time, 1 = two, 2..8 = that many")
     ap.add_argument("--split", default="complexes", choices=["complexes", "samples"],
                     help="N > 1: complexes = every rank runs K complexes of its own (weak scaling, default); samples = the samples of each "
