@@ -643,3 +643,52 @@ def test_sampling_with_svgd_matches_reference(dev, golden):
     # (the reference's reshape of the torsion scores to [1, N, R] fails unless batch_size >= N)
     out, _ = sampling(data_list=fresh(), noise=noise, svgd_use_x0=False, **kw, **{**common, "batch_size": 2})
     assert float(rmsd(torch.stack([d["ligand"].pos.cpu() for d in out]), finals["a"]).max()) < 1e-5
+
+
+def test_eight_co_scheduled_complexes_equal_separate_calls():
+    """The bench's default since round 5: up to EIGHT complexes (the maximum of cbd_sample_multi) share every launch of the step loop.  Eight
+    different complexes / batch sizes: eager multi = hipGraph replay = eight separate cbd_sample calls, bitwise."""
+    import copy
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, make_complex
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule
+    from confidence_bootstrapping_amd.sampling import randomize_position
+    dev = torch.device("cuda:0")
+    model, args = make_score_model(device=dev, seed=0)
+    cps = [make_workload("tiny")] + [make_complex(Nl=8 + 3 * k, Nr=30 + 11 * k, R=k % 4, knn=8 + (k % 3), seed=300 + k) for k in range(7)]
+    Bs = [3, 5, 2, 6, 4, 1, 7, 3]
+    S = 3
+    steps = make_steps(get_t_schedule("expbeta", S), args, model.timestep_emb_func)
+    engs = [DockEngine.from_model(model, dev, max_batch=8)]
+    for _ in range(7):
+        e = DockEngine(dev, max_batch=8)
+        e.share_weights_from(engs[0])
+        engs.append(e)
+    g = torch.Generator().manual_seed(9)
+    inputs = []
+    for e, c, B in zip(engs, cps, Bs):
+        e.set_complex(c)
+        torch.manual_seed(B); np.random.seed(B)
+        dl = [Batch.from_data_list([copy.deepcopy(c)]) for _ in range(B)]
+        randomize_position(dl, False, False, 5.0)
+        R = int(c["ligand"].edge_mask.sum())
+        inputs.append((torch.stack([d["ligand"].pos for d in dl]).to(dev).contiguous(),
+                       [torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B, 3, generator=g).to(dev), torch.randn(S, B * R, generator=g).to(dev)]))
+    ref = []
+    for e, (p, nz) in zip(engs, inputs):
+        q = p.clone()
+        e.sample(q, steps, *nz)
+        ref.append(q)
+    for graph in (0, 1):
+        for e in engs:
+            e.set_option("graph", graph)
+        for _ in range(2 if graph else 1):
+            ps = [p.clone() for p, _ in inputs]
+            DockEngine.sample_multi(engs, ps, steps, [nz for _, nz in inputs])
+        torch.cuda.synchronize()
+        for a, b in zip(ps, ref):
+            assert torch.equal(a, b), graph
+    for e in engs:
+        e.set_option("graph", 1)
