@@ -6,18 +6,25 @@
 // the matrix pipe and that path saturate together at ~0.5 (PMC round 4), and a quarter of every wave's lifetime (index -> gather round
 // trips, first Linear, reduction) holds no MFMA at all.  Sharing tiles through LDS lost three times to the per-tile rendezvous, the role
 // split with LDS-resident tiles to the per-slice repetition of those fixed phases.  Here
-//   * a PERSISTENT workgroup of four waves (one per SIMD, up to 512 registers each) is bound to one FCBlock and keeps ALL of its second
-//     Linear in registers for the whole launch: 53 tiles x 24 registers, 14 / 14 / 14 / 11 tiles per wave.  No weight is fetched per
-//     edge any more; the vector-memory path carries only the gathers (0.7 KB per edge instead of 5.9);
+//   * a PERSISTENT workgroup of four waves (one per SIMD, up to 512 registers each) is bound to one FCBlock and keeps its second Linear
+//     on the CU for the whole launch: 49 of the 53 tiles in registers (13 / 12 / 13 / 11 per wave x 24 registers; ten per wave in the
+//     accumulation half of the register file, read by the MFMA as srcA directly -- the accumulators are forced into VGPRs for that,
+//     -mllvm --amdgpu-mfma-vgpr-form=1), four tiles and the three first-Linear tiles in LDS.  No weight is fetched per edge any more;
+//     the vector-memory path carries only the gathers (0.7 KB per edge instead of 5.9);
 //   * every wave processes ALL 32 edges of a unit, but only its own tiles: the fixed phases are paid once per unit by the workgroup,
 //     not once per wave or slice.  The unit's gathered destination rows (mids) and its hidden activations h (the B operand) are shared
 //     through LDS; ONE barrier per unit;
-//   * waves 0..2 (0e tiles [0,14), [14,28), [28,38) + the scalar-mid tiles of block 1o) write partial output sums to LDS; wave 3 works
-//     one unit behind them: it adds the three partials, runs the remaining vector tiles, finishes the message tile.  Wave 3 also runs
-//     the first Linear (its three tiles stay in LDS) one unit AHEAD, wave 2 the run-length reduction two units behind, and all four
-//     waves share the gathers three units ahead -- a software pipeline over units, every stage double- or quad-buffered in LDS;
-//   * inside a wave the CG epilogue of tile k sits between the MFMAs of tile k + 1 (two accumulator sets), since a wave that is alone on
-//     its SIMD has nobody else to fill its MFMA shadows.
+//   * waves 0..2 (0e mids [0,14), [14,28), [28,38) + the scalar-mid tiles of block 1o) write partial output sums to LDS; wave 3 works
+//     one unit behind them: it adds the three partials, runs the remaining vector tiles as software-pipelined steps, finishes the
+//     message tile.  Waves 0..2 also compute one hidden tile each of the first Linear one unit AHEAD (its chain interleaved into their
+//     first tile's), waves 0 / 1 half of the run-length reduction each two units behind, and all four waves share the gathers three
+//     units ahead -- a software pipeline over units, every stage double- or quad-buffered in LDS;
+//   * inside waves 0..2 the chains of consecutive tiles are staggered by half a tile (three accumulators: no MFMA waits for its
+//     predecessor) and the CG epilogue of tile k - 2, the first-Linear chain, the gather issue and the LDS writes sit in the issue slots
+//     between the MFMAs -- a wave that is alone on its SIMD has nobody else to fill its MFMA shadows;
+//   * the units of a launch, in role-major order, are cut into equal pieces per workgroup (a workgroup may straddle a role boundary and
+//     then reloads its weights once): dealing whole workgroups to roles cost up to 2x (profiles/r05_a_bf16_stationary_experiment.txt).
+// Measured (C4 64 x 40): 2 .. 4 % faster than the streaming kernel; what bounds it: DESIGN.md section 5 and the profile file above.
 // Results: the same pieces (first_sum / last_sum / run_acc per 32-edge tile) as the streaming kernel; the order in which a message's
 // tile contributions are added differs (partials per wave), so the two kernels agree to fp32 rounding of those sums, not bitwise.
 // Deterministic: no atomics, fixed orders.
