@@ -99,9 +99,10 @@ struct cbd_engine {
   // the group's and `piece_b_off[g]` floats behind them (first_sum, last_sum and run_acc alike)
   long long piece_b_off[4] = {0, 0, 0, 0};
   int bf16_roles = 0;      // 1: the slices run through the streaming kernel, 2: the 0e slices through the LDS-resident kernel (tp_conv_bf16p.hip)
-  // 1: the 74 -> 74 layers of the bf16 policy run through the register-stationary kernel (tp_conv_bf16s.hip; "bf16_stationary" option / CBD_BF16_STATIONARY,
-  // default off while it is being tuned); 0: through the streaming kernel.  Ignored under the role split.
-  int bf16_stat = 0;
+  // 1: the 74 -> 74 layers of the bf16 policy run through the register-stationary kernel (tp_conv_bf16s.hip; "bf16_stationary" option / CBD_BF16_STATIONARY;
+  // the default since the end of round 5: 2 .. 4 % faster than the streaming kernel on C2 and C4, profiles/r05_c_*); 0: through the streaming
+  // kernel.  Ignored under the role split.
+  int bf16_stat = 1;
   int n_cus = 256;
   int *rr_start = nullptr, *rr_cnt = nullptr;   // [max_batch*Nr] CSR ranges of the batched receptor edges
   int *rr0_start = nullptr;                     // [Nr] CSR starts of the single-copy receptor edges

@@ -219,6 +219,43 @@ __device__ __forceinline__ void s_reduce_runs(const float* __restrict__ msg, int
   if (last >= 0 && on) (a0 == 0 ? fs : ls)[col] = sum;
 }
 
+// The same reduction with its branch-free bulk taken out: `gs[g]` = the sum of the eight edges of group g of this lane's column, formed
+// between the MFMAs of the tile loop (two ds_read_b128 + seven adds per group, no control flow).  Here only the bookkeeping is left: a
+// group without a run boundary adds its sum; a group WITH one (one or two of four in a tile of two or three runs) is re-read and walked
+// edge by edge.  (A run's sum is therefore associated by groups of eight -- deterministic, not the association of reduce_runs.)
+template <int NODE_STR, int C_LO, int C_N>
+__device__ __forceinline__ void s_reduce_groups(const float* __restrict__ msg, const float (&gs)[4], const int s_me, const unsigned starts,
+                                                const int last, int lane, float* __restrict__ fs, float* __restrict__ ls,
+                                                float* __restrict__ run_acc) {
+  const bool on = lane < C_N;
+  const int col = C_LO + (on ? lane : 0);
+  const f32x4* oc = reinterpret_cast<const f32x4*>(msg + col * S_OSTR);
+  float sum = 0.f;
+  int a0 = 0;
+#pragma unroll
+  for (int g8 = 0; g8 < 4; ++g8) {
+    if (((starts >> (8 * g8)) & 0xffu) == 0u) {
+      sum += gs[g8];
+    } else {
+      const f32x4 a = oc[2 * g8], b = oc[2 * g8 + 1];
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int jj = 8 * g8 + k;
+        if (jj > 0 && ((starts >> jj) & 1u)) {   // run [a0, jj-1] is complete
+          const int node = __builtin_amdgcn_readlane(s_me, a0);
+          float* dst = a0 == 0 ? fs : run_acc + (size_t)node * NODE_STR;
+          if (on) dst[col] = sum;
+          sum = 0.f;
+          a0 = jj;
+        }
+        sum += v[k];
+      }
+    }
+  }
+  if (last >= 0 && on) (a0 == 0 ? fs : ls)[col] = sum;
+}
+
 // ---- biased tiles (vector / pseudoscalar blocks) as software-pipelined steps: the CG epilogue of step s - 1 sits between the MFMAs of
 //      step s (two accumulators, two sets of raw operands), the bias rows of step s + 1 are fetched from LDS behind MFMA 1 of step s
 //      (MFMA 0, which read them as its C operand, has completed by then).  Accumulator register 3 q + o of lane half hf = (mid slot q,
@@ -345,7 +382,7 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
   const GPtr<float> g_attr = (GPtr<float>)G.attr;
   int i_dst = 0, i_src = 0, i_attr = 0;            // indices of edge j of the unit whose gathers are issued next
   float vn[3] = {0.f, 0.f, 0.f};                   // edge direction of the unit this wave's tiles process next iteration (wave 2)
-  int red_src = 0;                                 // aggregating node of edge j of the unit reduced next iteration (wave 0)
+  int red_src = 0, red_prev = 0;                   // aggregating node of edge j (and of edge j - 1) of the unit reduced next iteration (waves 0 / 1)
   auto edge_of = [&](int u) __attribute__((always_inline)) -> int {      // clamped edge index of lane j in unit u (any u)
     int e = (u0 + u) * SU + j;
     e = e < cnt ? e : cnt - 1;
@@ -397,10 +434,27 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       const f32x4 vv = reinterpret_cast<const f32x4*>(G.vec)[edge_of(ut + 1)];
       vn[0] = vv.x; vn[1] = vv.y; vn[2] = vv.z;
     }
-    const int s_red = red_src;
-    if constexpr (W <= 1) red_src = G.src[edge_of(ur + 1)];
     const bool red_on = W <= 1 && ur >= 0 && ur < n;
+    // run boundaries of the unit reduced in this iteration -- the same for every column: found HERE (scalar mask), from the aggregating
+    // nodes of edge j and of edge j - 1 loaded during the previous iteration (no LDS shuffle in the tail)
+    int r_sme = -1, r_last = -1;
+    unsigned r_starts = 0;
+    if constexpr (W <= 1) {
+      const int e_me = (u0 + ur) * SU + j;
+      r_sme = e_me < cnt ? red_src : -1;                     // lanes past the end of the group: -1 (one run that is never stored)
+      const int r_prv = e_me - 1 < cnt ? red_prev : -1;
+      r_starts = (unsigned)__ballot(lane < 32 && j > 0 && r_sme != r_prv);
+      r_last = __builtin_amdgcn_readlane(r_sme, 31);
+      const int en = edge_of(ur + 1);
+      red_src = G.src[en];
+      red_prev = G.src[en > 0 ? en - 1 : 0];
+    }
 
+    // reduction of unit tau - 5 (waves 0 / 1): this lane's column of the message tile; its four group sums are formed in the tile loop
+    const float* const r_om = lds + L_O + (ur & 1) * L_O_SLOT;
+    const f32x4* const r_oc = reinterpret_cast<const f32x4*>(r_om + ((W == 0 ? 0 : RED_COLS) + (lane < (W == 0 ? RED_COLS : NODE_DIM - RED_COLS) ? lane : 0)) * S_OSTR);
+    f32x4 r_v[2];
+    float r_gs[4] = {0.f, 0.f, 0.f, 0.f};
     // ================= the side work of pair p, slot s (0 .. 11)
     f32x16 o0e;
     {
@@ -408,6 +462,12 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       o0e = zero;
     }
     bf16x8 bm, aw[3];
+    float bsrc[8];
+    f32x16 ob;      // wave 1: accumulator of the bias product of the 0e block's 32 scalar mids (sum_i b_i m_i as two bf16 MFMAs, tp_conv_bf16.hip)
+    {
+      const f32x16 zero = {};
+      ob = zero;
+    }
     float* const xw = lds + L_X + (ug & 3) * L_X_SLOT;
     __bf16* const bxw = reinterpret_cast<__bf16*>(lds + L_BX + (ug & 1) * L_FRAG_SLOT);
     bf16x8* const hs = reinterpret_cast<bf16x8*>(lds + L_H + h_slot(uf) * L_FRAG_SLOT) + lane;
@@ -429,6 +489,28 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
 #pragma unroll
           for (int r = 0; r < 8; ++r) hh[r] = (__bf16)relu1(fac[8 * s2 + r]);
           hs[(2 * W + s2) * 64] = hh;
+        }
+      }
+      if constexpr (W == 1) {
+        // ---- bias product, k-steps 0 and 1: operands from LDS at slot 0, converted at slot 3, MFMA at slot 5 of half-steps 12 and 13
+        //      (into an accumulator of its own: the epilogue FMAs of the tiles write o0e in the same half-steps)
+        if ((hs_ == 12 || hs_ == 13) && sl == 0) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) bsrc[jj] = xc[(16 * (hs_ - 12) + 8 * hf + jj) * 32];
+        }
+        if ((hs_ == 12 || hs_ == 13) && sl == 3) {
+#pragma unroll
+          for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)bsrc[jj];
+        }
+        if ((hs_ == 12 || hs_ == 13) && sl == 5) ob = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[hs_ - 12], bm, ob, 0, 0, 0);
+      }
+      if constexpr (W <= 1) {
+        // ---- reduction, branch-free part: group g8 of eight edges is read in half-step 4 + 2 g8 and summed one half-step later
+        if (hs_ >= 4 && hs_ <= 11) {
+          const int g8 = (hs_ - 4) >> 1;
+          if (((hs_ - 4) & 1) == 0 && sl == 0) { r_v[0] = r_oc[2 * g8]; r_v[1] = r_oc[2 * g8 + 1]; }
+          if (((hs_ - 4) & 1) == 1 && sl == 2)
+            r_gs[g8] = ((((((r_v[0].x + r_v[0].y) + r_v[0].z) + r_v[0].w) + r_v[1].x) + r_v[1].y) + r_v[1].z) + r_v[1].w;
         }
       }
       // first two fragments of an LDS-resident tile, one half-step ahead of its first MFMA
@@ -520,15 +602,9 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)((jj < SS.n1o && hf == 0) ? dots[jj < 6 ? jj : 0] : 0.f);
       o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[2], bm, o0e, 0, 0, 0);
     }
-    if constexpr (W == 1) {
-      // bias product, k-steps 0 and 1 (sum over the 32 scalar mids of b_i m_i): accumulated onto the finished partial sums, when the
-      // registers of the first-Linear chain and of the gathers are free again (this wave waits at the barrier anyway)
+    if constexpr (W == 1) {      // the bias product (accumulated between the MFMAs of half-steps 12 / 13, `ob`) onto the finished partial sums
 #pragma unroll
-      for (int s3 = 0; s3 < 2; ++s3) {
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) bm[jj] = (__bf16)xc[(16 * s3 + 8 * hf + jj) * 32];
-        o0e = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab0e[s3], bm, o0e, 0, 0, 0);
-      }
+      for (int r = 0; r < 16; ++r) o0e[r] += ob[r];
     }
     VOut vo;
     vo.s1o[0] = vo.s1o[1] = vo.s1o[2] = 0.f;
@@ -557,9 +633,9 @@ __device__ __forceinline__ void s_segment_a(const ConvGroup& G, const int cnt, c
       if (red_on) {
         const float* const om = lds + L_O + (ur & 1) * L_O_SLOT;
         const size_t tile = (size_t)(u0 + ur);
-        const int sm = (u0 + ur) * SU + j < cnt ? s_red : -1;      // lanes past the end of the group
-        s_reduce_runs<NODE_STRIDE, W * RED_COLS, W == 0 ? RED_COLS : NODE_DIM - RED_COLS>(om, sm, lane, G.first_sum + tile * NODE_STRIDE,
-                                                                                          G.last_sum + tile * NODE_STRIDE, G.run_acc);
+        s_reduce_groups<NODE_STRIDE, W * RED_COLS, W == 0 ? RED_COLS : NODE_DIM - RED_COLS>(om, r_gs, r_sme, r_starts, r_last, lane,
+                                                                                            G.first_sum + tile * NODE_STRIDE,
+                                                                                            G.last_sum + tile * NODE_STRIDE, G.run_acc);
       }
     }
     if constexpr (DIAG == 4 || DIAG == 6) c5 = stamp();
@@ -600,8 +676,8 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
 
 #pragma unroll 1
   for (int tau = 0; tau < n + 5; ++tau) {
-    unsigned long long c0 = 0;
-    if constexpr (DIAG == 4) c0 = stamp();
+    unsigned long long c0 = 0, e_pre = 0, e_a = 0, e_b = 0, e_c = 0;      // DIAG 6: prologue | block 1o steps | block 1e steps | block 0o steps | message tile | barrier
+    if constexpr (DIAG == 4 || DIAG == 6) c0 = stamp();
     const int ug = tau - 1, ut = tau - 4;
     // ================= LDS operands: h, the three partial sums of the 0e block, wave 2's scalar sums of block 1o
     const float* const xc = lds + L_X + (ut & 3) * L_X_SLOT + j;
@@ -672,20 +748,24 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
     for (int r = 0; r < 9; ++r) { vo.k1o[r] = 0.f; vo.k1e[r] = 0.f; }
     f32x16 a2[2];
     RawT raw2[2];
+    if constexpr (DIAG == 6) e_pre = stamp();
     v_step<VK_1O, 4, 0, 0>(wt[0], h, cb, bias_lds, S_T1O + 5, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
     v_step<VK_1O, 5, VK_1O, 4>(wt[1], h, cb, bias_lds, S_T1O + 6, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
     v_step<VK_1O, 6, VK_1O, 5>(wt[2], h, cb, bias_lds, S_T1O + 7, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
     v_step<VK_1O, 7, VK_1O, 6>(wt[3], h, cb, bias_lds, S_T1O + 8, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
     v_step<VK_1O, 8, VK_1O, 7>(wt[4], h, cb, bias_lds, S_T1E + 0, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
+    if constexpr (DIAG == 6) e_a = stamp();
     v_step<VK_1E, 0, VK_1O, 8>(wt[5], h, cb, bias_lds, S_T1E + 1, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo,
                                [&](int q) __attribute__((always_inline)) { gather_write(0, q); });
     v_step<VK_1E, 1, VK_1E, 0>(wt[6], h, cb, bias_lds, S_T1E + 2, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo,
                                [&](int q) __attribute__((always_inline)) { gather_write(1, q); });
     v_step<VK_1E, 2, VK_1E, 1>(wt[7], h, cb, bias_lds, S_T0O + 0, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
+    if constexpr (DIAG == 6) e_b = stamp();
     v_step<VK_0O, 0, VK_1E, 2>(wt[8], h, cb, bias_lds, S_T0O + 1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
     v_step<VK_0O, 1, VK_0O, 0>(wt[9], h, cb, bias_lds, S_T0O + 2, hf, xc, a2[1], a2[0], raw2[1], raw2[0], v, vo);
     v_step<VK_0O, 2, VK_0O, 1>(wt[10], h, cb, bias_lds, -1, hf, xc, a2[0], a2[1], raw2[0], raw2[1], v, vo);
     v_drain<VK_0O, 2>(a2[0], raw2[0], v, vo);
+    if constexpr (DIAG == 6) e_c = stamp();
     // ---- message tile [col][36]
     {
       float* const om = lds + L_O + (ut & 1) * L_O_SLOT;
@@ -702,11 +782,15 @@ __device__ __forceinline__ void s_segment_b(const ConvGroup& G, const int cnt, c
       }
     }
     unsigned long long c5 = 0;
-    if constexpr (DIAG == 4) c5 = stamp();
+    if constexpr (DIAG == 4 || DIAG == 6) c5 = stamp();
     lds_barrier();
     if constexpr (DIAG == 4) {
       const unsigned long long c6 = stamp();
       clk[2] += c5 - c0; clk[5] += c6 - c5;
+    }
+    if constexpr (DIAG == 6) {
+      const unsigned long long c6 = stamp();
+      clk[0] += e_pre - c0; clk[1] += e_a - e_pre; clk[2] += e_b - e_a; clk[3] += e_c - e_b; clk[4] += c5 - e_c; clk[5] += c6 - c5;
     }
   }
 }

@@ -142,8 +142,8 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
  * clears itself.  Default: both off = v_mfma_f32_32x32x2_f32 (exact fp32 products).
  * With "bf16": "bf16_roles" (0/1/2) -- experimental role split of the cross / receptor groups; "bf16_stationary" (0/1) -- the
  * 74 -> 74 layers through persistent workgroups that keep a whole FCBlock in registers (tp_conv_bf16s.hip; same bf16 products,
- * message sums equal to fp32 rounding; deterministic).  Both default 0 and are baked into captured graphs (changing them drops
- * the graphs); co-scheduled engines must agree on them. */
+ * message sums equal to fp32 rounding; deterministic; default 1, 0 selects the streaming kernel tp_conv_bf16.hip).  "bf16_roles"
+ * defaults to 0.  Both are baked into captured graphs (changing them drops the graphs); co-scheduled engines must agree on them. */
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value);
 
 /* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
