@@ -50,6 +50,12 @@ def get_t_schedule(sigma_schedule, inference_steps, inf_sched_alpha=1, inf_sched
     return beta.ppf(c, a=inf_sched_alpha, b=inf_sched_beta)
 
 
+def get_inverse_schedule(t, sched_alpha=1, sched_beta=1):
+    """Component time of the asynchronous noise schedule: the Beta(alpha, beta) quantile of the common time
+    (utils/diffusion_utils.py:146-147; callers inference.py:387-389, finetune_train.py:138-140)."""
+    return beta.ppf(t, a=sched_alpha, b=sched_beta)
+
+
 def set_time(complex_graphs, t, t_tr, t_rot, t_tor, batchsize, all_atoms, asyncronous_noise_schedule, device,
              include_miscellaneous_atoms=False):
     """Attach the diffusion time to a batch.  Same fields as the reference (node_t / complex_t dicts of fp32

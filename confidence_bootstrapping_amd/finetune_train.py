@@ -16,7 +16,7 @@ from functools import partial
 import numpy as np
 import torch
 
-from .diffusion_utils import get_t_schedule
+from .diffusion_utils import get_inverse_schedule, get_t_schedule
 from .hetero import Batch
 from .molecules_utils import get_symmetry_rmsd
 from .sampling import randomize_position, sampling
@@ -40,8 +40,13 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
     """Sample + score every complex; returns (metrics, [(graph, confidence), ...] above the cutoff, top-confidence RMSDs)
     (reference finetune_train.py:133-245)."""
     t_schedule = get_t_schedule(sigma_schedule="expbeta", inference_steps=args.inference_steps, inf_sched_alpha=1, inf_sched_beta=1)
-    if getattr(args, "asyncronous_noise_schedule", False):
-        raise NotImplementedError("asynchronous noise schedules are outside the MI355X hot path")
+    asyn = bool(getattr(args, "asyncronous_noise_schedule", False))
+    if asyn:      # finetune_train.py:137-140: every component runs on its own Beta quantile of the common time grid
+        tr_schedule = get_inverse_schedule(t_schedule, args.sampling_alpha, args.sampling_beta)
+        rot_schedule = get_inverse_schedule(t_schedule, args.rot_alpha, args.rot_beta)
+        tor_schedule = get_inverse_schedule(t_schedule, args.tor_alpha, args.tor_beta)
+    else:
+        tr_schedule = rot_schedule = tor_schedule = t_schedule
     rmsds, min_rmsds, top_rmsds, confidences_list, complexes_to_keep = [], [], [], [], []
     model.eval()
     n = args.inference_samples
@@ -50,10 +55,10 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
         """one sampling() call over the poses of all `items` (complexes): consecutive complexes are co-scheduled on the GPU"""
         flat = [g for it in items for g in it[1]]
         filt = [g for it in items for g in it[2]] if items[0][2] is not None else None
-        preds, conf = sampling(data_list=flat, model=model, inference_steps=args.inference_steps, tr_schedule=t_schedule,
-                               rot_schedule=t_schedule, tor_schedule=t_schedule, device=device, t_to_sigma=t_to_sigma, model_args=args,
+        preds, conf = sampling(data_list=flat, model=model, inference_steps=args.inference_steps, tr_schedule=tr_schedule,
+                               rot_schedule=rot_schedule, tor_schedule=tor_schedule, device=device, t_to_sigma=t_to_sigma, model_args=args,
                                confidence_model=filtering_model, filtering_data_list=filt, filtering_model_args=filtering_args,
-                               batch_size=bs)
+                               asyncronous_noise_schedule=asyn, t_schedule=t_schedule, batch_size=bs)
         return [(preds[k * n:(k + 1) * n], None if conf is None else conf[k * n:(k + 1) * n]) for k in range(len(items))]
 
     prepared = []

@@ -234,3 +234,13 @@ def test_get_optimizer_and_scheduler_stages():
     assert sum(p.numel() for g in opt.param_groups for p in g["params"]) == total
     a.scheduler = "none"
     assert get_optimizer_and_scheduler(a, model)[1] is None
+
+
+def test_inverse_schedule_is_the_beta_quantile():
+    """utils/diffusion_utils.py:146-147: Beta(1, 1) is the identity; Beta(2, 1) has CDF t^2, Beta(1, 2) has CDF 1 - (1 - t)^2."""
+    import numpy as np
+    from confidence_bootstrapping_amd.diffusion_utils import get_inverse_schedule, get_t_schedule
+    t = get_t_schedule("expbeta", 20)
+    assert np.allclose(get_inverse_schedule(t), t)
+    assert np.allclose(get_inverse_schedule(t, 2, 1), np.sqrt(t))
+    assert np.allclose(get_inverse_schedule(t, 1, 2), 1 - np.sqrt(1 - t))

@@ -59,6 +59,55 @@ def test_confidence_bootstrapping_round_trip():
     assert len(kept2) == 4 and np.isfinite(m2["avg_confidence"])
 
 
+def test_inference_epoch_with_an_asyncronous_noise_schedule():
+    """finetune_train.py:137-140,185-186: with args.asyncronous_noise_schedule the three component schedules are the Beta quantiles of the
+    common time grid and sampling() gets the grid itself for the model's time embedding.  The epoch's sampling call must equal a direct
+    sampling() call with those schedules (same seeds), and differ from the synchronous one."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms
+    from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model, load_model_args
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma, get_t_schedule, get_inverse_schedule
+    from confidence_bootstrapping_amd.finetune_train import inference_epoch
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    margs.asyncronous_noise_schedule = True
+    margs.sampling_alpha, margs.sampling_beta, margs.rot_alpha, margs.rot_beta, margs.tor_alpha, margs.tor_beta = 1.0, 1.0, 2.0, 1.0, 1.0, 2.0
+    model, _ = make_score_model(device=dev, seed=0, args=margs)
+    assert model.asyncronous_noise_schedule
+    conf_model, conf_args = make_confidence_model(device=dev, seed=5)
+    g = add_atoms(make_complex(Nl=10, Nr=40, R=2, knn=8, seed=41, name="1abc_A_l0"), seed=41)
+    args = copy.copy(margs)
+    args.__dict__.update(inference_steps=5, inference_samples=4, inference_batch_size=4)
+    t2s = partial(t_to_sigma, args=margs)
+    model.eval()
+    torch.manual_seed(3); np.random.seed(3)
+    metrics, kept, _ = inference_epoch(model, conf_model, [g], None, dev, t2s, args, conf_args, confidence_cutoff=-1e9)
+    assert len(kept) == 4 and np.isfinite(metrics["avg_confidence"])
+    pos_epoch = np.stack([k[0]["ligand"].pos.cpu().numpy() for k in kept])
+    conf_epoch = np.array([float(k[1]) for k in kept])
+
+    t = get_t_schedule("expbeta", 5)
+    sched = dict(tr_schedule=get_inverse_schedule(t, 1.0, 1.0), rot_schedule=get_inverse_schedule(t, 2.0, 1.0), tor_schedule=get_inverse_schedule(t, 1.0, 2.0))
+    assert np.allclose(sched["tr_schedule"], t) and not np.allclose(sched["rot_schedule"], t)
+
+    def direct(**kw):
+        torch.manual_seed(3); np.random.seed(3)
+        dl = [Batch.from_data_list([copy.deepcopy(g)]) for _ in range(4)]
+        randomize_position(dl, args.no_torsion, False, args.tr_sigma_max)
+        out, conf = sampling(data_list=dl, model=model, inference_steps=5, device=dev, t_to_sigma=t2s, model_args=args, confidence_model=conf_model,
+                             filtering_model_args=conf_args, batch_size=4, asyncronous_noise_schedule=True, t_schedule=t, **kw)
+        return np.stack([d["ligand"].pos.cpu().numpy() for d in out]), conf.cpu().numpy().reshape(-1)
+
+    pos, conf = direct(**sched)
+    order = np.argsort(-conf_epoch, kind="stable")
+    assert np.array_equal(np.sort(conf), np.sort(conf_epoch))
+    for k in range(4):      # same poses (the epoch keeps them with their confidences; order may be the ranked one)
+        assert any(np.array_equal(pos[k], pe) for pe in pos_epoch)
+    pos_sync, _ = direct(tr_schedule=t, rot_schedule=t, tor_schedule=t)
+    assert not np.allclose(pos_sync, pos, atol=1e-3)
+
+
 def test_sampling_co_schedules_complexes_identically():
     """sampling() over the poses of six different complexes: any co-scheduling (cbd_sample_multi with 6 or 4 engines) gives bitwise the
     poses and confidences of one complex at a time."""
