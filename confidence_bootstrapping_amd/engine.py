@@ -688,6 +688,26 @@ def _single_complex(data):
     return g, B, Nl
 
 
+def _copies_of_one_complex(data):
+    """True when every graph of the batch is a pose of the same complex (what sampling() builds): equal names and equal node counts."""
+    B = data.num_graphs
+    if B <= 1:
+        return True
+    names = getattr(data, "name", None)
+    if isinstance(names, (list, tuple)) and len(names) == B:
+        flat = [n[0] if isinstance(n, (list, tuple)) and len(n) else n for n in names]
+        if any(n != flat[0] for n in flat[1:]):
+            return False
+    for kind in ("ligand", "receptor"):
+        b = getattr(data[kind], "batch", None)
+        if b is None:
+            continue
+        cnt = torch.bincount(b.detach().cpu(), minlength=B)
+        if not bool(torch.all(cnt == cnt[0])):
+            return False
+    return True
+
+
 def complex_fingerprint(data):
     """Cheap identity of the complex a batch is made of (names + sizes), to skip re-uploading it every step."""
     name = getattr(data, "name", None)
@@ -713,8 +733,11 @@ def score_batch(model, data):
     eng = model.engine()
     ct = data.complex_t
     t_tr, t_rot, t_tor = (ct[k].detach().cpu() for k in ("tr", "rot", "tor"))
-    if not all(bool(torch.all(x == x[0])) for x in (t_tr, t_rot, t_tor)):
-        raise NotImplementedError("per-sample diffusion times within one batch are outside the MI355X hot path")
+    if not all(bool(torch.all(x == x[0])) for x in (t_tr, t_rot, t_tor)) or not _copies_of_one_complex(data):
+        # a diffusion time per complex or different complexes in one batch (validation batches, utils/training.py:236-252): the fused
+        # engine advances copies of ONE complex at ONE time, so these go through the batched HIP forward of the fine-tuning path in eval mode (same kernels' arithmetic, no autograd)
+        with torch.no_grad():
+            return model.forward_train(data)
     g, B, Nl = _single_complex(data)
     key = complex_fingerprint(data)
     if eng.complex_key != key:

@@ -171,6 +171,10 @@ class Batch(HeteroData):
             vals = [d.__dict__.get(k) for d in data_list]
             if torch.is_tensor(v):
                 out.__dict__[k] = torch.cat([x if x.dim() > 0 else x[None] for x in vals], dim=0)
+            elif isinstance(v, dict) and v and all(isinstance(x, dict) and x.keys() == v.keys() and all(torch.is_tensor(t) for t in x.values())
+                                                   for x in vals):
+                # a dict of tensors per graph (complex_t: the diffusion times): torch_geometric collates it key by key
+                out.__dict__[k] = {kk: torch.cat([x[kk] if x[kk].dim() > 0 else x[kk][None] for x in vals], dim=0) for kk in v}
             else:
                 out.__dict__[k] = list(vals)
         return out

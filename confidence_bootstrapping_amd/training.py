@@ -1,5 +1,6 @@
-"""Fine-tuning step of the confidence-bootstrapping loop: `loss_function`, `train_epoch`, `AverageMeter`
-(reference utils/training.py:17-126, 129-181, 184-233), with the reference's signatures and return values.
+"""Fine-tuning step of the confidence-bootstrapping loop and its validation loops: `loss_function`, `train_epoch`, `AverageMeter`,
+`test_epoch`, `inference_epoch_fix` (reference utils/training.py:17-126, 129-181, 184-233, 236-289, 292-373), with the reference's
+signatures and return values.
 
 MI355X design: the batch (a list of HeteroData, as the reference's DataListLoader yields on CUDA) is collated once, the forward
 and backward passes run on the device (train_forward.py + the HIP tensor-product kernels), the loss is evaluated on the device
@@ -105,23 +106,42 @@ def loss_function(tr_pred, rot_pred, tor_pred, sidechain_pred, data, t_to_sigma,
 
 
 class AverageMeter:
-    """Running means of named scalars (pooled metrics of reference utils/training.py:129-181)."""
+    """Running means of named values (reference utils/training.py:129-181).  Pooled scalars (train_epoch) are accumulated on the values'
+    device -- no read-back per step, one in summary(); `unpooled_metrics` (per-complex vectors, test_epoch: the count advances by the
+    number of complexes) and `intervals` > 1 (per-noise-level bins selected by `interval_idx`) follow the reference's host arithmetic."""
 
-    def __init__(self, types):
+    def __init__(self, types, unpooled_metrics=False, intervals=1):
         self.types = types
-        self.acc = None         # one tensor of running sums on the values' device: no read-back per step, one in summary()
-        self.count = 0
+        self.intervals = intervals
+        self.unpooled_metrics = unpooled_metrics
+        self.acc = None if intervals == 1 else torch.zeros(len(types), intervals)
+        self.count = 0 if intervals == 1 else torch.zeros(len(types), intervals)
 
-    def add(self, vals):
-        self.count += 1
+    def add(self, vals, interval_idx=None):
+        if self.intervals > 1:
+            for k, v in enumerate(vals):
+                v = torch.as_tensor(v).detach().float().cpu().reshape(-1)
+                idx = torch.as_tensor(interval_idx[k]).long().cpu().reshape(-1)
+                self.count[k].index_add_(0, idx, torch.ones(len(v)))
+                if not torch.allclose(v, torch.tensor(0.0)):
+                    self.acc[k].index_add_(0, idx, v)
+            return
         dev = next((v.device for v in vals if torch.is_tensor(v)), torch.device("cpu"))
-        if all(torch.is_tensor(v) and v.numel() == 1 and v.dtype == torch.float32 and v.device == dev for v in vals):
-            row = torch.cat([v.detach().reshape(1) for v in vals])          # the usual case (apply_mean=True): one launch
+        if self.unpooled_metrics:
+            v0 = torch.as_tensor(vals[0])
+            self.count += 1 if v0.dim() == 0 else len(v0)
+            row = torch.stack([torch.as_tensor(v, device=dev).detach().float().sum() for v in vals])
         else:
-            row = torch.stack([torch.as_tensor(v, device=dev).detach().float().mean() for v in vals])
+            self.count += 1
+            if all(torch.is_tensor(v) and v.numel() == 1 and v.dtype == torch.float32 and v.device == dev for v in vals):
+                row = torch.cat([v.detach().reshape(1) for v in vals])          # the usual case (apply_mean=True): one launch
+            else:
+                row = torch.stack([torch.as_tensor(v, device=dev).detach().float().mean() for v in vals])
         self.acc = row if self.acc is None else self.acc + row
 
     def summary(self):
+        if self.intervals > 1:
+            return {f"int{i}_{t}": (self.acc[k][i] / self.count[k][i]).item() for i in range(self.intervals) for k, t in enumerate(self.types)}
         if self.acc is None:
             return {t: 0.0 for t in self.types}
         return {t: v / max(self.count, 1) for t, v in zip(self.types, self.acc.tolist())}
@@ -452,3 +472,100 @@ def train_epoch(model, loader, optimizer, device, t_to_sigma, loss_fn, ema_weigh
             pool.shutdown(wait=True)
     sync_batchnorm_buffers(model)
     return meter.summary()
+
+
+@with_glue_threads
+def test_epoch(model, loader, device, t_to_sigma, loss_fn, test_sigma_intervals=False, torsional=False):
+    """Validation pass (reference utils/training.py:236-289): eval mode, no gradients, per-complex losses (`apply_mean=False`) pooled over
+    the loader, and with `test_sigma_intervals` the same losses binned into ten noise levels of every component (`int{i}_{name}` keys).
+    The batches carry a diffusion time per complex, so the forward is the batched HIP path of train_forward.py in eval mode (the fused
+    sampling engine advances one time for a whole batch); tests/test_gpu_train_step.py checks it against the engine complex by complex."""
+    if torsional:
+        raise NotImplementedError("the torsional-only model is outside the score-model fine-tuning path")
+    model.eval()
+    meter = AverageMeter(_METRICS, unpooled_metrics=True)
+    meter_all = AverageMeter(_METRICS, unpooled_metrics=True, intervals=10) if test_sigma_intervals else None
+    net = getattr(model, "module", model)
+    for data in loader:
+        with torch.no_grad():
+            tr_pred, rot_pred, tor_pred, sidechain_pred = net.forward_train(data)
+        loss_tuple = loss_fn(tr_pred, rot_pred, tor_pred, sidechain_pred, data=data, t_to_sigma=t_to_sigma, apply_mean=False, device=device)
+        if loss_tuple is None:
+            continue
+        vals = [v.detach().cpu() for v in loss_tuple]
+        meter.add(vals)
+        if meter_all is not None:
+            lst = isinstance(data, (list, tuple))
+            ct = {k: (torch.cat([torch.as_tensor(d.complex_t[k], dtype=torch.float32).reshape(-1) for d in data]) if lst
+                      else data.complex_t[k]).cpu() for k in ("tr", "rot", "tor")}
+            i_tr, i_rot, i_tor = (torch.round(ct[k] * (10 - 1)).long() for k in ("tr", "rot", "tor"))
+            meter_all.add(vals, [i_tr, i_tr, i_rot, i_tor, i_tr, i_tr, i_tr, i_rot, i_tor, i_tr, i_tr])
+    out = meter.summary()
+    if meter_all is not None:
+        out.update(meter_all.summary())
+    return out
+
+
+@with_glue_threads
+def inference_epoch_fix(model, complex_graphs, device, t_to_sigma, args):
+    """Validation by docking (reference utils/training.py:292-373): `args.inference_samples` poses per complex through sampling() without a
+    confidence model, symmetry-corrected RMSD to the crystal pose(s); a complex whose sampling failed six times counts as 100 A.
+    -> {'rmsds_lt2', 'rmsds_lt5', 'min_rmsds_lt2', 'min_rmsds_lt5'} in percent."""
+    import copy
+    from .diffusion_utils import get_inverse_schedule, get_t_schedule
+    from .hetero import Batch
+    from .molecules_utils import get_symmetry_rmsd
+    from .sampling import randomize_position, sampling
+    t_schedule = get_t_schedule(sigma_schedule="expbeta", inference_steps=args.inference_steps, inf_sched_alpha=1, inf_sched_beta=1)
+    asyn = bool(getattr(args, "asyncronous_noise_schedule", False))
+    if asyn:
+        tr_schedule = get_inverse_schedule(t_schedule, args.sampling_alpha, args.sampling_beta)
+        rot_schedule = get_inverse_schedule(t_schedule, args.rot_alpha, args.rot_beta)
+        tor_schedule = get_inverse_schedule(t_schedule, args.tor_alpha, args.tor_beta)
+    else:
+        tr_schedule = rot_schedule = tor_schedule = t_schedule
+    net = getattr(model, "module", model)
+    net.eval()
+    rmsds, min_rmsds = [], []
+    for orig in complex_graphs:
+        orig = orig if isinstance(orig, Batch) else Batch.from_data_list([orig])
+        data_list = [orig.shallow_copy() if hasattr(orig, "shallow_copy") else copy.deepcopy(orig) for _ in range(args.inference_samples)]
+        randomize_position(data_list, args.no_torsion, False, args.tr_sigma_max, pocket_knowledge=getattr(args, "inf_pocket_knowledge", False),
+                           pocket_cutoff=getattr(args, "inf_pocket_cutoff", 7))
+        predictions_list, failed = None, 0
+        while predictions_list is None and failed <= 5:
+            try:
+                predictions_list, _ = sampling(data_list=data_list, model=net, inference_steps=args.inference_steps, tr_schedule=tr_schedule,
+                                               rot_schedule=rot_schedule, tor_schedule=tor_schedule, device=device, t_to_sigma=t_to_sigma,
+                                               model_args=args, asyncronous_noise_schedule=asyn, t_schedule=t_schedule)
+            except Exception as e:
+                failed += 1
+                print("failed 5 times - skipping the complex" if failed > 5 else f"Exception while running inference on complex: {e}")
+        if predictions_list is None:
+            rmsds.extend([100] * args.inference_samples)
+            min_rmsds.append(100)
+            continue
+        center = orig.original_center.cpu().numpy()
+        orig_pos = orig["ligand"].pos.cpu().numpy() + center if args.no_torsion else orig["ligand"].orig_pos
+        if isinstance(orig_pos, list):
+            orig_pos = orig_pos[0]
+        orig_pos = np.asarray(orig_pos, dtype=np.float32)
+        orig_pos = orig_pos[None] if orig_pos.ndim == 2 else orig_pos
+        filterHs = torch.not_equal(predictions_list[0]["ligand"].x[:, 0], 0).cpu().numpy()
+        ligand_pos = np.asarray([g["ligand"].pos.cpu().numpy()[filterHs] for g in predictions_list])
+        ref = orig_pos[:, filterHs] - center
+        mol = getattr(orig, "mol", None)
+        mol = mol[0] if isinstance(mol, (list, tuple)) else mol
+        per_ref = []
+        for r in ref:
+            try:
+                per_ref.append(np.asarray(get_symmetry_rmsd(mol, r, [l for l in ligand_pos], device=device)))
+            except Exception as e:
+                print("Using non corrected RMSD because of the error:", e)
+                per_ref.append(np.sqrt(((ligand_pos - r) ** 2).sum(axis=2).mean(axis=1)))
+        rmsd = np.min(np.asarray(per_ref), axis=0)
+        rmsds.extend(rmsd.tolist())
+        min_rmsds.append(rmsd.min())
+    rmsds, min_rmsds = np.asarray(rmsds, dtype=np.float64), np.asarray(min_rmsds, dtype=np.float64)
+    return {"rmsds_lt2": 100 * (rmsds < 2).sum() / len(rmsds), "rmsds_lt5": 100 * (rmsds < 5).sum() / len(rmsds),
+            "min_rmsds_lt2": 100 * (min_rmsds < 2).sum() / len(min_rmsds), "min_rmsds_lt5": 100 * (min_rmsds < 5).sum() / len(min_rmsds)}

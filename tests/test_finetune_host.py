@@ -5,6 +5,7 @@ import os
 from functools import partial
 
 import numpy as np
+import pytest
 import torch
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -244,3 +245,25 @@ def test_inverse_schedule_is_the_beta_quantile():
     assert np.allclose(get_inverse_schedule(t), t)
     assert np.allclose(get_inverse_schedule(t, 2, 1), np.sqrt(t))
     assert np.allclose(get_inverse_schedule(t, 1, 2), 1 - np.sqrt(1 - t))
+
+
+def test_average_meter_unpooled_and_interval_semantics():
+    """utils/training.py:129-181: unpooled metrics add per-complex vectors and count complexes; with intervals the values are binned by
+    `interval_idx` per metric and the summary holds `int{i}_{name}` = bin mean (nan for an empty bin, as the reference's 0 / 0)."""
+    import math
+    import torch
+    from confidence_bootstrapping_amd.training import AverageMeter
+    m = AverageMeter(["a", "b"], unpooled_metrics=True)
+    m.add([torch.tensor([1.0, 2.0, 3.0]), torch.tensor([0.5, 0.5, 2.0])])
+    m.add([torch.tensor([4.0]), torch.tensor([1.0])])
+    out = m.summary()
+    assert out["a"] == pytest.approx(10.0 / 4) and out["b"] == pytest.approx(4.0 / 4)
+    p = AverageMeter(["a", "b"])                      # pooled: one count per add, means of whatever is passed
+    p.add([torch.tensor([2.0]), torch.tensor([4.0])]); p.add([torch.tensor([4.0]), torch.tensor([0.0])])
+    assert p.summary() == {"a": 3.0, "b": 2.0}
+    mi = AverageMeter(["a", "b"], unpooled_metrics=True, intervals=3)
+    mi.add([torch.tensor([1.0, 2.0, 3.0]), torch.tensor([0.0, 0.0, 0.0])], [torch.tensor([0, 0, 2]), torch.tensor([1, 1, 1])])
+    mi.add([torch.tensor([5.0]), torch.tensor([6.0])], [torch.tensor([2]), torch.tensor([1])])
+    o = mi.summary()
+    assert o["int0_a"] == pytest.approx(1.5) and o["int2_a"] == pytest.approx(4.0) and math.isnan(o["int1_a"])
+    assert o["int1_b"] == pytest.approx(6.0 / 4) and math.isnan(o["int0_b"])

@@ -560,3 +560,51 @@ def test_edge_geometry_kernel_matches_the_torch_ops():
         assert float((unit4[:, :3] - want_u).abs().max()) <= 3e-7 and float(unit4[0].abs().max()) == 0.0
         want_s = torch.exp(exp.coeff * torch.pow(d.view(-1, 1) - exp.offset.view(1, -1), 2))
         assert float((smear - want_s).abs().max()) <= 2e-6
+
+
+def test_validation_epoch_on_per_complex_times_equals_the_engine_complex_by_complex():
+    """test_epoch (utils/training.py:236-289): eval-mode forward of batches with a diffusion time PER COMPLEX, per-complex losses pooled
+    over the loader and binned into ten noise levels.  Reference for the predictions: the fused sampling engine, one complex (= one time) at
+    a time; the same heterogeneous batch through model(batch) in eval mode takes the batched route too."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.utils import make_score_model, load_model_args
+    from confidence_bootstrapping_amd.training import loss_function, test_epoch as validation_epoch
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
+    dev = torch.device("cuda:0")
+    margs = load_model_args()
+    model, _ = make_score_model(device=dev, seed=0, args=margs)
+    data = _noised_batch()
+    ts = [float(d.complex_t["tr"]) for d in data]
+    assert len(set(ts)) == 3
+    t2s = partial(t_to_sigma, args=margs)
+    loss_fn = partial(loss_function, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33)
+    out = validation_epoch(model, [data, data[:2]], dev, t2s, loss_fn, test_sigma_intervals=True)
+    assert not model.training
+    # per-complex reference through the engine
+    per = []
+    for d in data:
+        b = Batch.from_data_list([copy.deepcopy(d)])
+        with torch.no_grad():
+            tr, rot, tor, _ = model(b)
+        lt = loss_function(tr, rot, tor, None, data=[d], t_to_sigma=t2s, device=dev, tr_weight=0.33, rot_weight=0.33, tor_weight=0.33, apply_mean=False)
+        per.append([float(v.reshape(-1)[0]) for v in lt])
+    per = np.asarray(per)
+    names = ["loss", "tr_loss", "rot_loss", "tor_loss", "backbone_loss", "sidechain_loss", "tr_base_loss", "rot_base_loss", "tor_base_loss",
+             "backbone_base_loss", "sidechain_base_loss"]
+    want = (per.sum(0) + per[:2].sum(0)) / 5
+    for k, n in enumerate(names):
+        assert out[n] == pytest.approx(want[k], rel=2e-3, abs=1e-6), (n, out[n], want[k])
+    # interval bins: complex i falls into bin round(9 t_i) of every component (one common time per complex here)
+    bins = [int(round(9 * t)) for t in ts]
+    for i, b in enumerate(bins):
+        members = [j for j in range(3) if bins[j] == b]
+        cnt = sum(2 if j < 2 else 1 for j in members)
+        w = sum(per[j, 1] * (2 if j < 2 else 1) for j in members) / cnt
+        assert out[f"int{b}_tr_loss"] == pytest.approx(w, rel=2e-3)
+    empty = next(b for b in range(10) if b not in bins)
+    assert np.isnan(out[f"int{empty}_loss"])
+    # model(batch) in eval mode: a batch of DIFFERENT complexes goes the batched way instead of being read as copies of the first
+    with torch.no_grad():
+        tr_b, rot_b, tor_b, _ = model(Batch.from_data_list([copy.deepcopy(d) for d in data]))
+        tr_f, rot_f, tor_f, _ = model.forward_train(data)
+    assert torch.equal(tr_b, tr_f) and torch.equal(rot_b, rot_f) and torch.equal(tor_b, tor_f)
