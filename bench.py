@@ -60,7 +60,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (~2.5 PF)
 # PMC traffic summaries (tools/pmc_summary.py) of the default command line per (workload, dtype, geometry, poses), newest first
 TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r05_z_traffic.json", "r04_z_traffic.json", "r03_z_traffic.json", "r02_z_traffic.json", "r02_t_traffic.json", "r02_e_traffic.json"],
                     ("c2_dockgen_median", "f32", "loose", "free"): ["r01_m_traffic.json"],
-                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r05_z_c4_bf16_traffic.json", "r04_z_c4_bf16_traffic.json", "r04_a_c4_bf16_traffic.json"]}
+                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r05_zz_c4_bf16_traffic.json", "r05_z_c4_bf16_traffic.json", "r04_z_c4_bf16_traffic.json", "r04_a_c4_bf16_traffic.json"]}
 
 
 def flops_per_edge(in_level: int, out_level: int) -> float:
@@ -580,7 +580,8 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
                    "sharding": (f"{world} rank(s), the {samples} samples of each of the {steps_timed} complexes split round-robin "
                                 f"({b_loc} on rank 0), one ranked gather per complex" if by_samples else
                                 f"{world} rank(s) x {steps_timed} complexes each, no data-path collective")},
-        "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": "tp_conv64_kernel (bf16 operands)", "f32_split": "tp_conv_kernel<OpsBf16x3>"}[dtype],
+        "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": ("tp_conv64s_kernel (bf16 operands, register-stationary weights)" if engines[0].get_option("bf16_stationary", int(os.environ.get("CBD_BF16_STATIONARY", "1") != "0")) else
+                                                                                      "tp_conv64_kernel (bf16 operands)"), "f32_split": "tp_conv_kernel<OpsBf16x3>"}[dtype],
                      "achieved": round(achieved * issue, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved * issue / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "flops_counted": "executed (layer-0 receptor->receptor messages once per complex)",
