@@ -1,7 +1,7 @@
 # One GPU-box job that regenerates the round's evidence under gpurun_out/<tag>/ (copy what is to be judged into profiles/):
 #   full -m gpu test log, the default bench line, rocprofv3 kernel stats + PMC passes of the default bench, C4 bf16 kernel stats + PMC
 #   passes, the fine-tuning step's profiles.      bash tools/final_evidence.sh r05_z
-TAG=${1:-r05_z}
+TAG=${1:-r05_zz}
 cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
