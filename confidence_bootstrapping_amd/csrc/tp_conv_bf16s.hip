@@ -108,55 +108,6 @@ __device__ __forceinline__ void s_chain(const bf16x8 (&w)[V2_NFRAG], const Act6&
   }
 }
 
-// One tile whose weight fragments are read from LDS (three rotating fragment registers: fragment q + 2 is requested behind MFMA q's
-// predecessor, never into the register an issued MFMA may still have to read); aw[0], aw[1] hold fragments 0 and 1 on entry.
-template <class Epi>
-__device__ __forceinline__ void s_chain_lds(const bf16x8* lw, bf16x8 (&aw)[3], const Act6& B, f32x16& acc, Epi epi) {
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < V2_NFRAG; ++q) {
-    if (q + 2 < V2_NFRAG) aw[(q + 2) % 3] = lw[(q + 2) * 64];
-    if (q == 0) {
-      const f32x16 zero = {};
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], B.v[q], zero, 0, 0, 0);
-    } else {
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aw[q % 3], B.v[q], acc, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    epi(q);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
-// Two tiles at once: two independent chains interleaved (a dependent MFMA issues ~40 cycles after its predecessor, an independent one
-// after 32: one chain alone keeps the matrix pipe at 0.8), `epi(s)` behind MFMA s = 0 .. 11 (the previous pair's epilogue slices).
-template <class Epi>
-__device__ __forceinline__ void s_chain2(const bf16x8 (&wa)[V2_NFRAG], const bf16x8 (&wb)[V2_NFRAG], const Act6& B, f32x16& acca, f32x16& accb,
-                                         Epi epi) {
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int q = 0; q < V2_NFRAG; ++q) {
-    if (q == 0) {
-      const f32x16 zero = {};
-      acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], B.v[q], zero, 0, 0, 0);
-    } else {
-      acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[q], B.v[q], acca, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    epi(2 * q);
-    __builtin_amdgcn_sched_barrier(0);
-    if (q == 0) {
-      const f32x16 zero = {};
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], B.v[q], zero, 0, 0, 0);
-    } else {
-      accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[q], B.v[q], accb, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    epi(2 * q + 1);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-}
-
 // bias rows of tile T as the C operand (accumulator layout: register r of lane half hf = row (r & 3) + 8 (r >> 2) + 4 hf)
 __device__ __forceinline__ void s_load_bias(const float* bias_lds, int T, int hf, f32x16& cb) {
   const f32x4* b4 = reinterpret_cast<const f32x4*>(bias_lds + bias_row(T) * 32);
@@ -175,52 +126,11 @@ __device__ __forceinline__ void s_load_act(const float* slot, int lane, Act6& h)
 
 constexpr int S_EPI_LO[V2_NFRAG + 1] = {0, 3, 6, 9, 12, 14, 16};
 
-// Run-length sums of one message tile for the columns [C_LO, C_LO + C_N): reduce_runs (reduce_runs.h) with the aggregating-node ids in a
-// register instead of LDS; lane l sums column C_LO + l.  The tile is read with ds_read_b128 (stride 36), and a group of eight edges
-// without a run boundary -- most of them: a unit holds one to three runs -- is summed without a single branch.  Same additions in the
-// same order as reduce_runs.  Waves 0 and 1 each take half of the 74 columns.
-template <int NODE_STR, int C_LO, int C_N>
-__device__ __forceinline__ void s_reduce_runs(const float* __restrict__ msg, int s_me, int lane, float* __restrict__ fs,
-                                              float* __restrict__ ls, float* __restrict__ run_acc) {
-  const int s_up = __shfl_up(s_me, 1, 64);
-  const int s_prev = (lane & 31) > 0 ? s_up : s_me;
-  const unsigned starts = (unsigned)__ballot(lane < 32 && s_me != s_prev);
-  const int last = __builtin_amdgcn_readlane(s_me, 31);
-  const bool on = lane < C_N;
-  const int col = C_LO + (on ? lane : 0);
-  const f32x4* oc = reinterpret_cast<const f32x4*>(msg + col * S_OSTR);
-  float v[32];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const f32x4 a = oc[k];
-    v[4 * k] = a.x; v[4 * k + 1] = a.y; v[4 * k + 2] = a.z; v[4 * k + 3] = a.w;
-  }
-  float sum = 0.f;
-  int a0 = 0;
-#pragma unroll
-  for (int g8 = 0; g8 < 4; ++g8) {
-    if (((starts >> (8 * g8)) & 0xffu) == 0u) {
-#pragma unroll
-      for (int jj = 8 * g8; jj < 8 * g8 + 8; ++jj) sum += v[jj];
-    } else {
-#pragma unroll
-      for (int jj = 8 * g8; jj < 8 * g8 + 8; ++jj) {
-        if (jj > 0 && ((starts >> jj) & 1u)) {   // run [a0, jj-1] is complete
-          const int node = __builtin_amdgcn_readlane(s_me, a0);
-          float* dst = a0 == 0 ? fs : run_acc + (size_t)node * NODE_STR;
-          if (on) dst[col] = sum;
-          sum = 0.f;
-          a0 = jj;
-        }
-        sum += v[jj];
-      }
-    }
-  }
-  if (last >= 0 && on) (a0 == 0 ? fs : ls)[col] = sum;
-}
-
-// The same reduction with its branch-free bulk taken out: `gs[g]` = the sum of the eight edges of group g of this lane's column, formed
-// between the MFMAs of the tile loop (two ds_read_b128 + seven adds per group, no control flow).  Here only the bookkeeping is left: a
+// Run-length sums of one message tile for the columns [C_LO, C_LO + C_N) (reduce_runs.h: segmented sums without atomics, a run that
+// touches the tile's first / last edge goes to first_sum / last_sum, any other to run_acc[node]); lane l sums column C_LO + l, waves 0 and
+// 1 each take half of the 74 columns.  The branch-free bulk is taken out: `gs[g]` = the sum of the eight edges of group g of this lane's
+// column, formed between the MFMAs of the tile loop (two ds_read_b128 + seven adds per group, no control flow; the aggregating-node ids
+// and the boundary mask come in registers).  Here only the bookkeeping is left: a
 // group without a run boundary adds its sum; a group WITH one (one or two of four in a tile of two or three runs) is re-read and walked
 // edge by edge.  (A run's sum is therefore associated by groups of eight -- deterministic, not the association of reduce_runs.)
 template <int NODE_STR, int C_LO, int C_N>
