@@ -665,7 +665,7 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
     ++used;
     CHK(record_event(e0, s, cap));
   }
-  if (e->use_bf16 == 1 && e->bf16_stat && e->bf16_roles == 0 && L.in_level == 3 && L.out_level == 3) HIPCHK(launch_tp_conv_bf16s(a, e->n_cus, s));
+  if (e->use_bf16 == 1 && e->bf16_stat && e->bf16_roles == 0 && L.in_level == 3 && L.out_level == 3 && tp_conv_bf16s_fits(a)) HIPCHK(launch_tp_conv_bf16s(a, e->n_cus, s));
   else if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));

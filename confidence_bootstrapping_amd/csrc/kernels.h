@@ -143,6 +143,7 @@ hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, i
 hipError_t launch_tp_conv_bf16p(const ConvArgs& a, int n_wg, hipStream_t s);
 // the 74 -> 74 layers of the bf16 policy with register-stationary weights: persistent workgroups of four waves, one per CU (tp_conv_bf16s.hip)
 hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s);
+bool tp_conv_bf16s_fits(const ConvArgs& a);      // false: the launch does not fit that kernel (virtual slices, more FCBlocks than its role table holds) -> streaming kernel
 hipError_t launch_tp_conv_x3(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);     // bf16x3 weight streams
 // segmented sum -> mean -> BatchNorm -> residual of one layer for every batch.  kind: which node types / group sets take part
 enum FinKind { FIN_EMB = 0, FIN_FIRST = 1, FIN_MID = 2, FIN_LAST = 3,     // ligand embedding layer; interaction layer 0; 1..3; 4

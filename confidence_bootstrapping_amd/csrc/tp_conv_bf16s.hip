@@ -830,22 +830,35 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
 }
 
 // a: the edge groups of a 74 -> 74 layer (whole tile chains); n_wg: workgroups (<= CUs).  Roles = distinct weight streams.
-hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s) {
-  if (a.n_groups <= 0) return hipSuccess;
-  RoleTableS rt{};
+// Role table of a launch: one role per distinct FCBlock (weight stream) among its groups.  false: the launch does not fit this kernel --
+// virtual slices of the role split, or more than S_MAX_ROLES FCBlocks (cannot happen through cbd_sample_multi, which wants shared weights:
+// four roles per launch; the check keeps the kernel's table safe whatever builds the arguments).
+static bool s_role_table(const ConvArgs& a, RoleTableS& rt) {
   for (int g = 0; g < a.n_groups; ++g) {
     const ConvGroup& G = a.g[g];
-    if (!G.vec_on || G.i0e_lo != 0 || G.i0e_hi != SS.t0e) return hipErrorInvalidValue;      // no virtual slices here
+    if (!G.vec_on || G.i0e_lo != 0 || G.i0e_hi != SS.t0e) return false;
     int r = -1;
     for (int k = 0; k < rt.n_roles; ++k)
       if (rt.wstream[k] == G.wstream) r = k;
     if (r < 0) {
-      if (rt.n_roles == S_MAX_ROLES) return hipErrorInvalidValue;
+      if (rt.n_roles == S_MAX_ROLES) return false;
       r = rt.n_roles++;
       rt.wstream[r] = G.wstream;
     }
     rt.role_of[g] = (unsigned char)r;
   }
+  return true;
+}
+
+bool tp_conv_bf16s_fits(const ConvArgs& a) {
+  RoleTableS rt{};
+  return s_role_table(a, rt);
+}
+
+hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s) {
+  if (a.n_groups <= 0) return hipSuccess;
+  RoleTableS rt{};
+  if (!s_role_table(a, rt)) return hipErrorInvalidValue;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);

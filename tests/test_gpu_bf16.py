@@ -272,7 +272,7 @@ def test_bf16_stationary_kernel_agrees_with_the_streaming_kernel(model_args):
                     assert float((p - q).abs().max()) <= 2e-5 * float(q.abs().max()), (workload, t, float((p - q).abs().max()), float(q.abs().max()))
                 assert not all(torch.equal(p, q) for p, q in zip(got, ref))      # the other kernel really ran
         finally:
-            eng.set_option("bf16_stationary", 0)
+            eng.set_option("bf16_stationary", 1)      # the default
             eng.set_option("bf16", 0)
     # three different complexes in one launch, S steps: stationary eager = stationary under hipGraph replay (bitwise), close to streaming
     cps = [make_workload("tiny"), make_complex(Nl=17, Nr=60, R=3, knn=10, seed=77), make_complex(Nl=9, Nr=33, R=0, knn=8, seed=78)]
@@ -309,7 +309,7 @@ def test_bf16_stationary_kernel_agrees_with_the_streaming_kernel(model_args):
         replay = run(1, 1)
     finally:
         for e in engs:
-            e.set_option("bf16_stationary", 0); e.set_option("bf16", 0); e.set_option("graph", 1)
+            e.set_option("bf16_stationary", 1); e.set_option("bf16", 0); e.set_option("graph", 1)
     for a, b, c in zip(eager, replay, stream):
         assert torch.equal(a, b)
         assert torch.isfinite(a).all() and float((a - c).norm(dim=-1).max()) < 2e-3      # positions after S steps, in Angstrom
