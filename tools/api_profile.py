@@ -14,6 +14,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--complexes", type=int, default=20)
+    ap.add_argument("--cprofile", action="store_true", help="host profile of the timed sampling() call (cumulative, top 45)")
     a = ap.parse_args()
     import bench
     from confidence_bootstrapping_amd.synthetic import scale_tr_head, BENCH_GEOMETRY
@@ -21,6 +22,23 @@ def main():
     dev = torch.device("cuda:0")
     model, margs = make_score_model(seed=0)
     scale_tr_head(model)
+    if a.cprofile:
+        import cProfile
+        import pstats
+        import confidence_bootstrapping_amd.sampling as smp
+        orig, calls = smp.sampling, []
+
+        def wrapped(**kw):
+            calls.append(1)
+            if len(calls) != 3:              # the leg's third call is the timed one
+                return orig(**kw)
+            pr = cProfile.Profile()
+            t = time.perf_counter()
+            out = pr.runcall(orig, **kw)
+            print("timed sampling() call under cProfile:", round(time.perf_counter() - t, 3), "s")
+            pstats.Stats(pr).sort_stats("cumulative").print_stats(45)
+            return out
+        smp.sampling = wrapped
     t0 = time.perf_counter()
     r = bench.python_api_leg(model, margs, dev, "c2_dockgen_median", 40, 20, dict(BENCH_GEOMETRY), a.complexes, 229.0)
     print({k: v for k, v in r.items() if k != "what"}, round(time.perf_counter() - t0, 1), flush=True)

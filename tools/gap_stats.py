@@ -9,6 +9,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("csv")
     ap.add_argument("--tail", type=float, default=0.5, help="analyse the last fraction of the trace (skips warm-up)")
+    ap.add_argument("--after-largest-gap", action="store_true", help="analyse from the first kernel behind the largest idle gap of the tail "
+                    "(a timed run that follows a host-side build) and list its largest gaps with their position in the run")
     a = ap.parse_args()
     rows = []
     with open(a.csv) as f:
@@ -18,6 +20,14 @@ def main():
     t0, t1 = rows[0][0], rows[-1][1]
     cut = t1 - (t1 - t0) * a.tail
     rows = [r for r in rows if r[0] >= cut]
+    if a.after_largest_gap:
+        end, best, at = rows[0][1], 0, 0
+        for i, (s0, e0, _) in enumerate(rows):
+            if s0 - end > best:
+                best, at = s0 - end, i
+            end = max(end, e0)
+        rows = rows[at:]
+        print(f"region: from kernel {at} behind a gap of {best / 1e6:.1f} ms")
     span = rows[-1][1] - rows[0][0]
     busy, end, gaps = 0, rows[0][0], []
     for s, e, name in rows:
@@ -39,6 +49,16 @@ def main():
         print("idle time before kernels (gaps >= 20 us), top 12:")
         for name, x in by.most_common(12):
             print(f"  {x / 1e6:8.2f} ms  {name}")
+    if a.after_largest_gap:
+        print("largest gaps of the region (offset into the region, gap, kernel that ends it):")
+        end = rows[0][0]
+        big = []
+        for s0, e0, name in rows:
+            if s0 > end:
+                big.append((s0 - end, end - rows[0][0], name))
+            end = max(end, e0)
+        for x, off, name in sorted(big, reverse=True)[:25]:
+            print(f"  +{off / 1e6:9.2f} ms  {x / 1e3:9.1f} us  {name[:80]}")
     dur = collections.Counter()
     cnt = collections.Counter()
     for s, e, name in rows:

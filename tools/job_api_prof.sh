@@ -4,7 +4,7 @@ OUT=gpurun_out/api_prof
 rm -rf $OUT; mkdir -p $OUT
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o p -- python3 tools/api_profile.py > $OUT/log.txt 2>&1
 f=$(find $OUT/prof -name "*kernel_trace.csv" | head -1)
-python tools/gap_stats.py $f --tail 0.45 > $OUT/gaps.txt 2>&1
+python tools/gap_stats.py $f --tail 0.6 --after-largest-gap > $OUT/gaps.txt 2>&1
 find $OUT/prof -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/prof
-tail -2 $OUT/log.txt; head -30 $OUT/gaps.txt
+tail -2 $OUT/log.txt; head -60 $OUT/gaps.txt
