@@ -14,6 +14,9 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--complexes", type=int, default=20)
+    ap.add_argument("--timeline", action="store_true", help="host timeline of the timed sampling() call: start / end of every engine call, "
+                    "with a device synchronisation in front of each one when --sync (what the GPU still had to do shows as the wait)")
+    ap.add_argument("--sync", action="store_true")
     ap.add_argument("--cprofile", action="store_true", help="host profile of the timed sampling() call (cumulative, top 45)")
     a = ap.parse_args()
     import bench
@@ -22,6 +25,43 @@ def main():
     dev = torch.device("cuda:0")
     model, margs = make_score_model(seed=0)
     scale_tr_head(model)
+    if a.timeline:
+        import confidence_bootstrapping_amd.sampling as smp
+        from confidence_bootstrapping_amd.engine import DockEngine, ConfidenceEngine
+        orig, calls, T = smp.sampling, [], {}
+
+        def stamp(tag, fn):
+            def w(*x, **k):
+                if "t0" not in T:
+                    return fn(*x, **k)
+                w0 = 0.0
+                if a.sync:
+                    ts = time.perf_counter(); torch.cuda.synchronize(); w0 = time.perf_counter() - ts
+                t1 = time.perf_counter()
+                out = fn(*x, **k)
+                t2 = time.perf_counter()
+                print(f"  +{1e3 * (t1 - T['t0']):8.1f} ms  {tag:28s} {1e3 * (t2 - t1):7.1f} ms" + (f"   (device was busy for {1e3 * w0:.1f} ms more)" if a.sync else ""))
+                return out
+            return w
+        DockEngine.set_complex = stamp("score set_complex", DockEngine.set_complex)
+        DockEngine.sample_multi = staticmethod(stamp("sample_multi", DockEngine.sample_multi))
+        ConfidenceEngine.set_complex = stamp("confidence set_complex", ConfidenceEngine.set_complex)
+        ConfidenceEngine.score_multi = staticmethod(stamp("confidence score_multi", ConfidenceEngine.score_multi))
+        import confidence_bootstrapping_amd.score_model as sm
+        sm.weights_version = stamp("weights_version", sm.weights_version)
+
+        def wrapped(**kw):
+            calls.append(1)
+            if len(calls) == 3:
+                torch.cuda.synchronize()
+                T["t0"] = time.perf_counter()
+                print("timed sampling() call:")
+            out = orig(**kw)
+            if len(calls) == 3:
+                print(f"  +{1e3 * (time.perf_counter() - T['t0']):8.1f} ms  sampling() returns")
+                T.pop("t0")
+            return out
+        smp.sampling = wrapped
     if a.cprofile:
         import cProfile
         import pstats
