@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <numeric>
 #include <string>
@@ -51,6 +52,14 @@ struct cbd_engine {
   std::map<std::string, HostTensor> host_w;
   bool weights_ready = false, complex_ready = false;
   DevPool wpool, cpool, bpool;   // weights / complex / batch workspace
+  // "async_setup" = 1: cbd_set_complex works on `setup` (a stream of its own) and waits only for THIS engine's last launches (`ev_last`,
+  // recorded by the sampling entry points) instead of synchronising the device and using the default stream -- the set-up of the next
+  // group of complexes then overlaps the step loop of the current one (sampling.py).  `sync_all`: a launch through another entry point
+  // (cbd_score, cbd_modify_conformer, ...) since the last set-up: that set-up synchronises the device as before.
+  hipStream_t setup = nullptr;
+  hipEvent_t ev_last = nullptr;
+  bool last_used = false, sync_all = false;     // a fresh engine has launched nothing
+  int async_setup = 0;
 
   // ---- weights on device
   ConvLayerDev rec_emb[3], lig_emb[3], conv[5];
@@ -456,6 +465,13 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   if (const char* p = getenv("CBD_BF16P_WGS")) e->n_cus = std::max(1, atoi(p));                   // diagnostic: workgroups of the persistent kernel
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
+  {   // the set-up stream at the highest priority: HIP multiplexes the streams of a process onto a few hardware queues, and a set-up
+      // stream that shares the queue of the stream a step-loop graph is running on waits for that graph (measured: one engine in four)
+    int least = 0, greatest = 0;
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&e->setup, hipStreamNonBlocking, greatest));
+  }
+  HIPCHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
@@ -478,6 +494,8 @@ int cbd_destroy(cbd_engine* e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->own) (void)hipStreamDestroy(e->own);
+  if (e->setup) (void)hipStreamDestroy(e->setup);
+  if (e->ev_last) (void)hipEventDestroy(e->ev_last);
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
   delete e;
@@ -809,7 +827,23 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   if (!e->weights_ready) return fail(CBD_ERR_STATE, "cbd_finalize_weights must succeed before cbd_set_complex");
   if (Nl <= 0 || Nr <= 0 || nbd < 0 || R < 0 || Err < 0) return fail(CBD_ERR_ARG, "bad sizes");
   HIPCHK(hipSetDevice(e->cfg.device));
-  HIPCHK(hipDeviceSynchronize());
+  const bool own_stream = e->async_setup && !e->sync_all;
+  static const bool trace_setup = getenv("CBD_TRACE_SETUP") != nullptr;
+  const auto t_in = std::chrono::steady_clock::now();
+  auto since = [&](const char* what) {
+    if (trace_setup) fprintf(stderr, "      [set_complex %p] %-22s +%.2f ms\n", (void*)e, what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+  };
+  if (own_stream) {      // only this engine's buffers are rewritten: wait for ITS last launches, leave the rest of the device alone
+    if (e->last_used) HIPCHK(hipEventSynchronize(e->ev_last));
+    HIPCHK(hipStreamSynchronize(e->setup));
+  } else {
+    HIPCHK(hipDeviceSynchronize());
+  }
+  since(own_stream ? "waited (own launches)" : "waited (device)");
+  hipStream_t s = own_stream ? e->setup : nullptr;
+  e->cpool.stream = e->bpool.stream = s;
+  e->last_used = false;
+  e->sync_all = false;
   drop_graphs(e);
   e->g_pos = nullptr; e->g_S_cap = 0;
   e->cpool.reset(); e->bpool.reset();
@@ -894,6 +928,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->cpool.alloc(&e->rr_attr0, (size_t)Err * 32)); HIPCHK(e->cpool.alloc(&e->rr_attr_t, (size_t)Err * 32));
   HIPCHK(e->cpool.alloc(&e->rec_static, (size_t)Nr * NODE_STRIDE));
 
+  since("complex statics up");
   // ---- batch workspace (capacity max_batch)
   const int N = Bm * (Nl + Nr);
   e->n_nodes_cap = N;
@@ -915,7 +950,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(e->bpool.alloc(&e->ll_attr, cap_ll * 32)); HIPCHK(e->bpool.alloc(&e->lr_attr, cap_x * 32));
   HIPCHK(e->bpool.alloc(&e->X0, (size_t)N * NODE_STRIDE)); HIPCHK(e->bpool.alloc(&e->X1, (size_t)N * NODE_STRIDE));
   for (float*& pbuf : e->proj) HIPCHK(e->bpool.alloc(&pbuf, (size_t)N * KDIM));
-  HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
+  HIPCHK(hipMemsetAsync(e->X0, 0, (size_t)N * NODE_STRIDE * 4, s)); HIPCHK(hipMemsetAsync(e->X1, 0, (size_t)N * NODE_STRIDE * 4, s));
   float* vecs;
   HIPCHK(e->bpool.alloc(&vecs, 7 * 32));
   e->sv = StepVectors{vecs, vecs + 32, vecs + 64, vecs + 96, vecs + 128, vecs + 160, vecs + 192};
@@ -976,16 +1011,19 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   if ((getenv("CBD_CONV_VARIANT") && (atoi(getenv("CBD_CONV_VARIANT")) == 8 || atoi(getenv("CBD_CONV_VARIANT")) == 13)) ||
       (getenv("CBD_BF16_DIAG") && (atoi(getenv("CBD_BF16_DIAG")) >= 4 && atoi(getenv("CBD_BF16_DIAG")) <= 6))) {
     HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 8));
-    HIPCHK(hipMemset(e->stamps_dev, 0, 8192 * 8 * 8));
+    HIPCHK(hipMemsetAsync(e->stamps_dev, 0, 8192 * 8 * 8, s));
   } else e->stamps_dev = nullptr;
-  HIPCHK(hipMemset(e->stats_dev, 0, 4 * sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(e->stats_dev, 0, 4 * sizeof(unsigned long long), s));
   fill_static_desc(e);
-  hipStream_t s = nullptr;
+  since("workspace");
   CHK(embed_receptor(e, s));
+  since("embed_receptor queued");
   for (int b = 0; b < Bm; ++b)
     HIPCHK(hipMemcpyAsync(e->rr_vec + (size_t)b * Err * 4, d_vec0, (size_t)Err * 16, hipMemcpyDeviceToDevice, s));
+  HIPCHK(hipMemsetAsync(e->X0, 0, (size_t)N * NODE_STRIDE * 4, s)); HIPCHK(hipMemsetAsync(e->X1, 0, (size_t)N * NODE_STRIDE * 4, s));
   HIPCHK(hipStreamSynchronize(s));
-  HIPCHK(hipMemset(e->X0, 0, (size_t)N * NODE_STRIDE * 4)); HIPCHK(hipMemset(e->X1, 0, (size_t)N * NODE_STRIDE * 4));
+  since("done");
+  e->cpool.stream = e->bpool.stream = nullptr;
   e->complex_ready = true;
   return 0;
 }
@@ -1285,6 +1323,7 @@ int cbd_score(cbd_engine* e, int32_t B, const float* pos_dev, const cbd_step* st
   if (!pos_dev || !step || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  e->sync_all = true;
   HIPCHK(hipMemcpyAsync(e->sigma_emb_dev, step->sigma_emb, 64 * sizeof(float), hipMemcpyHostToDevice, s));   // sigma_emb | sigma_emb_t (adjacent)
   CHK(push_desc(e, B, const_cast<float*>(pos_dev), tr_dev, rot_dev, tor_dev ? tor_dev : e->tor_out, nullptr, nullptr, nullptr, s));
   cbd_engine* E[1] = {e};
@@ -1298,6 +1337,7 @@ int cbd_modify_conformer(cbd_engine* e, int32_t B, float* pos_dev, const float* 
   if (B <= 0 || B > e->cfg.max_batch || !pos_dev || !tr_dev || !rot_dev) return fail(CBD_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(e->cfg.device));
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  e->sync_all = true;
   // the given updates take the place of the scores (use_coefs = 0): descriptor outputs point at them
   CHK(push_desc(e, B, pos_dev, const_cast<float*>(tr_dev), const_cast<float*>(rot_dev), const_cast<float*>(tor_dev), nullptr, nullptr,
                 nullptr, s));
@@ -1353,6 +1393,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
     for (int k = 0; k < n; ++k)
       CHK(push_desc(E[k], B[k], pos_dev[k], E[k]->tr_out, E[k]->rot_out, E[k]->tor_out, nz(noise_tr, k), nz(noise_rot, k), nz(noise_tor, k), s));
     CHK(run_steps(scores_out));
+    for (int k = 0; k < n; ++k) { HIPCHK(hipEventRecord(E[k]->ev_last, s)); E[k]->last_used = true; }
     return 0;   // asynchronous: kernel-timing events are collected when cbd_kernel_timing is queried
   }
   // ---- the whole S-step loop of all batches as ONE hipGraph launch (static capacities + device-side edge counts make every launch
@@ -1421,6 +1462,7 @@ static int sample_impl(int n, cbd_engine* const* E, const int32_t* B, int32_t S,
   HIPCHK(hipGraphLaunch(exec, s));
   for (int k = 0; k < n; ++k)
     HIPCHK(hipMemcpyAsync(pos_dev[k], E[k]->g_pos, (size_t)B[k] * E[k]->gs.Nl * 3 * 4, hipMemcpyDeviceToDevice, s));
+  for (int k = 0; k < n; ++k) { HIPCHK(hipEventRecord(E[k]->ev_last, s)); E[k]->last_used = true; }      // what an asynchronous cbd_set_complex of these engines waits for
   if (!user) {
     HIPCHK(hipEventRecord(e0->ev_b, s));
     HIPCHK(hipStreamWaitEvent(user, e0->ev_b, 0));
@@ -1497,6 +1539,10 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
     drop_graphs(e);
     return 0;
   }
+  if (k == "async_setup") {   // cbd_set_complex on a stream of its own, waiting only for this engine's last cbd_sample* launches (see cbd_engine)
+    e->async_setup = value != 0;
+    return 0;
+  }
   if (k == "bf16_stationary") {   // bf16 only: register-stationary kernel for the 74 -> 74 layers (captured graphs bake it in)
     e->bf16_stat = value != 0;
     drop_graphs(e);
@@ -1531,6 +1577,7 @@ int cbd_share_weights(cbd_engine* dst, cbd_engine* src) {
 int cbd_recompute_receptor(cbd_engine* e, void* stream) {
   if (!e || !e->complex_ready) return fail(CBD_ERR_STATE, "complex must be set first");
   HIPCHK(hipSetDevice(e->cfg.device));
+  e->sync_all = true;
   CHK(embed_receptor(e, reinterpret_cast<hipStream_t>(stream)));
   return 0;
 }

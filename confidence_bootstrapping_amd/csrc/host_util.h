@@ -39,6 +39,7 @@ struct DevPool {
   struct Chunk { char* base; size_t size, used; };
   std::vector<Chunk> chunks;
   size_t cur = 0;
+  hipStream_t stream = nullptr;   // uploads: nullptr = synchronous copies on the default stream; else asynchronous on this stream + wait (the host vector may go away)
   static constexpr size_t kChunk = size_t(64) << 20, kAlign = 256;
 
   hipError_t raw(void** out, size_t bytes) {
@@ -71,8 +72,10 @@ struct DevPool {
   hipError_t upload(T** p, const std::vector<T>& h) {
     hipError_t e = alloc(p, h.size());
     if (e != hipSuccess) return e;
-    if (!h.empty()) e = hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
-    return e;
+    if (h.empty()) return e;
+    if (!stream) return hipMemcpy(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice);
+    e = hipMemcpyAsync(*p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, stream);
+    return e != hipSuccess ? e : hipStreamSynchronize(stream);
   }
   void reset() {
     for (Chunk& c : chunks) c.used = 0;

@@ -25,6 +25,8 @@ confidences with NaN -> -1000 like the reference.
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 import torch
 from scipy.spatial.transform import Rotation as R
@@ -96,11 +98,13 @@ def _draw_chunk_noise(b, R_, S, no_final_step_noise=False):
     return torch.stack(tr_l), torch.stack(rot_l), (torch.stack(tor_l) if R_ > 0 else None)
 
 
+@with_glue_threads
 def draw_noise_like_reference(N, R_, S, batch_size, no_final_step_noise=False):
     """The noise `sampling()` would draw for N poses of one complex (R_ rotatable bonds) walked in loader batches of `batch_size`,
     as a dict of 'tr' [S,N,3], 'rot' [S,N,3], 'tor' [S,N*R_] (None if R_ == 0) CPU tensors: `sampling(..., noise=this)` then equals
     `sampling(...)` under the same seed.  `sampling_distributed` draws it on every rank and slices, so results do not depend
-    on the number of ranks."""
+    on the number of ranks.  (Under glue_threads like sampling() itself: with torch's default intra-op pool the first small randn
+    after a thread-count change costs 2 .. 90 ms of pool start-up -- the run-to-run spread of bench.py's python_api leg in round 5.)"""
     parts = [_draw_chunk_noise(min(int(batch_size), N - start), R_, S, no_final_step_noise) for start in range(0, N, max(int(batch_size), 1))]
     return {"tr": torch.cat([p[0] for p in parts], 1), "rot": torch.cat([p[1] for p in parts], 1),
             "tor": torch.cat([p[2] for p in parts], 1) if R_ > 0 else None}
@@ -363,46 +367,92 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     pending_key = None
 
     groups = []           # closed groups (one complex each) waiting to be advanced together
+    waves = []            # lists of <= n_co groups, in order: each is ONE co-scheduled call
     conf_engines_used = set()
 
     def flush():
-        """close the pending group (consecutive loader batches of one complex); run when `co_schedule` groups are waiting"""
+        """close the pending group (consecutive loader batches of one complex); `n_co` closed groups make a wave"""
         nonlocal pending, pending_key
         if not pending:
             return
         groups.append((pending, pending_key))
         pending, pending_key = [], None
         if len(groups) >= n_co:
-            run_groups()
+            waves.append(list(groups))
+            groups.clear()
 
-    def run_groups():
-        """Up to eight complexes advance in lockstep (cbd_sample_multi: their tensor-product launches are merged, so a launch
-        carries several times the waves -- +24 % poses/s at 8 samples per complex); one group runs on cbd_sample.  Results are
-        bitwise those of separate calls (tests/test_gpu_parity.py::test_sample_pair_equals_two_samples)."""
-        if not groups:
-            return
-        engines = [eng] + (model.co_engines(len(groups) - 1, eng) if len(groups) > 1 else [])
+    # Set-up of the NEXT wave under the step loop of the current one: two alternating sets of engines (the partners share the main
+    # engine's weights), cbd_set_complex on a stream of its own ("async_setup": it waits for the launches of ITS engine only), the
+    # pose / noise uploads on a side stream.  The host is free for that as soon as the graph launch of the current wave returns.
+    plain = svgd is None and score_crop is None and n_streams == 1 and device.type == "cuda"
+    side = torch.cuda.Stream(device) if plain else None
+    sets = None
+
+    def engine_sets():
+        nonlocal sets
+        if sets is None:
+            need_a = max((len(w) for w in waves[0::2]), default=1)
+            need_b = max((len(w) for w in waves[1::2]), default=0) if plain else 0
+            partners = model.co_engines(need_a - 1 + need_b, eng) if need_a - 1 + need_b > 0 else []
+            set_a = [eng] + partners[:need_a - 1]
+            sets = [set_a, partners[need_a - 1:] if need_b else set_a]
+            for e in partners:      # partners run with the main engine's options (operand precision, graph replay, ...)
+                for name, val in getattr(eng, "_options", {}).items():
+                    if name != "async_setup" and e.get_option(name) != val:
+                        e.set_option(name, val)
+            if need_b:
+                for e in [eng] + partners:
+                    if e.get_option("async_setup", 0) != 1:
+                        e.set_option("async_setup", 1)
+        return sets
+
+    def prepare_wave(k):
+        """per-complex set-up (graph upload, receptor embedding) and the uploads of wave k on engine set k % 2.  Device tensors are
+        allocated from the CURRENT stream's pool (whatever it hands out was last used before the running wave was launched) and
+        only filled on the side stream: an allocation on the side stream would wait for the running wave (caching-allocator events)."""
+        engines = engine_sets()[k % 2]
+        ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+
+        def up(t):
+            if not plain:
+                return t                  # the other samplers take host noise
+            t = t.to(torch.float32).contiguous()
+            d = torch.empty(t.shape, dtype=torch.float32, device=device)
+            with ctx():
+                d.copy_(t, non_blocking=True)
+            return d
         work = []
-        for (pend, key), e in zip(groups, engines):
+        for (pend, key), e in zip(waves[k], engines):
             batch0 = pend[0][6]           # first graph of the group: all of them are poses of the same complex
             g, _, _ = _single_complex(batch0)
             if e.complex_key != key:
                 e.set_complex(g, key)
             R_ = e.R if not model_args.no_torsion else 0
-            pos = torch.cat([p[2] for p in pend], dim=0).to(device, torch.float32).contiguous()
-            cat = lambda k, dim: None if pend[0][k] is None else torch.cat([p[k] for p in pend], dim=dim)
-            work.append((pend, e, pos, (cat(3, 1), cat(4, 1), cat(5, 1) if R_ > 0 else None), batch0))
+            pos_h = torch.cat([p[2] for p in pend], dim=0)
+            pos = up(pos_h) if plain else pos_h.to(device, torch.float32).contiguous()
+            cat = lambda i, dim: None if pend[0][i] is None else up(torch.cat([p[i] for p in pend], dim=dim))
+            work.append((pend, e, pos, (cat(3, 1), cat(4, 1), cat(5, 1) if R_ > 0 else None), batch0, key))
+        return work
+
+    def launch_wave(work):
+        """Up to eight complexes advance in lockstep (cbd_sample_multi: their tensor-product launches are merged, so a launch
+        carries several times the waves -- +24 % poses/s at 8 samples per complex); one group runs on cbd_sample.  Results are
+        bitwise those of separate calls (tests/test_gpu_parity.py::test_sample_pair_equals_two_samples)."""
+        if side is not None:
+            torch.cuda.current_stream(device).wait_stream(side)
         if svgd is not None:
-            for _, e, pos, nz, batch0 in work:
+            for _, e, pos, nz, batch0, _ in work:
                 _sample_svgd(e, _single_complex(batch0)[0], pos, steps, nz, (tr_schedule, rot_schedule, tor_schedule), svgd, N)
         elif score_crop is not None:
-            for (pend, key), (_, e, pos, nz, batch0) in zip(groups, work):
+            for _, e, pos, nz, batch0, key in work:
                 _sample_cropped(e, _single_complex(batch0)[0], key, pos, steps, nz, float(score_crop))
         elif len(work) == 1:
             work[0][1].sample(work[0][2], steps, *work[0][3])
         else:
             DockEngine.sample_multi([w[1] for w in work], [w[2] for w in work], steps, [w[3] for w in work])
-        # Confidence of the group's final poses: up to four complexes per set of fused-conv launches (cbd_conf_score_multi: a launch then
+
+    def finish_wave(work):
+        # Confidence of the wave's final poses: up to four complexes per set of fused-conv launches (cbd_conf_score_multi: a launch then
         # covers ~4x the waves and its last, partly filled round of resident waves costs ~1 % instead of ~6 %).  No host sync per
         # complex: the capacity flag of a confidence engine is sticky and checked once at the end.
         from .engine import ConfidenceEngine
@@ -413,7 +463,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 for c, _ in ConfidenceEngine.score_multi([p[0] for p in scored], [p[1] for p in scored], scored[0][2], check=False):
                     confidence.append(c)
                 scored.clear()
-        for pend, e, pos, _, batch0 in work:
+        cmain = conf_model.engine(max_batch=eng.max_batch) if conf_model is not None else None
+        for pend, e, pos, _, batch0, _ in work:
             first, B, Nl = pend[0][0], pos.shape[0], pos.shape[1]
             flat = pos.reshape(B * Nl, 3)
             for i in range(B):
@@ -427,7 +478,6 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 fg, _, fNl = _single_all_atom_complex(fbatch)
                 if fNl != Nl:
                     raise RuntimeError("filtering graphs hold a different ligand than the sampled ones")
-                cmain = conf_model.engine(max_batch=eng.max_batch)
                 # the k-th complex of a group gets the k-th confidence engine (cbd_conf_score_multi takes one engine per complex)
                 k = len(scored)
                 ceng = cmain if k == 0 else conf_model.co_engines(k, cmain)[k - 1]
@@ -439,7 +489,17 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                 if len(scored) == 4:
                     score_waiting()
         score_waiting()
-        groups.clear()
+
+    def run_waves():
+        if groups:
+            waves.append(list(groups))
+            groups.clear()
+        work = prepare_wave(0) if waves else None
+        for k in range(len(waves)):
+            launch_wave(work)
+            ahead = prepare_wave(k + 1) if plain and k + 1 < len(waves) else None
+            finish_wave(work)
+            work = ahead if ahead is not None else (prepare_wave(k + 1) if k + 1 < len(waves) else None)
 
     def drop_stale_capacity_flags(exc_type):
         """The confidence engine's capacity flag is sticky and lives on the (cached) engine: if this call ends by an exception
@@ -492,7 +552,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
             pending_key = key
             offset += b
         flush()
-        run_groups()
+        run_waves()
         if visualization_list is not None:
             for idx, visualization in enumerate(visualization_list):
                 visualization.add((data_list[idx]["ligand"].pos.detach().cpu() + data_list[idx].original_center.detach().cpu()),

@@ -140,6 +140,11 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
  * fp32 kernel to fp32 rounding level (scores 2e-7..2e-6 relative, 20-step trajectories within 1e-4 A) at ~1.5x its
  * throughput.  "bf16" and "f32_split" are mutually exclusive: switching one on replaces the other, switching one off only
  * clears itself.  Default: both off = v_mfma_f32_32x32x2_f32 (exact fp32 products).
+ * "async_setup" (0/1, default 0): cbd_set_complex of this engine works on a stream of its own (highest priority, so that it does
+ * not share a hardware queue with a running step-loop graph) and waits only for the cbd_sample / cbd_sample_multi launches that used
+ * THIS engine, instead of synchronising the device and using the default stream: the caller can set the next complexes up on idle
+ * engines while others run (sampling.py does, with two alternating sets of engines).  A launch through any other entry point
+ * (cbd_score, cbd_modify_conformer, cbd_recompute_receptor) makes the next set-up synchronise the device as before.
  * With "bf16": "bf16_roles" (0/1/2) -- experimental role split of the cross / receptor groups; "bf16_stationary" (0/1) -- the
  * 74 -> 74 layers through persistent workgroups that keep a whole FCBlock in registers (tp_conv_bf16s.hip; same bf16 products,
  * message sums equal to fp32 rounding; deterministic; default 1, 0 selects the streaming kernel tp_conv_bf16.hip).  "bf16_roles"

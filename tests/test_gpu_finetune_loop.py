@@ -181,3 +181,44 @@ def test_sampling_co_schedules_complexes_identically():
     for other in outs[1:]:
         assert all(torch.equal(a, b) for a, b in zip(outs[0][0], other[0]))
         assert torch.equal(outs[0][1], other[1]) and other[1].shape == (12,)
+
+
+def test_pipelined_set_up_of_the_next_wave_gives_the_poses_of_synchronous_engines():
+    """sampling() sets the complexes of wave k + 1 up while wave k runs (two alternating engine sets, cbd_set_complex with "async_setup" on a
+    stream of its own, uploads on a side stream).  Seven different complexes in waves of two (engines re-used for other complexes while
+    the other set is busy, a last wave of one) must give bitwise the poses of one fresh, synchronous engine per complex -- twice in a row
+    (the second call finds the engines holding the LAST complexes of the first)."""
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_complex
+    from confidence_bootstrapping_amd.utils import make_score_model
+    from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma, get_t_schedule
+    from confidence_bootstrapping_amd.engine import DockEngine, make_steps, _single_complex
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position, draw_noise_like_reference
+    dev = torch.device("cuda:0")
+    model, margs = make_score_model(device=dev, seed=0)
+    S, per, R = 6, 3, 2
+    cps = [make_complex(Nl=8 + 2 * i, Nr=30 + 7 * i, R=R, knn=8, seed=60 + i, name=f"p{i}") for i in range(7)]
+    torch.manual_seed(2); np.random.seed(2)
+    base = [Batch.from_data_list([copy.deepcopy(c)]) for c in cps for _ in range(per)]
+    randomize_position(base, False, False, margs.tr_sigma_max)
+    sched = get_t_schedule("expbeta", S)
+    torch.manual_seed(5)
+    noise = draw_noise_like_reference(per * len(cps), R, S, per)
+    steps = make_steps(sched, margs, model.timestep_emb_func)
+    want = []
+    for i in range(len(cps)):       # reference: one fresh engine (synchronous set-up, no partners) per complex
+        e = DockEngine.from_model(model, dev, max_batch=8)
+        e.set_complex(_single_complex(base[i * per])[0])
+        pos = torch.stack([d["ligand"].pos for d in base[i * per:(i + 1) * per]]).to(dev).contiguous()
+        sl = slice(i * per, (i + 1) * per)
+        e.sample(pos, steps, noise["tr"][:, sl].to(dev), noise["rot"][:, sl].to(dev), noise["tor"][:, i * per * R:(i + 1) * per * R].to(dev))
+        torch.cuda.synchronize()
+        want.append(pos.cpu())
+    for rep in range(2):
+        out, _ = sampling(data_list=[copy.deepcopy(d) for d in base], model=model, inference_steps=S, tr_schedule=sched, rot_schedule=sched,
+                          tor_schedule=sched, device=dev, t_to_sigma=partial(t_to_sigma, args=margs), model_args=margs, batch_size=per,
+                          noise=noise, co_schedule=2)
+        for i in range(len(cps)):
+            got = torch.stack([d["ligand"].pos for d in out[i * per:(i + 1) * per]]).cpu()
+            assert torch.equal(got, want[i]), (rep, i, float((got - want[i]).abs().max()))
+    assert model.engine().get_option("async_setup") == 1
