@@ -684,6 +684,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--legs", default="", help="diagnostic: comma-separated subset of the secondary legs to run (default: all)")
     ap.add_argument("--headline-only", action="store_true", help="skip the secondary legs (python_api, c4_bf16, complex_set, confidence, "
                     "other operand modes, fine-tuning, CPU baseline): the command the rocprofv3 --pmc passes under profiles/ are taken over")
     ap.add_argument("--graph", type=int, default=1, help="1 (default): the whole step loop of a group of complexes is one hipGraph launch, the "
@@ -746,8 +747,12 @@ def main():
             legs[name] = obj
             print(json.dumps({"leg": name, **obj} if isinstance(obj, dict) else {"leg": name, "result": obj}), flush=True)
 
+        only = set(x for x in a.legs.split(",") if x)
+
         def leg(name, fn):
             """a secondary leg must never cost the headline line"""
+            if only and name not in only:
+                return
             t = time.perf_counter()
             try:
                 r = fn()

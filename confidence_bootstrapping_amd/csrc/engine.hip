@@ -9,6 +9,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -446,6 +447,47 @@ extern "C" {
 const char* cbd_last_error(void) { return g_err.c_str(); }
 const char* cbd_version(void) { return "cbdock-mi355x 0.1 (gfx950, fp32 MFMA)"; }
 
+// The set-up stream of "async_setup".  HIP multiplexes the streams of a process onto a few hardware queues (four by default), and a
+// stream that shares the queue of the stream a step-loop graph is running on waits for that graph: a set-up stream per engine lost
+// its overlap for one engine in four (uploads blocked for the 470 ms the running wave still had to go).  Priority streams get queues of
+// their own, but their mere existence cost the C4 bf16 leg of bench.py 10 % (226 -> 197 poses/s, either bf16 kernel; measured with one
+// per engine and with one per process).  So: a small pool of ordinary streams per device, created back to back (they land on different
+// queues), and every set-up PROBES for one whose queue is free -- an event recorded on the candidate must complete within a fraction
+// of a millisecond.  Never destroyed.
+struct SetupPool {
+  static constexpr int N = 4;
+  hipStream_t s[N] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[N] = {nullptr, nullptr, nullptr, nullptr};
+};
+static std::mutex g_setup_mu;
+static std::map<int, SetupPool> g_setup_pools;
+
+static int pick_setup_stream(int device, hipStream_t* out) {
+  std::lock_guard<std::mutex> lock(g_setup_mu);
+  auto it = g_setup_pools.find(device);
+  if (it == g_setup_pools.end()) {
+    SetupPool p;
+    for (int k = 0; k < SetupPool::N; ++k) {
+      HIPCHK(hipStreamCreateWithFlags(&p.s[k], hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&p.ev[k], hipEventDisableTiming));
+    }
+    it = g_setup_pools.emplace(device, p).first;
+  }
+  SetupPool& p = it->second;
+  for (int k = 0; k < SetupPool::N; ++k) {
+    HIPCHK(hipEventRecord(p.ev[k], p.s[k]));
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+      const hipError_t q = hipEventQuery(p.ev[k]);
+      if (q == hipSuccess) { *out = p.s[k]; return 0; }
+      if (q != hipErrorNotReady) HIPCHK(q);
+      if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 400.0) break;
+    }
+  }
+  *out = p.s[0];      // every queue is busy: wait on the first one
+  return 0;
+}
+
 int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   if (!cfg || !out) return fail(CBD_ERR_ARG, "null argument");
   if (cfg->ns != NS || cfg->nv != NV || cfg->num_conv_layers != 5 || cfg->num_prot_emb_layers != 3)
@@ -465,12 +507,6 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   if (const char* p = getenv("CBD_BF16P_WGS")) e->n_cus = std::max(1, atoi(p));                   // diagnostic: workgroups of the persistent kernel
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
-  {   // the set-up stream at the highest priority: HIP multiplexes the streams of a process onto a few hardware queues, and a set-up
-      // stream that shares the queue of the stream a step-loop graph is running on waits for that graph (measured: one engine in four)
-    int least = 0, greatest = 0;
-    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-    HIPCHK(hipStreamCreateWithPriority(&e->setup, hipStreamNonBlocking, greatest));
-  }
   HIPCHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_a, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&e->ev_b, hipEventDisableTiming));
@@ -494,7 +530,6 @@ int cbd_destroy(cbd_engine* e) {
   if (e->ev_join) (void)hipEventDestroy(e->ev_join);
   if (e->side) (void)hipStreamDestroy(e->side);
   if (e->own) (void)hipStreamDestroy(e->own);
-  if (e->setup) (void)hipStreamDestroy(e->setup);
   if (e->ev_last) (void)hipEventDestroy(e->ev_last);
   if (e->ev_a) (void)hipEventDestroy(e->ev_a);
   if (e->ev_b) (void)hipEventDestroy(e->ev_b);
@@ -835,7 +870,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   };
   if (own_stream) {      // only this engine's buffers are rewritten: wait for ITS last launches, leave the rest of the device alone
     if (e->last_used) HIPCHK(hipEventSynchronize(e->ev_last));
-    HIPCHK(hipStreamSynchronize(e->setup));
+    CHK(pick_setup_stream(e->cfg.device, &e->setup));
   } else {
     HIPCHK(hipDeviceSynchronize());
   }

@@ -140,8 +140,8 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
  * fp32 kernel to fp32 rounding level (scores 2e-7..2e-6 relative, 20-step trajectories within 1e-4 A) at ~1.5x its
  * throughput.  "bf16" and "f32_split" are mutually exclusive: switching one on replaces the other, switching one off only
  * clears itself.  Default: both off = v_mfma_f32_32x32x2_f32 (exact fp32 products).
- * "async_setup" (0/1, default 0): cbd_set_complex of this engine works on a stream of its own (highest priority, so that it does
- * not share a hardware queue with a running step-loop graph) and waits only for the cbd_sample / cbd_sample_multi launches that used
+ * "async_setup" (0/1, default 0): cbd_set_complex of this engine works on a set-up stream (picked from a small per-device pool by
+ * probing for one whose hardware queue is not behind a running step-loop graph) and waits only for the cbd_sample / cbd_sample_multi launches that used
  * THIS engine, instead of synchronising the device and using the default stream: the caller can set the next complexes up on idle
  * engines while others run (sampling.py does, with two alternating sets of engines).  A launch through any other entry point
  * (cbd_score, cbd_modify_conformer, cbd_recompute_receptor) makes the next set-up synchronise the device as before.
