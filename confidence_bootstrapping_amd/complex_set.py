@@ -30,12 +30,20 @@ class ComplexSetRunner:
         self.score_args, self.conf_args = score_args, conf_args
         self.sched = get_t_schedule("expbeta", self.S)
         self.steps = make_steps(self.sched, score_args, score_model.timestep_emb_func)
+        # two alternating sets of `group` engines (the partners share the first engine's weights): the complexes of the NEXT group are
+        # set up on the idle set while the current group runs (cbd_set_complex with "async_setup", uploads on a side stream)
         self.engines = [DockEngine.from_model(score_model, self.dev, max_batch=self.samples)]
-        for _ in range(self.group - 1):
+        for _ in range(2 * self.group - 1):
             p = DockEngine(self.dev, max_batch=self.samples, lm_embedding_dim=self.engines[0].cfg.lm_embedding_dim,
                            no_torsion=bool(self.engines[0].cfg.no_torsion))
             p.share_weights_from(self.engines[0])
             self.engines.append(p)
+        for e in self.engines:
+            e.set_option("async_setup", 1)
+        self.sets = [self.engines[:self.group], self.engines[self.group:]]
+        self.side = torch.cuda.Stream(self.dev)
+        self._staged = None          # (indices, set, staged inputs) of the group prepared ahead
+        self._turn = 0
         self.ceng = conf_model.engine(max_batch=self.samples) if conf_model is not None else None
         self.keep_poses = keep_poses
         self.times = {"setup": 0.0, "sample": 0.0, "conf": 0.0}
@@ -63,22 +71,46 @@ class ComplexSetRunner:
         self.prepared[i] = (cplx, pos0, noise)
         return self.prepared[i]
 
-    def sample_group(self, items: Sequence) -> List[dict]:
-        """`items` = [(index, complex), ...] (<= group): set-up of every complex (graph upload, receptor embedding, all-atom tables),
-        ONE co-scheduled sampling call, confidence ranking.  One picklable dict per complex."""
-        ta = time.perf_counter()
-        engines = self.engines[:len(items)]
+    def _stage(self, items, which):
+        """set-up of every complex of a group on engine set `which` + its pose / noise uploads (device buffers from the current stream's
+        pool, filled on the side stream: an allocation ON the side stream would wait for the running group)"""
+        def up(t):
+            t = t.to(torch.float32).contiguous()
+            d = torch.empty(t.shape, dtype=torch.float32, device=self.dev)
+            with torch.cuda.stream(self.side):
+                d.copy_(t, non_blocking=True)
+            return d
         staged = []
-        for e, (i, c) in zip(engines, items):
+        for e, (i, c) in zip(self.sets[which], items):
             cplx, pos0, noise = self.prepared[i] if i in self.prepared else self.prepare(i, c)
             e.set_complex(cplx)
-            staged.append((pos0.to(self.dev), [z.to(self.dev) for z in noise]))
-        torch.cuda.synchronize(self.dev)
+            staged.append((up(pos0), [up(z) for z in noise]))
+        return staged
+
+    def sample_group(self, items: Sequence, next_items: Sequence = None) -> List[dict]:
+        """`items` = [(index, complex), ...] (<= group): set-up of every complex (graph upload, receptor embedding, all-atom tables),
+        ONE co-scheduled sampling call, confidence ranking.  One picklable dict per complex.  `next_items`: the group that will be
+        asked for next -- its set-up runs on the other engine set while this group's step loop is on the GPU."""
+        ta = time.perf_counter()
+        key = tuple(i for i, _ in items)
+        if self._staged is not None and self._staged[0] == key:
+            _, which, staged = self._staged
+        else:
+            which, staged = self._turn, self._stage(items, self._turn)
+        self._staged = None
+        self._turn = 1 - which
+        engines = self.sets[which][:len(items)]
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
         tb = time.perf_counter()
         if len(items) == 1:
             engines[0].sample(staged[0][0], self.steps, *staged[0][1])
         else:
             DockEngine.sample_multi(engines, [s[0] for s in staged], self.steps, [s[1] for s in staged])
+        t_ahead = 0.0
+        if next_items:
+            t0 = time.perf_counter()
+            self._staged = (tuple(i for i, _ in next_items), 1 - which, self._stage(next_items, 1 - which))
+            t_ahead = time.perf_counter() - t0
         torch.cuda.synchronize(self.dev)
         tc = time.perf_counter()
         out = []
@@ -96,7 +128,7 @@ class ComplexSetRunner:
                 res["all_pos"] = pos.cpu()
             out.append(res)
         td = time.perf_counter()
-        self.times["setup"] += tb - ta
+        self.times["setup"] += tb - ta + t_ahead       # the part spent ahead ran under the step loop (inside "sample" as well)
         self.times["sample"] += tc - tb
         self.times["conf"] += td - tc
         return out

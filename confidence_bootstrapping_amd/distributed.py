@@ -173,9 +173,19 @@ def run_complex_set(complexes: Sequence, sample_group: Callable, world=None, ran
     parts = shard_lpt([cost(c) for c in complexes], world)
     mine = parts[rank]
     results = []
-    for k in range(0, len(mine), max(int(group), 1)):
-        idx = mine[k:k + max(int(group), 1)]
-        out = sample_group([(i, complexes[i]) for i in idx])
+    g = max(int(group), 1)
+    try:
+        import inspect
+        ahead = "next_items" in inspect.signature(sample_group).parameters      # a callee that can set the next group up meanwhile
+    except (TypeError, ValueError):
+        ahead = False
+    for k in range(0, len(mine), g):
+        idx = mine[k:k + g]
+        items = [(i, complexes[i]) for i in idx]
+        if ahead:
+            out = sample_group(items, next_items=[(i, complexes[i]) for i in mine[k + g:k + 2 * g]] or None)
+        else:
+            out = sample_group(items)
         if len(out) != len(idx):
             raise RuntimeError("sample_group must return one result per complex")
         results.extend(zip(idx, out))
