@@ -792,7 +792,7 @@ def main():
 
             def c4():
                 r, _ = measure(model.cpu(), margs, dev, workload="c4_large_pocket", samples=64, denoise_steps=40, dtype="bf16",
-                               geometry_name="globular", poses_mode="ideal", graph=a.graph, pair=2, warmup=1, steps_timed=4)
+                               geometry_name="globular", poses_mode="ideal", graph=a.graph, pair=2, warmup=2, steps_timed=6)
                 return {"what": "BASELINE.json configs[3]: large-pocket complex, 64 samples x 40 steps, bf16 operands / fp32 accumulate, "
                                 "not part of `value`", "value": r["value"], "unit": "poses/s", "ms_per_step": r["ms_per_step"],
                         "config": r["config"], "roofline": r["roofline"]}
