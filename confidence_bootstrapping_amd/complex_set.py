@@ -45,6 +45,8 @@ class ComplexSetRunner:
         self._staged = None          # (indices, set, staged inputs) of the group prepared ahead
         self._turn = 0
         self.ceng = conf_model.engine(max_batch=self.samples) if conf_model is not None else None
+        # one confidence engine per complex of a group: up to four complexes are scored in ONE set of fused-conv launches
+        self.cengs = ([self.ceng] + conf_model.co_engines(min(self.group, 4) - 1, self.ceng)) if conf_model is not None else []
         self.keep_poses = keep_poses
         self.times = {"setup": 0.0, "sample": 0.0, "conf": 0.0}
         self.prepared: Dict[int, tuple] = {}
@@ -113,12 +115,20 @@ class ComplexSetRunner:
             t_ahead = time.perf_counter() - t0
         torch.cuda.synchronize(self.dev)
         tc = time.perf_counter()
+        confs = [None] * len(items)
+        if self.ceng is not None:
+            from .engine import ConfidenceEngine
+            for k0 in range(0, len(items), len(self.cengs)):      # cbd_conf_score_multi: bitwise the results of separate score() calls
+                part = range(k0, min(k0 + len(self.cengs), len(items)))
+                for ce, k in zip(self.cengs, part):
+                    ce.set_complex(self.prepared[items[k][0]][0])
+                got = ConfidenceEngine.score_multi(self.cengs[:len(part)], [staged[k][0] for k in part], self.conf_args.crop_beyond)
+                for k, (c, _) in zip(part, got):
+                    confs[k] = c
         out = []
-        for (i, _), (pos, _) in zip(items, staged):
+        for (i, _), (pos, _), conf in zip(items, staged, confs):
             res = {"complex": i}
-            if self.ceng is not None:
-                self.ceng.set_complex(self.prepared[i][0])
-                conf, _ = self.ceng.score(pos, self.conf_args.crop_beyond)
+            if conf is not None:
                 order = torch.argsort(conf, descending=True, stable=True)
                 best = int(order[0])
                 res.update(confidence=float(conf[best]), best=best, pos=pos[best].cpu().numpy(), order=order.cpu().numpy())
