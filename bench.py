@@ -317,7 +317,7 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
         return out, conf
 
     run(*build(4, "w"))
-    run(*build(4, "v"))          # second warm-up on new names: engines, partner engines and graphs of the group shape exist now
+    run(*build(8, "v"))          # second warm-up on new names, two waves: both engine sets, partner engines and graphs of the group shape exist now
     dl, ztr = build(n_complexes, "t")
     torch.cuda.synchronize()
     # like `timeit`: no cyclic garbage collection inside the timed call (a generation-2 pass over the ~10^6 objects of the 800 graphs
