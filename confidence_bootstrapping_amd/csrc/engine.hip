@@ -481,6 +481,7 @@ static int pick_setup_stream(int device, hipStream_t* out) {
       const hipError_t q = hipEventQuery(p.ev[k]);
       if (q == hipSuccess) { *out = p.s[k]; return 0; }
       if (q != hipErrorNotReady) HIPCHK(q);
+      (void)hipGetLastError();      // "not ready" is an answer, not an error: it must not surface at a later hipGetLastError() of this thread
       if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 400.0) break;
     }
   }
