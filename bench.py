@@ -712,7 +712,13 @@ def main():
     ap.add_argument("--split", default="complexes", choices=["complexes", "samples"],
                     help="N > 1: complexes = every rank runs K complexes of its own (weak scaling, default); samples = the samples of each "
                          "of the K complexes are split round-robin over the ranks with one ranked gather per complex (north-star split, strong scaling)")
+    ap.add_argument("--diag-library", action="store_true", help="diagnostic runs only: bind experiments/libcbdock_diag.so (tools/diag_lib.py: "
+                    "phase stamps, timing-only kernel variants with WRONG results selected by CBD_CONV_VARIANT / CBD_BF16_DIAG, the role-split "
+                    "experiment) instead of the product library, which contains none of them and ignores those variables")
     a = ap.parse_args()
+    if a.diag_library:
+        from tools.diag_lib import use_diag_library
+        use_diag_library()
     if a.gpus < 1:
         ap.error("--gpus must be >= 1")
     if a.gpus > 1 and "RANK" not in os.environ:

@@ -107,8 +107,14 @@ struct cbd_engine {
   // bf16 role split ("bf16_roles" option): the cross / receptor groups (1 lr, 2 rr, 3 rl) run as three virtual slices per layer --
   // 0e tiles [0, 19), 0e tiles [19, 38), vector blocks; the second 0e slice writes piece buffers of its own, laid out exactly like
   // the group's and `piece_b_off[g]` floats behind them (first_sum, last_sum and run_acc alike)
+  // EXPERIMENT (lost: 217 -> 163 poses/s): compiled only into the diagnostic library (-DCBD_EXPERIMENTS,
+  // tools/diag_lib.py, experiments/csrc/tp_conv_bf16p.hip); in the product library `bf16_roles` is the constant 0 and the option is refused
+#ifdef CBD_EXPERIMENTS
   long long piece_b_off[4] = {0, 0, 0, 0};
   int bf16_roles = 0;      // 1: the slices run through the streaming kernel, 2: the 0e slices through the LDS-resident kernel (tp_conv_bf16p.hip)
+#else
+  static constexpr int bf16_roles = 0;
+#endif
   // 1: the 74 -> 74 layers of the bf16 policy run through the register-stationary kernel (tp_conv_bf16s.hip; "bf16_stationary" option / CBD_BF16_STATIONARY;
   // the default since the end of round 5: 2 .. 4 % faster than the streaming kernel on C2 and C4, profiles/r05_c_*); 0: through the streaming
   // kernel.  Ignored under the role split.
@@ -502,10 +508,14 @@ int cbd_create(const cbd_config* cfg, cbd_engine** out) {
   cbd_engine* e = new cbd_engine();
   e->cfg = *cfg;
   if (const char* p = getenv("CBD_PRECISION")) e->use_bf16 = std::max(0, std::min(2, atoi(p)));   // test hook: default operand policy
+#ifdef CBD_EXPERIMENTS
   if (const char* p = getenv("CBD_BF16_ROLES")) e->bf16_roles = std::max(0, std::min(2, atoi(p)));                     // test hook: role split of the bf16 policy
+#endif
   if (const char* p = getenv("CBD_BF16_STATIONARY")) e->bf16_stat = atoi(p) != 0;                                       // test hook: register-stationary bf16 kernel
   HIPCHK(hipDeviceGetAttribute(&e->n_cus, hipDeviceAttributeMultiprocessorCount, cfg->device));
+#ifdef CBD_EXPERIMENTS
   if (const char* p = getenv("CBD_BF16P_WGS")) e->n_cus = std::max(1, atoi(p));                   // diagnostic: workgroups of the persistent kernel
+#endif
   HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&e->own, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&e->ev_last, hipEventDisableTiming));
@@ -723,7 +733,11 @@ static int launch_conv_timed(cbd_engine* e, const ConvLayerDev& L, const ConvArg
   else if (e->use_bf16 == 1) HIPCHK(launch_tp_conv_bf16(L.in_level, L.out_level, a, grid, s));
   else if (e->use_bf16 == 2) HIPCHK(launch_tp_conv_x3(L.in_level, L.out_level, a, grid, s));
   else HIPCHK(launch_tp_conv(L.in_level, L.out_level, a, grid, s));
+#ifdef CBD_EXPERIMENTS
   if (resident) HIPCHK(launch_tp_conv_bf16p(*resident, e->n_cus, s));
+#else
+  (void)resident;
+#endif
   if (e->timing) CHK(record_event(e1, s, cap));
   return 0;
 }
@@ -1013,6 +1027,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
     for (int g = 0; g < 5; ++g) {
       const size_t tiles = (caps[g] + CONV_WG_EDGES - 1) / CONV_WG_EDGES + 1;
       const size_t sf = tiles * NODE_STRIDE, sr = (size_t)(g == 4 ? Nr : N) * NODE_STRIDE;
+#ifdef CBD_EXPERIMENTS
       if (g >= 1 && g <= 3) {   // one block: [first | last | run_acc] of the group, then the same again for its second 0e slice
         const size_t D = (2 * sf + sr + 63) / 64 * 64;
         float* base = nullptr;
@@ -1021,6 +1036,7 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
         e->piece_b_off[g] = (long long)D;
         continue;
       }
+#endif
       HIPCHK(e->bpool.alloc(&e->fsum[g], sf));
       HIPCHK(e->bpool.alloc(&e->lsum[g], sf));
       HIPCHK(e->bpool.alloc(&e->racc[g], sr));
@@ -1044,11 +1060,14 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   e->d_rec_x = d_rec_x; e->d_vec0 = d_vec0; e->d_dist0 = d_dist0; e->d_src0 = d_src0; e->d_dst0 = d_dst0;
   e->d_ident = d_ident; e->d_deg0 = d_deg0;
   HIPCHK(e->bpool.alloc(&e->stats_dev, 4));
+  e->stamps_dev = nullptr;
+#ifdef CBD_DIAG      // the stamping kernels exist in the diagnostic library only
   if ((getenv("CBD_CONV_VARIANT") && (atoi(getenv("CBD_CONV_VARIANT")) == 8 || atoi(getenv("CBD_CONV_VARIANT")) == 13)) ||
       (getenv("CBD_BF16_DIAG") && (atoi(getenv("CBD_BF16_DIAG")) >= 4 && atoi(getenv("CBD_BF16_DIAG")) <= 6))) {
     HIPCHK(e->bpool.alloc(&e->stamps_dev, 8192 * 8));
     HIPCHK(hipMemsetAsync(e->stamps_dev, 0, 8192 * 8 * 8, s));
-  } else e->stamps_dev = nullptr;
+  }
+#endif
   HIPCHK(hipMemsetAsync(e->stats_dev, 0, 4 * sizeof(unsigned long long), s));
   fill_static_desc(e);
   since("workspace");
@@ -1137,6 +1156,7 @@ static void fill_static_desc(cbd_engine* e) {
   D.fin_lig.n_groups = 2; D.fin_lig.g[0] = f_ll; D.fin_lig.g[1] = f_lr;
   D.fin_rec.n_groups = 2; D.fin_rec.g[0] = f_rr; D.fin_rec.g[1] = f_rl;
   D.fin_rec_shared.n_groups = 2; D.fin_rec_shared.g[0] = f_rr_shared; D.fin_rec_shared.g[1] = f_rl;
+#ifdef CBD_EXPERIMENTS
   {   // bf16 role split: + the second 0e slice (columns [0, NS) only, not counted in the degree) of every cross / receptor group
     auto second = [&](const FinGroup& f, int g) {
       FinGroup b = f;
@@ -1148,6 +1168,7 @@ static void fill_static_desc(cbd_engine* e) {
     D.fin_rec_r.n_groups = 4; D.fin_rec_r.g[0] = f_rr; D.fin_rec_r.g[1] = f_rl; D.fin_rec_r.g[2] = second(f_rr, 2); D.fin_rec_r.g[3] = second(f_rl, 3);
     D.fin_rec_shared_r.n_groups = 3; D.fin_rec_shared_r.g[0] = f_rr_shared; D.fin_rec_shared_r.g[1] = f_rl; D.fin_rec_shared_r.g[2] = second(f_rl, 3);
   }
+#endif
   ConvGroupH sl[EMB_SLICES];
   emb_slices(e, G.ll, 0, sl);   // the piece buffers of the slices do not depend on the layer
   D.fin_emb.n_groups = EMB_SLICES;
@@ -1261,6 +1282,7 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
       J = ConvJob{};
       J.e = E[k]; J.node_in = E[k]->desc_h.X[xi];
       const int cap_ll = E[k]->desc_h.cap_ll, cap_x = E[k]->desc_h.cap_x, cap_rr = Bk[k] * E[k]->gs.Err;
+#ifdef CBD_EXPERIMENTS
       if (roles) {
         // three virtual slices per cross / receptor group: 0e tiles [0, h0), [h0, t0e) and the vector blocks; what each costs a CU is
         // a third of the weight stream, and the persistent kernel keeps a 0e slice's tiles in LDS (tp_conv_bf16p.hip)
@@ -1280,7 +1302,9 @@ static int forward_multi(cbd_engine* const* E, int n, const cbd_step& st, const 
         add3(G[k].lr, 1, cap_x, 1);
         if (l >= 1 && l < 4) add3(G[k].rr, 2, cap_rr, 2);
         if (l < 4) add3(G[k].rl, 3, cap_x, 3);
-      } else if (l == 0) {          // the receptor->receptor group of layer 0 is the shared one computed on the side stream
+      } else
+#endif
+      if (l == 0) {          // the receptor->receptor group of layer 0 is the shared one computed on the side stream
         J.n_groups = 3;
         J.g[0] = G[k].ll; J.g[1] = G[k].lr; J.g[2] = G[k].rl;
         J.caps[0] = cap_ll; J.caps[1] = cap_x; J.caps[2] = cap_x;
@@ -1532,7 +1556,7 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
       if (engines[q] == e) return fail(CBD_ERR_ARG, "distinct engines are required");
     if (!pos_dev[k]) return fail(CBD_ERR_ARG, "null pose buffer");
     if (e->cfg.device != e0->cfg.device) return fail(CBD_ERR_ARG, "co-scheduled engines must live on the same device");
-    if (e->use_bf16 != e0->use_bf16 || e->bf16_roles != e0->bf16_roles || e->bf16_stat != e0->bf16_stat) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
+    if (e->use_bf16 != e0->use_bf16 || int(e->bf16_roles) - int(e0->bf16_roles) != 0 || e->bf16_stat != e0->bf16_stat) return fail(CBD_ERR_ARG, "co-scheduled engines must use the same operand precision");
     if (e->cfg.no_torsion != e0->cfg.no_torsion || e->cfg.lig_max_radius != e0->cfg.lig_max_radius ||
         e->cfg.lig_radius_cap != e0->cfg.lig_radius_cap)
       return fail(CBD_ERR_ARG, "co-scheduled engines must share one model configuration");
@@ -1571,9 +1595,14 @@ int cbd_set_option(cbd_engine* e, const char* name, int64_t value) {
     return 0;
   }
   if (k == "bf16_roles") {   // bf16 only: cross / receptor groups as three tile slices per layer (captured graphs bake it in)
+#ifdef CBD_EXPERIMENTS
     e->bf16_roles = (int)std::max<long long>(0, std::min<long long>(2, value));
     drop_graphs(e);
     return 0;
+#else
+    if (value == 0) return 0;
+    return fail(CBD_ERR_ARG, "bf16_roles is an experiment of the diagnostic library (tools/diag_lib.py), not part of libcbdock.so");
+#endif
   }
   if (k == "async_setup") {   // cbd_set_complex on a stream of its own, waiting only for this engine's last cbd_sample* launches (see cbd_engine)
     e->async_setup = value != 0;
@@ -1641,7 +1670,7 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
       return (int64_t)p.second.size();
     }
   if (k == "conv_clock_ghz") {   // median in-kernel shader clock of the last tp_conv<3,3> launch (diagnostic build)
-    if (!e->stamps_dev || capacity < 3) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_CONV_VARIANT=8)");
+    if (!e->stamps_dev || capacity < 3) return fail(CBD_ERR_ARG, "stamps not enabled: phase stamps exist in the diagnostic library only (tools/diag_lib.py)");
     std::vector<unsigned long long> h(8192 * 8);
     if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
     std::vector<double> ghz, dur, pro, g1, tiles, fin, g1a;
@@ -1664,7 +1693,7 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     return capacity >= 8 ? 8 : capacity >= 7 ? 7 : 3;
   }
   if (k == "conv_clock_s") {   // per-wave phase clocks of the last tp_conv64s launch (CBD_BF16_DIAG=4): 4 waves x 10 floats (medians)
-    if (!e->stamps_dev || capacity < 48) return fail(CBD_ERR_ARG, "stamps not enabled (CBD_BF16_DIAG=4) or capacity < 48");
+    if (!e->stamps_dev || capacity < 48) return fail(CBD_ERR_ARG, "stamps not enabled (diagnostic library only, tools/diag_lib.py) or capacity < 48");
     std::vector<unsigned long long> h(8192 * 8);
     if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
     auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };

@@ -68,7 +68,9 @@ struct PoseBatch {
   const float *z_tr, *z_rot, *z_tor;   // pre-drawn noise of the whole call [S][B][3], [S][B][3], [S][B*R] (or null)
   unsigned long long* stats;     // [4] work counters
   FinArgs fin_emb, fin_lig, fin_rec, fin_rec_shared;   // segmented-sum descriptions of the layer kinds (static per complex)
-  FinArgs fin_lig_r, fin_rec_r, fin_rec_shared_r;      // the same with the second 0e slice of the cross / receptor groups (bf16 role split)
+#ifdef CBD_EXPERIMENTS
+  FinArgs fin_lig_r, fin_rec_r, fin_rec_shared_r;      // the same with the second 0e slice of the cross / receptor groups (bf16 role split, diagnostic library only)
+#endif
 };
 
 struct Multi {
@@ -139,15 +141,18 @@ hipError_t launch_bond_conv(const BondHead& h, const Multi& m, int xi, const flo
 constexpr int BOND_CONV_TILES = 15;
 hipError_t launch_tp_conv(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);
 hipError_t launch_tp_conv_bf16(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);
+#ifdef CBD_EXPERIMENTS
 // the 0e-only slices of the bf16 role split (74 -> 74 layers) with LDS-resident weight tiles: persistent workgroups, one per CU
+// (experiments/csrc/tp_conv_bf16p.hip, linked into the diagnostic library only)
 hipError_t launch_tp_conv_bf16p(const ConvArgs& a, int n_wg, hipStream_t s);
+#endif
 // the 74 -> 74 layers of the bf16 policy with register-stationary weights: persistent workgroups of four waves, one per CU (tp_conv_bf16s.hip)
 hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s);
 bool tp_conv_bf16s_fits(const ConvArgs& a);      // false: the launch does not fit that kernel (virtual slices, more FCBlocks than its role table holds) -> streaming kernel
 hipError_t launch_tp_conv_x3(int in_level, int out_level, const ConvArgs& a, int grid, hipStream_t s);     // bf16x3 weight streams
 // segmented sum -> mean -> BatchNorm -> residual of one layer for every batch.  kind: which node types / group sets take part
 enum FinKind { FIN_EMB = 0, FIN_FIRST = 1, FIN_MID = 2, FIN_LAST = 3,     // ligand embedding layer; interaction layer 0; 1..3; 4
-               FIN_FIRST_R = 5, FIN_MID_R = 6, FIN_LAST_R = 7 };           // ... of the bf16 role split (fin_*_r group sets)
+               FIN_FIRST_R = 5, FIN_MID_R = 6, FIN_LAST_R = 7 };           // ... of the bf16 role split (fin_*_r group sets; diagnostic library only)
 hipError_t launch_conv_finalize_multi(const Multi& m, int kind, int xi_in, int xi_out, const float* bn_scale, const float* bn_mean,
                                       const float* bn_bias, int in_dim, int out_dim, hipStream_t s);
 // single list of nodes with explicit groups (receptor embedding at set-up time)

@@ -428,10 +428,16 @@ __global__ void conv_finalize_multi_kernel(Multi mm, int kind, int xi_in, int xi
   if (i >= n0 + n1) return;
   const float* node_in = PB.X[xi_in];
   float* node_out = PB.X[xi_out];
+#ifdef CBD_EXPERIMENTS
   if (i < n0) finalize_one(base == FIN_EMB ? PB.fin_emb : roles ? PB.fin_lig_r : PB.fin_lig, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim,
                            out_dim, 0);
   else finalize_one(base == FIN_FIRST ? (roles ? PB.fin_rec_shared_r : PB.fin_rec_shared) : (roles ? PB.fin_rec_r : PB.fin_rec), node_in, node_out,
                     bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim, PB.gs.rec_off);
+#else
+  if (i < n0) finalize_one(base == FIN_EMB ? PB.fin_emb : PB.fin_lig, node_in, node_out, bn_scale, bn_mean, bn_bias, i, c, in_dim, out_dim, 0);
+  else finalize_one(base == FIN_FIRST ? PB.fin_rec_shared : PB.fin_rec, node_in, node_out, bn_scale, bn_mean, bn_bias, i - n0, c, in_dim, out_dim,
+                    PB.gs.rec_off);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -597,18 +603,23 @@ hipError_t launch_bond_conv(const BondHead& h, const Multi& m, int xi, const flo
 template <int IN, int OUT>
 static hipError_t launch_one(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = conv_lds_floats(conv_shape(IN, OUT, true).ntiles) * 4;
-  // CBD_CONV_VARIANT=8 selects the diagnostic build of the 74->74 kernel that stamps s_memtime/s_memrealtime
+#ifdef CBD_DIAG
+  // Diagnostic library only (tools/diag_lib.py builds experiments/libcbdock_diag.so with -DCBD_DIAG; the product library holds the
+  // VAR = 0 kernels alone and never reads this variable).  CBD_CONV_VARIANT=8: the 74->74 kernel stamps s_memtime / s_memrealtime
+  // (correct results); 14: non-temporal gathers (correct results); 9 .. 13: timing-only bounds with WRONG results -- 9: every tile
+  // re-reads weight tile 0 (the L2 -> register weight stream becomes L1-resident: what a perfect weight-reuse scheme could gain),
+  // 10 .. 12: run-coherent / skipped gathers, 13: the stamps of 8 on the gather pattern of 12.
   static const int var = getenv("CBD_CONV_VARIANT") ? atoi(getenv("CBD_CONV_VARIANT")) : 0;
   if (IN == 3 && var == 8) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 8 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
-  // CBD_CONV_VARIANT=9 (diagnostic, WRONG results): every tile re-reads weight tile 0, i.e. the L2 -> register weight stream
-  // is replaced by L1-resident loads; the speed-up, if any, is what a perfect weight-reuse scheme could gain
   else if (IN == 3 && var == 9) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 9 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 10) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 10 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 11) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 11 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 14) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 14 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 13) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 13 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && var == 12) hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, (IN == 3 ? 12 : 0), OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
-  else hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
+  else
+#endif
+  hipLaunchKernelGGL((tp_conv_kernel<IN, OUT, 0, OpsF32>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }
 

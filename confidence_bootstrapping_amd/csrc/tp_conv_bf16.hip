@@ -470,6 +470,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
 template <int IN, int OUT>
 static hipError_t launch_one64(const ConvArgs& a, int grid, hipStream_t s) {
   constexpr int lds_bytes = (2 * V2_SUB_FLOATS + 64) * 4;
+#ifdef CBD_DIAG      // diagnostic library only (tools/diag_lib.py): timing-only variants with WRONG results, 4 = phase stamps
   static const int diag = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
   if (IN == 3 && diag == 1) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 1 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && diag == 2) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 2 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
@@ -481,6 +482,7 @@ static hipError_t launch_one64(const ConvArgs& a, int grid, hipStream_t s) {
   else if (IN == 3 && diag == 32) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 32 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else if (IN == 3 && diag == 26) hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT, (IN == 3 ? 26 : 0)>), dim3(grid), dim3(64), lds_bytes, s, a);
   else
+#endif
   hipLaunchKernelGGL((tp_conv64_kernel<IN, OUT>), dim3(grid), dim3(64), lds_bytes, s, a);
   return hipGetLastError();
 }

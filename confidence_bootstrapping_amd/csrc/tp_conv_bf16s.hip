@@ -28,6 +28,7 @@
 // Results: the same pieces (first_sum / last_sum / run_acc per 32-edge tile) as the streaming kernel; the order in which a message's
 // tile contributions are added differs (partials per wave), so the two kernels agree to fp32 rounding of those sums, not bitwise.
 // Deterministic: no atomics, fixed orders.
+#include <atomic>
 #include <cstdlib>
 
 #include "kernels.h"
@@ -859,25 +860,35 @@ hipError_t launch_tp_conv_bf16s(const ConvArgs& a, int n_wg, hipStream_t s) {
   if (a.n_groups <= 0) return hipSuccess;
   RoleTableS rt{};
   if (!s_role_table(a, rt)) return hipErrorInvalidValue;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+  // the opt-in LDS size is a per-DEVICE function attribute: one flag per device, not one per process
+  static std::atomic<unsigned long long> attr_set{0};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (!(attr_set.load(std::memory_order_acquire) & bit)) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e != hipSuccess) return e;
+#ifdef CBD_DIAG
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&tp_conv64s_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e != hipSuccess) return e;
-    attr_set = true;
+#endif
+    attr_set.fetch_or(bit, std::memory_order_release);
   }
+#ifdef CBD_DIAG      // diagnostic library only (tools/diag_lib.py): 4 = per-wave phase clocks, 5 = workgroup lifetimes, 6 = finer clocks (correct results)
   static const int diag_env = getenv("CBD_BF16_DIAG") ? atoi(getenv("CBD_BF16_DIAG")) : 0;
   static const int diag_min_roles = getenv("CBD_DIAG_MIN_ROLES") ? atoi(getenv("CBD_DIAG_MIN_ROLES")) : 0;      // stamps only from launches with at least so many roles
   const int diag = rt.n_roles >= diag_min_roles ? diag_env : 0;
   if (diag == 4) hipLaunchKernelGGL((tp_conv64s_kernel<4>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
   else if (diag == 5) hipLaunchKernelGGL((tp_conv64s_kernel<5>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
   else if (diag == 6) hipLaunchKernelGGL((tp_conv64s_kernel<6>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
-  else hipLaunchKernelGGL((tp_conv64s_kernel<0>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
+  else
+#endif
+  hipLaunchKernelGGL((tp_conv64s_kernel<0>), dim3(n_wg), dim3(SW_WAVES * 64), S_LDS_BYTES, s, a, rt);
   return hipGetLastError();
 }
 

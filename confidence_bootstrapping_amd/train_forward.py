@@ -3,7 +3,7 @@ models/score_model.py:282-449 under `model.train()`, called from utils/training.
 
 Heterogeneous batches (different complexes, one diffusion time each), training-mode e3nn BatchNorm (batch statistics, running
 averages updated), Dropout where the reference has it.  Every FasterTensorProduct layer -- > 99 % of the FLOPs -- runs on the
-hand-written gfx950 kernels of csrc/tp_train.hip through `train_ops.tensor_product`; the surrounding small ops (embeddings,
+hand-written gfx950 kernels of csrc/tp_train.hip through `train_ops.TensorProductHubFn`; the surrounding small ops (embeddings,
 radius graphs, scatter-mean, BatchNorm, the two e3nn heads) are autograd-visible torch ops on the same device.  The inference
 path (`model.eval()` + sampling) does not come through here: it runs on the fused engine (engine.py).
 
@@ -25,10 +25,10 @@ import torch.nn.functional as F
 from . import so3, torus, train_ops
 from .hetero import Batch, HeteroData
 from .score_model import parse_irreps
-from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, first_linear, gather_pad,
-                        grouped_first_linear, fc_first_stage, linear as _linear, mlp as _mlp,
+from .train_ops import (LEVEL_DIMS, NODE_STRIDE, Csr, IrrepsBatchNormFn, RadiusQuery, ScatterSumFn, csr_build_many, edge_geometry, radius_queries, use_csr_cache, StreamHub, TensorProductHubFn, csr_of, edge_cat, gather_pad,
+                        fc_first_stage, linear as _linear, mlp as _mlp,
                         gather_rows, scatter_mean as _scatter_mean_op,
-                        scatter_sum, stream_map, tensor_product)
+                        scatter_sum, stream_map)
 
 SQ3 = math.sqrt(3.0)
 
@@ -470,19 +470,17 @@ def conv_layer(layer, node_attr, edge_index, edge_attr, vec4, in_level, out_leve
         sm = stream_map(in_level, out_level)
         fcs = [layer.fc] if layer.edge_groups == 1 else list(layer.fc)
         # all edge groups of the layer in ONE launch of the HIP op (forward and backward); the first Linear of every group's FCBlock
-        # runs per group on slices of one buffer (train_ops.GroupedFirstLinearFn), ReLU and Dropout once over all rows (the groups of
+        # runs for all groups in one launch on slices of one buffer (train_ops.FcFirstStageFn), ReLU and Dropout fused (the groups of
         # a layer share the dropout rate)
         sizes = list(group_sizes) if group_sizes is not None else [edge_attr.shape[0]]
         live = [(fc, ne) for fc, ne in zip(fcs, sizes) if ne > 0]
         call = 0
-        if hub is not None:
-            hub.fc_calls = call = getattr(hub, "fc_calls", 0) + 1
+        if hub is None:
+            raise RuntimeError("conv_layer needs the step's StreamHub (train_forward._stream_hub): the model's tile streams are packed once per step")
+        hub.fc_calls = call = getattr(hub, "fc_calls", 0) + 1
         hid = fc_first_stage(edge_attr, [ne for _, ne in live], [fc for fc, _ in live], seed=getattr(hub, "drop_seed", None), call=call)
-        if hub is not None:     # the model's streams packed once per step (train_ops.StreamHub)
-            msg = TensorProductHubFn.apply(xrow, vec4, hid, hub.big, hub, in_level, out_level, tuple(ne for _, ne in live),
-                                           tuple(hub.block(fc) for fc, _ in live))
-        else:
-            msg = tensor_product(xrow, vec4, hid, [sm.stream(fc) for fc, _ in live], in_level, out_level, [ne for _, ne in live])
+        msg = TensorProductHubFn.apply(xrow, vec4, hid, hub.big, hub, in_level, out_level, tuple(ne for _, ne in live),
+                                       tuple(hub.block(fc) for fc, _ in live))
         # the 80-float message rows go through the segmented mean and into the BatchNorm kernel as they are (it reads the layout's
         # `dout` columns): no slice copy of the [E, 80] tensor
         return irreps_batch_norm(layer.batch_norm, scatter_mean(msg, src, n), residual=node_attr, exclude=bn_exclude)

@@ -201,38 +201,16 @@ def test_config_c4_bf16_as_specified(model_args, tables):
     assert float((d1 - d0[None]).abs().max()) < 5e-3
 
 
-def test_bf16_role_split_options_agree(model_args):
-    """cbd_set_option("bf16_roles", 1 | 2) (experimental): the cross / receptor groups as three weight-tile
-    slices -- through the streaming kernel (1) or with the two 0e slices in the persistent LDS-resident kernel (2, tp_conv_bf16p.hip).
-    Same products, summed slice by slice: 1e-5 relative to the single chain; the two forms are bitwise equal; both repeatable."""
-    from confidence_bootstrapping_amd import Batch
+def test_product_library_refuses_the_role_split_experiment(model_args):
+    """The bf16 role split (correct, slower) is compiled into the diagnostic library only (tools/diag_lib.py,
+    experiments/); the product library refuses the option loudly instead of silently ignoring it.  Its own test: experiments/test_role_split.py."""
     from confidence_bootstrapping_amd.synthetic import make_workload
-    from confidence_bootstrapping_amd.engine import make_steps
-    from confidence_bootstrapping_amd.sampling import randomize_position
-    model, args = model_args
-    cplx = make_workload("c2_dockgen_median")
-    torch.manual_seed(5); np.random.seed(5)
-    dl = [Batch.from_data_list([copy.deepcopy(cplx)]) for _ in range(5)]
-    randomize_position(dl, False, False, 5.0)
-    pos = torch.stack([d["ligand"].pos for d in dl]).cuda()
+    model, _ = model_args
     eng = model.engine()
-    eng.set_complex(cplx)
-    step = make_steps(np.array([0.5]), args, model.timestep_emb_func)[0]
-    res = {}
-    try:
-        eng.set_option("bf16", 1)
-        for mode in (0, 1, 2):
-            eng.set_option("bf16_roles", mode)
-            res[mode] = [x.clone() for x in eng.score(pos, step)]
-            again = eng.score(pos, step)
-            assert all(torch.equal(p, q) for p, q in zip(res[mode], again)), mode
-    finally:
-        eng.set_option("bf16_roles", 0)
-        eng.set_option("bf16", 0)
-    for p, q in zip(res[1], res[0]):
-        assert float((p - q).abs().max()) <= 1e-5 * float(q.abs().max())
-    assert not all(torch.equal(p, q) for p, q in zip(res[1], res[0]))      # the slices really ran
-    assert all(torch.equal(p, q) for p, q in zip(res[2], res[1]))
+    eng.set_complex(make_workload("tiny"))
+    eng.set_option("bf16_roles", 0)
+    with pytest.raises(RuntimeError, match="diagnostic library"):
+        eng.set_option("bf16_roles", 1)
 
 
 def test_bf16_stationary_kernel_agrees_with_the_streaming_kernel(model_args):

@@ -51,14 +51,11 @@ def test_fused_first_stage_equals_the_library_form():
         x = torch.randn(E, 96, device=dev)
         g = torch.randn(E, 96, device=dev)
         res = []
-        for fused in (True, False):
-            to.FUSED_FIRST_STAGE = fused
-            try:
-                xi = x.clone().requires_grad_()
-                h = to.fc_first_stage(xi, sizes, fcs)
-                res.append((h.detach(),) + torch.autograd.grad(h, [xi] + params, g))
-            finally:
-                to.FUSED_FIRST_STAGE = True
+        from experiments.train_ops_reference import first_stage_reference      # library GEMM per group + torch ReLU / Dropout
+        for fn in (to.fc_first_stage, first_stage_reference):
+            xi = x.clone().requires_grad_()
+            h = fn(xi, sizes, fcs)
+            res.append((h.detach(),) + torch.autograd.grad(h, [xi] + params, g))
         for a, b in zip(*res):      # fp32 MFMA here, the library's own tiling there: equal to the association of 96-term sums
             assert a.shape == b.shape and float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())) * 96 ** 0.5
     # dropout: Bernoulli(1 - p) on the active units, scaled by 1 / (1 - p), repeatable for a seed, independent between calls; the

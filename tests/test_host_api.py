@@ -22,6 +22,35 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.cbd_version()
 
 
+def test_product_library_holds_only_correct_kernels():
+    """the timing-only kernel variants with WRONG results (CBD_CONV_VARIANT 9-13, CBD_BF16_DIAG bits), the phase-stamp
+    builds and the losing role-split experiment are compiled into experiments/libcbdock_diag.so only (tools/diag_lib.py).  The product
+    library exports no non-zero VAR / DIAG instantiation of a tensor-product kernel, does not contain the persistent role-split kernel
+    and never reads the diagnostic environment variables; the package does not import experiments/ or a library GEMM for the TP op."""
+    import subprocess
+    lib = os.path.join(ROOT, "confidence_bootstrapping_amd", "libcbdock.so")
+    names = subprocess.run(["nm", "-C", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for m in re.finditer(r"__device_stub__(tp_conv_kernel|tp_conv64_kernel|tp_conv64s_kernel)<([^>]*)>", names):
+        args = [a.strip() for a in m.group(2).split(",")]
+        var = args[0] if m.group(1) == "tp_conv64s_kernel" else args[2]
+        assert var == "0", m.group(0)
+        seen += 1
+    assert seen >= 13, seen          # 4 levels x (fp32, bf16x3, bf16 streaming) + the register-stationary kernel
+    assert "tp_conv64p" not in names and "bf16p" not in names
+    raw = open(lib, "rb").read()
+    for env in (b"CBD_CONV_VARIANT", b"CBD_BF16_DIAG", b"CBD_BF16_ROLES", b"CBD_BF16P_WGS", b"CBD_DIAG_MIN_ROLES"):
+        assert env not in raw, env
+    pkg = os.path.join(ROOT, "confidence_bootstrapping_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+experiments\b", txt, re.M), f
+    ops = open(os.path.join(pkg, "train_ops.py")).read()
+    assert "torch.mm(" not in ops and "torch.bmm(" not in ops and "GH_KERNEL" not in ops
+
+
 def test_product_does_not_import_oracle():
     pkg = os.path.join(ROOT, "confidence_bootstrapping_amd")
     for dp, _, fs in os.walk(pkg):

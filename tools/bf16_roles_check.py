@@ -3,6 +3,8 @@ and against the fp32 policy; timing of a 64 x 40 C4 run through bench.measure.  
 import argparse, copy, json, os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+from tools.diag_lib import use_diag_library
+use_diag_library()      # the role split exists in experiments/libcbdock_diag.so only
 
 
 def main():

@@ -3,6 +3,8 @@ after >= 2 s of back-to-back work on random data (MI355X_MICROARCH.md 'DVFS give
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.diag_lib import use_diag_library
+use_diag_library()      # phase stamps / timing-only variants / role split exist in experiments/libcbdock_diag.so only
 from confidence_bootstrapping_amd.synthetic import make_workload
 from confidence_bootstrapping_amd.utils import make_score_model
 from confidence_bootstrapping_amd.engine import DockEngine, make_steps

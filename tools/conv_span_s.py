@@ -4,6 +4,8 @@ LAST 74 -> 74 launch of the pass, the launch span against the median / max / min
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tools.diag_lib import use_diag_library
+use_diag_library()      # phase stamps / timing-only variants / role split exist in experiments/libcbdock_diag.so only
 os.environ.setdefault("CBD_BF16_DIAG", "5")
 from confidence_bootstrapping_amd.synthetic import make_workload, BENCH_GEOMETRY
 from confidence_bootstrapping_amd.utils import make_score_model

@@ -4,7 +4,7 @@ export TAG=${1:-r02c}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/$TAG
-CMD="python bench.py --workload c4_large_pocket --dtype bf16 --samples 64 --denoise-steps 40 --steps 1 --warmup 0 --pair 0 --headline-only"
+CMD="python bench.py --workload c4_large_pocket --dtype bf16 --samples 64 --denoise-steps 40 --steps 1 --warmup 0 --pair 0 --headline-only --diag-library"
 i=0
 for grp in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_MFMA SQ_WAVES" "SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD"; do
   i=$((i+1))

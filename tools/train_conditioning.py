@@ -12,7 +12,8 @@ from confidence_bootstrapping_amd.utils import make_score_model, load_model_args
 from confidence_bootstrapping_amd.training import loss_function
 from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
 dev = torch.device("cuda:0")
-to.FUSED_LINEAR = False
+from experiments.train_ops_reference import linear_reference
+to.linear = lambda x, lin, act=0, p=0.0, seed=None, call=0: linear_reference(x, lin, act, p)      # all-torch Linear layers
 orig = tf._mlp
 EPS = [0.0]
 ONLY = None
