@@ -42,6 +42,10 @@ class ComplexSetRunner:
             e.set_option("async_setup", 1)
         self.sets = [self.engines[:self.group], self.engines[self.group:]]
         self.side = torch.cuda.Stream(self.dev)
+        # event on the current stream recorded just before a group is launched: the side-stream fills of the NEXT group follow everything
+        # queued up to it (their buffers come from the current stream's allocator pool and may have been freed by the host while work
+        # queued there still reads them -- ADVICE round 5), but not the running group itself
+        self._fill_after = None
         self._staged = None          # (indices, set, staged inputs) of the group prepared ahead
         self._turn = 0
         self.ceng = conf_model.engine(max_batch=self.samples) if conf_model is not None else None
@@ -73,7 +77,7 @@ class ComplexSetRunner:
         self.prepared[i] = (cplx, pos0, noise)
         return self.prepared[i]
 
-    def _stage(self, items, which):
+    def _stage(self, items, which, ahead=False):
         """set-up of every complex of a group on engine set `which` + its pose / noise uploads (device buffers from the current stream's
         pool, filled on the side stream: an allocation ON the side stream would wait for the running group)"""
         def up(t):
@@ -82,6 +86,10 @@ class ComplexSetRunner:
             with torch.cuda.stream(self.side):
                 d.copy_(t, non_blocking=True)
             return d
+        if ahead and self._fill_after is not None:
+            self.side.wait_event(self._fill_after)
+        else:       # nothing of this runner is on the GPU: simply behind whatever the caller has queued
+            self.side.wait_stream(torch.cuda.current_stream(self.dev))
         staged = []
         for e, (i, c) in zip(self.sets[which], items):
             cplx, pos0, noise = self.prepared[i] if i in self.prepared else self.prepare(i, c)
@@ -102,7 +110,10 @@ class ComplexSetRunner:
         self._staged = None
         self._turn = 1 - which
         engines = self.sets[which][:len(items)]
-        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_stream(self.side)
+        self._fill_after = torch.cuda.Event()
+        self._fill_after.record(cur)
         tb = time.perf_counter()
         if len(items) == 1:
             engines[0].sample(staged[0][0], self.steps, *staged[0][1])
@@ -111,7 +122,7 @@ class ComplexSetRunner:
         t_ahead = 0.0
         if next_items:
             t0 = time.perf_counter()
-            self._staged = (tuple(i for i, _ in next_items), 1 - which, self._stage(next_items, 1 - which))
+            self._staged = (tuple(i for i, _ in next_items), 1 - which, self._stage(next_items, 1 - which, ahead=True))
             t_ahead = time.perf_counter() - t0
         torch.cuda.synchronize(self.dev)
         tc = time.perf_counter()

@@ -892,6 +892,12 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   since(own_stream ? "waited (own launches)" : "waited (device)");
   hipStream_t s = own_stream ? e->setup : nullptr;
   e->cpool.stream = e->bpool.stream = s;
+  // the pools go back to the default stream on EVERY way out of this function (an early error return used to leave them
+  // pointed at the set-up stream for whoever allocates from them next)
+  struct PoolStreamGuard {
+    cbd_engine* e;
+    ~PoolStreamGuard() { e->cpool.stream = e->bpool.stream = nullptr; }
+  } pool_stream_guard{e};
   e->last_used = false;
   e->sync_all = false;
   drop_graphs(e);
@@ -1078,7 +1084,6 @@ int cbd_set_complex(cbd_engine* e, int32_t Nl, int32_t Nr, int32_t nbd, int32_t 
   HIPCHK(hipMemsetAsync(e->X0, 0, (size_t)N * NODE_STRIDE * 4, s)); HIPCHK(hipMemsetAsync(e->X1, 0, (size_t)N * NODE_STRIDE * 4, s));
   HIPCHK(hipStreamSynchronize(s));
   since("done");
-  e->cpool.stream = e->bpool.stream = nullptr;
   e->complex_ready = true;
   return 0;
 }

@@ -417,7 +417,7 @@ __global__ __launch_bounds__(64, 2) void fctp_conv_kernel(CArgs args) {
       if constexpr (OUT >= 2) xT[(CC_1E + 3 * (3 * hf + o) + c) * C_OUT_STRIDE + j] = k1e[3 * o + c];
     }
   __syncthreads();
-  reduce_runs<CN_STRIDE, C_OUT_STRIDE>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * CN_STRIDE,
+  reduce_runs<CN_STRIDE, C_OUT_STRIDE, S.out_dim, 0>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * CN_STRIDE,
                                        G.last_sum + (size_t)tile_local * CN_STRIDE, G.run_acc);
 }
 

@@ -95,9 +95,14 @@ __device__ __forceinline__ void reduce_runs_impl(const float* __restrict__ msg, 
   }
 }
 
-template <int NODE_STR, int OUT_STR>
+// MAX_COLS: compile-time bound of out_dim - col_lo at the call site.  The single pass covers at most 128 columns from col_lo (lane l:
+// col_lo + l and col_lo + 64 + l) -- a wider layer would silently lose its tail, so the bound is part of the signature.  MSG_OFF: offset
+// (floats) of `msg` from the 16-byte aligned LDS base; with an even stride the tile is read as f32x2, which needs it 8-byte aligned.
+template <int NODE_STR, int OUT_STR, int MAX_COLS, int MSG_OFF>
 __device__ __forceinline__ void reduce_runs(const float* __restrict__ msg, const int* __restrict__ sl, int lane, int out_dim,
                                             float* __restrict__ fs, float* __restrict__ ls, float* __restrict__ run_acc, int col_lo = 0) {
+  static_assert(MAX_COLS <= 128, "reduce_runs covers at most 128 columns in its single pass");
+  static_assert(OUT_STR % 2 != 0 || MSG_OFF % 2 == 0, "ds_read_b64 of the message tile needs an 8-byte aligned tile base");
   const int jl = lane & 31;
   const int s_me = sl[jl], s_prev = sl[jl > 0 ? jl - 1 : 0];
   const unsigned starts = (unsigned)__ballot(lane < 32 && s_me != s_prev);   // bit jj: edge jj starts a new run (bit 0 is never set)

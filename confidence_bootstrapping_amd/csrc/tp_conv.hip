@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64, 2) void tp_conv_kernel(ConvArgs args) {
   }
   __syncthreads();
   // Run-length sums per aggregating node (reduce_runs, tp_conv_dev.h)
-  reduce_runs<NODE_STRIDE, OUT_STRIDE>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * NODE_STRIDE, G.last_sum + (size_t)tile_local * NODE_STRIDE,
+  reduce_runs<NODE_STRIDE, OUT_STRIDE, S.out_dim, S.ntiles * 32>(xT, srcl, lane, S.out_dim, G.first_sum + (size_t)tile_local * NODE_STRIDE, G.last_sum + (size_t)tile_local * NODE_STRIDE,
               G.run_acc);
   if constexpr (STAMPS) {
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {

@@ -456,7 +456,8 @@ __global__ __launch_bounds__(64, 2) void tp_conv64_kernel(ConvArgs args) {
   const int col_lo = (vec_on && i_lo >= i_hi) ? NS : 0, col_hi = vec_on ? S.out_dim : NS;
 #pragma unroll 1
   for (int sub = 0; sub < 2; ++sub)
-    reduce_runs<NODE_STRIDE, OUT_STRIDE>(sub ? xT1 : xT0, srcl + 32 * sub, lane, col_hi, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
+    reduce_runs<NODE_STRIDE, OUT_STRIDE, S.out_dim, V2_SUB_FLOATS>(sub ? xT1 : xT0,      // (tile bases 0 and V2_SUB_FLOATS: both even)
+                                                                  srcl + 32 * sub, lane, col_hi, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
                 G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc, col_lo);
   if constexpr (DIAG == 4) {   // same record layout as tp_conv_kernel's CBD_CONV_VARIANT=8 stamps (tools/conv_clock.py)
     if (lane == 0 && args.stamps && blockIdx.x < 8192) {

@@ -18,7 +18,7 @@ import torch
 
 from .diffusion_utils import get_inverse_schedule, get_t_schedule
 from .hetero import Batch
-from .molecules_utils import get_symmetry_rmsd
+from .molecules_utils import get_symmetry_rmsd, remove_all_hs
 from .sampling import randomize_position, sampling
 from .training import loss_function, train_epoch
 from .hostcfg import with_glue_threads
@@ -115,6 +115,7 @@ def inference_epoch(model, filtering_model, complex_graphs, filtering_complex_di
             ref = orig_pos[:, filterHs] - orig.original_center.cpu().numpy()
             mol = getattr(orig, "mol", None)
             mol = mol[0] if isinstance(mol, (list, tuple)) else mol
+            mol = remove_all_hs(mol)          # RemoveAllHs(orig_complex_graph.mol[0]) in the reference; the coordinates are filtered with filterHs
             per_ref = []
             for r in ref:
                 try:

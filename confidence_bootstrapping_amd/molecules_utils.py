@@ -108,6 +108,26 @@ def _graph_of(mol):
     raise TypeError("mol must provide atomicnums/adjacency_matrix (spyrmsd Molecule) or the rdkit Mol API")
 
 
+class _HeavyAtomGraph:
+    """what rdkit's RemoveAllHs leaves of a molecule, as far as the symmetry-corrected RMSD needs it: atomic numbers and adjacency"""
+
+    def __init__(self, atomicnums, adjacency_matrix):
+        self.atomicnums, self.adjacency_matrix = atomicnums, adjacency_matrix
+
+
+def remove_all_hs(mol):
+    """Heavy-atom graph of `mol` (the reference passes RemoveAllHs(orig_complex_graph.mol[0]) to get_symmetry_rmsd next to coordinates
+    filtered with filterHs: utils/training.py:352, finetune_train.py:210).  A molecule without hydrogens comes back unchanged; None stays
+    None (the callers then take their non-symmetry-corrected branch, as they do for any failure)."""
+    if mol is None:
+        return None
+    nums, am = _graph_of(mol)
+    keep = nums != 1
+    if keep.all():
+        return mol
+    return _HeavyAtomGraph(nums[keep], am[np.ix_(keep, keep)])
+
+
 def get_symmetry_rmsd(mol, coords1, coords2, mol2=None, return_permutation=False, device=None):
     """Same call as the reference (utils/molecules_utils.py:3): coords1 = reference pose, coords2 = pose or list of poses.
     `device` (extension): the GPU to reduce on; default = the poses' device or the process's current device."""

@@ -387,6 +387,12 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     plain = svgd is None and score_crop is None and n_streams == 1 and device.type == "cuda"
     side = torch.cuda.Stream(device) if plain else None
     sets = None
+    # Ordering of the side-stream fills: their device buffers come from the CURRENT stream's allocator pool, and a block
+    # the host has freed may still be read by work already queued there (e.g. the confidence kernels of the previous wave).  `fill_after`
+    # is an event on the current stream recorded just BEFORE a wave is launched: the fills of the next wave follow everything queued up to
+    # it, but not the running wave itself.  Wave 0 (nothing of ours is running yet) simply follows the current stream.
+    fill_after = [None]
+    async_before = {}       # engines whose "async_setup" this call switched on -> previous value (restored on exit)
 
     def engine_sets():
         nonlocal sets
@@ -402,7 +408,9 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
                         e.set_option(name, val)
             if need_b:
                 for e in [eng] + partners:
-                    if e.get_option("async_setup", 0) != 1:
+                    was = e.get_option("async_setup", 0)
+                    if was != 1:
+                        async_before[e] = was
                         e.set_option("async_setup", 1)
         return sets
 
@@ -412,6 +420,11 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         only filled on the side stream: an allocation on the side stream would wait for the running wave (caching-allocator events)."""
         engines = engine_sets()[k % 2]
         ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
+        if side is not None:
+            if fill_after[0] is None:
+                side.wait_stream(torch.cuda.current_stream(device))
+            else:
+                side.wait_event(fill_after[0])
 
         def up(t):
             if not plain:
@@ -439,7 +452,10 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         carries several times the waves -- +24 % poses/s at 8 samples per complex); one group runs on cbd_sample.  Results are
         bitwise those of separate calls (tests/test_gpu_parity.py::test_sample_pair_equals_two_samples)."""
         if side is not None:
-            torch.cuda.current_stream(device).wait_stream(side)
+            cur = torch.cuda.current_stream(device)
+            cur.wait_stream(side)
+            fill_after[0] = torch.cuda.Event()
+            fill_after[0].record(cur)
         if svgd is not None:
             for _, e, pos, nz, batch0, _ in work:
                 _sample_svgd(e, _single_complex(batch0)[0], pos, steps, nz, (tr_schedule, rot_schedule, tor_schedule), svgd, N)
@@ -517,6 +533,8 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
 
         def __exit__(self, exc_type, exc, tb):
             drop_stale_capacity_flags(exc_type)
+            for e, was in async_before.items():      # the pipelined set-up is a property of THIS call, not of the model's cached engines
+                e.set_option("async_setup", was)
             return False
 
     with torch.no_grad(), _Guard():

@@ -514,7 +514,7 @@ def inference_epoch_fix(model, complex_graphs, device, t_to_sigma, args):
     import copy
     from .diffusion_utils import get_inverse_schedule, get_t_schedule
     from .hetero import Batch
-    from .molecules_utils import get_symmetry_rmsd
+    from .molecules_utils import get_symmetry_rmsd, remove_all_hs
     from .sampling import randomize_position, sampling
     t_schedule = get_t_schedule(sigma_schedule="expbeta", inference_steps=args.inference_steps, inf_sched_alpha=1, inf_sched_beta=1)
     asyn = bool(getattr(args, "asyncronous_noise_schedule", False))
@@ -556,6 +556,7 @@ def inference_epoch_fix(model, complex_graphs, device, t_to_sigma, args):
         ref = orig_pos[:, filterHs] - center
         mol = getattr(orig, "mol", None)
         mol = mol[0] if isinstance(mol, (list, tuple)) else mol
+        mol = remove_all_hs(mol)          # RemoveAllHs(orig_complex_graph.mol[0]) in the reference; the coordinates are filtered with filterHs
         per_ref = []
         for r in ref:
             try:

@@ -221,4 +221,5 @@ def test_pipelined_set_up_of_the_next_wave_gives_the_poses_of_synchronous_engine
         for i in range(len(cps)):
             got = torch.stack([d["ligand"].pos for d in out[i * per:(i + 1) * per]]).cpu()
             assert torch.equal(got, want[i]), (rep, i, float((got - want[i]).abs().max()))
-    assert model.engine().get_option("async_setup") == 1
+    # the pipelined set-up is a property of the call: the model's cached engines are handed back as they were
+    assert model.engine().get_option("async_setup", 0) == 0

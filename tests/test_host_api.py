@@ -223,3 +223,20 @@ def test_glue_threads_is_reference_counted_and_gpu_only():
         assert hostcfg.dev_key("cpu") == "cpu" and hostcfg.dev_key("cuda:1") == "cuda:1"
     finally:
         torch.set_num_threads(before)
+
+
+def test_remove_all_hs_gives_the_heavy_atom_graph():
+    """the reference passes RemoveAllHs(mol) to get_symmetry_rmsd next to filterHs-filtered coordinates
+    (utils/training.py:352, finetune_train.py:210); a molecule that still carries hydrogens must be reduced the same way."""
+    from confidence_bootstrapping_amd.molecules_utils import remove_all_hs, _graph_of
+
+    class Mol:          # methanol with explicit hydrogens: C O H H H H
+        atomicnums = np.array([6, 8, 1, 1, 1, 1])
+        adjacency_matrix = np.zeros((6, 6), dtype=int)
+    for i, j in ((0, 1), (0, 2), (0, 3), (0, 4), (1, 5)):
+        Mol.adjacency_matrix[i, j] = Mol.adjacency_matrix[j, i] = 1
+    nums, am = _graph_of(remove_all_hs(Mol))
+    assert nums.tolist() == [6, 8] and am.tolist() == [[0, 1], [1, 0]]
+    heavy = remove_all_hs(remove_all_hs(Mol))
+    assert _graph_of(heavy)[0].tolist() == [6, 8]       # idempotent: no hydrogens left -> returned as is
+    assert remove_all_hs(None) is None
