@@ -7,7 +7,10 @@ cpu_baseline leg of bench.py use it, and only as the checker.
 e3nn is an un-vendored dependency of the reference (environment.yml:129 `e3nn==0.5.0`) and is
 not installable here, so its published algorithm is restated.  PARITY UNPINNED at this
 boundary: the reference has no tests/golden vectors and e3nn cannot be imported to pin these
-functions.  Internal consistency is checked instead (tests/test_oracle_e3nn.py):
+functions.  Second pin since round 6 (oracle/pin_wigner_sympy.py, tests/golden/g20_wigner3j_sympy.npz): every real Wigner 3j
+with l <= 2 re-derived from sympy's exact Clebsch-Gordan coefficients and a change of basis fitted from sympy's Ynm against the
+real polynomials e3nn documents -- no code shared with this file -- agrees with wigner_3j() below to 1e-15, signs included.
+Internal consistency is checked as well (tests/test_oracle_e3nn.py):
   * O(3) equivariance of SH / tensor products under random rotations + inversion,
   * w3j(1,1,0) = delta/sqrt(3) and w3j(1,1,1) = eps/sqrt(6) with the SAME sign the reference's
     own hand-written FasterTensorProduct uses (models/tensor_layers.py:76-82), which was
