@@ -15,6 +15,9 @@ environment can run inference here from them:
                                   (`process_mols.py:489-490`) from the per-chain `.pt` dictionary;
   * `merge_ligand_receptor(...)` -- `moad.py:202-212`: ligand stores copied into the receptor graph, poses re-centred on
                                   `original_center`.
+STATUS: validated against a pickle EMULATED by this repository (oracle/make_cache_fixture.py writes the PyG 2.0.4 class layout by hand);
+no real torch_geometric pickle existed in the build image.  tools/pin_with_rdkit.py (run where rdkit + torch_geometric are installed)
+writes a real one and diffs what this reader returns.
 What is NOT here: producing the features from PDB / SDF files (rdkit chemistry, prody selections, ESM inference).
 """
 from __future__ import annotations
