@@ -407,6 +407,9 @@ def complex_set_leg(dev, n_complexes=24, samples=40, denoise_steps=20, seed=7):
             "confidence_s": round(runner.times["conf"], 3)}
 
 
+SHARED_GPU = os.environ.get("CBD_BENCH_ALLOW_SHARED_GPU") == "1"
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` run bare: start the N ranks as fresh child processes (torch.distributed.run, one per GPU) BEFORE
     this process makes any GPU call (torch.cuda.device_count() does not initialise the GPU on this image) and exit with their status.
@@ -414,7 +417,10 @@ def launch_ranks(n, argv):
     import socket
     import subprocess
     n_dev = torch.cuda.device_count()
-    if n_dev < n:
+    # CBD_BENCH_ALLOW_SHARED_GPU=1 is a TEST-ONLY switch (tests/test_gpu_bench_ranks.py): the ranks then share the visible GPU(s) and talk
+    # over gloo, so that the multi-rank branch of measure() -- barrier, MAX all-reduce, gathers, rank-0-only printing -- runs on a 1-GPU
+    # box.  The line it prints carries "shared_gpu": true and is not a scaling measurement.
+    if n_dev < n and not SHARED_GPU:
         sys.stderr.write(f"bench.py: --gpus {n} requested but only {n_dev} GPU(s) are visible; refusing to report a smaller run\n")
         sys.exit(2)
     s = socket.socket()
@@ -543,21 +549,27 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, n_runs)
+    # RCCL moves device tensors; under gloo (the shared-GPU test mode) the same collectives take host tensors
+    on_wire = (lambda t: t) if (world == 1 or dist.get_backend() == "nccl") else (lambda t: t.cpu())
     if by_samples:
         # one ranked gather per complex (inference.py:537-547 ranks the samples of a complex; without a confidence model here: by index)
         for k in range(warmup, n_runs):
-            gather_ranked(pos0[k], -idx.float().to(dev), world, rank, 0, ids=idx, rows=-(-samples // world))
+            gather_ranked(on_wire(pos0[k]), on_wire(-idx.float().to(dev)), world, rank, 0, ids=idx, rows=-(-samples // world))
     else:
-        gather_poses(pos0[n_runs - 1], world, rank)
+        gather_poses(on_wire(pos0[n_runs - 1]), world, rank)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    ranks_seen = 1
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = on_wire(torch.tensor([elapsed], device=dev, dtype=torch.float64))
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        ones = on_wire(torch.ones(1, device=dev, dtype=torch.float64))       # every rank that took part in the timed region adds one
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
     n_launch, total_ms = 0, 0.0
     st = {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0, "shared_rr_visits": 0}
     for e in engines:   # merged launches are timed by the engine that launched them
@@ -598,7 +610,7 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
                   f"poses/sec (whole node), {samples}-sample x {denoise_steps}-step diffusion, {workload}",
         "value": round(value, 3), "unit": "poses/s", "n_gpus": world, "steps": steps_timed, "warmup": warmup,
         "ms_per_step": round(elapsed / steps_timed * 1e3, 3), "higher_is_better": True, "scaling": "strong" if by_samples else "weak",
-        "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+        "vs_baseline": None, "dtype": dtype, "data": "synthetic", "ranks_seen": ranks_seen,
         "config": {"workload": workload, "samples_per_complex": samples, "denoise_steps": denoise_steps,
                    "co_scheduled_complexes": cosched, "hip_graph": int(graph),
                    "Nl": eng.Nl, "Nr": eng.Nr, "R": eng.R,
@@ -648,7 +660,9 @@ def final_line(out, legs):
     print(json.dumps(detail), flush=True)
     cfg, rf = out["config"], out["roofline"]
     line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                "vs_baseline", "dtype", "data")}
+                                "vs_baseline", "dtype", "data", "ranks_seen")}
+    if SHARED_GPU:
+        line["shared_gpu"] = True          # test mode: the ranks shared a GPU over gloo -- not a scaling measurement
     line["config"] = {k: cfg[k] for k in ("workload", "samples_per_complex", "denoise_steps", "co_scheduled_complexes", "hip_graph", "Nl", "Nr", "R")}
     line["config"]["split"] = "samples" if out["scaling"] == "strong" else "complexes"
     line["roofline"] = {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
@@ -730,15 +744,21 @@ def main():
     if world != a.gpus:
         sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or run bare)\n")
         sys.exit(2)
-    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+    n_dev = torch.cuda.device_count()
+    shared = SHARED_GPU and world > 1 and n_dev < world
+    if not torch.cuda.is_available() or (n_dev <= local_rank and not shared):
         sys.stderr.write("bench.py: no MI355X visible for this rank; there is no CPU path to fall back to\n")
         sys.exit(2)
     import torch.distributed as dist
+    dev_index = local_rank % n_dev if shared else local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if shared:      # RCCL refuses two ranks on one device: the test mode talks over gloo (host tensors)
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from confidence_bootstrapping_amd.synthetic import scale_tr_head, BENCH_GEOMETRY
     from confidence_bootstrapping_amd.utils import make_score_model

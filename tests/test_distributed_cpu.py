@@ -268,3 +268,59 @@ def test_train_epoch_skips_collectively_world2_gloo():
     torch.manual_seed(0)
     fresh = _TinyNet()
     assert not np.allclose(res[0][1][0], fresh.lin.weight.detach().numpy())      # the two good steps did update the weights
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# World 8 (the node the SCALE run uses), uneven shares: 37 samples over 8 ranks (5 ranks with five samples, 3 with four: padded rows in
+# the ranked gather), 13 complexes of different cost over 8 ranks (LPT: ranks with one and with two complexes), groups of 2.
+def _w8_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        r = _sd_call(None, None, 37, True)
+        res = None if r is None else {k: (None if v is None else v.numpy().copy()) for k, v in r.items()}
+        from confidence_bootstrapping_amd.distributed import run_complex_set, gather_ranked, shard_round_robin
+        from confidence_bootstrapping_amd.synthetic import make_complex
+        cps = [make_complex(Nl=5 + (i * 7) % 11, Nr=18 + (i * 5) % 13, R=1, knn=6, seed=80 + i) for i in range(13)]
+        seen = []
+
+        def sample_group(items):
+            seen.append([i for i, _ in items])
+            return [{"i": i, "nl": int(c["ligand"].pos.shape[0]), "rank": rank} for i, c in items]
+        rs = run_complex_set(cps, sample_group, group=2)
+        # the bare ranked gather with ties: every confidence equal -> the order must be the global sample order
+        mine = shard_round_robin(37, world, rank)
+        ids = torch.as_tensor(mine, dtype=torch.long)
+        pos = ids.float()[:, None, None].expand(len(mine), 4, 3).contiguous()
+        tied = gather_ranked(pos, torch.zeros(len(mine)), world, rank, 0, ids=ids, rows=-(-37 // world))
+        q.put((rank, res, rs, seen, None if tied[0] is None else (tied[0].numpy().copy(), tied[2].numpy().copy())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world8_uneven_shares_gloo():
+    import numpy as np
+    world, port = 8, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_w8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] is None and r[2] is None and r[4] is None for r in res[1:])          # only dst returns
+    single = _sd_call(1, 0, 37, True)
+    got = res[0][1]
+    assert got["pos"].shape == (37, 12, 3)
+    np.testing.assert_array_equal(got["index"], single["index"].numpy())
+    np.testing.assert_allclose(got["pos"], single["pos"].numpy(), rtol=0, atol=0)
+    np.testing.assert_array_equal(got["confidence"], single["confidence"].numpy())
+    rs = res[0][2]
+    assert [r["i"] for r in rs] == list(range(13))
+    per_rank = {k: sum(1 for r in rs if r["rank"] == k) for k in range(8)}
+    assert sorted(per_rank.values()) == [1, 1, 1, 2, 2, 2, 2, 2]                          # LPT of 13 over 8
+    assert all(len(g) <= 2 for r in res for g in r[3])
+    tied_pos, tied_idx = res[0][4]
+    assert tied_idx.tolist() == list(range(37)) and tied_pos[:, 0, 0].tolist() == [float(i) for i in range(37)]
