@@ -246,19 +246,23 @@ def finetune_leg(dev, batch=8, warm=8, steps=16):
            "batch": batch, "ms_per_step": round(dt * 1e3, 2), "ms_per_step_blocks": [round(b * 1e3, 2) for b in blocks],
            "steps_per_block": steps, "complexes_per_s": round(batch / dt, 1), "loss": round(float(summary["loss"]), 4), "dtype": "f32",
            "host_threads": int(os.environ.get("CBD_HOST_THREADS", "1"))}
-    # the same loop with forward + loss + backward of every step as ONE hipGraph launch (train_graph.py; capacity-padded batches): two
-    # untimed epochs capture the batch shapes, then three timed ones
+    # roofline of the tensor-product layer's four training kernels (HIP events around every launch, train_ops.TIMER): one more epoch,
+    # outside the timed ones (the events add ~100 host calls per step)
+    from confidence_bootstrapping_amd.train_ops import TIMER
+    TIMER.enabled = True
     try:
-        for _ in range(2):
-            train_epoch(model, [batches[k % 8] for k in range(12)], opt, dev, t2s, loss_fn, ema, hip_graph=True)
-        gblocks, gsummary = blocks_of(hip_graph=True)
-        from confidence_bootstrapping_amd.training import _GRAPHED
-        st = _GRAPHED[model][1].stats
-        res["hip_graph"] = {"ms_per_step": round(sorted(gblocks)[1] * 1e3, 2), "ms_per_step_blocks": [round(b * 1e3, 2) for b in gblocks],
-                            "graphs": len(_GRAPHED[model][1].graphs), "replays": st["replays"], "eager_steps": st["eager"],
-                            "loss": round(float(gsummary["loss"]), 4)}
-    except Exception as e:      # the graphed variant must never cost the eager figure
-        res["hip_graph"] = {"error": repr(e)[:200]}
+        train_epoch(model, [batches[(warm + k) % 8] for k in range(steps)], opt, dev, t2s, loss_fn, ema)
+        ks = TIMER.summary()
+    finally:
+        TIMER.enabled = False
+    names = {"fwd": "tp_train_fwd", "bwd": "tp_train_bwd", "gh": "tp_train_gh", "dw": "tp_train_dw"}
+    kern = {names[k]: {"ms_per_step": round(ms / steps, 3), "achieved": round(fl / (ms * 1e-3) / 1e12, 2), "frac": round(fl / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
+            for k, (ms, n, fl) in ks.items() if k in names and ms > 0}
+    tot_ms, tot_fl = sum(ms for k, (ms, n, fl) in ks.items() if k in names), sum(fl for k, (ms, n, fl) in ks.items() if k in names)
+    res["roofline"] = {"bound": "mfma", "kernel": "tp_train_fwd + bwd + gh + dw (fp32 MFMA; algorithmic FLOPs = 2*96*W + CG per edge and kernel)",
+                       "achieved": round(tot_fl / (tot_ms * 1e-3) / 1e12, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                       "frac": round(tot_fl / (tot_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4), "ms_per_step_in_these_kernels": round(tot_ms / steps, 3),
+                       "share_of_step": round(tot_ms / steps / (dt * 1e3), 4), "kernels": kern}
     return res
 
 
@@ -348,7 +352,17 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
     finally:
         if gc_was:
             gc.enable()
-    v, v2 = n_complexes * samples / dt, n_complexes * samples / dt2
+    # and once more as a caller runs it: the interpreter's cyclic garbage collector ON (a generation-2 pass over the ~10^6 objects of
+    # the 800 graphs costs 85-90 ms when its threshold falls inside the call)
+    dl3, ztr3 = build(n_complexes, "g")
+    torch.cuda.synchronize()
+    gc.enable()
+    t0 = time.perf_counter()
+    run(dl3, ztr3)
+    dt3 = time.perf_counter() - t0
+    if not gc_was:
+        gc.disable()
+    v, v2, v3 = n_complexes * samples / dt, n_complexes * samples / dt2, n_complexes * samples / dt3
     # engine-level sampling + the confidence model's own kernels (the `confidence` leg's time for these poses): what the same WORK costs
     # below the API -- the fraction of THAT is the API's overhead proper (noise drawing, copies, set-up, co-scheduling)
     both = None
@@ -358,6 +372,7 @@ def python_api_leg(model, margs, dev, workload, samples, denoise_steps, geometry
                     "set-up of both engines, step loops, confidence scoring of every pose, write-back (cyclic GC off inside the timed call, like "
                     "timeit); not part of `value`",
             "value": round(v, 2), "unit": "poses/s", "complexes": n_complexes, "s_total": round(dt, 3),
+            "value_gc_on": round(v3, 2), "s_total_gc_on": round(dt3, 3),
             "vs_engine_level_value": round(v / engine_value, 4) if engine_value else None,
             "engine_plus_confidence_kernels": round(both, 2) if both else None, "vs_engine_plus_confidence": round(v / both, 4) if both else None,
             "without_confidence_model": {"value": round(v2, 2), "s_total": round(dt2, 3),
@@ -410,6 +425,81 @@ def complex_set_leg(dev, n_complexes=24, samples=40, denoise_steps=20, seed=7):
 SHARED_GPU = os.environ.get("CBD_BENCH_ALLOW_SHARED_GPU") == "1"
 
 
+def single_complex_leg(model, margs, dev, workload, samples, denoise_steps, geometry_name, poses_mode, graph, engine_value, n_complexes=6):
+    """The reference's driver loop (inference.py:409-495, 566-580) makes ONE sampling() call per complex and times each (`run_times`):
+    no co-scheduling across complexes is possible for a caller who keeps that loop.  Two figures, neither part of `value`:
+      * engine level, one complex per launch (`--pair 0`) with its own roofline (a launch carries the 40-pose batch of one complex: the
+        last, partly filled round of resident waves is amortised over an eighth of the headline's work);
+      * API level: `sampling(data_list of ONE complex, ..., confidence_model=...)` per complex, everything the reference times inside
+        (copies, noise drawing, set-up of both engines, step loop, confidence scoring, write-back), mean over the complexes."""
+    r, _ = measure(model.cpu(), margs, dev, workload=workload, samples=samples, denoise_steps=denoise_steps, dtype="f32", geometry_name=geometry_name,
+                   poses_mode=poses_mode, graph=graph, pair=0, warmup=2, steps_timed=n_complexes)
+    from confidence_bootstrapping_amd import Batch
+    from confidence_bootstrapping_amd.synthetic import make_workload, ideal_path_noise, BENCH_GEOMETRY
+    from confidence_bootstrapping_amd.utils import make_confidence_model
+    from confidence_bootstrapping_amd.diffusion_utils import get_t_schedule, t_to_sigma
+    from confidence_bootstrapping_amd.sampling import sampling, randomize_position, draw_noise_like_reference
+    cmodel, cargs = make_confidence_model(device=dev, seed=5)
+    model = model.to(dev)
+    sched = get_t_schedule("expbeta", denoise_steps)
+    t2s = partial(t_to_sigma, args=margs)
+    geometry = dict(BENCH_GEOMETRY) if geometry_name == "globular" else {}
+    base = make_workload(workload, seed=1234, all_atoms=True, **geometry)
+    pocket = base["ligand"].pos.mean(0)
+    R = int(base["ligand"].edge_mask.sum())
+
+    def one(k):
+        c = base.shallow_copy()
+        c.name = f"{workload}_single{k}"
+        torch.manual_seed(700 + k)
+        np.random.seed(700 + k)
+        b1 = Batch.from_data_list([c])
+        dl = [b1.shallow_copy() for _ in range(samples)]
+        randomize_position(dl, False, False, margs.tr_sigma_max)
+        for g in dl:
+            g["ligand"].pos = g["ligand"].pos + (pocket - base["receptor"].pos.mean(0))
+        ztr = ideal_path_noise(torch.stack([g["ligand"].pos for g in dl]), pocket, sched, margs) if poses_mode == "ideal" else None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        filt = [g.shallow_copy() for g in dl]
+        noise = draw_noise_like_reference(len(dl), R, denoise_steps, samples)
+        if ztr is not None:
+            noise["tr"] = ztr
+        out, conf = sampling(data_list=dl, model=model, inference_steps=denoise_steps, tr_schedule=sched, rot_schedule=sched, tor_schedule=sched,
+                             device=dev, t_to_sigma=t2s, model_args=margs, confidence_model=cmodel, filtering_data_list=filt,
+                             filtering_model_args=cargs, batch_size=samples, noise=noise)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, bool(torch.isfinite(conf).all())
+    one(-1)
+    one(-2)
+    times = [one(k) for k in range(n_complexes)]
+    mean_s = float(np.mean([t for t, _ in times]))
+    rf = r["roofline"]
+    return {"what": "one complex per call, as the reference's inference.py loop runs it (no co-scheduling across complexes); not part of `value`",
+            "value": r["value"], "unit": "poses/s", "ms_per_step": r["ms_per_step"], "vs_headline_value": round(r["value"] / engine_value, 4) if engine_value else None,
+            "complexes": n_complexes, "co_scheduled_complexes": 1,
+            "roofline": {k: rf[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_ms", "launches", "executed_gflop_per_launch",
+                                            "tp_conv_share_of_wall")},
+            "api_per_call": {"value": round(samples / mean_s, 2), "unit": "poses/s", "s_per_complex_mean": round(mean_s, 4),
+                             "s_per_complex": [round(t, 4) for t, _ in times], "confidences_finite": all(ok for _, ok in times),
+                             "what": "sampling(data_list of one complex, ..., confidence_model=...) per complex: copies, noise drawing, set-up of both "
+                                     "engines, 20-step loop, confidence scoring, write-back"}}
+
+
+def cb_round_leg():
+    """BASELINE.json configs[4] end to end on this GPU (reference finetune_train.py:133-349, loop shape of its README: inference_samples 8,
+    inference_batch_size 4, batch_size 5, 20 denoising steps, EMA): per epoch `inference_epoch` over the cluster's complexes (sampling +
+    confidence model + symmetry-corrected RMSD) -> CBBuffer -> `train_epoch` over the buffer.  tools/cb_loop.py is the same code."""
+    from tools.cb_loop import run as cb_run
+    r = cb_run(complexes=12, epochs=3, quiet=True)
+    return {"what": "confidence-bootstrapping rounds end to end (sample -> confidence -> RMSD -> buffer -> train -> EMA), 12 C2-sized complexes "
+                    "x 3 epochs, inference_samples 8 / inference_batch_size 4 / batch_size 5; not part of `value`",
+            "value": r["poses_per_s_incl_confidence_and_rmsd"], "unit": "poses/s (sampling + confidence + RMSD phase)",
+            "complexes_per_s": r["complexes_per_s_whole_loop"], "total_s": r["total_s"], "sampling_confidence_rmsd_s": r["sampling_confidence_rmsd_s"],
+            "training_s": r["training_s"], "training_complexes_per_s": r["training_complexes_per_s"], "buffer": r["buffer"],
+            "final_train_loss": r["final_train_loss"]}
+
+
 def launch_ranks(n, argv):
     """`python bench.py --gpus N` run bare: start the N ranks as fresh child processes (torch.distributed.run, one per GPU) BEFORE
     this process makes any GPU call (torch.cuda.device_count() does not initialise the GPU on this image) and exit with their status.
@@ -437,7 +527,7 @@ def launch_ranks(n, argv):
 
 
 def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geometry_name, poses_mode, graph, pair, warmup, steps_timed,
-            rank=0, world=1, split="complexes", keep=False):
+            rank=0, world=1, split="complexes", keep=False, mark=False):
     """`steps_timed` complexes of `workload` (after `warmup` untimed ones) through the engine, inputs resident in HBM.
     Returns the JSON fields of this measurement (value, ms_per_step, config, roofline) and, with keep=True, the context the secondary
     legs re-use (engines, poses, noise)."""
@@ -547,6 +637,15 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marker = None
+    if mark:
+        # --mark-timed-region: one dispatch of a kernel nothing else in this process launches (an in-place add on int16) right before and
+        # right after the timed region; tools/timed_region_stats.py cuts the rocprofv3 kernel trace between the two, so that the tracked
+        # summary covers the timed launches ONLY (no warm-up, no graph instantiation runs) and `roofline.frac` can be recomputed from it
+        marker = torch.zeros(3, dtype=torch.int16, device=dev)
+        torch.cuda.synchronize()
+        marker.add_(1)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(warmup, n_runs)
     # RCCL moves device tensors; under gloo (the shared-GPU test mode) the same collectives take host tensors
@@ -562,6 +661,9 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if marker is not None:
+        marker.add_(1)
+        torch.cuda.synchronize()
     ranks_seen = 1
     if world > 1:
         tmax = on_wire(torch.tensor([elapsed], device=dev, dtype=torch.float64))
@@ -598,11 +700,21 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
     headline = (workload, samples, denoise_steps, dtype, geometry_name, poses_mode) == HEADLINE
     # HBM bytes per tp_conv launch from the PMC passes of THIS command line committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE,
     # separate --pmc runs): a recorded figure, not measured in this run -- the source file is named next to it
+    kernel_name = {"f32": "tp_conv_kernel<OpsF32>", "bf16": ("tp_conv64s_kernel (bf16 operands, register-stationary weights)" if engines[0].get_option("bf16_stationary", int(os.environ.get("CBD_BF16_STATIONARY", "1") != "0")) else
+                                                            "tp_conv64_kernel (bf16 operands)"), "f32_split": "tp_conv_kernel<OpsBf16x3>"}[dtype]
+    family = kernel_name.split("_kernel")[0] + "_kernel"          # tp_conv_kernel | tp_conv64_kernel | tp_conv64s_kernel
     traffic, traffic_src = None, None
     for tag in TRAFFIC_PROFILES.get((workload, dtype, geometry_name, poses_mode), []):
         q = os.path.join(ROOT, "profiles", tag)
         if os.path.exists(q):
-            traffic, traffic_src = round(json.load(open(q))["hbm_bytes_per_launch_all_tp_conv"]), "profiles/" + tag
+            rec = json.load(open(q))
+            # a recorded PMC figure is only reported for the kernel it was measured on (the c4 leg once printed the
+            # streaming kernel's bytes next to the register-stationary kernel's name): the summary's `kernel` field must name the same family
+            rk = rec.get("kernel", "tp_conv_kernel")
+            if (rk.split("_kernel")[0] + "_kernel").replace("<3,3>", "") != family:
+                traffic_src = f"none: newest summary profiles/{tag} was taken on {rk}, not on {family}"
+                break
+            traffic, traffic_src = round(rec["hbm_bytes_per_launch_all_tp_conv"]), "profiles/" + tag
             break
     value = poses / elapsed
     out = {
@@ -621,12 +733,12 @@ def measure(model, margs, dev, *, workload, samples, denoise_steps, dtype, geome
                    "sharding": (f"{world} rank(s), the {samples} samples of each of the {steps_timed} complexes split round-robin "
                                 f"({b_loc} on rank 0), one ranked gather per complex" if by_samples else
                                 f"{world} rank(s) x {steps_timed} complexes each, no data-path collective")},
-        "roofline": {"bound": "mfma", "kernel": {"f32": "tp_conv_kernel<OpsF32>", "bf16": ("tp_conv64s_kernel (bf16 operands, register-stationary weights)" if engines[0].get_option("bf16_stationary", int(os.environ.get("CBD_BF16_STATIONARY", "1") != "0")) else
-                                                                                      "tp_conv64_kernel (bf16 operands)"), "f32_split": "tp_conv_kernel<OpsBf16x3>"}[dtype],
+        "roofline": {"bound": "mfma", "kernel": kernel_name,
                      "achieved": round(achieved * issue, 3), "peak": peak,
                      "unit": "TFLOP/s", "frac": round(achieved * issue / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "flops_counted": "executed (layer-0 receptor->receptor messages once per complex)",
-                     "avg_launch_ms": round(avg_ms, 4), "launches": n_launch,
+                     "avg_launch_ms": round(avg_ms, 4), "launches": n_launch, "tp_conv_ms_total": round(total_ms, 3),
+                     "executed_tflop_total": round(executed_flops / 1e12, 4),
                      "executed_gflop_per_launch": round(executed_flops / max(n_launch, 1) / 1e9, 3),
                      # the reference formulation's count (every sample credited with its own layer-0 rr messages)
                      "algorithmic_gflop_per_launch": round(total_flops / max(n_launch, 1) / 1e9, 3),
@@ -683,16 +795,24 @@ def final_line(out, legs):
         line["legs"][name if not sub else sub] = [r.get(vkey), frac(r) if frac else None]
     if legs:
         line["legs"] = {}
-        line["legs_fields"] = "[value, fraction]: poses/s (ms for confidence/finetune); fraction = roofline frac; python_api: [poses/s, of `value`, of engine + confidence kernels]"
+        line["legs_fields"] = ("[value, roofline frac]: poses/s (ms: confidence, finetune*); python_api: [poses/s GC off, of `value`, of engine+confidence "
+                               "kernels, poses/s GC on]; single_complex: [engine, frac, API per call]; cb_round: [poses/s, complexes/s]")
         pair("python_api", "value", lambda r: r.get("vs_engine_level_value"))
         if isinstance(line["legs"].get("python_api"), list):
             line["legs"]["python_api"].append((legs.get("python_api") or {}).get("vs_engine_plus_confidence"))
         pair("c4_bf16", "value", lambda r: r["roofline"]["frac"])
         pair("confidence", "ms_per_40_poses", lambda r: r.get("frac"))
+        pair("single_complex", "value", lambda r: r["roofline"]["frac"])
+        if isinstance(line["legs"].get("single_complex"), list):
+            line["legs"]["single_complex"].append(((legs.get("single_complex") or {}).get("api_per_call") or {}).get("value"))
         pair("complex_set", "value")
-        pair("finetune", "ms_per_step")
-        pair("other_operand_modes", "value", sub="f32_split")
-        pair("other_operand_modes", "value", sub="bf16")
+        pair("finetune", "ms_per_step", lambda r: (r.get("roofline") or {}).get("frac"))
+        pair("finetune_b5", "ms_per_step", lambda r: (r.get("roofline") or {}).get("frac"))
+        pair("cb_round", "value", lambda r: r.get("complexes_per_s"))
+        pair("other_operand_modes", "value", lambda r: (r.get("roofline") or {}).get("frac"), sub="f32_split")
+        pair("other_operand_modes", "value", lambda r: (r.get("roofline") or {}).get("frac"), sub="bf16")
+        if isinstance(line["legs"].get("python_api"), list):
+            line["legs"]["python_api"].append((legs.get("python_api") or {}).get("value_gc_on"))
     s = json.dumps(line)
     if len(s) > 1800:      # never let the parsed line outgrow the driver's tail: drop the optional parts first
         for k in ("legs_fields",):
@@ -726,6 +846,8 @@ def main():
     ap.add_argument("--split", default="complexes", choices=["complexes", "samples"],
                     help="N > 1: complexes = every rank runs K complexes of its own (weak scaling, default); samples = the samples of each "
                          "of the K complexes are split round-robin over the ranks with one ranked gather per complex (north-star split, strong scaling)")
+    ap.add_argument("--mark-timed-region", action="store_true", help="profiling runs: bracket the timed region of the headline measurement with two "
+                    "dispatches of a marker kernel (tools/timed_region_stats.py cuts the rocprofv3 kernel trace between them)")
     ap.add_argument("--diag-library", action="store_true", help="diagnostic runs only: bind experiments/libcbdock_diag.so (tools/diag_lib.py: "
                     "phase stamps, timing-only kernel variants with WRONG results selected by CBD_CONV_VARIANT / CBD_BF16_DIAG, the role-split "
                     "experiment) instead of the product library, which contains none of them and ignores those variables")
@@ -768,7 +890,7 @@ def main():
         scale_tr_head(model)
     out, ctx = measure(model, margs, dev, workload=a.workload, samples=a.samples, denoise_steps=a.denoise_steps, dtype=a.dtype,
                        geometry_name=a.geometry, poses_mode=a.poses, graph=a.graph, pair=a.pair, warmup=a.warmup, steps_timed=a.steps,
-                       rank=rank, world=world, split=a.split, keep=True)
+                       rank=rank, world=world, split=a.split, keep=True, mark=a.mark_timed_region)
     if rank == 0:
         headline = (a.workload, a.samples, a.denoise_steps, a.dtype, a.geometry, a.poses) == HEADLINE
         extras = world == 1 and headline and not a.headline_only
@@ -808,12 +930,31 @@ def main():
                 for timed in (False, True):
                     for k in alt_k:
                         pos0[k].copy_(alt_init[k])
+                    for e in engines:
+                        e.kernel_timing(enable=True, reset=True)
+                        e.stats(reset=True)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     run(alt_k[0], n_runs)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter() - t1
-                modes[mode] = {"value": round(a.samples * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k)}
+                # roofline of the mode's tensor-product launches: executed FLOPs (as the headline counts them) over the HIP-event time;
+                # f32_split issues every fp32 product as SIX bf16 plane products -> priced at 6x against the bf16 peak
+                n_l, ms_l, st_l = 0, 0.0, {"ll_edges": 0, "conv_edge_visits": 0, "forwards": 0, "shared_rr_visits": 0}
+                for e in engines:
+                    _, n2, t2 = e.kernel_timing(enable=False)
+                    n_l, ms_l = n_l + n2, ms_l + t2
+                    st_l = {k: st_l[k] + v for k, v in e.stats().items()}
+                f33 = flops_per_edge(3, 3)
+                ex = (st_l["conv_edge_visits"] - st_l["shared_rr_visits"]) * f33 + st_l["ll_edges"] * (flops_per_edge(0, 1) + flops_per_edge(1, 2) + flops_per_edge(2, 3))
+                issue = 6.0 if mode == "f32_split" else 1.0
+                tf = ex / max(ms_l * 1e-3, 1e-12) / 1e12
+                modes[mode] = {"value": round(a.samples * len(alt_k) / t1, 1), "unit": "poses/s", "complexes": len(alt_k),
+                               "roofline": {"bound": "mfma", "kernel": "tp_conv_kernel<OpsBf16x3>" if mode == "f32_split" else "tp_conv64s_kernel / tp_conv64_kernel",
+                                            "achieved": round(tf * issue, 2), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(tf * issue / PEAK_BF16_MFMA_TFLOPS, 4), "issue_factor": issue,
+                                            "useful_fp32_tflops": round(tf, 2), "launches": n_l, "avg_launch_ms": round(ms_l / max(n_l, 1), 4),
+                                            "tp_conv_share_of_wall": round(ms_l * 1e-3 / t1, 4)}}
             for e in engines:
                 e.set_option("bf16", 0)
                 e.set_option("f32_split", 0)
@@ -831,8 +972,11 @@ def main():
                                 "not part of `value`", "value": r["value"], "unit": "poses/s", "ms_per_step": r["ms_per_step"],
                         "config": r["config"], "roofline": r["roofline"]}
             leg("c4_bf16", c4)
+            leg("single_complex", lambda: single_complex_leg(model, margs, dev, a.workload, a.samples, a.denoise_steps, a.geometry, a.poses, a.graph, out["value"]))
             leg("complex_set", lambda: complex_set_leg(dev))
-            leg("finetune", lambda: finetune_leg(dev))
+            leg("finetune", lambda: finetune_leg(dev, batch=8))
+            leg("finetune_b5", lambda: finetune_leg(dev, batch=5))      # the reference's own --batch_size (bootstrapping/parsing.py:30)
+            leg("cb_round", cb_round_leg)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(model.cpu(), cplx, margs, sched, a.workload, a.samples, a.denoise_steps)
         print(json.dumps(final_line(out, legs)), flush=True)

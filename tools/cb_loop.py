@@ -21,23 +21,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--complexes", type=int, default=12)
-    ap.add_argument("--epochs", type=int, default=3)
-    ap.add_argument("--cb-inference-freq", type=int, default=1)
-    ap.add_argument("--samples", type=int, default=8)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--workload", default="c2_dockgen_median")
-    ap.add_argument("--host-threads", type=int, default=16, help="intra-op threads of the host-side numpy/torch code (the reference's "
-                    "--restrict_cpu uses 16, inference.py:225-234); tiny LAPACK/BLAS calls crawl on an unrestricted 128-thread pool")
-    a = ap.parse_args()
+def run(complexes=12, epochs=3, cb_inference_freq=1, samples=8, steps=20, workload="c2_dockgen_median", host_threads=16, quiet=False):
+    """-> dict with the time split of the loop (bench.py's `cb_round` leg calls this with the reference's loop shape)"""
+    a = Namespace(complexes=complexes, epochs=epochs, cb_inference_freq=cb_inference_freq, samples=samples, steps=steps, workload=workload,
+                  host_threads=host_threads)
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(a.host_threads)
     try:
         from threadpoolctl import threadpool_limits
         threadpool_limits(limits=a.host_threads)
     except Exception:
         pass
+    try:
+        return _run(a, quiet)
+    finally:
+        torch.set_num_threads(threads_before)
+
+
+def _run(a, quiet):
     from confidence_bootstrapping_amd.synthetic import make_complex, add_atoms, WORKLOADS
     from confidence_bootstrapping_amd.utils import make_score_model, make_confidence_model, load_model_args, ExponentialMovingAverage
     from confidence_bootstrapping_amd.diffusion_utils import t_to_sigma
@@ -96,16 +97,35 @@ def main():
     for k in spent:
         spent[k] = 0 if isinstance(spent[k], int) else 0.0
     t0 = time.perf_counter()
-    hist = ft.inference_finetune(args, model, conf_model, conf_args, None, -1e9, opt, ema, buf, targets, t2s, dev)
+    try:
+        hist = ft.inference_finetune(args, model, conf_model, conf_args, None, -1e9, opt, ema, buf, targets, t2s, dev,
+                                     **({"log": (lambda s_: None)} if quiet else {}))
+    finally:
+        ft.inference_epoch, ft.train_epoch = inf0, tr0
     torch.cuda.synchronize()
     total = time.perf_counter() - t0
-    print(json.dumps({"what": "confidence-bootstrapping loop, synthetic cluster", "complexes": a.complexes, "epochs": a.epochs,
+    return {"what": "confidence-bootstrapping loop, synthetic cluster", "complexes": a.complexes, "epochs": a.epochs,
                       "samples_per_complex": a.samples, "denoise_steps": a.steps, "total_s": round(total, 2),
                       "sampling_confidence_rmsd_s": round(spent["inference"], 2),
                       "poses_per_s_incl_confidence_and_rmsd": round(spent["poses"] / max(spent["inference"], 1e-9), 1),
                       "training_s": round(spent["train"], 2),
                       "training_complexes_per_s": round(spent["train_items"] / max(spent["train"], 1e-9), 1),
-                      "buffer": len(buf.complexes), "final_train_loss": hist[-1].get("train_loss")}))
+                      "complexes_per_s_whole_loop": round(a.complexes * a.epochs / total, 2),
+                      "buffer": len(buf.complexes), "final_train_loss": hist[-1].get("train_loss")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--complexes", type=int, default=12)
+    ap.add_argument("--epochs", type=int, default=3)
+    ap.add_argument("--cb-inference-freq", type=int, default=1)
+    ap.add_argument("--samples", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--workload", default="c2_dockgen_median")
+    ap.add_argument("--host-threads", type=int, default=16, help="intra-op threads of the host-side numpy/torch code (the reference's "
+                    "--restrict_cpu uses 16, inference.py:225-234); tiny LAPACK/BLAS calls crawl on an unrestricted 128-thread pool")
+    a = ap.parse_args()
+    print(json.dumps(run(a.complexes, a.epochs, a.cb_inference_freq, a.samples, a.steps, a.workload, a.host_threads)))
 
 
 if __name__ == "__main__":
