@@ -11,6 +11,7 @@ Works in eval mode too (running statistics, no dropout), which the tests use to 
 """
 from __future__ import annotations
 
+import contextlib
 import math
 import os
 import weakref
@@ -531,6 +532,19 @@ def bond_tensor_product(x, edge_vec, bond_vec, w):
 _HUBS = weakref.WeakKeyDictionary()
 
 
+TWO_STREAM_EMBEDDING = os.environ.get("CBD_TRAIN_TWO_STREAMS", "1") != "0"
+_EMBED_STREAMS = {}
+
+
+def _embed_side_stream(dev):
+    """one side stream per device for the ligand embedding chain of the training forward (see forward())"""
+    k = dev_key(dev)
+    st = _EMBED_STREAMS.get(k)
+    if st is None:
+        st = _EMBED_STREAMS[k] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def _stream_hub(model, dev) -> StreamHub:
     """the model's StreamHub (every FCBlock that feeds a FasterTensorProduct, with the irreps levels of its layer), built once"""
     hub = _HUBS.get(model)          # kept beside the model, not on it: a hub holds non-leaf tensors, which copy.deepcopy(model) refuses
@@ -843,6 +857,14 @@ def forward(model, data):
 
     hub = _stream_hub(model, dev)
     hub.pack()
+    # (the time embeddings first: the ligand chain needs them, and its side stream forks from HERE -- behind the packed streams, the batch
+    #  tensors and these two small ops, in front of the receptor chain's launches)
+    graph_sigma_emb = model.timestep_emb_func(ct["tr"])
+    node_sigma_emb = take(graph_sigma_emb, lig_batch)
+    fork_ev = None
+    if TWO_STREAM_EMBEDDING and dev.type == "cuda" and not torch.cuda.is_current_stream_capturing():     # (a captured step stays on one stream)
+        fork_ev = torch.cuda.Event()
+        fork_ev.record(torch.cuda.current_stream(dev))
     hub.drop_seed, hub.fc_calls = getattr(g, "drop_seed", None), 0       # the step's dropout stream (train_ops.fc_first_stage)
     M = lambda seq, x, call: _mlp(seq, x, seed=hub.drop_seed, call=call)      # embeddings / heads: Linear (+ ReLU + Dropout) on the HIP kernels
 
@@ -852,19 +874,31 @@ def forward(model, data):
     for l, layer in enumerate(model.rec_emb_layers):
         ea = edge_cat(rec_edge_attr, rec_node, r_ei[0], r_ei[1])
         rec_node = conv_layer(layer, rec_node, r_ei, ea, g.r_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_rec)
-    graph_sigma_emb = model.timestep_emb_func(ct["tr"])
     rec_sigma_emb = M(model.rec_sigma_embedding, graph_sigma_emb, 110)
     rec_node = torch.cat([rec_node[:, :ns] + take(rec_sigma_emb, rec_batch), rec_node[:, ns:]], dim=1)
     rec_edge_attr = rec_edge_attr + take(rec_sigma_emb, g.rec_batch_src)
 
     # ---- ligand graph + embedding (score_model.py:492-522, 282-295)
-    node_sigma_emb = take(graph_sigma_emb, lig_batch)
-    l_attr = torch.cat([g.l_attr0, take(node_sigma_emb, l_ei[0]), g.l_smear], 1)
-    lig_node = atom_encoder(model.lig_node_embedding, g.lig_cat, node_sigma_emb)
-    lig_edge_attr = M(model.lig_edge_embedding, l_attr, 120)
-    for l, layer in enumerate(model.lig_emb_layers):
-        ea = edge_cat(lig_edge_attr, lig_node, l_ei[0], l_ei[1])
-        lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_lig)
+    # The ligand chain is independent of the receptor chain above until the joint graph, and its launches are tiny (a few dozen 32-edge
+    # waves on a 256-CU chip: pure latency, ~25 small kernels + 3 x 4 tensor-product kernels forward and backward).  It runs on a SIDE
+    # stream, forked here from everything queued so far and joined before the joint graph: the GPU overlaps it with the receptor chain
+    # (queued first, above), and autograd replays the same split in the backward pass (a node's backward runs on its forward's stream).
+    # Same kernels on the same inputs -> bitwise the single-stream step.  (The receptor chain's launches are queued BEFORE the fork, so
+    # the fork point lies behind them in stream order: the side stream must not wait for them -> it forks from an event recorded at
+    # the top of this function, behind the time embeddings the chain reads.)
+    side = _embed_side_stream(dev) if fork_ev is not None else None
+    cur = torch.cuda.current_stream(dev) if side is not None else None
+    if side is not None:
+        side.wait_event(fork_ev)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        l_attr = torch.cat([g.l_attr0, take(node_sigma_emb, l_ei[0]), g.l_smear], 1)
+        lig_node = atom_encoder(model.lig_node_embedding, g.lig_cat, node_sigma_emb)
+        lig_edge_attr = M(model.lig_edge_embedding, l_attr, 120)
+        for l, layer in enumerate(model.lig_emb_layers):
+            ea = edge_cat(lig_edge_attr, lig_node, l_ei[0], l_ei[1])
+            lig_node = conv_layer(layer, lig_node, l_ei, ea, g.l_vec4, min(l, 3), min(l + 1, 3), hub, bn_exclude=ex_lig)
+    if side is not None:
+        cur.wait_stream(side)
 
     # ---- cross graph (score_model.py:345-352, 564-587)
     lr_edge_attr = M(model.cross_edge_embedding, torch.cat([take(node_sigma_emb, lr[0]), g.c_smear], 1), 130)

@@ -304,18 +304,34 @@ class _HubFn(torch.autograd.Function):
 _DW_SCRATCH = {}
 
 
-def _dw_scratch(n_floats, device):
-    """One persistent buffer per device for the partial blocks of cbd_tp_backward_dw (up to 113 MB per edge group, 22 groups per
-    step, sizes changing with the edge counts: as fresh allocations they churn the caching allocator -- the fine-tuning leg of
-    bench.py, which runs after the other legs have filled the cache, went from 36 to 48 ms per step).  The groups of a step use it one
-    after the other on the same stream."""
-    buf = _DW_SCRATCH.get(dev_key(device))
+def _dw_scratch(n_floats, device, stream=None):
+    """One persistent buffer per (device, STREAM) for the partial blocks of cbd_tp_backward_dw (up to 113 MB per edge group, 22 groups
+    per step, sizes changing with the edge counts: as fresh allocations they churn the caching allocator -- the fine-tuning leg of
+    bench.py, which runs after the other legs have filled the cache, went from 36 to 48 ms per step).  The groups a stream runs use it
+    one after the other; the backward passes of the two embedding chains run on two streams (train_forward.forward) and must not share."""
+    key = (dev_key(device), int((stream if stream is not None else _stream_handle()).value or 0))
+    buf = _DW_SCRATCH.get(key)
     if buf is None or buf.numel() < n_floats:
-        buf = _DW_SCRATCH[dev_key(device)] = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
+        buf = _DW_SCRATCH[key] = torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32)
     return buf[:n_floats]
 
 
 DW_MAX_CHUNKS = int(os.environ.get("CBD_DW_MAX_CHUNKS", "96"))
+# The three backward kernels of a tensor-product layer (g_x | g_h | dW2p + its partial reduction) are independent of each other.  With
+# the fine-tuning loop's batches (5-8 complexes) every launch is a handful of rounds of resident waves (5.25 waves per SIMD at batch
+# 8: the SIMD that gets six sets the time), so each kernel on its own loses its last, partly filled round.  The dW2p pass therefore runs
+# on a side stream (one per launching stream), forked behind the layer's inputs and joined before the function returns: its waves fill
+# the g_x / g_h kernels' tails and vice versa.  Same kernels, same inputs, disjoint outputs -> bitwise the single-stream results.
+CONCURRENT_DW = os.environ.get("CBD_TRAIN_CONCURRENT_DW", "1") != "0"
+_DW_STREAMS = {}
+
+
+def _dw_side_stream(device, cur):
+    key = (dev_key(device), int(cur.cuda_stream))
+    st = _DW_STREAMS.get(key)
+    if st is None:
+        st = _DW_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class TensorProductHubFn(torch.autograd.Function):
@@ -352,9 +368,19 @@ class TensorProductHubFn(torch.autograd.Function):
         # kernels replaced live in experiments/train_ops_reference.py, the equivalence reference of tests/test_gpu_train_op.py)
         ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
         ws = (C.c_void_p * n)(*[hub.stream_ptr(b) for b in blocks])
+        gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
+        # every buffer is allocated from the LAUNCHING stream's pool (what it hands out was last used by work queued on that stream,
+        # i.e. in front of the fork event); the side stream only runs kernels
+        side = None
+        if CONCURRENT_DW and not TIMER.enabled and not torch.cuda.is_current_stream_capturing():
+            cur = torch.cuda.current_stream(xrow.device)
+            side = _dw_side_stream(xrow.device, cur)
+            fork = torch.cuda.Event()
+            fork.record(cur)
+            side.wait_event(fork)
+        dw_stream = C.c_void_p(side.cuda_stream) if side is not None else _stream_handle()
         TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
             in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), None, _stream_handle())))
-        gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
         if gh is not None:
             # g_h on the matrix cores from re-formed g_w tiles (cbd_tp_backward_gh): one launch for all groups
             wt = (C.c_void_p * n)(*[hub.stream_t_ptr(b) for b in blocks])
@@ -369,16 +395,18 @@ class TensorProductHubFn(torch.autograd.Function):
         # partial blocks (167 k floats each at 74 -> 74) stays small next to the pass itself
         chunks = [max(1, min(DW_MAX_CHUNKS, ((ne + 31) // 32) // 4)) for ne, _ in live]
         width = wp * KDIM + wp
-        part = _dw_scratch(sum(chunks) * width, xrow.device)
+        part = _dw_scratch(sum(chunks) * width, xrow.device, dw_stream)
         assert sum(ne for ne, _ in live) == E
         ge_l = (C.c_int64 * ng)(*[ne for ne, _ in live])
         nc = (C.c_int32 * ng)(*chunks)
         TIMER.wrap("dw", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward_dw_groups(
-            in_level, out_level, ng, ge_l, nc, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), _ptr(part), _stream_handle())))
+            in_level, out_level, ng, ge_l, nc, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), _ptr(part), dw_stream)))
         views = [hub.grad_views(b) for _, b in live]
         oa = (C.c_void_p * ng)(*[v[0].data_ptr() for v in views])
         ob = (C.c_void_p * ng)(*[v[1].data_ptr() for v in views])
-        _check(lib.cbd_partial_reduce(ng, nc, width, wp * KDIM, _ptr(part), oa, ob, _stream_handle()))
+        _check(lib.cbd_partial_reduce(ng, nc, width, wp * KDIM, _ptr(part), oa, ob, dw_stream))
+        if side is not None:
+            torch.cuda.current_stream(xrow.device).wait_stream(side)
         return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
 
 
