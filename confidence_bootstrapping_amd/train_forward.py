@@ -916,6 +916,10 @@ def forward(model, data):
             ea = edge_cat(edge_attr[:s2], node, g.ei2[0], g.ei2[1])
             node = conv_layer(layer, node, g.ei2, ea, g.vec4_2, 3, 3, hub, group_sizes=[s1, s2 - s1], bn_exclude=ex_joint)
     lig_node = node[:nL]
+    fork_heads = None
+    if side is not None:      # the torsion head (below) runs on the side stream next to the centre convolution: both read lig_node only
+        fork_heads = torch.cuda.Event()
+        fork_heads.record(cur)
 
     # ---- centre convolution -> translation / rotation scores (score_model.py:393-420, 635-648)
     c_attr = torch.cat([g.center_smear, node_sigma_emb], 1)
@@ -938,17 +942,22 @@ def forward(model, data):
     if model.no_torsion or sum(n_rot) == 0:
         return tr_pred, rot_pred, torch.empty(0, device=dev), None
 
-    # ---- torsion head (score_model.py:431-448, 650-664)
-    t_ei, bonds = g.t_ei, g.bonds
-    t_attr = M(model.final_edge_embedding, g.t_smear, 180)
-    bond_attr = take(lig_node, bonds[0]) + take(lig_node, bonds[1])
-    t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
-    msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, M(model.tor_bond_conv.fc, t_attr, 190))
-    tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
-    tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor, exclude=ex_bond)
-    torus_norm = g.torus_norm
-    if pad:
-        tor, torus_norm = tor[:pad["T_real"]], torus_norm[:pad["T_real"]]
-    tor_pred = M(model.tor_final_layer, tor, 200).squeeze(1)
-    tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
+    # ---- torsion head (score_model.py:431-448, 650-664); on the side stream, forked behind the joint layers (see the ligand chain above)
+    if fork_heads is not None:
+        side.wait_event(fork_heads)
+    with (torch.cuda.stream(side) if fork_heads is not None else contextlib.nullcontext()):
+        t_ei, bonds = g.t_ei, g.bonds
+        t_attr = M(model.final_edge_embedding, g.t_smear, 180)
+        bond_attr = take(lig_node, bonds[0]) + take(lig_node, bonds[1])
+        t_attr = torch.cat([t_attr, take(lig_node[:, :ns], t_ei[1]), take(bond_attr[:, :ns], t_ei[0])], -1)
+        msg = bond_tensor_product(take(lig_node, t_ei[1]), g.t_vec, g.bond_vec_e, M(model.tor_bond_conv.fc, t_attr, 190))
+        tor = scatter_mean(msg, t_ei[0], bonds.shape[1])
+        tor = irreps_batch_norm(model.tor_bond_conv.batch_norm, tor, exclude=ex_bond)
+        torus_norm = g.torus_norm
+        if pad:
+            tor, torus_norm = tor[:pad["T_real"]], torus_norm[:pad["T_real"]]
+        tor_pred = M(model.tor_final_layer, tor, 200).squeeze(1)
+        tor_pred = tor_pred * torus_norm   # sqrt(torus.score_norm(sigma_tor of the bond's graph)), score_model.py:443-447
+    if fork_heads is not None:
+        cur.wait_stream(side)
     return tr_pred, rot_pred, tor_pred, None

@@ -317,22 +317,6 @@ def _dw_scratch(n_floats, device, stream=None):
 
 
 DW_MAX_CHUNKS = int(os.environ.get("CBD_DW_MAX_CHUNKS", "96"))
-# The three backward kernels of a tensor-product layer (g_x | g_h | dW2p + its partial reduction) are independent of each other.  With
-# the fine-tuning loop's batches (5-8 complexes) every launch is a handful of rounds of resident waves (5.25 waves per SIMD at batch
-# 8: the SIMD that gets six sets the time), so each kernel on its own loses its last, partly filled round.  The dW2p pass therefore runs
-# on a side stream (one per launching stream), forked behind the layer's inputs and joined before the function returns: its waves fill
-# the g_x / g_h kernels' tails and vice versa.  Same kernels, same inputs, disjoint outputs -> bitwise the single-stream results.
-CONCURRENT_DW = os.environ.get("CBD_TRAIN_CONCURRENT_DW", "1") != "0"
-_DW_STREAMS = {}
-
-
-def _dw_side_stream(device, cur):
-    key = (dev_key(device), int(cur.cuda_stream))
-    st = _DW_STREAMS.get(key)
-    if st is None:
-        st = _DW_STREAMS[key] = torch.cuda.Stream(device=device)
-    return st
-
 
 class TensorProductHubFn(torch.autograd.Function):
     """TensorProductFn with the weight streams (and the way back for their gradients) in a StreamHub: `big` is an input only so that
@@ -369,16 +353,6 @@ class TensorProductHubFn(torch.autograd.Function):
         ge = (C.c_int64 * n)(*[int(x) for x in group_edges])
         ws = (C.c_void_p * n)(*[hub.stream_ptr(b) for b in blocks])
         gh = torch.empty_like(h) if ctx.needs_input_grad[2] else None
-        # every buffer is allocated from the LAUNCHING stream's pool (what it hands out was last used by work queued on that stream,
-        # i.e. in front of the fork event); the side stream only runs kernels
-        side = None
-        if CONCURRENT_DW and not TIMER.enabled and not torch.cuda.is_current_stream_capturing():
-            cur = torch.cuda.current_stream(xrow.device)
-            side = _dw_side_stream(xrow.device, cur)
-            fork = torch.cuda.Event()
-            fork.record(cur)
-            side.wait_event(fork)
-        dw_stream = C.c_void_p(side.cuda_stream) if side is not None else _stream_handle()
         TIMER.wrap("bwd", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward(
             in_level, out_level, n, ge, _ptr(xrow), _ptr(vec4), _ptr(h), ws, _ptr(gmsg), _ptr(gx), None, _stream_handle())))
         if gh is not None:
@@ -395,18 +369,16 @@ class TensorProductHubFn(torch.autograd.Function):
         # partial blocks (167 k floats each at 74 -> 74) stays small next to the pass itself
         chunks = [max(1, min(DW_MAX_CHUNKS, ((ne + 31) // 32) // 4)) for ne, _ in live]
         width = wp * KDIM + wp
-        part = _dw_scratch(sum(chunks) * width, xrow.device, dw_stream)
+        part = _dw_scratch(sum(chunks) * width, xrow.device)
         assert sum(ne for ne, _ in live) == E
         ge_l = (C.c_int64 * ng)(*[ne for ne, _ in live])
         nc = (C.c_int32 * ng)(*chunks)
         TIMER.wrap("dw", in_level, out_level, E, lambda: _check(lib.cbd_tp_backward_dw_groups(
-            in_level, out_level, ng, ge_l, nc, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), _ptr(part), dw_stream)))
+            in_level, out_level, ng, ge_l, nc, _ptr(xrow), _ptr(vec4), _ptr(h), _ptr(gmsg), _ptr(part), _stream_handle())))
         views = [hub.grad_views(b) for _, b in live]
         oa = (C.c_void_p * ng)(*[v[0].data_ptr() for v in views])
         ob = (C.c_void_p * ng)(*[v[1].data_ptr() for v in views])
-        _check(lib.cbd_partial_reduce(ng, nc, width, wp * KDIM, _ptr(part), oa, ob, dw_stream))
-        if side is not None:
-            torch.cuda.current_stream(xrow.device).wait_stream(side)
+        _check(lib.cbd_partial_reduce(ng, nc, width, wp * KDIM, _ptr(part), oa, ob, _stream_handle()))
         return (gx if ctx.needs_input_grad[0] else None), None, gh, None, None, None, None, None, None
 
 

@@ -255,7 +255,7 @@ def test_graphed_epoch_with_an_unindexed_device_and_eager_steps_in_between():
             junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]      # poison whatever the allocator got back
             del junk
         out = train_epoch(model, loader, opt, torch.device("cuda"), t2s, loss_fn, ema, hip_graph=True)
-        assert set(to._DW_SCRATCH) <= {dev_key("cuda")} and all(k[0] == dev_key("cuda") for k in tf._COPY_STREAMS)
+        assert all(k[0] == dev_key("cuda") for k in to._DW_SCRATCH) and all(k[0] == dev_key("cuda") for k in tf._COPY_STREAMS)
         return out["loss"], torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu(), model
 
     l0, w0, m0 = run(False)
