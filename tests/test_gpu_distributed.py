@@ -69,3 +69,37 @@ def test_two_ranks_one_gpu_gloo_equals_one_rank(reference_run, tmp_path):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_two_ranks_two_gpus_rccl_equals_one_rank(reference_run, tmp_path):
     _same(reference_run, _run(2, "nccl", str(tmp_path / "w2_nccl.npz")))
+
+
+def test_rccl_initialises_and_runs_the_gathers_on_this_gpu(tmp_path):
+    """No multi-GPU box was ever available to this build, so RCCL itself had never executed under this code.  What CAN
+    run on one GPU: a world of ONE rank on the "nccl" backend (= RCCL) in a fresh process -- communicator creation with the pool's
+    HSA_ENABLE_IPC_MODE_LEGACY=0 setting, an all-reduce and the two gathers of distributed.py on DEVICE tensors through RCCL kernels
+    (gather_ranked's early return for world 1 is bypassed by calling the collective the way it does)."""
+    code = (
+        "import os, sys, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r)\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=%r, RANK='0', WORLD_SIZE='1')\n"
+        "os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')\n"
+        "dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))\n"
+        "dev = torch.device('cuda', 0)\n"
+        "t = torch.arange(8, dtype=torch.float64, device=dev)\n"
+        "dist.all_reduce(t, op=dist.ReduceOp.MAX)\n"
+        "pos = torch.randn(5, 7, 3, device=dev); conf = torch.tensor([0.1, 0.9, 0.5, 0.9, -1.0], device=dev)\n"
+        "payload = torch.cat([conf[:, None].double(), pos.reshape(5, -1).double()], 1)\n"
+        "out = [torch.empty_like(payload)]\n"
+        "dist.gather(payload, out, dst=0)\n"
+        "dist.barrier()\n"
+        "torch.cuda.synchronize()\n"
+        "assert torch.equal(out[0], payload) and t.tolist() == list(range(8))\n"
+        "from confidence_bootstrapping_amd.distributed import gather_ranked\n"
+        "p, c, i = gather_ranked(pos, conf, 1, 0, 0, ids=torch.arange(5))\n"
+        "assert i.tolist() == [1, 3, 2, 0, 4]\n"
+        "print('rccl ok', dist.get_backend())\n"
+        "dist.destroy_process_group()\n") % (ROOT, str(_port()))
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "rccl ok nccl" in r.stdout
