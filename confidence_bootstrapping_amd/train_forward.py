@@ -537,11 +537,34 @@ _EMBED_STREAMS = {}
 
 
 def _embed_side_stream(dev):
-    """one side stream per device for the ligand embedding chain of the training forward (see forward())"""
-    k = dev_key(dev)
+    """One side stream per (device, launching stream) for the ligand embedding chain / torsion head of the training forward (see
+    forward()).  HIP multiplexes a process's streams onto a few hardware queues (four by default), and two streams that share a queue
+    run one after the other: a side stream created after many others (bench.py's earlier legs create dozens) landed on the launching
+    stream's queue in the full bench run and the overlap was gone (19.6 instead of 18.6 ms per step; alone: 18.6).  So four candidates
+    are created back to back (they land on different queues) and each is PROBED once: with a ~1 ms spin kernel running on the launching
+    stream, an event recorded on an idle candidate completes at once unless the candidate sits behind that kernel (the same test
+    csrc/engine.hip::pick_setup_stream makes for the set-up streams of the sampler)."""
+    cur = torch.cuda.current_stream(dev)
+    k = (dev_key(dev), int(cur.cuda_stream))
     st = _EMBED_STREAMS.get(k)
     if st is None:
-        st = _EMBED_STREAMS[k] = torch.cuda.Stream(device=dev)
+        import time
+        cands = [torch.cuda.Stream(device=dev) for _ in range(4)]
+        torch.cuda.synchronize(dev)
+        st = cands[0]
+        for c in cands:
+            torch.cuda._sleep(2_000_000)                  # ~1 ms of GPU spin on the launching stream
+            ev = torch.cuda.Event()
+            ev.record(c)
+            t0 = time.perf_counter()
+            while not ev.query() and time.perf_counter() - t0 < 3e-4:
+                pass
+            free = ev.query()
+            torch.cuda.synchronize(dev)
+            if free:
+                st = c
+                break
+        _EMBED_STREAMS[k] = st
     return st
 
 
