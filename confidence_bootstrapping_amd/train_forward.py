@@ -910,6 +910,7 @@ def forward(model, data):
     # the fork point lies behind them in stream order: the side stream must not wait for them -> it forks from an event recorded at
     # the top of this function, behind the time embeddings the chain reads.)
     side = _embed_side_stream(dev) if fork_ev is not None else None
+    hub.side_stream = side          # _HubFn.backward waits for it: the side stream's tensor-product calls write hub.grads (train_ops._HubFn)
     cur = torch.cuda.current_stream(dev) if side is not None else None
     if side is not None:
         side.wait_event(fork_ev)

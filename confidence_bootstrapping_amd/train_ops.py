@@ -298,6 +298,12 @@ class _HubFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         hub = ctx.hub
+        # The tensor-product calls return NO gradient for `big` (they write dW2p / db2p into hub.grads), so autograd orders this node
+        # behind them on the HOST but inserts no stream synchronisation for it.  The ligand chain's calls run on a side stream
+        # (train_forward.forward): wait for it here, or this gather could read hub.grads before their kernels have written it.
+        side = getattr(hub, "side_stream", None)
+        if side is not None:
+            torch.cuda.current_stream(hub.grads.device).wait_stream(side)
         return hub.grads.index_select(0, hub.p2g) * hub.pscale, None
 
 
