@@ -240,3 +240,49 @@ def test_remove_all_hs_gives_the_heavy_atom_graph():
     heavy = remove_all_hs(remove_all_hs(Mol))
     assert _graph_of(heavy)[0].tolist() == [6, 8]       # idempotent: no hydrogens left -> returned as is
     assert remove_all_hs(None) is None
+
+
+def test_timed_region_stats_cuts_the_trace_between_the_markers(tmp_path):
+    """tools/timed_region_stats.py (round 6): from a rocprofv3 kernel trace keep only the dispatches between the two marker kernels of
+    `bench.py --mark-timed-region` and recompute roofline.frac from them.  Synthetic trace: 3 warm-up tp_conv launches in front of the
+    first marker, 4 timed ones (1 ms each) + another kernel between the markers, 2 launches behind the second marker."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    d = tmp_path / "trace" / "sub"
+    d.mkdir(parents=True)
+    rows, t = [], 1000
+    def add(name, dur):
+        nonlocal t
+        rows.append({"Kernel_Name": name, "Start_Timestamp": t, "End_Timestamp": t + dur})
+        t += dur + 500
+    conv = "void cbd::tp_conv_kernel<3, 3, 0, cbd::OpsF32>(cbd::ConvArgs)"
+    mark = "void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctorOnSelf_add<short>, std::array<char*, 2ul> >(int, ...)"
+    for _ in range(3):
+        add(conv, 2_000_000)
+    add(mark, 3000)
+    for _ in range(4):
+        add(conv, 1_000_000)
+    add("cbd::node_proj_kernel(cbd::ProjArgs)", 50_000)
+    add(mark, 3000)
+    for _ in range(2):
+        add(conv, 1_000_000)
+    with open(d / "p_kernel_trace.csv", "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        w.writeheader()
+        w.writerows(rows)
+    rf = {"frac": 0.5, "peak": 100.0, "launches": 4, "executed_gflop_per_launch": 50.0, "executed_tflop_total": 0.2, "tp_conv_ms_total": 4.0}
+    line = {"metric": "m", "value": 1.0, "ms_per_step": 1.0, "steps": 4, "warmup": 3, "roofline": rf}
+    lf = tmp_path / "line.json"
+    lf.write_text(json.dumps({"leg": "headline_detail", "roofline": rf}) + "\n" + json.dumps(line) + "\n")
+    out = str(tmp_path / "rX")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "timed_region_stats.py"), str(tmp_path / "trace"), str(lf), out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    rec = json.load(open(out + "_timed_recompute.json"))
+    assert rec["tp_conv_launches_in_trace"] == 4 and rec["dispatches_in_region"] == 5 and rec["kernels_in_region"] == 2
+    assert abs(rec["tp_conv_ms_total_trace"] - 4.0) < 1e-9
+    assert abs(rec["frac_recomputed_from_trace"] - 0.2 / 4e-3 / 100.0) < 1e-4          # 0.2 TFLOP / 4 ms / 100 TFLOP/s = 0.5
+    stats = list(csv.DictReader(open(out + "_timed_kernel_stats.csv")))
+    assert stats[0]["Name"] == conv and stats[0]["Calls"] == "4" and stats[0]["TotalDurationNs"] == "4000000"
