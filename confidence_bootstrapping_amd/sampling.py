@@ -36,6 +36,10 @@ from .hostcfg import with_glue_threads
 
 
 
+# Test hook (tests/test_gpu_finetune_loop.py, tools/check_upload_ordering.py): False removes the ordering of the pipelined side-stream fills
+# behind the caller's stream -- the state before round 6 -- to show that the hazard of ADVICE round 5 is real.  Never switched off in use.
+_ORDER_SIDE_FILLS = True
+
 def _mask_rotate_of(graph):
     mr = graph["ligand"].mask_rotate
     while isinstance(mr, (list, tuple)):
@@ -420,7 +424,7 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
         only filled on the side stream: an allocation on the side stream would wait for the running wave (caching-allocator events)."""
         engines = engine_sets()[k % 2]
         ctx = (lambda: torch.cuda.stream(side)) if side is not None else contextlib.nullcontext
-        if side is not None:
+        if side is not None and _ORDER_SIDE_FILLS:
             if fill_after[0] is None:
                 side.wait_stream(torch.cuda.current_stream(device))
             else:
