@@ -231,7 +231,11 @@ def test_pipelined_uploads_wait_for_pending_work_on_the_callers_stream():
     ordered behind it (an event on the current stream at wave 0 / right before each wave's launch).  Here the caller leaves exactly that
     behind: tensors of the uploads' sizes, a long spin kernel, then fill_(NaN) on each -- queued, not executed -- and frees them on the
     host right before the call.  Unordered side-stream copies into those blocks would be overwritten with NaN when the spin ends; the
-    poses must come out bitwise those of fresh synchronous engines."""
+    poses must come out bitwise those of fresh synchronous engines.
+    (Measured, tools/check_upload_ordering.py: with today's library the scenario does not corrupt even with the ordering switched off --
+    0 of 6 runs -- because cbd_set_complex of wave 0 synchronises the device and cbd_sample* synchronise their stream after the sigma
+    upload; the explicit ordering is what keeps the uploads correct if those internal synchronisations are ever removed, and this test is
+    its regression guard.)"""
     from confidence_bootstrapping_amd import Batch
     from confidence_bootstrapping_amd.synthetic import make_complex
     from confidence_bootstrapping_amd.utils import make_score_model
