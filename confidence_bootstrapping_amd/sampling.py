@@ -39,6 +39,7 @@ from .hostcfg import with_glue_threads
 # Test hook (tests/test_gpu_finetune_loop.py, tools/check_upload_ordering.py): False removes the ordering of the pipelined side-stream fills
 # behind the caller's stream -- the state before round 6 -- to show that the hazard of ADVICE round 5 is real.  Never switched off in use.
 _ORDER_SIDE_FILLS = True
+_STEPS_CACHE = __import__("weakref").WeakKeyDictionary()       # model -> {schedule / flag key: engine.make_steps(...)} (see sampling())
 
 def _mask_rotate_of(graph):
     mr = graph["ligand"].mask_rotate
@@ -347,10 +348,23 @@ def sampling(data_list, model, inference_steps, tr_schedule, rot_schedule, tor_s
     eng = model.engine_pool(n_streams=n_streams, max_batch=max(int(batch_size), 1)) if n_streams > 1 else model.engine()
     # --different_schedules (inference.py:375-383): rot / tor run on their own time grids; everything schedule-dependent is a host
     # scalar of the step (engine.make_steps), the engine itself is agnostic
-    steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
-                       no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
-                       temp_sigma_data=temp_sigma_data, rot_schedule=rot_schedule, tor_schedule=tor_schedule,
-                       common_t_schedule=t_schedule if model_async else None)
+    # The per-step scalars are a pure function of the schedules, six sigma limits and a few flags, and cost ~4 ms of host arithmetic
+    # (20 steps x torch scalar ops in the reference's own dtypes) -- 2 % of a one-complex call in the reference's inference.py loop, where
+    # every call passes the same schedules: cached on the model (its timestep embedding is part of the result), eight entries.
+    common = np.asarray(t_schedule, dtype=np.float64) if model_async else None
+    tkey = lambda v: tuple(float(x) for x in v) if np.iterable(v) else float(v)
+    skey = (tr_schedule.tobytes(), rot_schedule.tobytes(), tor_schedule.tobytes(), None if common is None else common.tobytes(),
+            tuple(float(getattr(model_args, k)) for k in ("tr_sigma_min", "tr_sigma_max", "rot_sigma_min", "rot_sigma_max", "tor_sigma_min", "tor_sigma_max")),
+            bool(ode), bool(no_random), bool(no_final_step_noise), tkey(temp_sampling), tkey(temp_psi), float(temp_sigma_data))
+    cache = _STEPS_CACHE.setdefault(model, {})          # beside the model, not on it: copy.deepcopy(model) must not meet ctypes arrays
+    steps = cache.get(skey)
+    if steps is None:
+        steps = make_steps(tr_schedule, model_args, model.timestep_emb_func, ode=ode, no_random=no_random,
+                           no_final_step_noise=no_final_step_noise, temp_sampling=temp_sampling, temp_psi=temp_psi,
+                           temp_sigma_data=temp_sigma_data, rot_schedule=rot_schedule, tor_schedule=tor_schedule, common_t_schedule=common)
+        if len(cache) >= 8:
+            cache.pop(next(iter(cache)))
+        cache[skey] = steps
     S = inference_steps
     use_noise = not (no_random or ode)
     if co_schedule is None:
