@@ -145,10 +145,11 @@ int cbd_sample_multi(int32_t n, cbd_engine* const* engines, const int32_t* B, in
  * THIS engine, instead of synchronising the device and using the default stream: the caller can set the next complexes up on idle
  * engines while others run (sampling.py does, with two alternating sets of engines).  A launch through any other entry point
  * (cbd_score, cbd_modify_conformer, cbd_recompute_receptor) makes the next set-up synchronise the device as before.
- * With "bf16": "bf16_roles" (0/1/2) -- experimental role split of the cross / receptor groups; "bf16_stationary" (0/1) -- the
- * 74 -> 74 layers through persistent workgroups that keep a whole FCBlock in registers (tp_conv_bf16s.hip; same bf16 products,
- * message sums equal to fp32 rounding; deterministic; default 1, 0 selects the streaming kernel tp_conv_bf16.hip).  "bf16_roles"
- * defaults to 0.  Both are baked into captured graphs (changing them drops the graphs); co-scheduled engines must agree on them. */
+ * With "bf16": "bf16_stationary" (0/1) -- the 74 -> 74 layers through persistent workgroups that keep a whole FCBlock in registers
+ * (tp_conv_bf16s.hip; same bf16 products, message sums equal to fp32 rounding; deterministic; default 1, 0 selects the streaming
+ * kernel tp_conv_bf16.hip); baked into captured graphs (changing it drops the graphs); co-scheduled engines must agree on it.
+ * "bf16_roles" (the role-split experiment of rounds 4-5) is not part of this library since round 6: 0 is accepted, any other value is
+ * refused with CBD_ERR_ARG -- the experiment lives in the diagnostic twin library (tools/diag_lib.py, experiments/). */
 int cbd_set_option(cbd_engine* e, const char* name, int64_t value);
 
 /* Make `dst` use the device-resident (re-packed) weights of `src` instead of a copy of its own: several engines on one
