@@ -1697,6 +1697,29 @@ int64_t cbd_debug_fetch(cbd_engine* e, const char* name, float* out, int64_t cap
     out[0] = (float)ghz[ghz.size() / 2]; out[1] = (float)dur[dur.size() / 2]; out[2] = (float)ghz.size();
     return capacity >= 8 ? 8 : capacity >= 7 ? 7 : 3;
   }
+#ifdef CBD_DIAG
+  if (k == "conv_span_wg") {   // per workgroup of the last tp_conv64s launch (CBD_BF16_DIAG=5): start offset ns, lifetime ns, units, last role
+    if (!e->stamps_dev || capacity < 4) return fail(CBD_ERR_ARG, "stamps not enabled (diagnostic library only, tools/diag_lib.py)");
+    std::vector<unsigned long long> h(8192 * 8);
+    if (hipMemcpy(h.data(), e->stamps_dev, h.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(CBD_ERR_HIP, "memcpy failed");
+    unsigned long long t0 = ~0ull;
+    for (int rec = 0; rec < 4096; rec += 4) {
+      const unsigned long long* q = h.data() + 16 * (size_t)rec;
+      if (q[3] && q[3] > q[1] && q[10]) t0 = std::min(t0, q[1]);
+    }
+    int64_t n = 0;
+    for (int rec = 0; rec < 4096 && 4 * (n + 1) <= capacity; rec += 4) {
+      const unsigned long long* q = h.data() + 16 * (size_t)rec;
+      if (!q[3] || q[3] <= q[1] || q[10] == 0) continue;
+      out[4 * n + 0] = (float)((double)(q[1] - t0) * 10.0);
+      out[4 * n + 1] = (float)((double)(q[3] - q[1]) * 10.0);
+      out[4 * n + 2] = (float)q[10];
+      out[4 * n + 3] = (float)((double)q[11] + (double)(rec / 4) / 1024.0);      // role + workgroup index / 1024
+      ++n;
+    }
+    return 4 * n;
+  }
+#endif
   if (k == "conv_clock_s") {   // per-wave phase clocks of the last tp_conv64s launch (CBD_BF16_DIAG=4): 4 waves x 10 floats (medians)
     if (!e->stamps_dev || capacity < 48) return fail(CBD_ERR_ARG, "stamps not enabled (diagnostic library only, tools/diag_lib.py) or capacity < 48");
     std::vector<unsigned long long> h(8192 * 8);

@@ -31,6 +31,7 @@ constexpr int P_MID_ROWS = P_RES_TILES;                           // mids of the
 constexpr int P_WAVE_FLOATS = P_MID_ROWS * 64 + 64;               // + the 64 aggregating-node ids; >= one message tile [NS][33]
 static_assert(P_MID_ROWS * 64 >= NS * OUT_STRIDE, "the message tile re-uses the mid table");
 constexpr int P_LDS_BYTES = (P_W_FLOATS + P_WAVES * P_WAVE_FLOATS) * 4;
+static_assert(P_W_FLOATS % 2 == 0 && P_WAVE_FLOATS % 2 == 0, "reduce_runs reads the message tile as f32x2: even tile bases");
 static_assert(P_LDS_BYTES <= 160 * 1024, "one workgroup per CU");
 
 struct RoleTable {
@@ -279,7 +280,8 @@ __global__ __launch_bounds__(P_WAVES * 64, 1) void tp_conv64p_kernel(ConvArgs ar
 #pragma unroll
       for (int r = 0; r < 16; ++r) mids[((r & 3) + 8 * (r >> 2) + 4 * hf) * OUT_STRIDE + j] = o[r];
       wave_lds_fence();
-      reduce_runs<NODE_STRIDE, OUT_STRIDE>(mids, srcl + 32 * sub, lane, NS, G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
+      reduce_runs<NODE_STRIDE, OUT_STRIDE, NS, 0>(mids, srcl + 32 * sub, lane, NS,      // (tile base P_W_FLOATS + wave * P_WAVE_FLOATS: even, asserted below)
+                                                  G.first_sum + (size_t)(tile_local + sub) * NODE_STRIDE,
                                            G.last_sum + (size_t)(tile_local + sub) * NODE_STRIDE, G.run_acc);
     }
     wave_lds_fence();

@@ -286,3 +286,19 @@ def test_timed_region_stats_cuts_the_trace_between_the_markers(tmp_path):
     assert abs(rec["frac_recomputed_from_trace"] - 0.2 / 4e-3 / 100.0) < 1e-4          # 0.2 TFLOP / 4 ms / 100 TFLOP/s = 0.5
     stats = list(csv.DictReader(open(out + "_timed_kernel_stats.csv")))
     assert stats[0]["Name"] == conv and stats[0]["Calls"] == "4" and stats[0]["TotalDurationNs"] == "4000000"
+
+
+def test_diagnostic_library_still_builds():
+    """experiments/ is not linked into the product, so nothing else notices when a header change breaks it (round 6: reduce_runs' new
+    template parameters broke experiments/csrc/tp_conv_bf16p.hip unnoticed for hours).  Incremental build of the diagnostic twin
+    (tools/diag_lib.py: the product sources with -DCBD_DIAG -DCBD_EXPERIMENTS + experiments/csrc); it must export the whole C ABI too."""
+    import ctypes
+    sys_path = os.path.join(ROOT)
+    import sys
+    if sys_path not in sys.path:
+        sys.path.insert(0, sys_path)
+    from tools import diag_lib
+    from confidence_bootstrapping_amd import engine
+    lib = ctypes.CDLL(diag_lib.build())
+    for name in engine.SYMBOLS:
+        assert getattr(lib, name) is not None
