@@ -98,6 +98,9 @@ struct ConvGroup {
   // weight-tile slice executed for this group (run_conv fills the full range): 0e tiles [i0e_lo, i0e_hi) and, if vec_on, the
   // 1o/1e/0o blocks.  Virtual slices of one edge group write their own piece buffers; the finalize kernel adds them.
   int i0e_lo, i0e_hi, vec_on;
+  // relative cost of one 32-edge unit of this group in 1/64 (0 = 64): what the persistent bf16 kernel weighs a group's units with when it
+  // cuts a launch into equal pieces of WORK per workgroup (tp_conv_bf16s.hip; measured per role).  Other kernels ignore it.
+  int cost_w;
 };
 
 // Host-side view of a group: plus the node-row ranges its src / dst indices fall in (what node_proj_kernel has to cover).  Kept out

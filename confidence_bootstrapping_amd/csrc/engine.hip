@@ -1117,6 +1117,9 @@ static BatchGroups batch_groups(cbd_engine* e, int B) {
   G.lr.src_lo = 0; G.lr.src_n = nL; G.lr.dst_lo = gs.rec_off; G.lr.dst_n = nR;
   G.rr.src_lo = gs.rec_off; G.rr.src_n = nR; G.rr.dst_lo = gs.rec_off; G.rr.dst_n = nR;
   G.rl.src_lo = gs.rec_off; G.rl.src_n = nR; G.rl.dst_lo = 0; G.rl.dst_n = nL;
+  // cost of a 32-edge unit per role for the persistent bf16 kernel's work split, in 1/64 of a ligand->receptor unit (per-workgroup
+  // lifetimes on C4, tools/conv_span_wg.py; ConvGroup::cost_w)
+  G.ll.cost_w = 69; G.lr.cost_w = 64; G.rr.cost_w = 67; G.rl.cost_w = 66;
   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
   G.rr_shared.src = e->rr_src; G.rr_shared.dst = e->rr_dst; G.rr_shared.attr_idx = e->rr_aidx; G.rr_shared.vec = e->rr_vec;
   G.rr_shared.attr = e->rr_attr_t; G.rr_shared.count = e->rr_count_dev;

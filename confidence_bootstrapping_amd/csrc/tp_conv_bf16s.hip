@@ -73,6 +73,7 @@ __device__ __forceinline__ int h_slot(int u) { return (u + 9) % 3; }      // u >
 struct RoleTableS {
   int n_roles;
   unsigned char role_of[CONV_MAX_GROUPS];      // role of every entry of ConvArgs::g
+  unsigned char weight[S_MAX_ROLES];           // cost of one unit of the role in 1/64 (ConvGroup::cost_w of its groups)
   const float* wstream[S_MAX_ROLES];
 };
 
@@ -781,20 +782,31 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
     units = (*cp + SU - 1) / SU;
     my_role = *reinterpret_cast<const unsigned char*>(ka + ((sizeof(ConvArgs) + alignof(RoleTableS) - 1) / alignof(RoleTableS)) * alignof(RoleTableS) + offsetof(RoleTableS, role_of) + lane);
   }
+  //      Round 6: equal pieces of WORK, not of units.  A unit's cost depends on its role -- the run-length reduction walks every eight-edge
+  //      group that holds a run boundary, and the groups differ in run length: ligand-ligand units (runs of ~17 edges) cost 8 % more than
+  //      ligand->receptor units (runs of hundreds), receptor units 3-4 % more (per-workgroup lifetimes, tools/conv_span_wg.py:
+  //      2484 / 2292 / 2384 / 2364 ns per unit for ll / lr / rr / rl) -- and with equal unit counts the workgroups inside the expensive
+  //      roles finished 6-7 % after the mean and set the launch time.  Every role's units are weighed with RoleTableS::weight (1/64).
   const int total = s_wave_sum(units);
   if (total == 0) return;
   const int n_wg = gridDim.x;
-  const int U_lo = (int)((long long)total * blockIdx.x / n_wg), U_hi = (int)((long long)total * (blockIdx.x + 1) / n_wg);
-  if (U_lo >= U_hi) return;
-  int acc_units = 0;
+  long long total_cost = 0;
+#pragma unroll 1
+  for (int role = 0; role < rt.n_roles; ++role) total_cost += (long long)s_wave_sum(my_role == role ? units : 0) * rt.weight[role];
+  const long long C_lo = total_cost * blockIdx.x / n_wg, C_hi = total_cost * (blockIdx.x + 1) / n_wg;
+  if (C_lo >= C_hi) return;
+  long long acc_cost = 0;
 #pragma unroll 1
   for (int role = 0; role < rt.n_roles; ++role) {
     const int w = s_wave_sum(my_role == role ? units : 0);
-    const int R_lo = acc_units;
-    acc_units += w;
-    const int a = U_lo > R_lo ? U_lo : R_lo, b = U_hi < acc_units ? U_hi : acc_units;
+    const int W = rt.weight[role];
+    const long long A_r = acc_cost;
+    acc_cost += (long long)w * W;
+    const long long a = C_lo > A_r ? C_lo : A_r, b = C_hi < acc_cost ? C_hi : acc_cost;
     if (a >= b) continue;
-    const int u_lo = a - R_lo, u_hi = b - R_lo;
+    // unit boundaries = floor(cost offset / W): the piece boundaries of neighbouring workgroups coincide, so the units tile exactly
+    const int u_lo = (int)((a - A_r) / W), u_hi = (int)((b - A_r) / W);
+    if (u_lo >= u_hi) continue;
     const float* const wstream = rt.wstream[role];
     // ---- bias rows, the three first-Linear tiles and one second-Linear tile per wave 0 .. 2 -> LDS
     __syncthreads();
@@ -845,6 +857,7 @@ static bool s_role_table(const ConvArgs& a, RoleTableS& rt) {
       if (rt.n_roles == S_MAX_ROLES) return false;
       r = rt.n_roles++;
       rt.wstream[r] = G.wstream;
+      rt.weight[r] = (unsigned char)(G.cost_w > 0 && G.cost_w < 256 ? G.cost_w : 64);
     }
     rt.role_of[g] = (unsigned char)r;
   }
