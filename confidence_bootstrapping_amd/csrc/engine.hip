@@ -1119,7 +1119,13 @@ static BatchGroups batch_groups(cbd_engine* e, int B) {
   G.rl.src_lo = gs.rec_off; G.rl.src_n = nR; G.rl.dst_lo = 0; G.rl.dst_n = nL;
   // cost of a 32-edge unit per role for the persistent bf16 kernel's work split, in 1/64 of a ligand->receptor unit (per-workgroup
   // lifetimes on C4, tools/conv_span_wg.py; ConvGroup::cost_w)
-  G.ll.cost_w = 69; G.lr.cost_w = 64; G.rr.cost_w = 67; G.rl.cost_w = 66;
+  G.ll.cost_w = 70; G.lr.cost_w = 64; G.rr.cost_w = 68; G.rl.cost_w = 66;      // (sweep: profiles/r06_n_split_weights.txt)
+#ifdef CBD_DIAG      // diagnostic library only: CBD_S_WEIGHTS="ll,lr,rr,rl" (1/64) for tuning runs
+  if (const char* p = getenv("CBD_S_WEIGHTS")) {
+    int w[4] = {70, 64, 68, 66};
+    if (sscanf(p, "%d,%d,%d,%d", &w[0], &w[1], &w[2], &w[3]) == 4) { G.ll.cost_w = w[0]; G.lr.cost_w = w[1]; G.rr.cost_w = w[2]; G.rl.cost_w = w[3]; }
+  }
+#endif
   // sample 0's receptor edges (the first Err entries of the batched arrays) with their own piece buffers
   G.rr_shared.src = e->rr_src; G.rr_shared.dst = e->rr_dst; G.rr_shared.attr_idx = e->rr_aidx; G.rr_shared.vec = e->rr_vec;
   G.rr_shared.attr = e->rr_attr_t; G.rr_shared.count = e->rr_count_dev;

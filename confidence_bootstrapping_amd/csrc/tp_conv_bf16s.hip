@@ -786,7 +786,8 @@ __global__ __launch_bounds__(SW_WAVES * 64, 1) void tp_conv64s_kernel(ConvArgs a
   //      group that holds a run boundary, and the groups differ in run length: ligand-ligand units (runs of ~17 edges) cost 8 % more than
   //      ligand->receptor units (runs of hundreds), receptor units 3-4 % more (per-workgroup lifetimes, tools/conv_span_wg.py:
   //      2484 / 2292 / 2384 / 2364 ns per unit for ll / lr / rr / rl) -- and with equal unit counts the workgroups inside the expensive
-  //      roles finished 6-7 % after the mean and set the launch time.  Every role's units are weighed with RoleTableS::weight (1/64).
+  //      roles finished 6-7 % after the mean and set the launch time.  Every role's units are weighed with RoleTableS::weight (1/64;
+  //      70 / 64 / 68 / 66 from a sweep on the C4 leg: 220.9 -> 228.7 .. 233 poses/s on one box, profiles/r06_n_split_weights.txt).
   const int total = s_wave_sum(units);
   if (total == 0) return;
   const int n_wg = gridDim.x;
@@ -858,6 +859,10 @@ static bool s_role_table(const ConvArgs& a, RoleTableS& rt) {
       r = rt.n_roles++;
       rt.wstream[r] = G.wstream;
       rt.weight[r] = (unsigned char)(G.cost_w > 0 && G.cost_w < 256 ? G.cost_w : 64);
+#ifdef CBD_DIAG      // diagnostic library only: CBD_S_EQUAL_UNITS=1 restores the equal-unit split of round 5 for A/B runs in one process / on one box
+      static const bool equal_units = getenv("CBD_S_EQUAL_UNITS") && atoi(getenv("CBD_S_EQUAL_UNITS")) != 0;
+      if (equal_units) rt.weight[r] = 64;
+#endif
     }
     rt.role_of[g] = (unsigned char)r;
   }
