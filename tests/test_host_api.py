@@ -39,7 +39,7 @@ def test_product_library_holds_only_correct_kernels():
     assert seen >= 13, seen          # 4 levels x (fp32, bf16x3, bf16 streaming) + the register-stationary kernel
     assert "tp_conv64p" not in names and "bf16p" not in names
     raw = open(lib, "rb").read()
-    for env in (b"CBD_CONV_VARIANT", b"CBD_BF16_DIAG", b"CBD_BF16_ROLES", b"CBD_BF16P_WGS", b"CBD_DIAG_MIN_ROLES"):
+    for env in (b"CBD_CONV_VARIANT", b"CBD_BF16_DIAG", b"CBD_BF16_ROLES", b"CBD_BF16P_WGS", b"CBD_DIAG_MIN_ROLES", b"CBD_S_WEIGHTS", b"CBD_S_EQUAL_UNITS"):
         assert env not in raw, env
     pkg = os.path.join(ROOT, "confidence_bootstrapping_amd")
     for dp, _, fs in os.walk(pkg):
