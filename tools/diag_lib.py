@@ -8,7 +8,8 @@ results and reads none of the diagnostic environment variables.  Everything that
   * the bf16 role split (option `bf16_roles`, CBD_BF16_ROLES, CBD_BF16P_WGS; experiments/csrc/tp_conv_bf16p.hip): correct, slower, kept
     as the record of DESIGN.md section 5
 Usage from a tool (BEFORE any engine is created):   from tools.diag_lib import use_diag_library; use_diag_library()
-Command line:                                       python tools/diag_lib.py [--force]      (build only)
+Command line:                                       python tools/diag_lib.py [--force]      (build only; CBD_DIAG_EXTRA_FLAGS="-DX=0 ..." adds
+                                                    compile flags, e.g. to A/B a compile-time kernel switch against the product library)
 """
 import os
 import subprocess
@@ -33,7 +34,7 @@ def build(force: bool = False) -> str:
         o = os.path.join(OBJ_DIR, os.path.basename(s).replace(".hip", ".o"))
         if force or ge._stale(o, [s] + headers):
             subprocess.check_call([ge.HIPCC] + ge.FLAGS + ge.EXTRA_FLAGS.get(os.path.basename(s), []) +
-                                  ["-DCBD_DIAG", "-DCBD_EXPERIMENTS", "-I", ge.CSRC, "-c", s, "-o", o])
+                                  ["-DCBD_DIAG", "-DCBD_EXPERIMENTS"] + os.environ.get("CBD_DIAG_EXTRA_FLAGS", "").split() + ["-I", ge.CSRC, "-c", s, "-o", o])
         objs.append(o)
     if force or ge._stale(LIB, objs):
         subprocess.check_call([ge.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
