@@ -68,7 +68,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md: bf16 dense (~2.5 PF)
 # PMC traffic summaries (tools/pmc_summary.py) of the default command line per (workload, dtype, geometry, poses), newest first
 TRAFFIC_PROFILES = {("c2_dockgen_median", "f32", "globular", "ideal"): ["r06_z_traffic.json", "r05_z_traffic.json", "r04_z_traffic.json", "r03_z_traffic.json", "r02_z_traffic.json", "r02_t_traffic.json", "r02_e_traffic.json"],
                     ("c2_dockgen_median", "f32", "loose", "free"): ["r01_m_traffic.json"],
-                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r06_y_c4_bf16_traffic.json", "r06_z_c4_bf16_traffic.json", "r05_zz_c4_bf16_traffic.json", "r05_z_c4_bf16_traffic.json", "r04_z_c4_bf16_traffic.json", "r04_a_c4_bf16_traffic.json"]}
+                    ("c4_large_pocket", "bf16", "globular", "ideal"): ["r06_x_c4_bf16_traffic.json", "r06_y_c4_bf16_traffic.json", "r06_z_c4_bf16_traffic.json", "r05_zz_c4_bf16_traffic.json", "r05_z_c4_bf16_traffic.json", "r04_z_c4_bf16_traffic.json", "r04_a_c4_bf16_traffic.json"]}
 
 
 def flops_per_edge(in_level: int, out_level: int) -> float:
@@ -972,7 +972,7 @@ def main():
 
             def c4():
                 r, _ = measure(model.cpu(), margs, dev, workload="c4_large_pocket", samples=64, denoise_steps=40, dtype="bf16",
-                               geometry_name="globular", poses_mode="ideal", graph=a.graph, pair=2, warmup=2, steps_timed=6)
+                               geometry_name="globular", poses_mode="ideal", graph=a.graph, pair=8, warmup=2, steps_timed=8)
                 return {"what": "BASELINE.json configs[3]: large-pocket complex, 64 samples x 40 steps, bf16 operands / fp32 accumulate, "
                                 "not part of `value`", "value": r["value"], "unit": "poses/s", "ms_per_step": r["ms_per_step"],
                         "config": r["config"], "roofline": r["roofline"]}

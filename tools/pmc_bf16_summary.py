@@ -40,7 +40,7 @@ def main():
          "hbm_bytes_per_launch_all_tp_conv": (2 * sum(allf) / len(allf) + sum(allw) / len(allw)) * 1024, "launches_all_tp_conv": len(allf),
          "mfma_busy_frac": busy, "valu_insts_per_mfma": valu_per_mfma,
          "note": "rocprofv3 --pmc, one counter per pass, over `bench.py --workload c4_large_pocket --dtype bf16 --samples 64 --denoise-steps 40 "
-                 f"--steps 1 --warmup 0 --pair {pair} --headline-only`; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section)"}
+                 f"--steps {pair} --warmup 0 --pair {pair} --headline-only`; FETCH_SIZE doubled (gfx950 correction, MI355X_MICROARCH.md HBM section)"}
     lines.append(f"# matrix-pipe busy (SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024)) = {busy:.4f}; VALU per MFMA = {valu_per_mfma}")
     open(os.path.join(prof, f"{tag}_pmc_bf16_c4_tp_conv64_summary.txt"), "w").write("\n".join(lines) + "\n")
     json.dump(j, open(os.path.join(prof, f"{tag}_c4_bf16_traffic.json"), "w"), indent=1)
