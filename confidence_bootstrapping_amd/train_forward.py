@@ -552,8 +552,9 @@ def _embed_side_stream(dev):
         cands = [torch.cuda.Stream(device=dev) for _ in range(4)]
         torch.cuda.synchronize(dev)
         st = cands[0]
-        for c in cands:
-            torch.cuda._sleep(2_000_000)                  # ~1 ms of GPU spin on the launching stream
+        spin = getattr(torch.cuda, "_sleep", None)        # (private torch helper; without it the first candidate is taken unprobed)
+        for c in cands if spin is not None else []:
+            spin(2_000_000)                               # ~1 ms of GPU spin on the launching stream
             ev = torch.cuda.Event()
             ev.record(c)
             t0 = time.perf_counter()
