@@ -1,7 +1,7 @@
 # round 6, final: the complete -m gpu suite, the experiments' test, smoke and the default bench (driver's flags) on the final tree
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/r06_final
+OUT=gpurun_out/r06_final2
 mkdir -p $OUT
 timeout 1800 python -m pytest tests -q -m gpu > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 600 python -m pytest experiments/test_role_split.py -q > $OUT/pytest_experiments.log 2>&1; tail -1 $OUT/pytest_experiments.log
